@@ -1,0 +1,227 @@
+/*
+ * panfusion_hip.h -- C ABI of the MI355X-native (gfx950) PanFusion denoising hot path.
+ *
+ * Drop-in boundary.  The reference (chengzhag/PanFusion) is pure Python and has
+ * no FFI of its own; the arithmetic on its denoising path lives in third-party CUDA wheels reached
+ * through the call sites cited on every entry point below (paths relative to the reference tree).
+ * This header is what a ctypes / cffi binding on the reference side binds (INTEGRATION.md shows
+ * the stub); `panfusion_amd/_lib.py` is that binding for the in-tree Python host.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no C++/torch types.  All data pointers are DEVICE
+ *     pointers owned by the caller unless the name says `host_`.  Scratch is passed in
+ *     (`workspace`, size from the matching *_workspace_size); the only device memory the library
+ *     owns is a few-KB buffer of per-camera constants created on the first geometry call.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*); no implicit device sync.
+ *   - Activations are 16-bit (PF_BF16 or PF_F16), token-major / NHWC: [image][y][x][channel].
+ *     Statistics, biases, tables and accumulators are fp32.
+ *   - Every function returns pf_status; on failure pf_last_error_string() describes the problem
+ *     (thread-local).  Arguments are validated before any launch.  Nothing throws or aborts.
+ */
+#ifndef PANFUSION_HIP_H
+#define PANFUSION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { PF_OK = 0, PF_ERR_ARG = 1, PF_ERR_LAUNCH = 2, PF_ERR_UNSUPPORTED = 3 } pf_status;
+typedef enum { PF_BF16 = 0, PF_F16 = 1, PF_F32 = 2 } pf_dtype;
+
+int pf_version(void);
+const char* pf_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Spherical geometry (replaces external/Perspective_and_Equirectangular/{e2p,p2e}.py and
+ * models/pano/utils.py; angles in DEGREES as host doubles, one entry per camera).
+ * ------------------------------------------------------------------------------------------ */
+
+/* e2p.py:39-51 map_pers_pix_to_equi for `ncam` cameras: sampling position (pixel units of an
+ * (eh,ew) panorama) of every pixel of an (h,w) view.  map_x/map_y: [ncam][h][w] fp32 (the
+ * float64 result cast as e2p.py:74-75 does).  lonlat (optional, may be NULL): [ncam][h][w][2]
+ * fp32 = e2p.py:9-36 map_pers_coords_to_equi (lon, lat) -- models/pano/utils.py:97-104. */
+pf_status pf_e2p_grid(const double* host_fov, const double* host_theta, const double* host_phi,
+                      int ncam, int eh, int ew, int h, int w,
+                      float* map_x, float* map_y, float* lonlat, void* stream);
+
+/* p2e.py:9-49 map_equi_pix_to_pers: for every pixel of an (h,w) panorama its position in the
+ * (ph,pw) view (0 where invisible) and the visibility mask.  [ncam][h][w]. */
+pf_status pf_p2e_grid(const double* host_fov, const double* host_theta, const double* host_phi,
+                      int ncam, int ph, int pw, int h, int w,
+                      float* map_u, float* map_v, uint8_t* mask, void* stream);
+
+/* Integer gather indices of kornia.remap(mode='nearest', align_corners=True) -> F.grid_sample
+ * (e2p.py:76): idx[i] = iy*src_w+ix or -1 when the sample falls outside.  n entries. */
+pf_status pf_nearest_indices(const float* map_x, const float* map_y, long n, int src_h, int src_w,
+                             int32_t* idx, void* stream);
+
+/* kornia.remap == grid_sample(zeros padding, align_corners=True) on NCHW images (e2p.py:76,
+ * p2e.py:70-71).  src [B][C][hs][ws], maps [map_batch][ho][wo] (map_batch == B or 1), dst
+ * [B][C][ho][wo]; mode 0 = nearest, 1 = bilinear; mask (optional) [map_batch][ho][wo]
+ * multiplies the result (p2e.py:71).  dtype: PF_F32 / PF_F16 / PF_BF16 (same in and out). */
+pf_status pf_remap(const void* src, int dtype, int B, int C, int hs, int ws,
+                   const float* map_x, const float* map_y, const uint8_t* mask, int map_batch,
+                   int ho, int wo, int mode, void* dst, void* stream);
+
+/* models/pano/utils.py:92-95: (lon,lat) of every pixel of an (H,W) panorama, [H][W][2] fp32. */
+pf_status pf_equi_coords(int H, int W, float* lonlat, void* stream);
+
+/* models/modules/transformer.py:185-201 SphericalPE.forward: coords [n][2] fp32, freq_bands
+ * [nfreq] fp32 -> out [n][4*nfreq] fp32 = [sin(lon f) | sin(lat f) | cos(lon f) | cos(lat f)].
+ * Full-range accurate sinf/cosf (frequencies reach 2^79). */
+pf_status pf_spherical_pe(const float* coords, long n, const float* freq_bands, int nfreq,
+                          float* out, void* stream);
+
+/* models/pano/utils.py:10-84 get_masks, restated as shift-invariant tables: bias_x = mask + 1
+ * in [0,2] (softmax is shift invariant per query row, and 98-99% of the entries are exactly 0).
+ *   bias_e [E][m*P]   panorama pixel queries, keys ordered (view, y, x)   (modules.py:47)
+ *   bias_p [m*P][E]   view pixel queries                                   (modules.py:53)
+ *   flags_e [ceil(E/32)][ceil(m*P/32)], flags_p [ceil(m*P/32)][ceil(E/32)]: 1 where the 32x32
+ *   tile of the table holds any non-zero.  E = eh*ew, P = ph*pw.  m = ncam. */
+size_t pf_epa_tables_workspace_size(int ncam, int ph, int pw, int eh, int ew);
+pf_status pf_epa_tables_build(const double* host_fov, const double* host_theta,
+                              const double* host_phi, int ncam, int ph, int pw, int eh, int ew,
+                              float* bias_e, float* bias_p, uint8_t* flags_e, uint8_t* flags_p,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation / element-wise (replace torch GroupNorm / LayerNorm / SiLU / GELU / F.pad /
+ * torch.cat / torch.roll kernels reached from diffusers ResnetBlock2D, Transformer2DModel and
+ * models/modules/transformer.py:151-162).
+ * ------------------------------------------------------------------------------------------ */
+
+/* GroupNorm statistics folded with the affine: for x [n_img][hw][C] (C = c0+c1 when two
+ * sources are concatenated along channels, MVGenModel.py:231-233) writes scale/shift
+ * [n_img][C] fp32 such that GN(x) = x*scale + shift.  workspace: pf_groupnorm_workspace_size. */
+size_t pf_groupnorm_workspace_size(int n_img, int hw, int C);
+pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, int c1, int dtype,
+                             int n_img, int hw, int groups, float eps,
+                             const float* gamma, const float* beta,
+                             float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/* y = act(x*scale + shift), act 0 = identity, 1 = SiLU.  Same concat convention; y [n_img][hw][C]. */
+pf_status pf_scale_shift_act(const void* x0, int c0, const void* x1, int c1, int dtype,
+                             int n_img, int hw, const float* scale, const float* shift, int act,
+                             void* y, void* stream);
+
+/* y = LayerNorm(x + pe) * gamma + beta over the last dim; x,y [rows][C]; pe (optional) fp32
+ * [pe_rows][C], row r uses pe row (r % pe_rows) (transformer.py:155-158; eps 1e-5). */
+pf_status pf_layernorm(const void* x, const float* pe, long pe_rows, int dtype, long rows, int C,
+                       const float* gamma, const float* beta, float eps, void* y, void* stream);
+
+/* GEGLU: in [rows][2*inner] = [a | gate] -> out [rows][inner] = a * gelu(gate) (erf GELU). */
+pf_status pf_geglu(const void* in, int dtype, long rows, int inner, void* out, void* stream);
+
+/* Sinusoidal timestep features [cos | sin] (diffusers Timesteps, flip_sin_to_cos, shift 0)
+ * followed by nothing: t [n] int64 -> out [n][dim] in `dtype`. */
+pf_status pf_timestep_features(const int64_t* t, int n, int dim, int out_dtype, void* out, void* stream);
+
+/* y = silu(x) element-wise, n elements. */
+pf_status pf_silu(const void* x, int dtype, long n, void* y, void* stream);
+
+/* Circular width pad (utils/pano.py:74-99) and crop (:102-105) on NHWC: x [n][h][w][C]. */
+pf_status pf_pad_width(const void* x, int dtype, int n, int h, int w, int C, int pad, void* y, void* stream);
+pf_status pf_crop_width(const void* x, int dtype, int n, int h, int w, int C, int crop, void* y, void* stream);
+
+/* The reference's pad_pano on NCHW tensors (utils/pano.py:74-99): x [rows][w] -> y [rows][w+2 pad],
+ * circular; elem_bytes 2 or 4. */
+pf_status pf_pad_width_rows(const void* x, int elem_bytes, long rows, int w, int pad, void* y, void* stream);
+/* torch.roll(x, shift, dims=-1) of rotate_latent (PanoGenerator.py:264-269): y[r][(i+shift) mod w] = x[r][i]. */
+pf_status pf_roll_width_rows(const void* x, int elem_bytes, long rows, int w, int shift, void* y, void* stream);
+
+/* Layout/precision converters at the boundary: NCHW (src_dtype) <-> NHWC (dst_dtype). */
+pf_status pf_nchw_to_nhwc(const void* x, int src_dtype, int n, int C, int h, int w, int dst_dtype, void* y, void* stream);
+pf_status pf_nhwc_to_nchw(const void* x, int src_dtype, int n, int C, int h, int w, int dst_dtype, void* y, void* stream);
+
+/* y = a + b element-wise (ControlNet residual adds, MVGenModel.py:154-170,200-203). */
+pf_status pf_add(const void* a, const void* b, int dtype, long n, void* y, void* stream);
+
+/* Fused classifier-free-guidance merge + DDIM update (+ optional width roll of the result):
+ * eps = eps_uncond + g*(eps_cond - eps_uncond)                (PanoGenerator.py:253-262)
+ * x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t); x' = sqrt(a_prev) x0 + sqrt(1-a_prev) eps  (DDIM eta=0)
+ * out[..., (w + roll) mod W] = x'                              (PanoGenerator.py:264-269)
+ * x, out: fp32 [n_img][C][H][W]; eps_uncond/eps_cond fp32 same shape. */
+pf_status pf_cfg_ddim_step(const float* x, const float* eps_uncond, const float* eps_cond,
+                           float guidance, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
+                           float sqrt_1m_a_prev, long rows, int W, int roll, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MFMA GEMM / implicit-GEMM convolution (replaces cuDNN/cuBLAS behind diffusers Conv2d/Linear:
+ * MVGenModel.py:86-144,174-198,224-294 and transformer.py:57-74,8-38).
+ *   out[m][n] = sum_k A[m][k] * W[n][k]  (+ bias[n]) (+ rowvec[img(m)][n]) (+ residual[m][n])
+ * A is gathered on the fly: m = (img, yo, xo), k = (ky, kx, c); zero padding; optional nearest
+ * x2 upsampling of the input (Upsample2D) and optional channel concat of two sources.
+ * A plain linear layer is ksize = 1, n_img = 1, h_in = 1, w_in = rows.
+ * Requirements: (c0 + c1) % 64 == 0, c0 % 64 == 0; pointers 16-byte aligned; ld's % 8 == 0.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* a0;      /* source 0, [n_img][h_in][w_in][a0_ld]                            */
+    const void* a1;      /* source 1 (channel concat after source 0) or NULL                */
+    int c0, c1;          /* channels taken from each source                                 */
+    int a0_ld, a1_ld;    /* per-pixel stride in elements (>= c0 / c1)                       */
+    int n_img, h_in, w_in;
+    int h_out, w_out;    /* output spatial size                                              */
+    int ksize;           /* 1 or 3                                                          */
+    int stride;          /* 1 or 2                                                          */
+    int pad;             /* 0 or 1 (zeros)                                                  */
+    int upsample;        /* 1: input is nearest-upsampled x2 before the convolution         */
+    const void* w;       /* [n_out][ksize*ksize*(c0+c1)], k ordered (ky, kx, c)             */
+    int n_out;
+    const float* bias;   /* [n_out] or NULL                                                 */
+    const float* rowvec; /* [n_img][rowvec_ld] added per image (time embedding) or NULL     */
+    int rowvec_ld;
+    const void* residual;/* [M][res_ld] 16-bit or NULL                                      */
+    int res_ld;
+    void* out;           /* [M][out_ld]                                                     */
+    int out_ld;
+    int out_dtype;       /* PF_BF16 / PF_F16 (== dtype) or PF_F32                           */
+    int dtype;           /* PF_BF16 or PF_F16: A, W, residual                               */
+    int batch;           /* >= 1: independent problems, strides below (elements)            */
+    long a_bstride, w_bstride, out_bstride, res_bstride;
+} pf_conv_desc;
+
+pf_status pf_conv_gemm(const pf_conv_desc* desc, void* stream);
+
+/* 3x3 convolutions with 4 input or 4 output channels at the UNet boundary:
+ * conv_in  (MVGenModel.py:86,89): x fp32 NCHW [n][cin][h][w] -> y NHWC 16-bit [n][h][w][cout],
+ *          weights fp32 [3][3][cin][cout];
+ * conv_out (MVGenModel.py:283,292): x NHWC 16-bit [n][h][w][cin] -> y fp32 NCHW [n][cout][h][w],
+ *          weights fp32 [cout][3][3][cin], cout <= 8.
+ * bias fp32 [cout]; zero padding 1 in y.  wrap = 1: the width axis is circular, which is exactly
+ * pad_pano(x,1) -> conv(zero pad) -> unpad_pano(.,1) of the pano branch (MVGenModel.py:87-91,
+ * 290-294); wrap = 0: zero padding in x. */
+pf_status pf_conv_in(const float* x, int n, int cin, int h, int w, const float* wgt, const float* bias,
+                     int cout, int wrap, int out_dtype, void* y, void* stream);
+pf_status pf_conv_out(const void* x, int dtype, int n, int cin, int h, int w, const float* wgt,
+                      const float* bias, int cout, int wrap, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flash attention on MFMA (replaces xformers memory_efficient_attention, transformer.py:71,
+ * and the diffusers AttnProcessor baddbmm+softmax+bmm inside unet.*.attentions[j]).
+ *   out[b][i][h*D + :] = softmax_j(scale * q_i.k_j + bias[i][j]) v_j      D in {32, 64}
+ * q [B][nq][q_ld], k [B][nk][k_ld] (head h at column h*D), vt = V transposed:
+ * [B][H*D][vt_ld] (keys contiguous), out [B][nq][o_ld].  bias (optional) fp32 [nq][bias_ld]
+ * shared by all batches and heads, consulted only for 32x32 tiles whose flag byte is non-zero.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* q; const void* k; const void* vt; void* out;
+    int dtype;
+    int B, H, D;
+    int nq, nk;
+    int q_ld, k_ld, vt_ld, o_ld;
+    long q_bs, k_bs, vt_bs, o_bs;
+    float scale;
+    const float* bias; long bias_ld;
+    const uint8_t* flags; int flags_ld;
+} pf_attn_desc;
+
+pf_status pf_attention(const pf_attn_desc* desc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANFUSION_HIP_H */

@@ -1,0 +1,121 @@
+"""ctypes binding of ``libpanfusion_hip.so`` (C ABI in ``include/panfusion_hip.h``).
+
+The product path has NO fallback: if the shared library is missing or a symbol
+is absent, importing/using the ops raises.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C panfusion_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpanfusion_hip.so")
+
+PF_OK = 0
+PF_BF16, PF_F16, PF_F32 = 0, 1, 2
+
+c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+c_dp = C.POINTER(C.c_double)
+
+
+class ConvDesc(C.Structure):
+    """pf_conv_desc"""
+    _fields_ = [
+        ("a0", c_void_p), ("a1", c_void_p), ("c0", c_int), ("c1", c_int),
+        ("a0_ld", c_int), ("a1_ld", c_int),
+        ("n_img", c_int), ("h_in", c_int), ("w_in", c_int), ("h_out", c_int), ("w_out", c_int),
+        ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int),
+        ("w", c_void_p), ("n_out", c_int),
+        ("bias", c_void_p), ("rowvec", c_void_p), ("rowvec_ld", c_int),
+        ("residual", c_void_p), ("res_ld", c_int),
+        ("out", c_void_p), ("out_ld", c_int), ("out_dtype", c_int), ("dtype", c_int),
+        ("batch", c_int),
+        ("a_bstride", c_long), ("w_bstride", c_long), ("out_bstride", c_long), ("res_bstride", c_long),
+    ]
+
+
+class AttnDesc(C.Structure):
+    """pf_attn_desc"""
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("vt", c_void_p), ("out", c_void_p),
+        ("dtype", c_int), ("B", c_int), ("H", c_int), ("D", c_int), ("nq", c_int), ("nk", c_int),
+        ("q_ld", c_int), ("k_ld", c_int), ("vt_ld", c_int), ("o_ld", c_int),
+        ("q_bs", c_long), ("k_bs", c_long), ("vt_bs", c_long), ("o_bs", c_long),
+        ("scale", c_float),
+        ("bias", c_void_p), ("bias_ld", c_long), ("flags", c_void_p), ("flags_ld", c_int),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/panfusion_hip.h declares
+SIGNATURES = {
+    "pf_version": (c_int, []),
+    "pf_last_error_string": (C.c_char_p, []),
+    "pf_e2p_grid": (c_int, [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_int, c_int,
+                            c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_p2e_grid": (c_int, [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_int, c_int,
+                            c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_nearest_indices": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
+    "pf_remap": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                         c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_equi_coords": (c_int, [c_int, c_int, c_void_p, c_void_p]),
+    "pf_spherical_pe": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p]),
+    "pf_epa_tables_workspace_size": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "pf_epa_tables_build": (c_int, [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pf_groupnorm_workspace_size": (c_size_t, [c_int, c_int, c_int]),
+    "pf_groupnorm_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pf_scale_shift_act": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "pf_layernorm": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_int, c_void_p, c_void_p,
+                             c_float, c_void_p, c_void_p]),
+    "pf_geglu": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p]),
+    "pf_timestep_features": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_silu": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "pf_pad_width": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_crop_width": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_pad_width_rows": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p]),
+    "pf_roll_width_rows": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p]),
+    "pf_nchw_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_nhwc_to_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_add": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "pf_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,
+                                 c_long, c_int, c_int, c_void_p, c_void_p]),
+    "pf_conv_gemm": (c_int, [C.POINTER(ConvDesc), c_void_p]),
+    "pf_conv_in": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                           c_void_p, c_void_p]),
+    "pf_conv_out": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                            c_void_p, c_void_p]),
+    "pf_attention": (c_int, [C.POINTER(AttnDesc), c_void_p]),
+}
+
+
+class PanFusionHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the CDLL with typed entry points.  Raises if the
+    extension has not been built -- there is deliberately no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PanFusionHipError(
+            "HIP extension %s not built; run `make -C panfusion_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)      # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return handle
+
+
+def check(status, what=""):
+    if status != PF_OK:
+        msg = lib().pf_last_error_string()
+        raise PanFusionHipError("%s failed (status %d): %s" % (what, status, msg.decode() if msg else ""))

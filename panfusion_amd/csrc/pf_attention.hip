@@ -1,0 +1,228 @@
+// Flash attention on MFMA for gfx950 (CDNA4): UNet self / text cross attention (head dim 64)
+// and the EPA pano<->view cross attention (head dim 32) with its sparse correspondence bias.
+//
+//   out[b][i][h*D+:] = softmax_j(scale * q_i.k_j + bias[i][j]) v_j
+//
+// One wavefront owns 32 query rows and walks the keys in tiles of 32 with an online softmax.
+// Both products are computed TRANSPOSED so that a lane owns one query column:
+//   S^T = K Q^T  : v_mfma_f32_32x32x16 with A = K tile (rows = keys), B = Q^T.  Lane (q, hi)
+//                  then holds 16 of the 32 scores of query q -> row max / row sum are 15 local
+//                  ops + one exchange with lane^32, no LDS.
+//   O^T += V^T P^T: A = V^T tile (rows = head dim, keys contiguous -- the V projection is written
+//                  transposed by the GEMM), B = P^T straight from the score registers: the k-slot
+//                  order of the MFMA is a permutation of the keys that is applied identically to
+//                  both operands, so no cross-lane movement of P is needed.
+// The additive bias is a dense fp32 table of (mask + 1) that is zero for 98-99 % of its entries;
+// a byte flag per 32x32 tile says whether the tile has to be read at all.
+//
+// Replaces xformers.ops.memory_efficient_attention (models/modules/transformer.py:57-74) and the
+// diffusers AttnProcessor (baddbmm + softmax + bmm) inside unet.*.attentions[j]
+// (models/pano/MVGenModel.py:104,116,185,190,227,241).
+#include "pf_common.h"
+
+namespace pf {
+
+struct AttnParams {
+    const unsigned short* q; const unsigned short* k; const unsigned short* vt; unsigned short* out;
+    int H, nq, nk;
+    int q_ld, k_ld, vt_ld, o_ld;
+    long q_bs, k_bs, vt_bs, o_bs;
+    float scale_log2e;
+    const float* bias; long bias_ld; const uint8_t* flags; int flags_ld;
+};
+
+template <typename T> struct Mfma32;
+template <> struct Mfma32<Bf16> {
+    typedef __attribute__((ext_vector_type(8))) __bf16 frag;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma32<F16> {
+    typedef __attribute__((ext_vector_type(8))) _Float16 frag;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_attention(const AttnParams p) {
+    constexpr int KS = D / 16;      // k-slabs of the QK^T product
+    constexpr int DB = D / 32;      // 32-row blocks of O^T
+    typedef typename Mfma32<T>::frag frag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 31, hi = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= p.nq) return;
+    const int h = blockIdx.y;
+    const long b = blockIdx.z;
+    const unsigned short* qp = p.q + b * p.q_bs + h * D;
+    const unsigned short* kp = p.k + b * p.k_bs + h * D;
+    const unsigned short* vp = p.vt + b * p.vt_bs + static_cast<long>(h) * D * p.vt_ld;
+    const int qrow = min(q0 + ql, p.nq - 1);
+
+    frag qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        qf[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(qp + static_cast<long>(qrow) * p.q_ld + 16 * s + 8 * hi));
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = (p.nk + 31) / 32;
+    u16x8 kcur[KS], knext[KS];
+    auto load_k = [&](int kt, u16x8 (&dst)[KS]) {
+        const int krow = min(kt * 32 + ql, p.nk - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            dst[s] = *reinterpret_cast<const u16x8*>(kp + static_cast<long>(krow) * p.k_ld + 16 * s + 8 * hi);
+    };
+    load_k(0, kcur);
+    const uint8_t* flag_row = p.flags ? p.flags + static_cast<long>(q0 >> 5) * p.flags_ld : nullptr;
+    const float* bias_row = p.bias ? p.bias + static_cast<long>(qrow) * p.bias_ld : nullptr;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 32;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s = Mfma32<T>::run(__builtin_bit_cast(frag, kcur[ks]), qf[ks], s);
+        if (kt + 1 < nkt) load_k(kt + 1, knext);
+
+        // V^T fragments for this key tile (issued early, consumed after the softmax)
+        u16x8 vf[2][DB];
+        const bool tail = k0 + 32 > p.nk;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const unsigned short* vrow = vp + static_cast<long>(d * 32 + ql) * p.vt_ld + k0 + 16 * s2 + 4 * hi;
+                const u16x4 lo = *reinterpret_cast<const u16x4*>(vrow);
+                const u16x4 up = *reinterpret_cast<const u16x4*>(vrow + 8);
+                u16x8 v = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+                if (tail) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = k0 + 16 * s2 + 4 * hi + (j & 3) + 8 * (j >> 2);
+                        if (key >= p.nk) v[j] = 0;
+                    }
+                }
+                vf[s2][d] = v;
+            }
+
+        float sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = s[r] * p.scale_log2e;
+        if (flag_row && flag_row[kt]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int key = k0 + 8 * g + 4 * hi;
+                if (key + 3 < p.nk) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias_row + key);
+                    sv[4 * g + 0] += bv.x * 1.44269504088896340736f;
+                    sv[4 * g + 1] += bv.y * 1.44269504088896340736f;
+                    sv[4 * g + 2] += bv.z * 1.44269504088896340736f;
+                    sv[4 * g + 3] += bv.w * 1.44269504088896340736f;
+                }
+            }
+        }
+        if (tail) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (key >= p.nk) sv[r] = -INFINITY;
+            }
+        }
+        float mt = sv[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sv[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp2f(m_run - m_new);
+        float ls = 0.f;
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pv[r] = exp2f(sv[r] - m_new);
+            ls += pv[r];
+        }
+        ls += __shfl_xor(ls, 32);
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+        u16x8 pb[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[s2][j] = from_f32<T>(pv[8 * s2 + j]);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+                o[d] = Mfma32<T>::run(__builtin_bit_cast(frag, vf[s2][d]), __builtin_bit_cast(frag, pb[s2]), o[d]);
+
+        if (kt + 1 < nkt) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kcur[ks] = knext[ks];
+        }
+    }
+
+    if (q0 + ql < p.nq) {
+        const float inv = 1.0f / l_run;
+        unsigned short* op = p.out + b * p.o_bs + static_cast<long>(q0 + ql) * p.o_ld + h * D;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u16x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(o[d][4 * g + e] * inv);
+                *reinterpret_cast<u16x4*>(op + d * 32 + 8 * g + 4 * hi) = w;
+            }
+    }
+}
+
+}  // namespace pf
+
+using namespace pf;
+
+extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
+    PF_REQUIRE(d, "pf_attention: null descriptor");
+    PF_REQUIRE(d->q && d->k && d->vt && d->out, "pf_attention: null pointer");
+    PF_REQUIRE(d->D == 32 || d->D == 64, "pf_attention: head dim %d unsupported (32 or 64)", d->D);
+    PF_REQUIRE(d->B > 0 && d->H > 0 && d->nq > 0 && d->nk > 0, "pf_attention: bad sizes");
+    PF_REQUIRE(d->q_ld % 8 == 0 && d->k_ld % 8 == 0 && d->o_ld % 4 == 0 && d->vt_ld % 4 == 0,
+               "pf_attention: leading dimensions must be multiples of 8 (q,k) / 4 (out, vt)");
+    PF_REQUIRE(d->vt_ld >= ((d->nk + 31) / 32) * 32, "pf_attention: vt_ld=%d must cover nk=%d rounded up to 32", d->vt_ld, d->nk);
+    PF_REQUIRE(d->q_bs % 8 == 0 && d->k_bs % 8 == 0 && d->vt_bs % 4 == 0 && d->o_bs % 4 == 0, "pf_attention: batch strides misaligned");
+    PF_REQUIRE(aligned16(d->q) && aligned16(d->k) && aligned16(d->vt) && aligned16(d->out), "pf_attention: pointers must be 16-byte aligned");
+    PF_REQUIRE((d->bias == nullptr) == (d->flags == nullptr), "pf_attention: bias and flags come together");
+    if (d->bias) {
+        PF_REQUIRE(d->nk % 4 == 0 && d->bias_ld % 4 == 0 && d->bias_ld >= d->nk && aligned16(d->bias), "pf_attention: bias needs nk %% 4 == 0 and an aligned ld >= nk");
+        PF_REQUIRE(d->flags_ld >= (d->nk + 31) / 32, "pf_attention: flags_ld too small");
+    }
+    AttnParams p;
+    p.q = static_cast<const unsigned short*>(d->q); p.k = static_cast<const unsigned short*>(d->k);
+    p.vt = static_cast<const unsigned short*>(d->vt); p.out = static_cast<unsigned short*>(d->out);
+    p.H = d->H; p.nq = d->nq; p.nk = d->nk;
+    p.q_ld = d->q_ld; p.k_ld = d->k_ld; p.vt_ld = d->vt_ld; p.o_ld = d->o_ld;
+    p.q_bs = d->q_bs; p.k_bs = d->k_bs; p.vt_bs = d->vt_bs; p.o_bs = d->o_bs;
+    p.scale_log2e = d->scale * 1.44269504088896340736f;
+    p.bias = d->bias; p.bias_ld = d->bias_ld; p.flags = d->flags; p.flags_ld = d->flags_ld;
+    dim3 grid(cdiv(d->nq, 128), d->H, d->B), block(256);
+    hipStream_t st = as_stream(stream);
+    PF_DISPATCH_16(d->dtype, "pf_attention",
+        if (d->D == 64) hipLaunchKernelGGL((k_attention<T, 64>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((k_attention<T, 32>), grid, block, 0, st, p));
+    PF_CHECK_LAUNCH("pf_attention");
+    return PF_OK;
+}

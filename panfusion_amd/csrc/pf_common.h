@@ -1,0 +1,89 @@
+// Shared helpers for the gfx950 kernels: status/error plumbing, 16-bit element traits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/panfusion_hip.h"
+
+namespace pf {
+
+void set_error(const char* fmt, ...);
+
+#define PF_REQUIRE(cond, ...)                         \
+    do {                                              \
+        if (!(cond)) {                                \
+            pf::set_error(__VA_ARGS__);               \
+            return PF_ERR_ARG;                        \
+        }                                             \
+    } while (0)
+
+#define PF_CHECK_LAUNCH(name)                                                        \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            pf::set_error("%s: launch failed: %s", name, hipGetErrorString(e__));    \
+            return PF_ERR_LAUNCH;                                                    \
+        }                                                                            \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// ---- 16-bit element types ------------------------------------------------------------------
+// Storage is always a raw 16-bit word; Bf16 / F16 tag types select the conversion and the MFMA.
+struct Bf16 { static constexpr int id = PF_BF16; };
+struct F16  { static constexpr int id = PF_F16; };
+
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <typename T> __device__ __forceinline__ float to_f32(unsigned short v);
+template <> __device__ __forceinline__ float to_f32<Bf16>(unsigned short v) {
+    return __uint_as_float(static_cast<unsigned>(v) << 16);
+}
+template <> __device__ __forceinline__ float to_f32<F16>(unsigned short v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return static_cast<float>(h);
+}
+
+template <typename T> __device__ __forceinline__ unsigned short from_f32(float f);
+template <> __device__ __forceinline__ unsigned short from_f32<Bf16>(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);   // round to nearest even
+    return static_cast<unsigned short>(u >> 16);
+}
+template <> __device__ __forceinline__ unsigned short from_f32<F16>(float f) {
+    _Float16 h = static_cast<_Float16>(f);   // v_cvt_f16_f32, RNE
+    unsigned short v;
+    __builtin_memcpy(&v, &h, 2);
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ void unpack8(const u16x8& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = to_f32<T>(v[i]);
+}
+template <typename T> __device__ __forceinline__ u16x8 pack8(const float (&f)[8]) {
+    u16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = from_f32<T>(f[i]);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// Dispatch a 16-bit dtype id to a tag type.
+#define PF_DISPATCH_16(dtype, name, ...)                                         \
+    do {                                                                         \
+        if ((dtype) == PF_BF16) { using T = pf::Bf16; __VA_ARGS__; }             \
+        else if ((dtype) == PF_F16) { using T = pf::F16; __VA_ARGS__; }          \
+        else { pf::set_error("%s: dtype must be PF_BF16 or PF_F16", name); return PF_ERR_ARG; } \
+    } while (0)
+
+}  // namespace pf

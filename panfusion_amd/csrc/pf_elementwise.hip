@@ -1,0 +1,613 @@
+// HBM-bound kernels of the denoising path for gfx950: GroupNorm statistics / apply(+SiLU),
+// LayerNorm(+positional encoding), GEGLU, timestep features, circular width pad / crop, layout
+// converters, CFG+DDIM update, and the two 4-channel boundary convolutions.
+//
+// All activations are NHWC 16-bit, moved as 16-byte (8-element) vectors; statistics are fp32
+// (fp64 for the final GroupNorm moments); reductions are wavefront (64-lane) shuffles.
+//
+// Reference call sites: diffusers ResnetBlock2D / Transformer2DModel driven from
+// models/pano/MVGenModel.py:98-294; models/modules/transformer.py:8-38,151-162;
+// utils/pano.py:74-105; models/pano/PanoGenerator.py:253-269; DDIMScheduler.step
+// (models/pano/PanFusion.py:159-162).
+#include "pf_common.h"
+#include <math.h>
+
+namespace pf {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- GroupNorm statistics ----------------------------------------------------------------------
+// Stage 1: per (image, pixel chunk) block -> per-group (sum, sumsq) partials, deterministic order.
+template <typename T>
+__global__ void k_gn_partial(const unsigned short* __restrict__ x0, int c0,
+                             const unsigned short* __restrict__ x1, int c1, int hw, int groups,
+                             int pix_per_chunk, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = c0 + c1, OCT = C / 8, cpg = C / groups;
+    const int OCTB = OCT < 256 ? OCT : 256;
+    const int pix_par = 256 / OCTB;
+    float* csum = sm;                    // [pix_par][C]
+    float* csq = sm + pix_par * C;       // [pix_par][C]
+    const int img = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * pix_per_chunk;
+    const int p1 = min(p0 + pix_per_chunk, hw);
+    const int t = threadIdx.x;
+    const int slot = t / OCTB, olane = t % OCTB;
+    for (int ob = 0; ob < OCT; ob += OCTB) {
+        const int oct = ob + olane;
+        float s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+        if (slot < pix_par && oct < OCT) {
+            const int c = oct * 8;
+            const unsigned short* base;
+            int ld, cc;
+            if (c < c0) { base = x0; ld = c0; cc = c; } else { base = x1; ld = c1; cc = c - c0; }
+            for (int p = p0 + slot; p < p1; p += pix_par) {
+                u16x8 v = *reinterpret_cast<const u16x8*>(base + (static_cast<long>(img) * hw + p) * ld + cc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float f = to_f32<T>(v[j]);
+                    s[j] += f;
+                    q[j] += f * f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                csum[slot * C + c + j] = s[j];
+                csq[slot * C + c + j] = q[j];
+            }
+        }
+    }
+    __syncthreads();
+    for (int g = t; g < groups; g += 256) {
+        float s = 0.f, q = 0.f;
+        for (int sl = 0; sl < pix_par; ++sl)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                s += csum[sl * C + c];
+                q += csq[sl * C + c];
+            }
+        long o = ((static_cast<long>(img) * gridDim.x + chunk) * groups + g) * 2;
+        partial[o] = s;
+        partial[o + 1] = q;
+    }
+}
+
+// Stage 2: moments in fp64, folded with gamma/beta into per-(image, channel) scale / shift.
+__global__ void k_gn_finalize(const float* __restrict__ partial, int nchunks, int groups, int C,
+                              int hw, float eps, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float* __restrict__ scale,
+                              float* __restrict__ shift) {
+    const int img = blockIdx.x;
+    const int cpg = C / groups;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nchunks; ++k) {
+            long o = ((static_cast<long>(img) * nchunks + k) * groups + g) * 2;
+            s += partial[o];
+            q += partial[o + 1];
+        }
+        const double cnt = static_cast<double>(hw) * cpg;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+        const float sc = rstd * gamma[c];
+        scale[static_cast<long>(img) * C + c] = sc;
+        shift[static_cast<long>(img) * C + c] = beta[c] - static_cast<float>(mean) * sc;
+    }
+}
+
+template <typename T>
+__global__ void k_scale_shift_act(const unsigned short* __restrict__ x0, int c0,
+                                  const unsigned short* __restrict__ x1, int c1, int hw, long total_oct,
+                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                  int act, unsigned short* __restrict__ y) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= total_oct) return;
+    const int C = c0 + c1, OCT = C / 8;
+    const int oct = i % OCT;
+    const long pix = i / OCT;           // img*hw + p
+    const int img = pix / hw;
+    const int c = oct * 8;
+    const unsigned short* src = (c < c0) ? x0 + pix * c0 + c : x1 + pix * c1 + (c - c0);
+    u16x8 v = *reinterpret_cast<const u16x8*>(src);
+    const float4* sc = reinterpret_cast<const float4*>(scale + static_cast<long>(img) * C + c);
+    const float4* sh = reinterpret_cast<const float4*>(shift + static_cast<long>(img) * C + c);
+    float4 s0 = sc[0], s1 = sc[1], h0 = sh[0], h1 = sh[1];
+    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float r = to_f32<T>(v[j]) * sv[j] + hv[j];
+        f[j] = act ? r / (1.0f + expf(-r)) : r;
+    }
+    *reinterpret_cast<u16x8*>(y + pix * C + c) = pack8<T>(f);
+}
+
+// ---- LayerNorm (+ PE) ------------------------------------------------------------------------
+// One wavefront per row; the row lives in registers (<= 4 octets per lane, C <= 2048).
+template <typename T>
+__global__ void k_layernorm(const unsigned short* __restrict__ x, const float* __restrict__ pe,
+                            long pe_rows, long rows, int C, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, float eps, unsigned short* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * static_cast<long>(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int OCT = C / 8;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int oct = lane + 64 * k;
+        if (oct < OCT) {
+            u16x8 r = *reinterpret_cast<const u16x8*>(x + row * C + oct * 8);
+            unpack8<T>(r, v[k]);
+            if (pe) {
+                const float4* pp = reinterpret_cast<const float4*>(pe + (row % pe_rows) * C + oct * 8);
+                float4 a = pp[0], b = pp[1];
+                v[k][0] += a.x; v[k][1] += a.y; v[k][2] += a.z; v[k][3] += a.w;
+                v[k][4] += b.x; v[k][5] += b.y; v[k][6] += b.z; v[k][7] += b.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[k][j];
+        }
+    }
+    const float mean = wave_sum(s) / static_cast<float>(C);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int oct = lane + 64 * k;
+        if (oct < OCT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float d = v[k][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / static_cast<float>(C) + eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int oct = lane + 64 * k;
+        if (oct < OCT) {
+            const float4* gp = reinterpret_cast<const float4*>(gamma + oct * 8);
+            const float4* bp = reinterpret_cast<const float4*>(beta + oct * 8);
+            float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
+            const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (v[k][j] - mean) * rstd * gv[j] + bv[j];
+            *reinterpret_cast<u16x8*>(y + row * C + oct * 8) = pack8<T>(f);
+        }
+    }
+}
+
+// ---- GEGLU -----------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_geglu(const unsigned short* __restrict__ in, long total_oct, int inner,
+                        unsigned short* __restrict__ out) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= total_oct) return;
+    const int OCT = inner / 8;
+    const long row = i / OCT;
+    const int c = (i % OCT) * 8;
+    u16x8 a = *reinterpret_cast<const u16x8*>(in + row * 2 * inner + c);
+    u16x8 g = *reinterpret_cast<const u16x8*>(in + row * 2 * inner + inner + c);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float gv = to_f32<T>(g[j]);
+        float gelu = 0.5f * gv * (1.0f + erff(gv * 0.70710678118654752440f));
+        f[j] = to_f32<T>(a[j]) * gelu;
+    }
+    *reinterpret_cast<u16x8*>(out + row * inner + c) = pack8<T>(f);
+}
+
+template <typename T>
+__global__ void k_silu(const unsigned short* __restrict__ x, long n, unsigned short* __restrict__ y) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    float v = to_f32<T>(x[i]);
+    y[i] = from_f32<T>(v / (1.0f + expf(-v)));
+}
+
+template <typename T>
+__global__ void k_add(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b, long n,
+                      unsigned short* __restrict__ y) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    y[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[i]));
+}
+
+// diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0): [cos(t f_i) | sin(t f_i)], fp32 math.
+template <typename T>
+__global__ void k_timestep_features(const int64_t* __restrict__ t, int n, int dim,
+                                    unsigned short* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= n * half) return;
+    const int r = i / half, k = i % half;
+    const float e = (-9.210340371976184f * static_cast<float>(k)) / static_cast<float>(half);
+    const float arg = static_cast<float>(t[r]) * expf(e);
+    out[static_cast<long>(r) * dim + k] = from_f32<T>(cosf(arg));
+    out[static_cast<long>(r) * dim + half + k] = from_f32<T>(sinf(arg));
+}
+
+// ---- circular width pad / crop on NHWC ------------------------------------------------------
+__global__ void k_shift_width(const u16x8* __restrict__ x, int h_rows, int w_in, int w_out, int oct,
+                              int offset, u16x8* __restrict__ y) {
+    // y[row][xo][:] = x[row][(xo + offset) mod w_in][:]; row = img*h + yy
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    long total = static_cast<long>(h_rows) * w_out * oct;
+    if (i >= total) return;
+    const int o = i % oct;
+    const long px = i / oct;
+    const int xo = px % w_out;
+    const long row = px / w_out;
+    int xi = (xo + offset) % w_in;
+    if (xi < 0) xi += w_in;
+    y[i] = x[(row * w_in + xi) * oct + o];
+}
+
+// circular pad of the innermost (width) axis of a row-major [rows][w] array (NCHW tensors)
+template <typename E>
+__global__ void k_pad_rows(const E* __restrict__ x, long rows, int w, int wo, int pad, E* __restrict__ y) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= rows * wo) return;
+    const int xo = i % wo;
+    const long r = i / wo;
+    int xi = (xo - pad) % w;
+    if (xi < 0) xi += w;
+    y[i] = x[r * w + xi];
+}
+
+// ---- layout converters ------------------------------------------------------------------------
+template <typename S> __device__ __forceinline__ float ld_any(const void* p, long i);
+struct AnyF32 {}; struct AnyBf16 {}; struct AnyF16 {};
+template <> __device__ __forceinline__ float ld_any<AnyF32>(const void* p, long i) { return static_cast<const float*>(p)[i]; }
+template <> __device__ __forceinline__ float ld_any<AnyBf16>(const void* p, long i) { return to_f32<Bf16>(static_cast<const unsigned short*>(p)[i]); }
+template <> __device__ __forceinline__ float ld_any<AnyF16>(const void* p, long i) { return to_f32<F16>(static_cast<const unsigned short*>(p)[i]); }
+template <typename S> __device__ __forceinline__ void st_any(void* p, long i, float v);
+template <> __device__ __forceinline__ void st_any<AnyF32>(void* p, long i, float v) { static_cast<float*>(p)[i] = v; }
+template <> __device__ __forceinline__ void st_any<AnyBf16>(void* p, long i, float v) { static_cast<unsigned short*>(p)[i] = from_f32<Bf16>(v); }
+template <> __device__ __forceinline__ void st_any<AnyF16>(void* p, long i, float v) { static_cast<unsigned short*>(p)[i] = from_f32<F16>(v); }
+
+// out index enumerates the DESTINATION (coalesced writes).
+template <typename SI, typename SO, bool TO_NHWC>
+__global__ void k_permute(const void* x, int n, int C, long hw, void* y) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    long total = static_cast<long>(n) * C * hw;
+    if (i >= total) return;
+    long src;
+    if (TO_NHWC) {
+        int c = i % C; long p = (i / C) % hw; long b = i / (C * hw);
+        src = (b * C + c) * hw + p;
+    } else {
+        long p = i % hw; int c = (i / hw) % C; long b = i / (hw * C);
+        src = (b * hw + p) * C + c;
+    }
+    st_any<SO>(y, i, ld_any<SI>(x, src));
+}
+
+// ---- CFG + DDIM ------------------------------------------------------------------------------
+__global__ void k_cfg_ddim(const float* __restrict__ x, const float* __restrict__ eu,
+                           const float* __restrict__ ec, float g, float sa, float sb, float sap,
+                           float sbp, long rows, int W, int roll, float* __restrict__ out) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= rows * W) return;
+    const int w = i % W;
+    const long r = i / W;
+    const float u = eu[i];
+    const float eps = u + g * (ec[i] - u);
+    const float x0 = (x[i] - sb * eps) / sa;
+    const float xn = sap * x0 + sbp * eps;
+    int wo = (w + roll) % W;
+    if (wo < 0) wo += W;
+    out[r * W + wo] = xn;
+}
+
+// ---- boundary convolutions ---------------------------------------------------------------------
+// conv_in: x fp32 NCHW [n][cin][h][w] -> y NHWC 16-bit; weights fp32 [3][3][cin][cout].
+template <typename T>
+__global__ void k_conv_in(const float* __restrict__ x, int n, int cin, int h, int w,
+                          const float* __restrict__ wgt, const float* __restrict__ bias, int cout,
+                          int wrap, unsigned short* __restrict__ y) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    const int OCT = cout / 8;
+    long total = static_cast<long>(n) * h * w * OCT;
+    if (i >= total) return;
+    const int oct = i % OCT;
+    const long pix = i / OCT;
+    const int xx = pix % w, yy = (pix / w) % h, b = pix / (static_cast<long>(w) * h);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[oct * 8 + j] : 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yi = yy + ky - 1;
+        if (yi < 0 || yi >= h) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            int xi = xx + kx - 1;
+            if (wrap) xi = (xi + w) % w;
+            else if (xi < 0 || xi >= w) continue;
+            for (int c = 0; c < cin; ++c) {
+                const float v = x[((static_cast<long>(b) * cin + c) * h + yi) * w + xi];
+                const float4* wp = reinterpret_cast<const float4*>(wgt + (static_cast<long>((ky * 3 + kx) * cin + c)) * cout + oct * 8);
+                float4 w0 = wp[0], w1 = wp[1];
+                acc[0] += v * w0.x; acc[1] += v * w0.y; acc[2] += v * w0.z; acc[3] += v * w0.w;
+                acc[4] += v * w1.x; acc[5] += v * w1.y; acc[6] += v * w1.z; acc[7] += v * w1.w;
+            }
+        }
+    }
+    *reinterpret_cast<u16x8*>(y + pix * cout + oct * 8) = pack8<T>(acc);
+}
+
+// conv_out: x NHWC 16-bit [n][h][w][cin] -> y fp32 NCHW [n][cout<=8][h][w]; weights fp32
+// [cout][3][3][cin].  One wavefront per output pixel, lanes over the channel octets of each tap.
+template <typename T>
+__global__ void k_conv_out(const unsigned short* __restrict__ x, int n, int cin, int h, int w,
+                           const float* __restrict__ wgt, const float* __restrict__ bias, int cout,
+                           int wrap, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long pix = blockIdx.x * static_cast<long>(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long npix = static_cast<long>(n) * h * w;
+    if (pix >= npix) return;
+    const int xx = pix % w, yy = (pix / w) % h, b = pix / (static_cast<long>(w) * h);
+    const int OCT = cin / 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yi = yy + tap / 3 - 1;
+        int xi = xx + tap % 3 - 1;
+        if (wrap) xi = (xi + w) % w;
+        if (yi < 0 || yi >= h || xi < 0 || xi >= w) continue;   // wave-uniform
+        const unsigned short* src = x + ((static_cast<long>(b) * h + yi) * w + xi) * cin;
+        for (int oct = lane; oct < OCT; oct += 64) {
+            float f[8];
+            unpack8<T>(*reinterpret_cast<const u16x8*>(src + oct * 8), f);
+#pragma unroll
+            for (int co = 0; co < 8; ++co) {
+                if (co >= cout) break;
+                const float4* wp = reinterpret_cast<const float4*>(wgt + (static_cast<long>(co) * 9 + tap) * cin + oct * 8);
+                float4 w0 = wp[0], w1 = wp[1];
+                acc[co] += f[0] * w0.x + f[1] * w0.y + f[2] * w0.z + f[3] * w0.w +
+                           f[4] * w1.x + f[5] * w1.y + f[6] * w1.z + f[7] * w1.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+        if (co >= cout) break;
+        float s = wave_sum(acc[co]);
+        if (lane == 0) y[((static_cast<long>(b) * cout + co) * h + yy) * w + xx] = s + (bias ? bias[co] : 0.f);
+    }
+}
+
+}  // namespace pf
+
+using namespace pf;
+
+extern "C" size_t pf_groupnorm_workspace_size(int n_img, int hw, int C) {
+    (void)C;
+    const int ppc = hw < 256 ? hw : 256;
+    const long nchunks = cdiv(hw, ppc);
+    return static_cast<size_t>(n_img) * nchunks * 64 * 2 * sizeof(float);   // up to 64 groups
+}
+
+extern "C" pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, int c1, int dtype,
+                                        int n_img, int hw, int groups, float eps, const float* gamma,
+                                        const float* beta, float* scale, float* shift, void* workspace,
+                                        size_t ws_bytes, void* stream) {
+    const int C = c0 + (x1 ? c1 : 0);
+    if (!x1) c1 = 0;
+    PF_REQUIRE(x0 && gamma && beta && scale && shift && workspace, "pf_groupnorm_stats: null pointer");
+    PF_REQUIRE(n_img > 0 && hw > 0 && groups > 0 && groups <= 64, "pf_groupnorm_stats: bad sizes");
+    PF_REQUIRE(C % 8 == 0 && c0 % 8 == 0 && C % groups == 0, "pf_groupnorm_stats: C=%d must be a multiple of 8 and of groups=%d", C, groups);
+    PF_REQUIRE(aligned16(x0) && (!x1 || aligned16(x1)), "pf_groupnorm_stats: inputs must be 16-byte aligned");
+    PF_REQUIRE(ws_bytes >= pf_groupnorm_workspace_size(n_img, hw, C), "pf_groupnorm_stats: workspace too small");
+    const int ppc = hw < 256 ? hw : 256;
+    const int nchunks = static_cast<int>(cdiv(hw, ppc));
+    const int OCT = C / 8, OCTB = OCT < 256 ? OCT : 256, pix_par = 256 / OCTB;
+    const size_t smem = static_cast<size_t>(2) * pix_par * C * sizeof(float);
+    PF_REQUIRE(smem <= 64 * 1024, "pf_groupnorm_stats: C=%d too large", C);
+    hipStream_t st = as_stream(stream);
+    float* partial = static_cast<float*>(workspace);
+    PF_DISPATCH_16(dtype, "pf_groupnorm_stats",
+        hipLaunchKernelGGL(k_gn_partial<T>, dim3(nchunks, n_img), dim3(256), smem, st,
+                           static_cast<const unsigned short*>(x0), c0, static_cast<const unsigned short*>(x1), c1,
+                           hw, groups, ppc, partial));
+    hipLaunchKernelGGL(k_gn_finalize, dim3(n_img), dim3(256), 0, st, partial, nchunks, groups, C, hw, eps,
+                       gamma, beta, scale, shift);
+    PF_CHECK_LAUNCH("pf_groupnorm_stats");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_scale_shift_act(const void* x0, int c0, const void* x1, int c1, int dtype,
+                                        int n_img, int hw, const float* scale, const float* shift,
+                                        int act, void* y, void* stream) {
+    if (!x1) c1 = 0;
+    const int C = c0 + c1;
+    PF_REQUIRE(x0 && scale && shift && y, "pf_scale_shift_act: null pointer");
+    PF_REQUIRE(C % 8 == 0 && c0 % 8 == 0 && n_img > 0 && hw > 0, "pf_scale_shift_act: bad sizes");
+    PF_REQUIRE(aligned16(x0) && aligned16(y) && (!x1 || aligned16(x1)) && aligned16(scale) && aligned16(shift),
+               "pf_scale_shift_act: pointers must be 16-byte aligned");
+    const long total = static_cast<long>(n_img) * hw * (C / 8);
+    PF_DISPATCH_16(dtype, "pf_scale_shift_act",
+        hipLaunchKernelGGL(k_scale_shift_act<T>, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                           static_cast<const unsigned short*>(x0), c0, static_cast<const unsigned short*>(x1), c1,
+                           hw, total, scale, shift, act, static_cast<unsigned short*>(y)));
+    PF_CHECK_LAUNCH("pf_scale_shift_act");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_layernorm(const void* x, const float* pe, long pe_rows, int dtype, long rows,
+                                  int C, const float* gamma, const float* beta, float eps, void* y,
+                                  void* stream) {
+    PF_REQUIRE(x && gamma && beta && y && rows > 0, "pf_layernorm: bad arguments");
+    PF_REQUIRE(C % 8 == 0 && C <= 2048, "pf_layernorm: C=%d must be a multiple of 8 and <= 2048", C);
+    PF_REQUIRE(!pe || pe_rows > 0, "pf_layernorm: pe_rows must be > 0 with pe");
+    PF_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!pe || aligned16(pe)),
+               "pf_layernorm: pointers must be 16-byte aligned");
+    PF_DISPATCH_16(dtype, "pf_layernorm",
+        hipLaunchKernelGGL(k_layernorm<T>, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream),
+                           static_cast<const unsigned short*>(x), pe, pe_rows, rows, C, gamma, beta, eps,
+                           static_cast<unsigned short*>(y)));
+    PF_CHECK_LAUNCH("pf_layernorm");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_geglu(const void* in, int dtype, long rows, int inner, void* out, void* stream) {
+    PF_REQUIRE(in && out && rows > 0 && inner > 0 && inner % 8 == 0, "pf_geglu: bad arguments");
+    PF_REQUIRE(aligned16(in) && aligned16(out), "pf_geglu: pointers must be 16-byte aligned");
+    const long total = rows * (inner / 8);
+    PF_DISPATCH_16(dtype, "pf_geglu",
+        hipLaunchKernelGGL(k_geglu<T>, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                           static_cast<const unsigned short*>(in), total, inner, static_cast<unsigned short*>(out)));
+    PF_CHECK_LAUNCH("pf_geglu");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_timestep_features(const int64_t* t, int n, int dim, int out_dtype, void* out,
+                                          void* stream) {
+    PF_REQUIRE(t && out && n > 0 && dim > 0 && dim % 2 == 0, "pf_timestep_features: bad arguments");
+    PF_DISPATCH_16(out_dtype, "pf_timestep_features",
+        hipLaunchKernelGGL(k_timestep_features<T>, dim3(cdiv(static_cast<long>(n) * (dim / 2), 256)), dim3(256),
+                           0, as_stream(stream), t, n, dim, static_cast<unsigned short*>(out)));
+    PF_CHECK_LAUNCH("pf_timestep_features");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_silu(const void* x, int dtype, long n, void* y, void* stream) {
+    PF_REQUIRE(x && y && n > 0, "pf_silu: bad arguments");
+    PF_DISPATCH_16(dtype, "pf_silu",
+        hipLaunchKernelGGL(k_silu<T>, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream),
+                           static_cast<const unsigned short*>(x), n, static_cast<unsigned short*>(y)));
+    PF_CHECK_LAUNCH("pf_silu");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_add(const void* a, const void* b, int dtype, long n, void* y, void* stream) {
+    PF_REQUIRE(a && b && y && n > 0, "pf_add: bad arguments");
+    PF_DISPATCH_16(dtype, "pf_add",
+        hipLaunchKernelGGL(k_add<T>, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream),
+                           static_cast<const unsigned short*>(a), static_cast<const unsigned short*>(b), n,
+                           static_cast<unsigned short*>(y)));
+    PF_CHECK_LAUNCH("pf_add");
+    return PF_OK;
+}
+
+static pf_status shift_width(const void* x, int dtype, int n, int h, int w_in, int w_out, int C, int offset,
+                             void* y, void* stream, const char* who) {
+    PF_REQUIRE(x && y && n > 0 && h > 0 && w_in > 0 && w_out > 0, "%s: bad sizes", who);
+    PF_REQUIRE(dtype == PF_BF16 || dtype == PF_F16, "%s: dtype must be 16-bit", who);
+    PF_REQUIRE(C % 8 == 0 && aligned16(x) && aligned16(y), "%s: C %% 8 and 16-byte alignment required", who);
+    const long total = static_cast<long>(n) * h * w_out * (C / 8);
+    hipLaunchKernelGGL(k_shift_width, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                       static_cast<const u16x8*>(x), n * h, w_in, w_out, C / 8, offset, static_cast<u16x8*>(y));
+    PF_CHECK_LAUNCH(who);
+    return PF_OK;
+}
+
+extern "C" pf_status pf_pad_width(const void* x, int dtype, int n, int h, int w, int C, int pad, void* y, void* stream) {
+    PF_REQUIRE(pad >= 0 && pad <= w, "pf_pad_width: pad must be in [0, w]");
+    return shift_width(x, dtype, n, h, w, w + 2 * pad, C, -pad, y, stream, "pf_pad_width");
+}
+
+extern "C" pf_status pf_crop_width(const void* x, int dtype, int n, int h, int w, int C, int crop, void* y, void* stream) {
+    PF_REQUIRE(crop >= 0 && 2 * crop < w, "pf_crop_width: crop too large");
+    return shift_width(x, dtype, n, h, w, w - 2 * crop, C, crop, y, stream, "pf_crop_width");
+}
+
+static pf_status pad_rows(const void* x, int elem_bytes, long rows, int w, int wo, int shift, void* y,
+                          void* stream, const char* who) {
+    PF_REQUIRE(x && y && x != y && rows > 0 && w > 0, "%s: bad arguments", who);
+    PF_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "%s: element size must be 2 or 4 bytes", who);
+    const long total = rows * wo;
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(k_pad_rows<unsigned short>, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                           static_cast<const unsigned short*>(x), rows, w, wo, shift, static_cast<unsigned short*>(y));
+    else
+        hipLaunchKernelGGL(k_pad_rows<unsigned>, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                           static_cast<const unsigned*>(x), rows, w, wo, shift, static_cast<unsigned*>(y));
+    PF_CHECK_LAUNCH(who);
+    return PF_OK;
+}
+
+extern "C" pf_status pf_pad_width_rows(const void* x, int elem_bytes, long rows, int w, int pad, void* y, void* stream) {
+    PF_REQUIRE(pad >= 0 && pad <= w, "pf_pad_width_rows: pad must be in [0, w]");
+    return pad_rows(x, elem_bytes, rows, w, w + 2 * pad, pad, y, stream, "pf_pad_width_rows");
+}
+
+extern "C" pf_status pf_roll_width_rows(const void* x, int elem_bytes, long rows, int w, int shift, void* y, void* stream) {
+    // torch.roll(x, shift, -1): y[..., (i + shift) mod w] = x[..., i]
+    return pad_rows(x, elem_bytes, rows, w, w, ((shift % w) + w) % w, y, stream, "pf_roll_width_rows");
+}
+
+template <bool TO_NHWC>
+static pf_status permute(const void* x, int sd, int n, int C, int h, int w, int dd, void* y, void* stream,
+                         const char* who) {
+    PF_REQUIRE(x && y && n > 0 && C > 0 && h > 0 && w > 0, "%s: bad arguments", who);
+    const long hw = static_cast<long>(h) * w, total = hw * n * C;
+    dim3 grid(cdiv(total, 256)), block(256);
+    hipStream_t st = as_stream(stream);
+#define PF_PERM(SI, SO) hipLaunchKernelGGL((k_permute<SI, SO, TO_NHWC>), grid, block, 0, st, x, n, C, hw, y)
+    if (sd == PF_F32 && dd == PF_F32) PF_PERM(AnyF32, AnyF32);
+    else if (sd == PF_F32 && dd == PF_BF16) PF_PERM(AnyF32, AnyBf16);
+    else if (sd == PF_F32 && dd == PF_F16) PF_PERM(AnyF32, AnyF16);
+    else if (sd == PF_BF16 && dd == PF_F32) PF_PERM(AnyBf16, AnyF32);
+    else if (sd == PF_F16 && dd == PF_F32) PF_PERM(AnyF16, AnyF32);
+    else if (sd == PF_BF16 && dd == PF_BF16) PF_PERM(AnyBf16, AnyBf16);
+    else if (sd == PF_F16 && dd == PF_F16) PF_PERM(AnyF16, AnyF16);
+    else PF_REQUIRE(false, "%s: unsupported dtype pair %d -> %d", who, sd, dd);
+#undef PF_PERM
+    PF_CHECK_LAUNCH(who);
+    return PF_OK;
+}
+
+extern "C" pf_status pf_nchw_to_nhwc(const void* x, int sd, int n, int C, int h, int w, int dd, void* y, void* stream) {
+    return permute<true>(x, sd, n, C, h, w, dd, y, stream, "pf_nchw_to_nhwc");
+}
+extern "C" pf_status pf_nhwc_to_nchw(const void* x, int sd, int n, int C, int h, int w, int dd, void* y, void* stream) {
+    return permute<false>(x, sd, n, C, h, w, dd, y, stream, "pf_nhwc_to_nchw");
+}
+
+extern "C" pf_status pf_cfg_ddim_step(const float* x, const float* eu, const float* ec, float g, float sa,
+                                      float sb, float sap, float sbp, long rows, int W, int roll, float* out,
+                                      void* stream) {
+    PF_REQUIRE(x && eu && ec && out && rows > 0 && W > 0, "pf_cfg_ddim_step: bad arguments");
+    PF_REQUIRE(out != x || roll % W == 0, "pf_cfg_ddim_step: in-place update requires roll == 0");
+    hipLaunchKernelGGL(k_cfg_ddim, dim3(cdiv(rows * W, 256)), dim3(256), 0, as_stream(stream), x, eu, ec, g, sa,
+                       sb, sap, sbp, rows, W, roll, out);
+    PF_CHECK_LAUNCH("pf_cfg_ddim_step");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_conv_in(const float* x, int n, int cin, int h, int w, const float* wgt,
+                                const float* bias, int cout, int wrap, int out_dtype, void* y, void* stream) {
+    PF_REQUIRE(x && wgt && y && n > 0 && cin > 0 && h > 0 && w > 0, "pf_conv_in: bad arguments");
+    PF_REQUIRE(cout % 8 == 0 && aligned16(wgt) && aligned16(y), "pf_conv_in: cout %% 8 and 16-byte alignment required");
+    const long total = static_cast<long>(n) * h * w * (cout / 8);
+    PF_DISPATCH_16(out_dtype, "pf_conv_in",
+        hipLaunchKernelGGL(k_conv_in<T>, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), x, n, cin, h, w,
+                           wgt, bias, cout, wrap, static_cast<unsigned short*>(y)));
+    PF_CHECK_LAUNCH("pf_conv_in");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_conv_out(const void* x, int dtype, int n, int cin, int h, int w, const float* wgt,
+                                 const float* bias, int cout, int wrap, float* y, void* stream) {
+    PF_REQUIRE(x && wgt && y && n > 0 && h > 0 && w > 0, "pf_conv_out: bad arguments");
+    PF_REQUIRE(cin % 8 == 0 && cout > 0 && cout <= 8, "pf_conv_out: cin %% 8 == 0 and cout <= 8 required");
+    PF_REQUIRE(aligned16(x) && aligned16(wgt), "pf_conv_out: 16-byte alignment required");
+    const long npix = static_cast<long>(n) * h * w;
+    PF_DISPATCH_16(dtype, "pf_conv_out",
+        hipLaunchKernelGGL(k_conv_out<T>, dim3(cdiv(npix, 4)), dim3(256), 0, as_stream(stream),
+                           static_cast<const unsigned short*>(x), n, cin, h, w, wgt, bias, cout, wrap, y));
+    PF_CHECK_LAUNCH("pf_conv_out");
+    return PF_OK;
+}

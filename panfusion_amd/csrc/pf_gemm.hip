@@ -1,0 +1,300 @@
+// MFMA GEMM / implicit-GEMM convolution for gfx950 (CDNA4).
+//
+//   out[m][n] = sum_k A[m][k] * W[n][k]  (+ bias[n]) (+ rowvec[img(m)][n]) (+ residual[m][n])
+//
+// A is never materialised for convolutions: row m = (image, yo, xo) and K-block kb = (tap, 64
+// channels) address 128 contiguous bytes of the NHWC activation (zero padding, optional nearest
+// x2 upsampling, optional channel concat of two sources are folded into the address).
+//
+// Structure: 256 threads = 4 wavefronts (2 x 2), block tile (32*MREP) x (32*NREP), K-step 64,
+// v_mfma_f32_16x16x32 (bf16 or f16) with fp32 accumulation.  The weight tile is the MFMA "A"
+// operand and the activation tile the "B" operand, so every lane ends up with 4 CONSECUTIVE
+// output channels of one output row (8-byte stores, float4 bias loads).  Global -> registers ->
+// LDS staging, double buffered (one barrier per K-step, next tile's loads in flight during the
+// MFMAs).  LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row>>1)&7 which
+// makes the ds_read_b128 fragment reads and the ds_write_b128 staging writes conflict free.
+// Workgroup ids are remapped so that the tiles sharing an activation row-panel run on one XCD
+// (private L2 per XCD).
+//
+// Replaces cuDNN / cuBLAS behind diffusers Conv2d / Linear (reference call sites
+// models/pano/MVGenModel.py:86-144,174-198,224-294; models/modules/transformer.py:8-74).
+#include "pf_common.h"
+
+namespace pf {
+
+struct GemmParams {
+    const unsigned short* a0; const unsigned short* a1;
+    int c0, c1, a0_ld, a1_ld;
+    int h_in, w_in, h_out, w_out;
+    int ksize, stride, pad, up;
+    const unsigned short* w;
+    int M, N, K;                 // K = ksize*ksize*(c0+c1)
+    int rows_per_img;
+    const float* bias; const float* rowvec; int rowvec_ld;
+    const unsigned short* residual; int res_ld;
+    void* out; int out_ld; int out_f32;
+    long a_bs, w_bs, out_bs, res_bs;
+    int mtiles, ntiles;
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<Bf16> {
+    typedef __attribute__((ext_vector_type(8))) __bf16 frag;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<F16> {
+    typedef __attribute__((ext_vector_type(8))) _Float16 frag;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {   // in 16-bit elements
+    return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+template <typename T, int MREP, int NREP>
+__global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
+    constexpr int BM = 32 * MREP, BN = 32 * NREP;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    unsigned short* As = smem;                       // [2][BM][64]
+    unsigned short* Bs = smem + 2 * BM * 64;         // [2][BN][64]
+
+    // XCD-aware, bijective remap of the 1-D tile id (8 XCDs, block b runs on XCD b % 8).
+    const int ntile_total = p.mtiles * p.ntiles;
+    int tid_lin = blockIdx.x;
+    {
+        const int q = ntile_total / 8, r = ntile_total % 8;
+        const int xcd = tid_lin % 8, idx = tid_lin / 8;
+        tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = tid_lin % p.ntiles, tile_m = tid_lin / p.ntiles;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long bz = blockIdx.z;
+    const unsigned short* a0 = p.a0 + bz * p.a_bs;
+    const unsigned short* a1 = p.a1 ? p.a1 + bz * p.a_bs : nullptr;
+    const unsigned short* wg = p.w + bz * p.w_bs;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int chunk = t & 7, lrow = t >> 3;          // staging: 8 x 16B chunks per 128-B row
+
+    // per-thread staging rows of the activation tile
+    int a_img[MREP], a_y[MREP], a_x[MREP];
+    bool a_ok[MREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + i * 32 + lrow;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int img = mm / p.rows_per_img, rem = mm % p.rows_per_img;
+        a_img[i] = img;
+        a_y[i] = (rem / p.w_out) * p.stride - p.pad;
+        a_x[i] = (rem % p.w_out) * p.stride - p.pad;
+    }
+    const int Ctot = p.c0 + p.c1;
+    const int Hl = p.h_in << p.up, Wl = p.w_in << p.up;
+
+    u16x8 ra[MREP], rb[NREP];
+    auto gload = [&](int kb) {
+        const int kg = kb * 64;
+        const int tap = kg / Ctot, cc = kg % Ctot;
+        const int ky = tap / p.ksize, kx = tap % p.ksize;
+        const unsigned short* src;
+        int ld, coff;
+        if (cc < p.c0) { src = a0; ld = p.a0_ld; coff = cc; } else { src = a1; ld = p.a1_ld; coff = cc - p.c0; }
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            const int yi = a_y[i] + ky, xi = a_x[i] + kx;
+            const bool ok = a_ok[i] && yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
+            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) {
+                const long pix = (static_cast<long>(a_img[i]) * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up);
+                v = *reinterpret_cast<const u16x8*>(src + pix * ld + coff + chunk * 8);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const int n = n0 + j * 32 + lrow;
+            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (n < p.N) v = *reinterpret_cast<const u16x8*>(wg + static_cast<long>(n) * p.K + kg + chunk * 8);
+            rb[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+            *reinterpret_cast<u16x8*>(As + buf * BM * 64 + lds_off(i * 32 + lrow, chunk)) = ra[i];
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+            *reinterpret_cast<u16x8*>(Bs + buf * BN * 64 + lds_off(j * 32 + lrow, chunk)) = rb[j];
+    };
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    typedef typename Mfma<T>::frag frag;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    auto compute = [&](int buf) {
+        const unsigned short* as = As + buf * BM * 64 + (wm * 16 * MREP) * 64;
+        const unsigned short* bs = Bs + buf * BN * 64 + (wn * 16 * NREP) * 64;
+#pragma unroll
+        for (int slab = 0; slab < 2; ++slab) {
+            frag af[MREP], bf[NREP];
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) {
+                const int row = i * 16 + frow;
+                // rows of the wave's sub-tile start at a multiple of 16, so the swizzle term only
+                // depends on the row inside the block tile: add the wave offset back.
+                const int brow = wm * 16 * MREP + row;
+                u16x8 v = *reinterpret_cast<const u16x8*>(As + buf * BM * 64 + lds_off(brow, slab * 4 + fchunk));
+                af[i] = __builtin_bit_cast(frag, v);
+            }
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) {
+                const int brow = wn * 16 * NREP + j * 16 + frow;
+                u16x8 v = *reinterpret_cast<const u16x8*>(Bs + buf * BN * 64 + lds_off(brow, slab * 4 + fchunk));
+                bf[j] = __builtin_bit_cast(frag, v);
+            }
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) acc[i][j] = Mfma<T>::run(bf[j], af[i], acc[i][j]);
+        }
+        (void)as; (void)bs;
+    };
+
+    const int nkb = p.K / 64;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb + 1 < nkb) gload(kb + 1);
+        compute(kb & 1);
+        if (kb + 1 < nkb) lstore((kb + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds out[m][n4 .. n4+3], m = lane&15, n4 = 4*(lane>>4)
+    const unsigned short* res = p.residual ? p.residual + bz * p.res_bs : nullptr;
+    char* outp = static_cast<char*>(p.out) + bz * p.out_bs * (p.out_f32 ? 4 : 2);
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + wm * 16 * MREP + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int img = m / p.rows_per_img;
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const int n4 = n0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
+            if (n4 >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(p.bias + n4);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (p.rowvec) {
+                const float4 b = *reinterpret_cast<const float4*>(p.rowvec + static_cast<long>(img) * p.rowvec_ld + n4);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (res) {
+                const u16x4 r = *reinterpret_cast<const u16x4*>(res + static_cast<long>(m) * p.res_ld + n4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(r[e]);
+            }
+            if (p.out_f32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + static_cast<long>(m) * p.out_ld + n4) =
+                    float4{v[0], v[1], v[2], v[3]};
+            } else {
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+                *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(outp) + static_cast<long>(m) * p.out_ld + n4) = o;
+            }
+        }
+    }
+}
+
+template <typename T, int MREP, int NREP>
+static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
+    constexpr int BM = 32 * MREP, BN = 32 * NREP;
+    GemmParams p = gp;
+    p.mtiles = static_cast<int>(cdiv(p.M, BM));
+    p.ntiles = static_cast<int>(cdiv(p.N, BN));
+    const size_t smem = static_cast<size_t>(2) * (BM + BN) * 64 * sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP>), dim3(p.mtiles * p.ntiles, 1, batch), dim3(256), smem, st, p);
+    PF_CHECK_LAUNCH("pf_conv_gemm");
+    return PF_OK;
+}
+
+}  // namespace pf
+
+using namespace pf;
+
+extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
+    PF_REQUIRE(d, "pf_conv_gemm: null descriptor");
+    PF_REQUIRE(d->a0 && d->w && d->out, "pf_conv_gemm: null pointer");
+    PF_REQUIRE(d->dtype == PF_BF16 || d->dtype == PF_F16, "pf_conv_gemm: dtype must be PF_BF16 or PF_F16");
+    PF_REQUIRE(d->out_dtype == d->dtype || d->out_dtype == PF_F32, "pf_conv_gemm: out_dtype must equal dtype or be PF_F32");
+    const int c1 = d->a1 ? d->c1 : 0;
+    const int Ctot = d->c0 + c1;
+    PF_REQUIRE(d->c0 > 0 && d->c0 % 64 == 0 && c1 % 64 == 0, "pf_conv_gemm: channel counts (%d,%d) must be multiples of 64", d->c0, c1);
+    PF_REQUIRE(d->ksize == 1 || d->ksize == 3, "pf_conv_gemm: ksize must be 1 or 3");
+    PF_REQUIRE(d->stride == 1 || d->stride == 2, "pf_conv_gemm: stride must be 1 or 2");
+    PF_REQUIRE(d->pad == 0 || d->pad == 1, "pf_conv_gemm: pad must be 0 or 1");
+    PF_REQUIRE(d->upsample == 0 || d->upsample == 1, "pf_conv_gemm: upsample must be 0 or 1");
+    PF_REQUIRE(d->n_img > 0 && d->h_in > 0 && d->w_in > 0 && d->h_out > 0 && d->w_out > 0, "pf_conv_gemm: bad spatial sizes");
+    // n_out that is not a multiple of 4 is allowed for a bare product (no epilogue operands) when
+    // out_ld leaves room for the 4-wide store; the extra columns are written as zeros.
+    PF_REQUIRE(d->n_out > 0 && (d->n_out % 4 == 0 || (!d->bias && !d->rowvec && !d->residual && d->out_ld >= (d->n_out + 3) / 4 * 4)),
+               "pf_conv_gemm: n_out=%d must be a multiple of 4 (or no epilogue operands and a padded out_ld)", d->n_out);
+    PF_REQUIRE(d->a0_ld >= d->c0 && d->a0_ld % 8 == 0, "pf_conv_gemm: a0_ld must be >= c0 and a multiple of 8");
+    PF_REQUIRE(!d->a1 || (d->a1_ld >= c1 && d->a1_ld % 8 == 0), "pf_conv_gemm: a1_ld must be >= c1 and a multiple of 8");
+    PF_REQUIRE(d->out_ld >= d->n_out && d->out_ld % 4 == 0, "pf_conv_gemm: out_ld must be >= n_out and a multiple of 4");
+    PF_REQUIRE(!d->residual || (d->res_ld >= d->n_out && d->res_ld % 4 == 0), "pf_conv_gemm: res_ld must be >= n_out and a multiple of 4");
+    PF_REQUIRE(!d->rowvec || (d->rowvec_ld >= d->n_out && d->rowvec_ld % 4 == 0), "pf_conv_gemm: rowvec_ld must be >= n_out and a multiple of 4");
+    PF_REQUIRE(aligned16(d->a0) && aligned16(d->w) && aligned16(d->out) && (!d->a1 || aligned16(d->a1)) &&
+               (!d->bias || aligned16(d->bias)) && (!d->rowvec || aligned16(d->rowvec)) &&
+               (!d->residual || aligned16(d->residual)), "pf_conv_gemm: pointers must be 16-byte aligned");
+    PF_REQUIRE(d->batch >= 1, "pf_conv_gemm: batch must be >= 1");
+    {   // the output size must be what the conv arithmetic produces
+        const int hl = d->h_in << d->upsample, wl = d->w_in << d->upsample;
+        const int ho = (hl + 2 * d->pad - d->ksize) / d->stride + 1, wo = (wl + 2 * d->pad - d->ksize) / d->stride + 1;
+        PF_REQUIRE(ho == d->h_out && wo == d->w_out, "pf_conv_gemm: output size (%d,%d) does not match (%d,%d)", d->h_out, d->w_out, ho, wo);
+    }
+    GemmParams p;
+    p.a0 = static_cast<const unsigned short*>(d->a0);
+    p.a1 = static_cast<const unsigned short*>(d->a1);
+    p.c0 = d->c0; p.c1 = c1; p.a0_ld = d->a0_ld; p.a1_ld = d->a1 ? d->a1_ld : 0;
+    p.h_in = d->h_in; p.w_in = d->w_in; p.h_out = d->h_out; p.w_out = d->w_out;
+    p.ksize = d->ksize; p.stride = d->stride; p.pad = d->pad; p.up = d->upsample;
+    p.w = static_cast<const unsigned short*>(d->w);
+    p.rows_per_img = d->h_out * d->w_out;
+    p.M = d->n_img * p.rows_per_img; p.N = d->n_out; p.K = d->ksize * d->ksize * Ctot;
+    p.bias = d->bias; p.rowvec = d->rowvec; p.rowvec_ld = d->rowvec_ld;
+    p.residual = static_cast<const unsigned short*>(d->residual); p.res_ld = d->res_ld;
+    p.out = d->out; p.out_ld = d->out_ld; p.out_f32 = d->out_dtype == PF_F32;
+    p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;
+    p.mtiles = p.ntiles = 0;
+    hipStream_t st = as_stream(stream);
+    // Tile choice: 160-wide N tiles when they divide N exactly (all UNet widths are multiples of
+    // 160), 128-wide otherwise; 64-row M tiles when 128-row tiles would not fill the 256 CUs.
+    const bool n160 = (p.N % 160 == 0);
+    const long tiles128 = cdiv(p.M, 128) * cdiv(p.N, n160 ? 160 : 128) * d->batch;
+    const bool small_m = tiles128 < 512;
+    PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
+        if (n160) return small_m ? launch<T, 2, 5>(p, d->batch, st) : launch<T, 4, 5>(p, d->batch, st);
+        else return small_m ? launch<T, 2, 4>(p, d->batch, st) : launch<T, 4, 4>(p, d->batch, st));
+    return PF_OK;
+}

@@ -1,0 +1,359 @@
+"""Host-side driver of the HIP denoiser: weight packing and layer sequencing.
+
+Takes module trees with the diffusers SD-2 UNet attribute layout (what
+``MultiViewBaseModel`` receives in the reference, models/pano/MVGenModel.py:9-36)
+and the EPA blocks, repacks their weights ONCE into the kernel layouts
+(16-bit, K-contiguous, LoRA folded, q|k projections fused, all time-embedding
+projections of a UNet concatenated), and runs the forward as a sequence of
+C-ABI calls on the current stream.  Activations stay NHWC / token-major 16-bit
+between kernels; nothing here computes on the host.
+"""
+from types import SimpleNamespace as NS
+
+import torch
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------- packing helpers
+def _f32(t, dev):
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+def _w16(t, dev, dtype):
+    return t.detach().to(device=dev, dtype=torch.float32).to(dtype).contiguous()
+
+
+def _lin_weight(lin):
+    """Effective weight of a (LoRA-compatible) linear: W + up @ down
+    (PanoGenerator.py:132-151, rank-4 LoRA with scale 1 folded for inference)."""
+    w = lin.weight.detach().float()
+    lora = getattr(lin, "lora_layer", None)
+    if lora is not None:
+        delta = lora.up.weight.detach().float() @ lora.down.weight.detach().float()
+        alpha = getattr(lora, "network_alpha", None)
+        if alpha is not None:
+            delta = delta * (alpha / lora.down.weight.shape[0])
+        w = w + delta
+    return w
+
+
+def _conv3_weight(conv, dev, dtype):
+    # torch [Cout, Cin, ky, kx] -> [Cout, ky, kx, Cin] (K ordered tap-major, channel-minor)
+    return _w16(conv.weight.detach().float().permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1), dev, dtype)
+
+
+def _norm(n, dev):
+    return NS(g=_f32(n.weight, dev), b=_f32(n.bias, dev), eps=float(n.eps),
+              groups=getattr(n, "num_groups", None))
+
+
+def _bias(m, dev):
+    return None if m.bias is None else _f32(m.bias, dev)
+
+
+def pack_resnet(res, dev, dtype):
+    r = NS()
+    r.cin, r.cout = res.conv1.weight.shape[1], res.conv1.weight.shape[0]
+    r.norm1, r.norm2 = _norm(res.norm1, dev), _norm(res.norm2, dev)
+    r.w1, r.b1 = _conv3_weight(res.conv1, dev, dtype), _bias(res.conv1, dev)
+    r.w2, r.b2 = _conv3_weight(res.conv2, dev, dtype), _bias(res.conv2, dev)
+    sc = getattr(res, "conv_shortcut", None)
+    if sc is not None:
+        r.ws = _w16(sc.weight.detach().float().reshape(r.cout, r.cin), dev, dtype)
+        r.bs = _bias(sc, dev)
+    else:
+        r.ws = r.bs = None
+    r.temb = res.time_emb_proj      # consumed by pack_unet (concatenated projection)
+    return r
+
+
+def pack_attention(attn, dev, dtype, self_attn):
+    a = NS()
+    a.heads = attn.heads
+    wq, wk, wv = _lin_weight(attn.to_q), _lin_weight(attn.to_k), _lin_weight(attn.to_v)
+    a.dim = wq.shape[0]
+    if self_attn:
+        a.wqk = _w16(torch.cat([wq, wk], 0), dev, dtype)
+    else:
+        a.wq, a.wk = _w16(wq, dev, dtype), _w16(wk, dev, dtype)
+    a.wv = _w16(wv, dev, dtype)
+    a.wo, a.bo = _w16(_lin_weight(attn.to_out[0]), dev, dtype), _bias(attn.to_out[0], dev)
+    return a
+
+
+def pack_transformer(tf, dev, dtype):
+    t = NS()
+    blk = tf.transformer_blocks[0]
+    t.norm = _norm(tf.norm, dev)
+    t.w_in, t.b_in = _w16(tf.proj_in.weight, dev, dtype), _bias(tf.proj_in, dev)
+    t.w_out, t.b_out = _w16(tf.proj_out.weight, dev, dtype), _bias(tf.proj_out, dev)
+    t.ln1, t.ln2, t.ln3 = _norm(blk.norm1, dev), _norm(blk.norm2, dev), _norm(blk.norm3, dev)
+    t.attn1 = pack_attention(blk.attn1, dev, dtype, True)
+    t.attn2 = pack_attention(blk.attn2, dev, dtype, False)
+    t.w_ff1, t.b_ff1 = _w16(blk.ff.net[0].proj.weight, dev, dtype), _bias(blk.ff.net[0].proj, dev)
+    t.w_ff2, t.b_ff2 = _w16(blk.ff.net[2].weight, dev, dtype), _bias(blk.ff.net[2], dev)
+    return t
+
+
+def pack_unet(unet, dev, dtype):
+    """Walks the diffusers attribute tree exactly as MVGenModel.py does."""
+    u = NS()
+    u.dtype = dtype
+    ci = unet.conv_in
+    u.cin, u.c0 = ci.weight.shape[1], ci.weight.shape[0]
+    u.w_conv_in = _f32(ci.weight.detach().permute(2, 3, 1, 0), dev)           # [3,3,cin,cout]
+    u.b_conv_in = _bias(ci, dev)
+    co = unet.conv_out
+    u.cout = co.weight.shape[0]
+    u.w_conv_out = _f32(co.weight.detach().permute(0, 2, 3, 1), dev)          # [cout,3,3,cin]
+    u.b_conv_out = _bias(co, dev)
+    u.norm_out = _norm(unet.conv_norm_out, dev)
+    te = unet.time_embedding
+    u.t_dim = te.linear_1.weight.shape[1]
+    u.w_t1, u.b_t1 = _w16(te.linear_1.weight, dev, dtype), _bias(te.linear_1, dev)
+    u.w_t2, u.b_t2 = _w16(te.linear_2.weight, dev, dtype), _bias(te.linear_2, dev)
+
+    resnets = []
+
+    def res(r):
+        p = pack_resnet(r, dev, dtype)
+        resnets.append(p)
+        return p
+
+    u.down = []
+    for blk in unet.down_blocks:
+        b = NS(resnets=[res(r) for r in blk.resnets], attns=None, down=None)
+        if getattr(blk, "has_cross_attention", False):
+            b.attns = [pack_transformer(a, dev, dtype) for a in blk.attentions]
+        if blk.downsamplers is not None:
+            c = blk.downsamplers[0].conv
+            b.down = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0])
+        u.down.append(b)
+    mid = unet.mid_block
+    u.mid = NS(resnets=[res(r) for r in mid.resnets],
+               attns=[pack_transformer(a, dev, dtype) for a in mid.attentions])
+    u.up = []
+    for blk in unet.up_blocks:
+        b = NS(resnets=[res(r) for r in blk.resnets], attns=None, up=None)
+        if getattr(blk, "has_cross_attention", False):
+            b.attns = [pack_transformer(a, dev, dtype) for a in blk.attentions]
+        if blk.upsamplers is not None:
+            c = blk.upsamplers[0].conv
+            b.up = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0])
+        u.up.append(b)
+
+    # one GEMM for every resnet's Linear(silu(temb)) (diffusers ResnetBlock2D.time_emb_proj)
+    off = 0
+    ws, bs = [], []
+    for p in resnets:
+        p.temb_off = off
+        ws.append(p.temb.weight.detach().float())
+        bs.append(p.temb.bias.detach().float())
+        off += p.cout
+        del p.temb
+    u.w_temb = _w16(torch.cat(ws, 0), dev, dtype)
+    u.b_temb = _f32(torch.cat(bs, 0), dev)
+    u.temb_total = off
+    return u
+
+
+def pack_epa(block, dev, dtype):
+    """block: module with the reference WarpAttn parameter names (modules.py:8-13)."""
+    tr = block.transformer
+    e = NS()
+    e.dim = tr.norm1.weight.shape[0]
+    e.heads = e.dim // 32
+    e.ln1, e.ln2 = _norm(tr.norm1, dev), _norm(tr.norm2, dev)
+    a = tr.attn1
+    e.wqk = _w16(torch.cat([a.to_q.weight.detach().float(), a.to_k.weight.detach().float()], 0), dev, dtype)
+    e.wv = _w16(a.to_v.weight, dev, dtype)
+    e.wo, e.bo = _w16(a.to_out.weight, dev, dtype), _bias(a.to_out, dev)
+    e.w_ff1, e.b_ff1 = _w16(tr.ff.net[0].proj.weight, dev, dtype), _bias(tr.ff.net[0].proj, dev)
+    e.w_ff2, e.b_ff2 = _w16(tr.ff.net[2].weight, dev, dtype), _bias(tr.ff.net[2], dev)
+    e.freq = _f32(block.pe.freq_bands, dev)
+    return e
+
+
+# ---------------------------------------------------------------------------- layer runners
+def run_resnet(r, x, skip, temb_all, groups_eps=None):
+    """x [n, h, w, C] (+ skip concatenated along channels) -> [n, h, w, cout].
+    GN -> SiLU -> conv3x3 (+bias +temb) -> GN -> SiLU -> conv3x3 (+bias) + shortcut(x)."""
+    n, h, w, _ = x.shape
+    hw = h * w
+    sc, sh = ops.groupnorm_scale_shift(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, r.norm1.b)
+    y = ops.scale_shift_act(x, skip, n, hw, sc, sh, 1)
+    rowvec = temb_all[:, r.temb_off:]
+    h1 = ops.conv_gemm(y, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec)
+    h1 = h1.view(n, hw, r.cout)
+    sc, sh = ops.groupnorm_scale_shift(h1, None, n, hw, r.norm2.groups, r.norm2.eps, r.norm2.g, r.norm2.b)
+    y2 = ops.scale_shift_act(h1, None, n, hw, sc, sh, 1)
+    if r.ws is not None:
+        short = ops.conv_gemm(x, r.ws, r.cout, a1=skip, n_img=n, h_in=h, w_in=w, ksize=1, bias=r.bs)
+    else:
+        short = x.view(n * hw, r.cout)
+    out = ops.conv_gemm(y2, r.w2, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b2, residual=short)
+    return out.view(n, h, w, r.cout)
+
+
+def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual):
+    """q_src [n*nq, C] already layer-normed; kv_tokens [n*nk, Ckv]."""
+    Cq = a.dim
+    if self_attn:
+        qk = ops.linear(q_src, a.wqk)                         # [rows, 2C]  (q | k)
+        q, k, ld = qk, qk[:, Cq:], 2 * Cq
+    else:
+        q, ld = ops.linear(q_src, a.wq), Cq
+        k = ops.linear(kv_tokens, a.wk)
+    vt = ops.linear_t(kv_tokens.view(n, nk, -1), a.wv)        # [n, C, ld_v] keys contiguous
+    o = ops.attention(q, k, vt, n, a.heads, head_dim, nq, nk,
+                      q_ld=ld, k_ld=(ld if self_attn else Cq), vt_ld=vt.shape[-1],
+                      q_bs=nq * ld, k_bs=nk * (ld if self_attn else Cq), vt_bs=vt.shape[1] * vt.shape[2])
+    return ops.linear(o.view(n * nq, Cq), a.wo, bias=a.bo, residual=residual)
+
+
+def run_transformer(t, x, text):
+    """diffusers Transformer2DModel (linear projections) on x [n, h, w, C]; text [n, L, Dt]."""
+    n, h, w, Cc = x.shape
+    hw = h * w
+    sc, sh = ops.groupnorm_scale_shift(x, None, n, hw, t.norm.groups, t.norm.eps, t.norm.g, t.norm.b)
+    y = ops.scale_shift_act(x, None, n, hw, sc, sh, 0)
+    tok = ops.linear(y.view(n * hw, Cc), t.w_in, bias=t.b_in)
+    dh = t.attn1.dim // t.attn1.heads
+    ln = ops.layernorm(tok, t.ln1.g, t.ln1.b, t.ln1.eps)
+    tok = _attend(t.attn1, ln, ln, n, hw, hw, dh, self_attn=True, residual=tok)
+    ln = ops.layernorm(tok, t.ln2.g, t.ln2.b, t.ln2.eps)
+    L = text.shape[1]
+    tok = _attend(t.attn2, ln, text.reshape(n * L, -1), n, hw, L, dh, self_attn=False, residual=tok)
+    ln = ops.layernorm(tok, t.ln3.g, t.ln3.b, t.ln3.eps)
+    g = ops.geglu(ops.linear(ln, t.w_ff1, bias=t.b_ff1))
+    tok = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok)
+    out = ops.linear(tok, t.w_out, bias=t.b_out, residual=x.view(n * hw, Cc))
+    return out.view(n, h, w, Cc)
+
+
+class Branch:
+    """One UNet driven layer by layer (cf. the per-branch statements of MVGenModel.py:85-297).
+    ``pano=True`` wraps every conv-bearing module in circular width padding / cropping with
+    the reference's pad and crop widths."""
+
+    def __init__(self, u, latent, timestep, text, pano, pad):
+        self.u, self.text, self.pad = u, text, (pano and pad)
+        n = latent.shape[0]
+        feats = ops.timestep_features(timestep, u.t_dim, u.dtype)              # [n, 320]
+        e = ops.linear(feats, u.w_t1, bias=u.b_t1)
+        e = ops.linear(ops.silu(e), u.w_t2, bias=u.b_t2)                       # emb [n, 1280]
+        self.temb = ops.linear(ops.silu(e), u.w_temb, bias=u.b_temb, out_dtype=torch.float32)
+        # pano: pad 1 / conv / crop 1 (MVGenModel.py:87-91) == circular-width convolution
+        self.h = ops.conv_in(latent.float(), u.w_conv_in, u.b_conv_in, u.c0, u.dtype, wrap=self.pad)
+        self.skips = [self.h]
+
+    def _padded(self, t, p):
+        return ops.pad_width(t, p) if (self.pad and t is not None) else t
+
+    def resnet(self, r, skip=False):
+        s = self.skips.pop() if skip else None
+        if self.pad:
+            out = run_resnet(r, self._padded(self.h, 2), self._padded(s, 2), self.temb)
+            self.h = ops.crop_width(out, 2)
+        else:
+            self.h = run_resnet(r, self.h, s, self.temb)
+
+    def attention(self, t):
+        self.h = run_transformer(t, self.h, self.text)
+
+    def push(self):
+        self.skips.append(self.h)
+
+    def downsample(self, d):            # pano: pad 2, conv s2, crop 1   (MVGenModel.py:138-144)
+        x = self._padded(self.h, 2)
+        n, h, w, Cc = x.shape
+        y = ops.conv_gemm(x, d.w, d.c, n_img=n, h_in=h, w_in=w, ksize=3, stride=2, pad=1, bias=d.b)
+        y = y.view(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, d.c)
+        self.h = ops.crop_width(y, 1) if self.pad else y
+
+    def upsample(self, up):             # pano: pad 1, nearest x2 + conv, crop 2   (:272-277)
+        x = self._padded(self.h, 1)
+        n, h, w, Cc = x.shape
+        y = ops.conv_gemm(x, up.w, up.c, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1, bias=up.b)
+        y = y.view(n, 2 * h, 2 * w, up.c)
+        self.h = ops.crop_width(y, 2) if self.pad else y
+
+    def head(self):                     # GN + SiLU un-padded; conv_out padded by 1   (:279-294)
+        u = self.u
+        n, h, w, Cc = self.h.shape
+        sc, sh = ops.groupnorm_scale_shift(self.h, None, n, h * w, u.norm_out.groups, u.norm_out.eps,
+                                           u.norm_out.g, u.norm_out.b)
+        y = ops.scale_shift_act(self.h, None, n, h * w, sc, sh, 1).view(n, h, w, Cc)
+        return ops.conv_out(y, u.w_conv_out, u.b_conv_out, u.cout, wrap=self.pad)      # fp32 NCHW
+
+
+class EPATables:
+    """Geometry that depends only on (cameras, sizes): bias tables, tile flags, PE tables.
+    Built once per key on the device and kept (immutable keyed caches)."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, fov, theta, phi, ph, pw, eh, ew, freq, device):
+        key = (tuple(float(v) for v in fov), tuple(float(v) for v in theta),
+               tuple(float(v) for v in phi), ph, pw, eh, ew, freq.numel(), freq.data_ptr())
+        hit = self.cache.get(key)
+        if hit is None:
+            bias_e, bias_p, flags_e, flags_p = ops.epa_tables(fov, theta, phi, ph, pw, eh, ew, device)
+            _, _, lonlat = ops.e2p_grid(fov, theta, phi, eh, ew, ph, pw, device, want_lonlat=True)
+            pe_p = ops.spherical_pe(lonlat.view(-1, 2), freq)              # [m*P, C]
+            pe_e = ops.spherical_pe(ops.equi_coords(eh, ew, device).view(-1, 2), freq)   # [E, C]
+            hit = NS(bias_e=bias_e, bias_p=bias_p, flags_e=flags_e, flags_p=flags_p, pe_p=pe_p, pe_e=pe_e)
+            self.cache[key] = hit
+        return hit
+
+
+def run_epa(e, tables, xp, xe, m):
+    """EPA fusion (modules.py:15-59) on NHWC activations.
+    xp [b*m, ph, pw, C], xe [b, eh, ew, C]; tables: list with one EPATables entry per batch
+    element (or a single shared entry)."""
+    bm, ph, pw, Cc = xp.shape
+    b, eh, ew, _ = xe.shape
+    P, E = ph * pw, eh * ew
+    mP = m * P
+    tp, te = xp.view(b * mP, Cc), xe.view(b * E, Cc)
+    shared = len(tables) == 1
+    if shared:
+        lnp = ops.layernorm(tp, e.ln1.g, e.ln1.b, e.ln1.eps, pe=tables[0].pe_p)
+        lne = ops.layernorm(te, e.ln1.g, e.ln1.b, e.ln1.eps, pe=tables[0].pe_e)
+    else:
+        lnp, lne = torch.empty_like(tp), torch.empty_like(te)
+        for i, t in enumerate(tables):
+            ops.layernorm(tp[i * mP:(i + 1) * mP], e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_p, out=lnp[i * mP:(i + 1) * mP])
+            ops.layernorm(te[i * E:(i + 1) * E], e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_e, out=lne[i * E:(i + 1) * E])
+    qk_p, qk_e = ops.linear(lnp, e.wqk), ops.linear(lne, e.wqk)           # [., 2C] = (q | k)
+    vt_p = ops.linear_t(lnp.view(b, mP, Cc), e.wv)                         # [b, C, mP]
+    vt_e = ops.linear_t(lne.view(b, E, Cc), e.wv)                          # [b, C, E]
+    ld = 2 * Cc
+
+    def attend(q, k, vt, nq, nk, which):
+        kw = dict(q_ld=ld, k_ld=ld, vt_ld=vt.shape[-1], q_bs=nq * ld, k_bs=nk * ld,
+                  vt_bs=vt.shape[1] * vt.shape[2])
+        if shared:
+            t = tables[0]
+            bias, flags = (t.bias_e, t.flags_e) if which == "e" else (t.bias_p, t.flags_p)
+            return ops.attention(q, k, vt, b, e.heads, 32, nq, nk, bias=bias, flags=flags, **kw)
+        out = torch.empty(b, nq, Cc, device=q.device, dtype=q.dtype)
+        for i, t in enumerate(tables):
+            bias, flags = (t.bias_e, t.flags_e) if which == "e" else (t.bias_p, t.flags_p)
+            ops.attention(q[i * nq:], k[i * nk:], vt[i], 1, e.heads, 32, nq, nk, bias=bias, flags=flags,
+                          out=out[i], **kw)
+        return out
+
+    def tail(attn_out, x):
+        y = ops.linear(attn_out.view(-1, Cc), e.wo, bias=e.bo, residual=x)
+        ln2 = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps)
+        g = ops.geglu(ops.linear(ln2, e.w_ff1, bias=e.b_ff1))
+        return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y)
+
+    # panorama pixels query the views (modules.py:43-48), then views query the panorama with the
+    # ORIGINAL view activations (modules.py:50-55)
+    out_e = tail(attend(qk_e, qk_p[:, Cc:], vt_p, E, mP, "e"), te)
+    out_p = tail(attend(qk_p, qk_e[:, Cc:], vt_e, mP, E, "p"), tp)
+    return out_p.view(bm, ph, pw, Cc), out_e.view(b, eh, ew, Cc)

@@ -1,0 +1,133 @@
+"""Dual-branch denoiser with the reference's constructor, attributes and
+forward signature (reference ``models/pano/MVGenModel.py:9-297``), executed on
+the HIP kernels.
+
+``MultiViewBaseModel(unet, pano_unet, pers_cn=None, pano_cn=None, pano_pad=True)``
+accepts the same diffusers ``UNet2DConditionModel`` objects the reference
+passes (``PanFusion.instantiate_model``, PanFusion.py:23-28; ``unet=None`` is the
+PanoOnly shape, PanoOnly.py:13).  Their weights are repacked once per device
+into kernel layouts; ``forward`` then sequences C-ABI kernel calls and never
+touches the modules' own ``forward``.
+"""
+import torch
+import torch.nn as nn
+
+from ... import engine
+from .modules import WarpAttn, camera_groups
+
+
+class MultiViewBaseModel(nn.Module):
+    def __init__(self, unet, pano_unet, pers_cn=None, pano_cn=None, pano_pad=True,
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.unet = unet
+        self.pano_unet = pano_unet
+        self.pers_cn = pers_cn
+        self.pano_cn = pano_cn
+        self.pano_pad = pano_pad
+        self.compute_dtype = compute_dtype
+        self._packed = {}
+
+        if self.unet is not None:      # EPA block widths, reference MVGenModel.py:19-32
+            self.cp_blocks_encoder = nn.ModuleList(
+                [WarpAttn(blk.downsamplers[-1].out_channels, compute_dtype)
+                 for blk in self.unet.down_blocks if blk.downsamplers is not None])
+            self.cp_blocks_mid = WarpAttn(self.unet.mid_block.resnets[-1].out_channels, compute_dtype)
+            self.cp_blocks_decoder = nn.ModuleList(
+                [WarpAttn(blk.upsamplers[0].channels, compute_dtype)
+                 for blk in self.unet.up_blocks if blk.upsamplers is not None])
+            self.trainable_parameters = [(list(self.cp_blocks_mid.parameters())
+                                          + list(self.cp_blocks_decoder.parameters())
+                                          + list(self.cp_blocks_encoder.parameters()), 1.0)]
+
+    # ------------------------------------------------------------------ weights
+    def packed(self, which, device):
+        key = (which, str(device), self.compute_dtype)
+        if key not in self._packed:
+            self._packed[key] = engine.pack_unet(getattr(self, which), device, self.compute_dtype)
+        return self._packed[key]
+
+    def repack(self):
+        """Drop the packed 16-bit weights (call after changing parameters / loading a checkpoint)."""
+        self._packed.clear()
+        if self.unet is not None:
+            for blk in [*self.cp_blocks_encoder, self.cp_blocks_mid, *self.cp_blocks_decoder]:
+                blk.compute_dtype = self.compute_dtype
+                blk.repack()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.repack()
+        return out
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras,
+                pers_layout_cond=None, pano_layout_cond=None):
+        if (self.pers_cn is not None and pers_layout_cond is not None) or \
+                (self.pano_cn is not None and pano_layout_cond is not None):
+            raise NotImplementedError(
+                "ControlNet (layout-conditioned) residuals are not on the HIP path yet (SURVEY.md §8 row a21)")
+        dev = pano_latent.device
+        dt = self.compute_dtype
+        two = self.unet is not None
+        branches = []
+        if two:
+            b, m = latents.shape[:2]
+            flat_cams = {k: v.reshape(-1) for k, v in cameras.items()}
+            _, groups = camera_groups(flat_cams, b)
+            pers = engine.Branch(self.packed("unet", dev), latents.flatten(0, 1), timestep.reshape(-1),
+                                 prompt_embd.flatten(0, 1).to(dt).contiguous(), pano=False, pad=False)
+            pano_t = timestep[:, 0]
+            branches.append(pers)
+        else:
+            pano_t = timestep
+        pano = engine.Branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
+                             pano_prompt_embd.flatten(0, 1).to(dt).contiguous(), pano=True, pad=self.pano_pad)
+        branches.append(pano)
+
+        def fuse(block):
+            pers.h, pano.h = block.forward_nhwc(pers.h, pano.h, groups, m)
+
+        pu = pano.u
+        # encoder (reference :98-152): EPA after each downsample
+        for i in range(len(pu.down)):
+            for br in branches:
+                blk = br.u.down[i]
+                for j, r in enumerate(blk.resnets):
+                    br.resnet(r)
+                    if blk.attns is not None:
+                        br.attention(blk.attns[j])
+                    br.push()
+                if blk.down is not None:
+                    br.downsample(blk.down)
+                    br.push()
+            if pu.down[i].down is not None and two:
+                fuse(self.cp_blocks_encoder[i])
+        # mid (reference :172-207)
+        for br in branches:
+            mid = br.u.mid
+            br.resnet(mid.resnets[0])
+            for a, r in zip(mid.attns, mid.resnets[1:]):
+                br.attention(a)
+                br.resnet(r)
+        if two:
+            fuse(self.cp_blocks_mid)
+        # decoder (reference :210-277): EPA before each upsample
+        for i in range(len(pu.up)):
+            for br in branches:
+                blk = br.u.up[i]
+                for j, r in enumerate(blk.resnets):
+                    br.resnet(r, skip=True)
+                    if blk.attns is not None:
+                        br.attention(blk.attns[j])
+            if pu.up[i].up is not None:
+                if two:
+                    fuse(self.cp_blocks_decoder[i])
+                for br in branches:
+                    br.upsample(br.u.up[i].up)
+
+        out_dtype = pano_latent.dtype
+        pano_sample = pano.head().to(out_dtype).unflatten(0, (-1, 1))
+        sample = pers.head().to(out_dtype).unflatten(0, (b, m)) if two else None
+        return sample, pano_sample

@@ -1,0 +1,60 @@
+"""EPA fusion block with the reference's name and call signature
+(reference ``models/pano/modules.py:8-59``): ``WarpAttn(dim).forward(pers_x,
+equi_x, cameras) -> (pers_x_out, equi_x_out)`` on NCHW tensors.
+"""
+import torch
+import torch.nn as nn
+
+from ... import engine, ops
+from ..modules.transformer import BasicTransformerBlock, SphericalPE
+
+
+def camera_groups(cameras, b):
+    """cameras: dict of flattened (b*m,) values -> per-batch-element host tuples."""
+    host = lambda v: v.detach().cpu().tolist() if isinstance(v, torch.Tensor) else list(v)
+    fov, theta, phi = host(cameras["FoV"]), host(cameras["theta"]), host(cameras["phi"])
+    m = len(fov) // b
+    return m, [(tuple(fov[i * m:(i + 1) * m]), tuple(theta[i * m:(i + 1) * m]), tuple(phi[i * m:(i + 1) * m]))
+               for i in range(b)]
+
+
+class WarpAttn(nn.Module):
+    def __init__(self, dim, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.transformer = BasicTransformerBlock(dim, dim // 32, 32, context_dim=dim)
+        self.pe = SphericalPE(dim // 4)
+        self.compute_dtype = compute_dtype
+        self._packed = None
+        self._tables = engine.EPATables()
+
+    def packed(self, device):
+        if self._packed is None or self._packed.device != device or self._packed.dtype != self.compute_dtype:
+            self._packed = engine.pack_epa(self, device, self.compute_dtype)
+            self._packed.device, self._packed.dtype = device, self.compute_dtype
+        return self._packed
+
+    def repack(self):
+        self._packed = None
+
+    def tables_for(self, groups, ph, pw, eh, ew, device):
+        e = self.packed(device)
+        uniq = [groups[0]] if all(g == groups[0] for g in groups) else groups
+        return [self._tables.get(f, t, p, ph, pw, eh, ew, e.freq, device) for f, t, p in uniq]
+
+    @torch.no_grad()
+    def forward_nhwc(self, xp, xe, groups, m):
+        """xp [b*m, ph, pw, C], xe [b, eh, ew, C] 16-bit NHWC (the denoiser's internal layout)."""
+        e = self.packed(xp.device)
+        tabs = self.tables_for(groups, xp.shape[1], xp.shape[2], xe.shape[1], xe.shape[2], xp.device)
+        return engine.run_epa(e, tabs, xp, xe, m)
+
+    @torch.no_grad()
+    def forward(self, pers_x, equi_x, cameras):
+        b = equi_x.shape[0]
+        m, groups = camera_groups(cameras, b)
+        dt = self.compute_dtype
+        xp = ops.nchw_to_nhwc(pers_x.float(), dt)
+        xe = ops.nchw_to_nhwc(equi_x.float(), dt)
+        op, oe = self.forward_nhwc(xp, xe, groups, m)
+        return (ops.nhwc_to_nchw(op, torch.float32).to(pers_x.dtype),
+                ops.nhwc_to_nchw(oe, torch.float32).to(equi_x.dtype))

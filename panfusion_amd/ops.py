@@ -1,0 +1,345 @@
+"""Torch-tensor front end of the C-ABI HIP kernels.
+
+PyTorch is used here for device memory and streams only: every function below
+hands raw device pointers + sizes to ``libpanfusion_hip.so`` on the caller's
+current stream.  No function has a torch / CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PF_BF16, PF_F16, PF_F32, AttnDesc, ConvDesc, check
+
+_DT = {torch.bfloat16: PF_BF16, torch.float16: PF_F16, torch.float32: PF_F32}
+
+
+def dt(t):
+    return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t):
+    """Row stride (elements) of a [.., rows, cols] tensor or column-sliced view of one."""
+    assert t.stride(-1) == 1, "innermost dimension must be contiguous"
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+def _cams(fov, theta, phi):
+    """Host double arrays (degrees) for the C ABI; accepts tensors / arrays / lists."""
+    def host(v):
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        return np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
+    f, t, p = host(fov), host(theta), host(phi)
+    n = max(len(f), len(t), len(p))
+    f, t, p = (np.ascontiguousarray(np.broadcast_to(a, (n,))) if len(a) != n else a for a in (f, t, p))
+    as_p = lambda a: a.ctypes.data_as(_lib.c_dp)
+    return n, (f, t, p), (as_p(f), as_p(t), as_p(p))
+
+
+# ---------------------------------------------------------------------------- geometry
+def e2p_grid(fov, theta, phi, eh, ew, h, w, device, want_lonlat=False):
+    n, keep, (f, t, p) = _cams(fov, theta, phi)
+    mx = torch.empty(n, h, w, device=device, dtype=torch.float32)
+    my = torch.empty_like(mx)
+    ll = torch.empty(n, h, w, 2, device=device, dtype=torch.float32) if want_lonlat else None
+    check(_lib.lib().pf_e2p_grid(f, t, p, n, eh, ew, h, w, _p(mx), _p(my), _p(ll), _stream()), "pf_e2p_grid")
+    return (mx, my, ll) if want_lonlat else (mx, my)
+
+
+def p2e_grid(fov, theta, phi, ph, pw, h, w, device):
+    n, keep, (f, t, p) = _cams(fov, theta, phi)
+    mu = torch.empty(n, h, w, device=device, dtype=torch.float32)
+    mv = torch.empty_like(mu)
+    mask = torch.empty(n, h, w, device=device, dtype=torch.uint8)
+    check(_lib.lib().pf_p2e_grid(f, t, p, n, ph, pw, h, w, _p(mu), _p(mv), _p(mask), _stream()), "pf_p2e_grid")
+    return mu, mv, mask
+
+
+def nearest_indices(map_x, map_y, src_h, src_w):
+    idx = torch.empty(map_x.shape, device=map_x.device, dtype=torch.int32)
+    check(_lib.lib().pf_nearest_indices(_p(map_x), _p(map_y), map_x.numel(), src_h, src_w, _p(idx), _stream()),
+          "pf_nearest_indices")
+    return idx
+
+
+def remap(src, map_x, map_y, mode, mask=None):
+    """src NCHW (fp32 / 16-bit), maps (B or 1, ho, wo) fp32."""
+    src = src.contiguous()
+    B, Cc, hs, ws = src.shape
+    mb, ho, wo = map_x.shape
+    out = torch.empty(B, Cc, ho, wo, device=src.device, dtype=src.dtype)
+    check(_lib.lib().pf_remap(_p(src), dt(src), B, Cc, hs, ws, _p(map_x), _p(map_y), _p(mask), mb, ho, wo,
+                              {"nearest": 0, "bilinear": 1}[mode], _p(out), _stream()), "pf_remap")
+    return out
+
+
+def equi_coords(H, W, device):
+    out = torch.empty(H, W, 2, device=device, dtype=torch.float32)
+    check(_lib.lib().pf_equi_coords(H, W, _p(out), _stream()), "pf_equi_coords")
+    return out
+
+
+def spherical_pe(coords, freq_bands):
+    coords = coords.contiguous()
+    n = coords.numel() // 2
+    nf = freq_bands.numel()
+    out = torch.empty(*coords.shape[:-1], 4 * nf, device=coords.device, dtype=torch.float32)
+    check(_lib.lib().pf_spherical_pe(_p(coords), n, _p(freq_bands), nf, _p(out), _stream()), "pf_spherical_pe")
+    return out
+
+
+def epa_tables(fov, theta, phi, ph, pw, eh, ew, device):
+    """-> bias_e [E, m*P], bias_p [m*P, E] (fp32, mask + 1), flags_e, flags_p (uint8 tile maps)."""
+    m, keep, (f, t, p) = _cams(fov, theta, phi)
+    E, P = eh * ew, ph * pw
+    mP = m * P
+    bias_e = torch.empty(E, mP, device=device, dtype=torch.float32)
+    bias_p = torch.empty(mP, E, device=device, dtype=torch.float32)
+    flags_e = torch.empty((E + 31) // 32, (mP + 31) // 32, device=device, dtype=torch.uint8)
+    flags_p = torch.empty((mP + 31) // 32, (E + 31) // 32, device=device, dtype=torch.uint8)
+    nbytes = _lib.lib().pf_epa_tables_workspace_size(m, ph, pw, eh, ew)
+    ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
+    check(_lib.lib().pf_epa_tables_build(f, t, p, m, ph, pw, eh, ew, _p(bias_e), _p(bias_p), _p(flags_e),
+                                         _p(flags_p), _p(ws), nbytes, _stream()), "pf_epa_tables_build")
+    return bias_e, bias_p, flags_e, flags_p
+
+
+# ---------------------------------------------------------------------------- norms / pointwise
+def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
+    """x0 [n, hw, c0] (+ x1 [n, hw, c1] concatenated along channels) -> (scale, shift) [n, C] fp32."""
+    c0 = x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    Cc = c0 + c1
+    scale = torch.empty(n_img, Cc, device=x0.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    nbytes = _lib.lib().pf_groupnorm_workspace_size(n_img, hw, Cc)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, device=x0.device, dtype=torch.uint8)
+    check(_lib.lib().pf_groupnorm_stats(_p(x0), c0, _p(x1), c1, dt(x0), n_img, hw, groups, eps, _p(gamma),
+                                        _p(beta), _p(scale), _p(shift), _p(ws), ws.numel(), _stream()),
+          "pf_groupnorm_stats")
+    return scale, shift
+
+
+def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None):
+    c0 = x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    if out is None:
+        out = torch.empty(n_img, hw, c0 + c1, device=x0.device, dtype=x0.dtype)
+    check(_lib.lib().pf_scale_shift_act(_p(x0), c0, _p(x1), c1, dt(x0), n_img, hw, _p(scale), _p(shift),
+                                        int(act), _p(out), _stream()), "pf_scale_shift_act")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pe=None, out=None):
+    """x [rows, C] 16-bit; pe optional fp32 [pe_rows, C] (row r uses pe[r % pe_rows])."""
+    rows, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().pf_layernorm(_p(x), _p(pe), 0 if pe is None else pe.shape[0], dt(x), rows, Cc,
+                                  _p(gamma), _p(beta), eps, _p(out), _stream()), "pf_layernorm")
+    return out
+
+
+def geglu(x, out=None):
+    rows, two_inner = x.shape
+    inner = two_inner // 2
+    if out is None:
+        out = torch.empty(rows, inner, device=x.device, dtype=x.dtype)
+    check(_lib.lib().pf_geglu(_p(x), dt(x), rows, inner, _p(out), _stream()), "pf_geglu")
+    return out
+
+
+def timestep_features(t, dim, dtype):
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty(t.numel(), dim, device=t.device, dtype=dtype)
+    check(_lib.lib().pf_timestep_features(_p(t), t.numel(), dim, dt(dtype), _p(out), _stream()),
+          "pf_timestep_features")
+    return out
+
+
+def silu(x, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().pf_silu(_p(x), dt(x), x.numel(), _p(out), _stream()), "pf_silu")
+    return out
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.lib().pf_add(_p(a), _p(b), dt(a), a.numel(), _p(out), _stream()), "pf_add")
+    return out
+
+
+def pad_width(x, pad, out=None):
+    """x NHWC [n, h, w, C] -> circularly padded [n, h, w + 2 pad, C]."""
+    n, h, w, Cc = x.shape
+    if out is None:
+        out = torch.empty(n, h, w + 2 * pad, Cc, device=x.device, dtype=x.dtype)
+    check(_lib.lib().pf_pad_width(_p(x), dt(x), n, h, w, Cc, pad, _p(out), _stream()), "pf_pad_width")
+    return out
+
+
+def crop_width(x, crop, out=None):
+    n, h, w, Cc = x.shape
+    if out is None:
+        out = torch.empty(n, h, w - 2 * crop, Cc, device=x.device, dtype=x.dtype)
+    check(_lib.lib().pf_crop_width(_p(x), dt(x), n, h, w, Cc, crop, _p(out), _stream()), "pf_crop_width")
+    return out
+
+
+def pad_width_rows(x, pad):
+    """Circular pad of the last axis of a contiguous tensor of any rank (pad_pano on NCHW)."""
+    x = x.contiguous()
+    w = x.shape[-1]
+    rows = x.numel() // w
+    out = torch.empty(*x.shape[:-1], w + 2 * pad, device=x.device, dtype=x.dtype)
+    check(_lib.lib().pf_pad_width_rows(_p(x), x.element_size(), rows, w, pad, _p(out), _stream()),
+          "pf_pad_width_rows")
+    return out
+
+
+def roll_width(x, shift, out=None):
+    """torch.roll(x, shift, dims=-1) on a contiguous tensor."""
+    x = x.contiguous()
+    w = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().pf_roll_width_rows(_p(x), x.element_size(), x.numel() // w, w, int(shift), _p(out), _stream()),
+          "pf_roll_width_rows")
+    return out
+
+
+def nchw_to_nhwc(x, dtype, out=None):
+    x = x.contiguous()
+    n, Cc, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, h, w, Cc, device=x.device, dtype=dtype)
+    check(_lib.lib().pf_nchw_to_nhwc(_p(x), dt(x), n, Cc, h, w, dt(dtype), _p(out), _stream()), "pf_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, dtype, out=None):
+    n, h, w, Cc = x.shape
+    if out is None:
+        out = torch.empty(n, Cc, h, w, device=x.device, dtype=dtype)
+    check(_lib.lib().pf_nhwc_to_nchw(_p(x), dt(x), n, Cc, h, w, dt(dtype), _p(out), _stream()), "pf_nhwc_to_nchw")
+    return out
+
+
+def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
+    """x / eps fp32 [..., W]; coef = (sqrt a_t, sqrt(1-a_t), sqrt a_prev, sqrt(1-a_prev))."""
+    W = x.shape[-1]
+    rows = x.numel() // W
+    if out is None:
+        out = torch.empty_like(x)
+    sa, sb, sap, sbp = (float(c) for c in coef)
+    check(_lib.lib().pf_cfg_ddim_step(_p(x), _p(eps_uncond), _p(eps_cond), float(guidance), sa, sb, sap, sbp,
+                                      rows, W, int(roll), _p(out), _stream()), "pf_cfg_ddim_step")
+    return out
+
+
+# ---------------------------------------------------------------------------- GEMM / conv
+def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
+              bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,
+              a_bstride=0, w_bstride=0, out_bstride=0, res_bstride=0, a0_ld=None, a1_ld=None, c0=None, c1=None,
+              out_ld=None, res_ld=None):
+    """out[m, n] = sum_k A[m, k] W[n, k] (+bias +rowvec[img] +residual).  a0/a1 NHWC, the last
+    dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out)."""
+    c0 = c0 if c0 is not None else a0.shape[-1]
+    c1 = (c1 if c1 is not None else a1.shape[-1]) if a1 is not None else 0
+    if w_in is None:
+        w_in = a0.numel() // (a0.shape[-1] * max(batch, 1)) if ksize == 1 else None
+    hl, wl = h_in << upsample, w_in << upsample
+    h_out = (hl + 2 * pad - ksize) // stride + 1
+    w_out = (wl + 2 * pad - ksize) // stride + 1
+    M = n_img * h_out * w_out
+    out_dtype = out_dtype or a0.dtype
+    if out is None:
+        out = torch.empty((batch, M, n_out) if batch > 1 else (M, n_out), device=a0.device, dtype=out_dtype)
+    d = ConvDesc()
+    d.a0, d.a1, d.c0, d.c1 = _p(a0), _p(a1), c0, c1
+    d.a0_ld = a0_ld if a0_ld is not None else _ld(a0)
+    d.a1_ld = (a1_ld if a1_ld is not None else _ld(a1)) if a1 is not None else 0
+    d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n_img, h_in, w_in, h_out, w_out
+    d.ksize, d.stride, d.pad, d.upsample = ksize, stride, pad, upsample
+    d.w, d.n_out = _p(w), n_out
+    d.bias = _p(bias)
+    d.rowvec, d.rowvec_ld = _p(rowvec), (_ld(rowvec) if rowvec is not None else 0)
+    d.residual = _p(residual)
+    d.res_ld = (res_ld if res_ld is not None else _ld(residual)) if residual is not None else 0
+    d.out, d.out_ld = _p(out), (out_ld if out_ld is not None else _ld(out))
+    d.out_dtype, d.dtype = dt(out_dtype), dt(a0)
+    d.batch = batch
+    d.a_bstride, d.w_bstride, d.out_bstride, d.res_bstride = a_bstride, w_bstride, out_bstride, res_bstride
+    check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm")
+    return out
+
+
+def linear(x, w, bias=None, residual=None, out=None, out_dtype=None):
+    """x [rows, K] 16-bit, w [N, K] 16-bit."""
+    rows, K = x.shape
+    return conv_gemm(x, w, w.shape[0], w_in=rows, bias=bias, residual=residual, out=out, out_dtype=out_dtype)
+
+
+def linear_t(x, w, out=None, ld=None):
+    """Transposed projection for attention values: x [B, rows, K], w [N, K] ->
+    out [B, N, ld] with out[b, n, r] = sum_k w[n,k] x[b,r,k]   (keys contiguous)."""
+    B, rows, K = x.shape
+    N = w.shape[0]
+    ld = ld or ((rows + 31) // 32) * 32
+    if out is None:
+        out = torch.empty(B, N, ld, device=x.device, dtype=x.dtype)
+    # roles swapped: GEMM rows = weight rows (N of them), GEMM columns = tokens
+    conv_gemm(w, x, rows, w_in=N, out=out, out_ld=ld, batch=B,
+              a_bstride=0, w_bstride=rows * K, out_bstride=N * ld, c0=K, a0_ld=K)
+    return out
+
+
+def conv_in(x, wgt, bias, cout, dtype, wrap=False, out=None):
+    x = x.contiguous()
+    n, cin, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, h, w, cout, device=x.device, dtype=dtype)
+    check(_lib.lib().pf_conv_in(_p(x), n, cin, h, w, _p(wgt), _p(bias), cout, int(wrap), dt(dtype), _p(out), _stream()),
+          "pf_conv_in")
+    return out
+
+
+def conv_out(x, wgt, bias, cout, wrap=False, out=None):
+    n, h, w, cin = x.shape
+    if out is None:
+        out = torch.empty(n, cout, h, w, device=x.device, dtype=torch.float32)
+    check(_lib.lib().pf_conv_out(_p(x), dt(x), n, cin, h, w, _p(wgt), _p(bias), cout, int(wrap), _p(out), _stream()),
+          "pf_conv_out")
+    return out
+
+
+# ---------------------------------------------------------------------------- attention
+def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, k_bs, vt_bs, o_bs=None,
+              scale=None, bias=None, flags=None, out=None):
+    o_ld = o_ld or H * D
+    o_bs = o_bs if o_bs is not None else nq * o_ld
+    if out is None:
+        out = torch.empty(B, nq, o_ld, device=q.device, dtype=q.dtype)
+    d = AttnDesc()
+    d.q, d.k, d.vt, d.out = _p(q), _p(k), _p(vt), _p(out)
+    d.dtype, d.B, d.H, d.D, d.nq, d.nk = dt(q), B, H, D, nq, nk
+    d.q_ld, d.k_ld, d.vt_ld, d.o_ld = q_ld, k_ld, vt_ld, o_ld
+    d.q_bs, d.k_bs, d.vt_bs, d.o_bs = q_bs, k_bs, vt_bs, o_bs
+    d.scale = scale if scale is not None else D ** -0.5
+    d.bias, d.bias_ld = _p(bias), (_ld(bias) if bias is not None else 0)
+    d.flags, d.flags_ld = _p(flags), (_ld(flags) if flags is not None else 0)
+    check(_lib.lib().pf_attention(C.byref(d), _stream()), "pf_attention")
+    return out

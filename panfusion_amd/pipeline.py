@@ -1,0 +1,135 @@
+"""The DDIM sampling loop around the denoiser (reference
+``models/pano/PanFusion.py:30-43,100-164``, ``PanoGenerator.py:240-269``).
+
+``DenoiseLoop`` owns the static device buffers of one sampling run and runs
+one loop iteration -- 90-degree latent roll, CFG-paired dual-branch denoiser,
+CFG merge, two DDIM updates -- per ``step()``.  The denoiser call can be
+captured into one hipGraph per rotation offset (the geometry is 4-periodic,
+SURVEY.md §4) and replayed; the CFG+DDIM update is a separate fused kernel
+whose scalar coefficients change every step.
+"""
+import torch
+
+from . import ops
+from .external.Perspective_and_Equirectangular import e2p
+
+
+class DDIMSchedule:
+    """diffusers DDIMScheduler with the SD-2-base config (scaled-linear betas 0.00085..0.012,
+    1000 train steps, steps_offset 1, leading spacing, eta 0, epsilon prediction)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self.num_train_timesteps, self.steps_offset = num_train_timesteps, steps_offset
+
+    def set_timesteps(self, n):
+        self.num_inference_steps = n
+        ratio = self.num_train_timesteps // n
+        self.timesteps = [int(i * ratio) + self.steps_offset for i in range(n)][::-1]
+        return self.timesteps
+
+    def coefficients(self, t):
+        prev = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        return (float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_prev ** 0.5), float((1 - a_prev) ** 0.5))
+
+
+def init_noise(pano_noise, cameras, pers_h, pers_w):
+    """View noise = nearest-neighbour e2p of the SAME panorama noise (PanFusion.py:30-43).
+    pano_noise (bs, 1, 4, H, W) on the GPU; cameras: dict of (bs, m)."""
+    bs = pano_noise.shape[0]
+    m = cameras["FoV"].shape[1]
+    flat = {k: v.reshape(-1) for k, v in cameras.items()}
+    rep = pano_noise.expand(-1, m, -1, -1, -1).flatten(0, 1)
+    noise = e2p(rep, flat["FoV"], flat["theta"], flat["phi"], (pers_h, pers_w), mode="nearest")
+    return pano_noise, noise.unflatten(0, (bs, m))
+
+
+def rotate_cameras(cameras, degree):
+    cams = dict(cameras)
+    cams["theta"] = (cams["theta"] + degree) % 360
+    return cams
+
+
+class DenoiseLoop:
+    """One text-to-panorama sampling run (batch 1 prompt, CFG pair inside)."""
+
+    def __init__(self, model, latents, pano_latent, prompt_embd, pano_prompt_embd, cameras,
+                 steps=50, rot_diff=90.0, guidance_scale=9.0, use_graphs=False):
+        """latents (1, m, 4, h, w), pano_latent (1, 1, 4, H, W) fp32 on the GPU;
+        prompt_embd (2, m, L, D) / pano_prompt_embd (2, 1, L, D) = [null ; prompt];
+        cameras: dict of (1, m) CPU tensors (FoV, theta, phi in degrees)."""
+        self.model, self.guidance, self.rot_diff = model, guidance_scale, rot_diff
+        self.lat = latents.float().contiguous().clone()
+        self.pano = pano_latent.float().contiguous().clone()
+        self.prompt, self.pano_prompt = prompt_embd, pano_prompt_embd
+        self.cameras = {k: v.detach().cpu() for k, v in cameras.items()}
+        self.m = latents.shape[1]
+        self.W = pano_latent.shape[-1]
+        self.shift = int(rot_diff / 360 * self.W)          # PanoGenerator.py:269
+        self.sched = DDIMSchedule()
+        self.timesteps = self.sched.set_timesteps(steps)
+        self.tstep = torch.empty(2, self.m, dtype=torch.long, device=latents.device)
+        self.i = 0
+        self.total_rot = 0.0
+        self.use_graphs = use_graphs
+        self.graphs = {}
+        self.eps = self.pano_eps = None
+        # the loop rolls the panorama BEFORE each denoiser call (PanFusion.py:149); afterwards the
+        # DDIM kernel writes the next latent already rolled for the following step.
+        self._pano_tmp = torch.empty_like(self.pano)
+        if rot_diff % 360:
+            self.pano.copy_(ops.roll_width(self.pano, self.shift, out=self._pano_tmp))
+        self.cameras = rotate_cameras(self.cameras, rot_diff)
+        self.total_rot += rot_diff
+
+    def _denoise(self, cams):
+        pair = lambda x: torch.cat([x, x])
+        cams2 = {k: torch.cat([v, v]) for k, v in cams.items()}
+        return self.model(pair(self.lat), pair(self.pano), self.tstep, self.prompt, self.pano_prompt, cams2)
+
+    def _denoise_graphed(self, cams):
+        key = tuple(float(v) for v in cams["theta"].reshape(-1))
+        g = self.graphs.get(key)
+        if g is None:
+            self._denoise(cams)                      # warm-up: builds tables, sets kernel attributes
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._denoise(cams)
+            g = (graph, out)
+            self.graphs[key] = g
+        g[0].replay()
+        return g[1]
+
+    def step(self):
+        """One iteration of the loop body (PanFusion.py:146-162)."""
+        t = self.timesteps[self.i]
+        self.tstep.fill_(t)
+        run = self._denoise_graphed if self.use_graphs else self._denoise
+        eps, pano_eps = run(self.cameras)
+        coef = self.sched.coefficients(t)
+        last = self.i == len(self.timesteps) - 1
+        # views: plain update; panorama: update + roll for the next iteration
+        ops.cfg_ddim_step(self.lat, eps[0], eps[1], self.guidance, coef, 0, out=self.lat)
+        # (self.pano keeps its storage: captured graphs read it by address)
+        ops.cfg_ddim_step(self.pano, pano_eps[0], pano_eps[1], self.guidance, coef,
+                          0 if last else self.shift, out=self._pano_tmp)
+        self.pano.copy_(self._pano_tmp)
+        self.i += 1
+        if not last:
+            self.cameras = rotate_cameras(self.cameras, self.rot_diff)
+            self.total_rot += self.rot_diff
+
+    def run(self):
+        while self.i < len(self.timesteps):
+            self.step()
+        return self.result()
+
+    def result(self):
+        """Latents with the accumulated rotation undone (PanFusion.py:164)."""
+        back = int(-self.total_rot / 360 * self.W)
+        return self.lat, ops.roll_width(self.pano, back)

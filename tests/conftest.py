@@ -1,0 +1,60 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+TINY = dict(width=64, cross_attention_dim=128, heads=(1, 2, 4, 4), groups=32)
+
+
+def build_tiny_oracle(seed=11):
+    """Same construction as tools/make_golden.py:build_tiny_models, on the oracle classes."""
+    from oracle import mvgen as MV
+    from oracle import sd2_unet as U
+    cfg = U.tiny_config(**TINY)
+    unet, pano_unet = U.UNet2DConditionModel(**cfg), U.UNet2DConditionModel(**cfg)
+    unet.add_lora(4)
+    pano_unet.add_lora(4)
+    U.init_synthetic(unet, seed)
+    U.init_synthetic(pano_unet, seed + 1)
+    model = MV.DualBranchDenoiser(unet, pano_unet, None, None, True)
+    U.init_synthetic(model.cp_blocks_encoder, seed + 2)
+    U.init_synthetic(model.cp_blocks_mid, seed + 3)
+    U.init_synthetic(model.cp_blocks_decoder, seed + 4)
+    MV.randomize_epa(model, seed + 5)
+    return model
+
+
+def cam4():
+    return {"FoV": torch.full((4,), 90), "theta": torch.tensor([0., 90, 180, 270], dtype=torch.float64),
+            "phi": torch.tensor([0., 10, -20, 45], dtype=torch.float64)}

@@ -1,0 +1,128 @@
+"""The oracle restatement vs the fixtures tools/make_golden.py generated from the
+reference's own code (runs everywhere, CPU only)."""
+import numpy as np
+import torch
+
+from conftest import build_tiny_oracle, cam4, golden, rel_l2
+from oracle import ddim as oddim
+from oracle import geometry as G
+from oracle import mvgen as MV
+from oracle import sd2_unet as U
+
+
+def test_icosahedron_known_answers():
+    th, ph = G.icosahedron_cameras()
+    g = golden("grids.npz")
+    assert np.array_equal(np.degrees(th), g["theta"]) and np.array_equal(np.degrees(ph), g["phi"])
+    # theta in {-144,-72,0,72,144} x2, {-180,-108,-36,36,108} x2; phi +-52.623, +-10.812
+    assert np.allclose(sorted(set(np.round(np.degrees(ph), 3))), [-52.623, -10.812, 10.812, 52.623])
+    assert np.allclose(np.degrees(th)[:5], [-144, -72, 0, 72, 144])
+
+
+def test_nearest_indices_bit_exact():
+    g = golden("grids.npz")
+    for rot in (0, 90, 180, 270):
+        for name, (eh, ew, h, w) in {"64": (64, 128, 64, 64), "8": (8, 16, 8, 8)}.items():
+            want = g["idx_%s_rot%d" % (name, rot)]
+            for i in range(20):
+                mx, my = G.e2p_grid(eh, ew, 90, (g["theta"][i] + rot) % 360, g["phi"][i], h, w)
+                assert np.array_equal(G.nearest_indices(mx, my, eh, ew), want[i].astype(np.int64))
+
+
+def test_grids_bit_exact():
+    g = golden("grids.npz")
+    for i in range(20):
+        t, p = (g["theta"][i] + 90) % 360, g["phi"][i]
+        mx, my = G.e2p_grid(16, 32, 90, t, p, 16, 16)
+        assert np.array_equal(np.stack([mx, my]), g["e2p_maps_16"][i])
+        u, v, mask = G.p2e_grid(16, 16, 90, t, p, 16, 32)
+        assert np.array_equal(u, g["p2e_u_16"][i]) and np.array_equal(v, g["p2e_v_16"][i])
+        assert np.array_equal(mask, g["p2e_mask_16"][i])
+
+
+def test_init_noise_gather():
+    g, gn = golden("grids.npz"), golden("init_noise.npz")
+    gen = torch.Generator().manual_seed(0)
+    pano_noise = torch.randn(1, 1, 4, 64, 128, generator=gen)
+    cams = {"FoV": torch.full((1, 20), 90), "theta": torch.tensor(g["theta"])[None], "phi": torch.tensor(g["phi"])[None]}
+    _, views = oddim.init_noise(pano_noise, cams, 64, 64)
+    assert np.array_equal(views[0, :, 0].numpy(), gn["view_noise_c0"])
+
+
+def test_epa_tables_and_pe():
+    g, ge = golden("grids.npz"), golden("epa_tables.npz")
+    cams = {"FoV": torch.full((20,), 90), "theta": torch.tensor((g["theta"] + 90) % 360), "phi": torch.tensor(g["phi"])}
+    pm, em = G.get_masks(8, 8, 8, 16, cams)
+    assert np.array_equal(pm.numpy(), ge["pers_masks"]) and np.array_equal(em.numpy(), ge["equi_masks"])
+    pc, ec = G.get_coords(8, 8, 8, 16, cams)
+    assert np.array_equal(pc.numpy(), ge["pers_coords"]) and np.array_equal(ec.numpy(), ge["equi_coords"])
+    assert np.array_equal(G.spherical_freq_bands(80).numpy(), ge["freq80"])
+    assert np.array_equal(G.spherical_freq_bands(320).numpy(), ge["freq320"])
+    assert np.array_equal(G.spherical_pe(pc, G.spherical_freq_bands(80)).numpy(), ge["pe80_pers"])
+    assert np.array_equal(G.spherical_pe(ec, G.spherical_freq_bands(320)).numpy(), ge["pe320_equi"])
+    # properties of the reference tables: rows in [-1,1], max exactly +1 or constant -1
+    rows = pm.reshape(20 * 128, -1)
+    mx = rows.amax(1)
+    assert float(rows.min()) >= -1.0 and bool(((mx == 1) | (mx == -1)).all())
+    seen = (pm.reshape(20, 128, -1).amax(2) > -1).sum(0)          # views that see each pano pixel
+    assert int(seen.min()) >= 3        # every pano pixel is covered by several of the 20 views
+
+
+def test_epa_block_identity_at_init():
+    blk = MV.EPABlock(64)
+    px, ex = torch.randn(4, 64, 8, 8), torch.randn(1, 64, 8, 16)
+    with torch.no_grad():
+        po, eo = blk(px, ex, cam4())
+    assert torch.equal(po, px) and torch.equal(eo, ex)
+
+
+def test_warpattn_golden():
+    g = golden("warpattn_c64.npz")
+    blk = MV.EPABlock(64)
+    U.init_synthetic(blk, 21)
+    MV.randomize_epa(blk, 22)
+    cam8 = {k: torch.cat([v, v]) for k, v in cam4().items()}
+    with torch.no_grad():
+        po, eo = blk(torch.from_numpy(g["pers_x"]), torch.from_numpy(g["equi_x"]), cam8)
+    assert rel_l2(po, torch.from_numpy(g["pers_out"])) < 1e-5
+    assert rel_l2(eo, torch.from_numpy(g["equi_out"])) < 1e-5
+
+
+def test_denoiser_golden():
+    g = golden("mvgen_tiny.npz")
+    model = build_tiny_oracle()
+    camb = {k: torch.stack([v, v]) for k, v in cam4().items()}
+    t = torch.full((2, 4), 981, dtype=torch.long)
+    with torch.no_grad():
+        s, ps = model(*(torch.from_numpy(g[k]) for k in ("latents", "pano_latent")), t,
+                      torch.from_numpy(g["prompt_embd"]), torch.from_numpy(g["pano_prompt_embd"]), camb)
+    assert rel_l2(s, torch.from_numpy(g["sample"])) < 1e-5
+    assert rel_l2(ps, torch.from_numpy(g["pano_sample"])) < 1e-5
+    # PanoOnly call shape
+    po = MV.DualBranchDenoiser(None, model.pano_unet)
+    with torch.no_grad():
+        _, ps1 = po(None, torch.from_numpy(g["pano_latent"]), torch.tensor([981, 981]), None,
+                    torch.from_numpy(g["pano_prompt_embd"]), None)
+    assert rel_l2(ps1, torch.from_numpy(golden("panoonly_tiny.npz")["pano_sample"])) < 1e-5
+
+
+def test_ddim_three_steps_golden():
+    g, gd = golden("mvgen_tiny.npz"), golden("ddim3_tiny.npz")
+    model = build_tiny_oracle()
+    cam1 = {k: v[None] for k, v in cam4().items()}
+    lat, pl = torch.from_numpy(g["latents"][:1]), torch.from_numpy(g["pano_latent"][:1])
+    l3, p3 = oddim.denoise_loop(model, lat, pl, torch.from_numpy(g["prompt_embd"]),
+                                torch.from_numpy(g["pano_prompt_embd"]), cam1, steps=3)
+    assert rel_l2(l3, torch.from_numpy(gd["latents"])) < 1e-4
+    assert rel_l2(p3, torch.from_numpy(gd["pano_latent"])) < 1e-4
+
+
+def test_unet_driven_equals_plain_forward():
+    """The layer-by-layer driver with pano_pad=False must equal the UNet's own forward."""
+    cfg = U.tiny_config(width=32, cross_attention_dim=64, heads=(1, 2, 4, 4), groups=8)
+    unet = U.init_synthetic(U.UNet2DConditionModel(**cfg), 5)
+    x, txt = torch.randn(2, 1, 4, 16, 16), torch.randn(2, 1, 5, 64)
+    with torch.no_grad():
+        _, a = MV.DualBranchDenoiser(None, unet, pano_pad=False)(None, x, torch.tensor([500, 20]), None, txt, None)
+        b = unet(x[:, 0], torch.tensor([500, 20]), txt[:, 0])
+    assert rel_l2(a[:, 0], b) < 1e-5
