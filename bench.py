@@ -1,0 +1,202 @@
+"""DDIM denoise steps/s of the PanFusion hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one iteration of the loop body of PanFusion.inference (reference
+models/pano/PanFusion.py:146-162): 90-degree latent roll, CFG-paired dual-branch SD-2 UNet
+forward with 7 EPA fusions, CFG merge, two DDIM updates.  Workload = BASELINE.json configs[1]:
+512x1024 panorama (64x128 latent) + 20 perspective views of 512^2 (64x64 latents), batch 1 prompt
+(CFG pair => 40 view samples + 2 pano samples per step), SD-2-base UNet shapes, synthetic seeded
+weights and inputs (no checkpoint / dataset is reachable offline).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with device events around every launch
+of the dominant kernel family in an extra instrumented step after the timed region; `cpu_baseline`
+times the CPU oracle (oracle/, test infrastructure) on a bounded sample on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_STEP_CFG2 = 38.66e12        # SURVEY.md §8d / BASELINE.md §2 (2 FLOPs per MAC)
+PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
+
+
+def build_model(dev, dtype, cfg):
+    import torch
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    from panfusion_amd.models.sd2_unet_params import UNetParams, fill_synthetic
+    with torch.device(dev):
+        unet, pano_unet = UNetParams(**cfg), UNetParams(**cfg)
+        unet.add_lora(4)
+        pano_unet.add_lora(4)
+    fill_synthetic(unet, 1)
+    fill_synthetic(pano_unet, 2)
+    model = MultiViewBaseModel(unet, pano_unet, None, None, True, compute_dtype=dtype).to(dev)
+    for i, blk in enumerate([*model.cp_blocks_encoder, model.cp_blocks_mid, *model.cp_blocks_decoder]):
+        fill_synthetic(blk, 10 + i)     # EPA output projections are zero-initialised in the reference
+    model.repack()
+    return model
+
+
+def build_inputs(dev, m, lat_hw, pano_hw, ctx_dim, cams_deg):
+    import torch
+    from panfusion_amd.pipeline import init_noise
+    g = lambda s: torch.Generator().manual_seed(s)
+    pano_noise = torch.randn(1, 1, 4, *pano_hw, generator=g(0)).to(dev)
+    theta, phi = cams_deg
+    cameras = {"FoV": torch.full((1, m), 90), "theta": torch.tensor(theta, dtype=torch.float64)[None],
+               "phi": torch.tensor(phi, dtype=torch.float64)[None]}
+    _, latents = init_noise(pano_noise, cameras, *lat_hw)
+    prompt = torch.randn(1, m, 77, ctx_dim, generator=g(1))
+    pano_prompt = torch.randn(1, 1, 77, ctx_dim, generator=g(2))
+    null = torch.randn(1, 1, 77, ctx_dim, generator=g(3))
+    prompt_embd = torch.cat([null.expand(-1, m, -1, -1), prompt]).to(dev)
+    pano_prompt_embd = torch.cat([null, pano_prompt]).to(dev)
+    return latents, pano_noise, prompt_embd, pano_prompt_embd, cameras
+
+
+def cpu_baseline(cfg, ctx_dim, lat_hw, flop_per_step):
+    """Times the CPU oracle (fp32, all host cores) on a bounded sample: ONE view sample through the
+    SD-2-base UNet (1/40 of the view-branch work of a step), scaled to a whole step by FLOPs."""
+    import torch
+    from oracle import sd2_unet as U
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.device("meta"):
+        unet = U.UNet2DConditionModel(**cfg)
+    unet = unet.to_empty(device="cpu")
+    with torch.no_grad():
+        for p in unet.parameters():
+            p.normal_(0.0, 0.02)
+        x = torch.randn(1, 4, *lat_hw)
+        txt = torch.randn(1, 77, ctx_dim)
+        t = torch.tensor([981])
+        unet(x, t, txt)                              # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        unet(x, t, txt)
+        dt = time.perf_counter() - t0
+    sample_flop = 804.3e9 * (lat_hw[0] * lat_hw[1]) / (64 * 64)     # per 64x64 view sample
+    est_step_s = dt * flop_per_step / sample_flop
+    return {"value": 1.0 / est_step_s, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle SD-2-base UNet forward of 1 of the 40 view samples (%.2f TFLOP) in %.2f s, "
+                      "scaled by FLOPs to one %.2f-TFLOP step; EPA host-side mask building of the "
+                      "reference (~7 s per block on 8 cores, SURVEY.md §3C) not included"
+                      % (sample_flop / 1e12, dt, flop_per_step / 1e12)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--small", action="store_true", help="reduced widths/sizes (debug only, not the metric)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from panfusion_amd import ops
+    from panfusion_amd.models.sd2_unet_params import SD2_BASE
+    from panfusion_amd.pipeline import DenoiseLoop
+    from panfusion_amd.utils.pano import icosahedron_sample_camera
+    import numpy as np
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
+    cfg = dict(SD2_BASE)
+    m, lat_hw, pano_hw, flop = 20, (64, 64), (64, 128), FLOP_PER_STEP_CFG2
+    workload = "cfg2: 512x1024 pano + 20x512^2 views, CFG pair, SD-2-base UNet shapes"
+    if args.small:
+        cfg.update(block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4), cross_attention_dim=128)
+        lat_hw, pano_hw, flop, workload = (16, 16), (16, 32), float("nan"), "debug-small"
+    th, ph = icosahedron_sample_camera()
+    cams_deg = (np.degrees(th), np.degrees(ph))
+
+    if world > 1:
+        from panfusion_amd import sharding
+        model, loop = sharding.build_sharded(build_model, build_inputs, dev, dtype, cfg, m, lat_hw, pano_hw,
+                                             cams_deg, args.steps + args.warmup + 1, not args.no_graphs)
+    else:
+        model = build_model(dev, dtype, cfg)
+        inputs = build_inputs(dev, m, lat_hw, pano_hw, cfg["cross_attention_dim"], cams_deg)
+        loop = DenoiseLoop(model, *inputs, steps=args.steps + args.warmup + 1, use_graphs=not args.no_graphs)
+
+    loop.prepare()                                    # tables + one graph per rotation offset, untimed
+    for _ in range(args.warmup):
+        loop.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loop.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- instrumented step: device events around every GEMM / attention launch ------------------
+    trace = []
+    ops.TRACE = trace
+    loop.step_eager()
+    torch.cuda.synchronize()
+    ops.TRACE = None
+    fam = {}
+    for name, flops, e0, e1 in trace:
+        f = fam.setdefault(name, [0.0, 0.0, 0])
+        f[0] += flops
+        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[2] += 1
+    dom = max(fam, key=lambda k: fam[k][1]) if fam else None
+    roofline = None
+    if dom:
+        fl, sec, n = fam[dom]
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS,
+                    "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
+                    "launches_per_step": n, "avg_launch_us": sec / n * 1e6, "algorithmic_flop_per_launch": fl / n,
+                    "share_of_step_time": sec / (elapsed / args.steps),
+                    "other": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]}
+                              for k, v in fam.items() if k != dom}}
+
+    if rank == 0:
+        res = {"metric": "DDIM denoise steps/sec, 512x1024 pano + 20x512^2 views", "value": args.steps / elapsed,
+               "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (seeded inputs, random-init SD-2-base-shaped weights)",
+               "config": {"workload": workload, "views": m, "view_latent": list(lat_hw), "pano_latent": list(pano_hw),
+                          "cfg_pair": True, "hip_graphs": not args.no_graphs,
+                          "parallelism": "single" if world == 1 else getattr(loop, "layout", "sharded")},
+               "tflops_per_step": flop / 1e12, "frac_of_mfma_ceiling": (flop * args.steps / elapsed) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+               "roofline": roofline}
+        if not args.no_cpu_baseline and world == 1 and not args.small:
+            res["cpu_baseline"] = cpu_baseline(cfg, cfg["cross_attention_dim"], lat_hw, flop)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

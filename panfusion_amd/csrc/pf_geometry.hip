@@ -406,7 +406,13 @@ static pf_status upload_cams(const double* fov, const double* theta, const doubl
         set_error("%s: camera upload failed: %s", who, hipGetErrorString(e));
         return PF_ERR_LAUNCH;
     }
-    // pageable source: the runtime has staged the bytes when the call returns
+    // The source is a pageable host temporary: wait until the bytes have left it.  Geometry is built
+    // once per (camera set, size) outside the steady-state loop, so this sync is off the hot path.
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        set_error("%s: stream sync failed: %s", who, hipGetErrorString(e));
+        return PF_ERR_LAUNCH;
+    }
     return PF_OK;
 }
 

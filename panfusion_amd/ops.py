@@ -14,6 +14,20 @@ from ._lib import PF_BF16, PF_F16, PF_F32, AttnDesc, ConvDesc, check
 
 _DT = {torch.bfloat16: PF_BF16, torch.float16: PF_F16, torch.float32: PF_F32}
 
+# When set to a list, every MFMA-kernel launch appends (kernel family, algorithmic FLOPs, start event,
+# end event) -- used by bench.py's instrumented step for the roofline line.  None = no overhead.
+TRACE = None
+
+
+def _traced(name, flops, launch):
+    if TRACE is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    TRACE.append((name, float(flops), e0, e1))
+
 
 def dt(t):
     return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
@@ -283,7 +297,8 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     d.out_dtype, d.dtype = dt(out_dtype), dt(a0)
     d.batch = batch
     d.a_bstride, d.w_bstride, d.out_bstride, d.res_bstride = a_bstride, w_bstride, out_bstride, res_bstride
-    check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm")
+    _traced("k_conv_gemm", 2.0 * M * n_out * ksize * ksize * (c0 + c1) * batch,
+            lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"))
     return out
 
 
@@ -341,5 +356,6 @@ def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, 
     d.scale = scale if scale is not None else D ** -0.5
     d.bias, d.bias_ld = _p(bias), (_ld(bias) if bias is not None else 0)
     d.flags, d.flags_ld = _p(flags), (_ld(flags) if flags is not None else 0)
-    check(_lib.lib().pf_attention(C.byref(d), _stream()), "pf_attention")
+    _traced("k_attention", 4.0 * B * H * nq * nk * D,
+            lambda: check(_lib.lib().pf_attention(C.byref(d), _stream()), "pf_attention"))
     return out

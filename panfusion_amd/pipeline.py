@@ -105,6 +105,27 @@ class DenoiseLoop:
         g[0].replay()
         return g[1]
 
+    def prepare(self):
+        """Untimed set-up: build the geometry tables (and capture one hipGraph) for every rotation
+        offset the loop will visit (4 at rot_diff = 90)."""
+        cams, seen = self.cameras, set()
+        self.tstep.fill_(self.timesteps[0])
+        for _ in range(64):
+            key = tuple(float(v) for v in cams["theta"].reshape(-1))
+            if key in seen:
+                break
+            seen.add(key)
+            (self._denoise_graphed if self.use_graphs else self._denoise)(cams)
+            cams = rotate_cameras(cams, self.rot_diff)
+        torch.cuda.synchronize()
+
+    def step_eager(self):
+        keep, self.use_graphs = self.use_graphs, False
+        try:
+            self.step()
+        finally:
+            self.use_graphs = keep
+
     def step(self):
         """One iteration of the loop body (PanFusion.py:146-162)."""
         t = self.timesteps[self.i]

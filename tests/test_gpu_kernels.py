@@ -1,0 +1,408 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle / a plain
+fp32 torch statement of the same op, on seeded inputs.  Needs an MI355X: `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import cam4, golden, rel_l2
+from oracle import ddim as oddim
+from oracle import geometry as G
+from oracle import sd2_unet as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DTYPES = [torch.bfloat16, torch.float16]
+# tolerance of ONE 16-bit rounding of the output (+ fp32 accumulation order): bf16 has 8
+# significand bits (rel. rounding error <= 2^-9), fp16 has 11 (<= 2^-12)
+TOL = {torch.bfloat16: 4e-3, torch.float16: 6e-4}
+
+
+def ops():
+    from panfusion_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q16(x, dtype):
+    """Round to the 16-bit storage type and return (device tensor, fp32 CPU copy of the rounded values)."""
+    d = x.to(dtype)
+    return d.to(DEV), d.float()
+
+
+def check(name, got, want, tol):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, tuple(got.shape), tuple(want.shape))
+    assert torch.isfinite(got).all(), "%s: non-finite output" % name
+    err = rel_l2(got, want)
+    assert err <= tol, "%s: rel-L2 %.3e > %.1e (max abs %.3e)" % (name, err, tol, float((got - want).abs().max()))
+
+
+def ico():
+    th, ph = G.icosahedron_cameras()
+    return np.degrees(th), np.degrees(ph)
+
+
+# ------------------------------------------------------------------------------------ geometry
+@pytest.mark.parametrize("rot", [0, 90, 180, 270])
+def test_e2p_nearest_indices_bit_exact(rot):
+    """north_star: the e2p gather indices are bit-exact (all 20 benchmark cameras, 4 rotations)."""
+    g = golden("grids.npz")
+    thd, phd = g["theta"], g["phi"]
+    for name, (eh, ew, h, w) in {"64": (64, 128, 64, 64), "8": (8, 16, 8, 8)}.items():
+        mx, my = ops().e2p_grid([90] * 20, (thd + rot) % 360, phd, eh, ew, h, w, DEV)
+        idx = ops().nearest_indices(mx, my, eh, ew).cpu().numpy()
+        want = g["idx_%s_rot%d" % (name, rot)].astype(np.int32)
+        assert np.array_equal(idx, want), "%d index mismatches at %s rot %d" % ((idx != want).sum(), name, rot)
+
+
+def test_e2p_p2e_grids_vs_oracle():
+    thd, phd = ico()
+    th = (thd + 90) % 360
+    mx, my, ll = ops().e2p_grid([90] * 20, th, phd, 16, 32, 16, 16, DEV, want_lonlat=True)
+    g = golden("grids.npz")
+    want = torch.from_numpy(g["e2p_maps_16"]).float()           # float64 -> float32 like e2p.py:74-75
+    assert float((mx.cpu() - want[:, 0]).abs().max()) <= 4e-6 and float((my.cpu() - want[:, 1]).abs().max()) <= 4e-6
+    mu, mv, mask = ops().p2e_grid([90] * 20, th, phd, 16, 16, 16, 32, DEV)
+    assert np.array_equal(mask.cpu().numpy().astype(bool), g["p2e_mask_16"])
+    assert float((mu.cpu() - torch.from_numpy(g["p2e_u_16"]).float()).abs().max()) <= 2e-5
+    assert float((mv.cpu() - torch.from_numpy(g["p2e_v_16"]).float()).abs().max()) <= 2e-5
+    cams = {"FoV": torch.full((20,), 90), "theta": torch.tensor(th), "phi": torch.tensor(phd)}
+    pc, ec = G.get_coords(16, 16, 16, 32, cams)
+    assert float((ll.cpu() - pc).abs().max()) <= 1e-6
+    assert float((ops().equi_coords(16, 32, DEV).cpu() - ec).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+def test_remap_e2p_p2e_vs_oracle(mode):
+    from panfusion_amd.external.Perspective_and_Equirectangular import e2p, p2e
+    thd, phd = ico()
+    cams = (torch.full((20,), 90), torch.tensor(thd), torch.tensor(phd))
+    x = rnd(20, 3, 16, 32, seed=1)
+    got = e2p(x.to(DEV), *cams, (16, 16), mode=mode)
+    want = G.e2p(x, *cams, (16, 16), mode=mode)
+    if mode == "nearest":
+        assert torch.equal(got.cpu(), want)
+    else:
+        check("e2p bilinear", got, want, 1e-5)
+    y = rnd(20, 3, 16, 16, seed=2)
+    ge, gm = p2e(y.to(DEV), *cams, (16, 32), mode=mode)
+    we, wm = G.p2e(y, *cams, (16, 32), mode=mode)
+    assert torch.equal(gm.cpu(), wm)
+    check("p2e " + mode, ge, we, 1e-5)
+    # scalar camera broadcast
+    assert torch.equal(e2p(x.to(DEV), 90, 30.0, 10.0, (8, 8), mode="nearest").cpu(),
+                       G.e2p(x, 90, 30.0, 10.0, (8, 8), mode="nearest"))
+
+
+def test_init_noise_golden():
+    from panfusion_amd.pipeline import init_noise
+    g, gn = golden("grids.npz"), golden("init_noise.npz")
+    pano_noise = torch.randn(1, 1, 4, 64, 128, generator=torch.Generator().manual_seed(0))
+    cams = {"FoV": torch.full((1, 20), 90), "theta": torch.tensor(g["theta"])[None], "phi": torch.tensor(g["phi"])[None]}
+    _, views = init_noise(pano_noise.to(DEV), cams, 64, 64)
+    assert np.array_equal(views[0, :, 0].cpu().numpy(), gn["view_noise_c0"])      # pure gather: exact
+
+
+def test_spherical_pe_golden():
+    ge = golden("epa_tables.npz")
+    for n, ck, pk in ((80, "pers_coords", "pe80_pers"), (80, "equi_coords", "pe80_equi"), (320, "equi_coords", "pe320_equi")):
+        coords = torch.from_numpy(ge[ck]).to(DEV)
+        freq = torch.from_numpy(ge["freq%d" % n]).to(DEV)
+        got = ops().spherical_pe(coords, freq).cpu()
+        want = torch.from_numpy(ge[pk])
+        # sin/cos of identical fp32 arguments: full-range accurate implementations agree to a few ulp
+        assert float((got - want).abs().max()) <= 2e-6, (n, ck, float((got - want).abs().max()))
+
+
+def test_epa_tables_golden_and_flags():
+    g, ge = golden("grids.npz"), golden("epa_tables.npz")
+    th = (g["theta"] + 90) % 360
+    be, bp, fe, fp = ops().epa_tables([90] * 20, th, g["phi"], 8, 8, 8, 16, DEV)
+    E, P, m = 128, 64, 20
+    pers = torch.from_numpy(ge["pers_masks"]).reshape(m, E, P).permute(1, 0, 2).reshape(E, m * P) + 1
+    equi = torch.from_numpy(ge["equi_masks"]).reshape(m * P, E) + 1
+    assert float((be.cpu() - pers).abs().max()) <= 2e-5, float((be.cpu() - pers).abs().max())
+    assert float((bp.cpu() - equi).abs().max()) <= 2e-5, float((bp.cpu() - equi).abs().max())
+    assert torch.equal(be.cpu() != 0, pers != 0) and torch.equal(bp.cpu() != 0, equi != 0)     # same support
+    for bias, flags in ((be, fe), (bp, fp)):
+        nq, nk = bias.shape
+        tiles = bias.cpu().reshape(nq // 32, 32, nk // 32, 32).abs().amax((1, 3)) > 0
+        assert torch.equal(flags.cpu().bool(), tiles)
+    # second camera set (m=4, 16x16 / 16x32), stored sparsely
+    c = cam4()
+    be, bp, _, _ = ops().epa_tables(c["FoV"], c["theta"], c["phi"], 16, 16, 16, 32, DEV)
+    pm = torch.zeros(4 * 512 * 256)
+    pm[torch.from_numpy(ge["m4_pers_idx"]).long()] = torch.from_numpy(ge["m4_pers_val"])
+    pm = pm.reshape(4, 512, 256).permute(1, 0, 2).reshape(512, 1024)
+    assert float((be.cpu() - pm).abs().max()) <= 2e-5
+    em = torch.zeros(4 * 256 * 512)
+    em[torch.from_numpy(ge["m4_equi_idx"]).long()] = torch.from_numpy(ge["m4_equi_val"])
+    assert float((bp.cpu() - em.reshape(1024, 512)).abs().max()) <= 2e-5
+
+
+def test_epa_tables_properties_at_benchmark_size():
+    """cfg-2 scale s=2: 20 views of 32x32 against a 32x64 panorama (oracle would need minutes)."""
+    thd, phd = ico()
+    be, bp, fe, fp = ops().epa_tables([90] * 20, (thd + 90) % 360, phd, 32, 32, 32, 64, DEV)
+    E, P, m = 2048, 1024, 20
+    assert float(be.min()) >= 0 and float(be.max()) <= 2.0 + 1e-6
+    per_view_max = be.view(E, m, P).amax(2)
+    assert bool(((per_view_max - 2).abs().le(1e-6) | (per_view_max == 0)).all())     # max +1 or constant -1
+    rowmax = bp.amax(1)
+    assert bool((rowmax - 2).abs().le(1e-6).all())          # every view pixel lands somewhere on the sphere
+    frac = float((be > 0).float().mean())
+    assert 0.005 < frac < 0.02, frac                         # ~1.0 %
+    seen = (per_view_max > 0).sum(1)
+    assert int(seen.min()) >= 3 and int(seen.max()) <= 7
+    assert 0.03 < float(fe.float().mean()) < 0.5
+
+
+def test_get_masks_api_layout():
+    from panfusion_amd.models.pano import get_coords, get_masks
+    ge, g = golden("epa_tables.npz"), golden("grids.npz")
+    cams = {"FoV": torch.full((20,), 90), "theta": torch.tensor((g["theta"] + 90) % 360), "phi": torch.tensor(g["phi"])}
+    pm, em = get_masks(8, 8, 8, 16, cams, DEV)
+    assert pm.shape == (20, 8, 16, 8, 8) and em.shape == (20, 8, 8, 8, 16)
+    assert float((pm.cpu() - torch.from_numpy(ge["pers_masks"])).abs().max()) <= 2e-5
+    assert float((em.cpu() - torch.from_numpy(ge["equi_masks"])).abs().max()) <= 2e-5
+    pc, ec = get_coords(8, 8, 8, 16, cams, DEV)
+    assert float((pc.cpu() - torch.from_numpy(ge["pers_coords"])).abs().max()) <= 1e-6
+    assert float((ec.cpu() - torch.from_numpy(ge["equi_coords"])).abs().max()) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------ norms / pointwise
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(3, 40, 64, 32, 0), (2, 300, 320, 32, 0), (2, 70, 192, 32, 128), (1, 64, 2560, 32, 1280)])
+def test_groupnorm_silu(dtype, shape):
+    n, hw, C, groups, c1 = shape
+    x, xf = q16(rnd(n, hw, C, seed=3) * 2 + 0.5, dtype)
+    gam, bet = rnd(C, seed=4) * 0.2 + 1, rnd(C, seed=5) * 0.1
+    x0 = x[..., :C - c1].contiguous()
+    x1 = x[..., C - c1:].contiguous() if c1 else None
+    sc, sh = ops().groupnorm_scale_shift(x0, x1, n, hw, groups, 1e-5, gam.to(DEV), bet.to(DEV))
+    y = ops().scale_shift_act(x0, x1, n, hw, sc, sh, 1)
+    want = F.silu(F.group_norm(xf.permute(0, 2, 1), groups, gam, bet, 1e-5)).permute(0, 2, 1)
+    check("groupnorm+silu", y, want, TOL[dtype])
+    y0 = ops().scale_shift_act(x0, x1, n, hw, sc, sh, 0)
+    check("groupnorm", y0, F.group_norm(xf.permute(0, 2, 1), groups, gam, bet, 1e-5).permute(0, 2, 1), TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [64, 320, 1280])
+def test_layernorm_with_pe(dtype, C):
+    rows, pe_rows = 37 * 3, 37
+    x, xf = q16(rnd(rows, C, seed=6) + 0.3, dtype)
+    pe = rnd(pe_rows, C, seed=7)
+    gam, bet = rnd(C, seed=8) * 0.2 + 1, rnd(C, seed=9) * 0.1
+    y = ops().layernorm(x, gam.to(DEV), bet.to(DEV), 1e-5, pe=pe.to(DEV))
+    check("layernorm+pe", y, F.layer_norm(xf + pe.repeat(3, 1), (C,), gam, bet, 1e-5), TOL[dtype])
+    y = ops().layernorm(x, gam.to(DEV), bet.to(DEV), 1e-5)
+    check("layernorm", y, F.layer_norm(xf, (C,), gam, bet, 1e-5), TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pointwise_ops(dtype):
+    o = ops()
+    x, xf = q16(rnd(50, 2 * 256, seed=10) * 2, dtype)
+    a, g = xf.chunk(2, -1)
+    check("geglu", o.geglu(x), a * F.gelu(g), TOL[dtype])
+    check("silu", o.silu(x), F.silu(xf), TOL[dtype])
+    y, yf = q16(rnd(50, 512, seed=11), dtype)
+    check("add", o.add(x, y), xf + yf, TOL[dtype])
+    t = torch.tensor([981, 961, 1, 0, 500])
+    check("timestep features", o.timestep_features(t.to(DEV), 320, dtype), U.Timesteps(320)(t), TOL[dtype])
+    z, zf = q16(rnd(2, 5, 16, 64, seed=12), dtype)                  # NHWC
+    want = G.pad_pano(zf.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.equal(o.pad_width(z, 2).float().cpu(), want)
+    assert torch.equal(o.crop_width(o.pad_width(z, 2), 2).float().cpu(), zf)
+    assert torch.equal(o.crop_width(z, 1).float().cpu(), zf[:, :, 1:-1])
+    n = rnd(2, 6, 5, 16, seed=13)
+    assert torch.equal(o.nchw_to_nhwc(n.to(DEV), dtype).float().cpu(), n.to(dtype).float().permute(0, 2, 3, 1))
+    assert torch.equal(o.nhwc_to_nchw(z, torch.float32).cpu(), zf.permute(0, 3, 1, 2))
+
+
+def test_pad_pano_and_roll_api():
+    from panfusion_amd.utils.pano import pad_pano, unpad_pano
+    for x in (rnd(2, 3, 5, 16, seed=14), rnd(2, 2, 3, 5, 16, seed=15)):
+        for dt in (torch.float32, torch.float16):
+            xx = x.to(dt)
+            assert torch.equal(pad_pano(xx.to(DEV), 2).cpu(), G.pad_pano(xx, 2))
+            assert torch.equal(unpad_pano(pad_pano(xx.to(DEV), 3), 3).cpu(), xx)
+    x = rnd(3, 4, 7, 32, seed=16)
+    for s in (8, -8, 0, 40, -1600):
+        assert torch.equal(ops().roll_width(x.to(DEV), s).cpu(), torch.roll(x, s, -1))
+
+
+def test_cfg_ddim_step_vs_oracle():
+    sched = oddim.DDIM()
+    sched.set_timesteps(50)
+    x, eu, ec = rnd(20, 4, 16, 32, seed=17), rnd(20, 4, 16, 32, seed=18), rnd(20, 4, 16, 32, seed=19)
+    for t in (981, 501, 1):
+        want = sched.step(oddim.cfg_merge(torch.cat([eu, ec]), 9.0), t, x)
+        coef = [float(c) for c in sched.coefficients(t)]
+        got = ops().cfg_ddim_step(x.to(DEV), eu.to(DEV), ec.to(DEV), 9.0, coef, 0)
+        assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        got = ops().cfg_ddim_step(x.to(DEV), eu.to(DEV), ec.to(DEV), 9.0, coef, 8)
+        assert float((got.cpu() - torch.roll(want, 8, -1)).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("wrap", [False, True])
+def test_boundary_convs(dtype, wrap):
+    o = ops()
+    conv = torch.nn.Conv2d(4, 64, 3, padding=1)
+    x = rnd(3, 4, 9, 16, seed=20)
+    with torch.no_grad():
+        want = conv(G.pad_pano(x, 1))[..., 1:-1] if wrap else conv(x)
+    y = o.conv_in(x.to(DEV), conv.weight.detach().permute(2, 3, 1, 0).contiguous().to(DEV), conv.bias.detach().to(DEV),
+                  64, dtype, wrap=wrap)
+    check("conv_in", y.permute(0, 3, 1, 2), want, TOL[dtype])
+    conv2 = torch.nn.Conv2d(64, 4, 3, padding=1)
+    z, zf = q16(rnd(3, 9, 16, 64, seed=21), dtype)
+    with torch.no_grad():
+        zi = zf.permute(0, 3, 1, 2)
+        want = conv2(G.pad_pano(zi, 1))[..., 1:-1] if wrap else conv2(zi)
+    y = o.conv_out(z, conv2.weight.detach().permute(0, 2, 3, 1).contiguous().to(DEV), conv2.bias.detach().to(DEV), 4, wrap=wrap)
+    check("conv_out", y, want, 2e-5)
+
+
+# ------------------------------------------------------------------------------------ GEMM / conv
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mnk", [(300, 320, 320), (128, 160, 64), (1000, 640, 1280), (77, 64, 128), (4100, 960, 320), (520, 200, 192)])
+def test_linear(dtype, mnk):
+    M, N, K = mnk
+    x, xf = q16(rnd(M, K, seed=22), dtype)
+    w, wf = q16(rnd(N, K, seed=23) / K ** 0.5, dtype)
+    b = rnd(N, seed=24)
+    r, rf = q16(rnd(M, N, seed=25), dtype)
+    check("linear", ops().linear(x, w), xf @ wf.T, TOL[dtype])
+    check("linear+bias+res", ops().linear(x, w, bias=b.to(DEV), residual=r), xf @ wf.T + b + rf, TOL[dtype])
+    got = ops().linear(x, w, bias=b.to(DEV), out_dtype=torch.float32)
+    assert got.dtype == torch.float32
+    check("linear fp32 out", got, xf @ wf.T + b, 2e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_strided_views_and_rowvec(dtype):
+    o = ops()
+    M, C = 200, 128
+    big, bigf = q16(rnd(M, 2 * C, seed=26), dtype)                # (q | k) buffer: use the k half as input
+    w, wf = q16(rnd(64, C, seed=27) / C ** 0.5, dtype)
+    check("linear on column view", o.conv_gemm(big[:, C:], w, 64, w_in=M), bigf[:, C:] @ wf.T, TOL[dtype])
+    # per-image row vector from a wider table (time-embedding projection slice)
+    table = rnd(4, 256, seed=28)
+    x, xf = q16(rnd(4 * 50, C, seed=29), dtype)
+    got = o.conv_gemm(x, w, 64, n_img=4, h_in=5, w_in=10, rowvec=table.to(DEV)[:, 128:])
+    want = xf @ wf.T + table[:, 128:192].repeat_interleave(50, 0)
+    check("rowvec", got, want, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["s1", "s2", "up", "cat", "1x1cat", "pano"])
+def test_conv_gemm_vs_conv2d(dtype, case):
+    o = ops()
+    n, h, w, cin, cout = 3, 10, 12, 128, 192
+    if case == "pano":
+        n, h, w = 2, 8, 20
+    x, xf = q16(rnd(n, h, w, cin, seed=30), dtype)
+    skip, skipf = q16(rnd(n, h, w, 64, seed=31), dtype)
+    a1 = skip if "cat" in case else None
+    ctot = cin + (64 if a1 is not None else 0)
+    ks = 1 if case == "1x1cat" else 3
+    wt = rnd(cout, ctot, ks, ks, seed=32) / (ctot * ks * ks) ** 0.5
+    wq, wqf = q16(wt.permute(0, 2, 3, 1).reshape(cout, -1), dtype)
+    wref = wqf.reshape(cout, ks, ks, ctot).permute(0, 3, 1, 2)
+    b = rnd(cout, seed=33)
+    xin = xf.permute(0, 3, 1, 2)
+    if a1 is not None:
+        xin = torch.cat([xin, skipf.permute(0, 3, 1, 2)], 1)
+    kw = dict(n_img=n, h_in=h, w_in=w, ksize=ks, pad=ks // 2, bias=b.to(DEV), a1=a1)
+    if case == "s2":
+        want = F.conv2d(xin, wref, b, stride=2, padding=1)
+        kw["stride"] = 2
+    elif case == "up":
+        want = F.conv2d(F.interpolate(xin, scale_factor=2.0, mode="nearest"), wref, b, padding=1)
+        kw["upsample"] = 1
+    else:
+        want = F.conv2d(xin, wref, b, padding=ks // 2)
+    got = o.conv_gemm(x, wq, cout, **kw)
+    check("conv " + case, got.view(n, want.shape[2], want.shape[3], cout).permute(0, 3, 1, 2), want, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows", [77, 256, 1000])
+def test_linear_transposed_batched(dtype, rows):
+    B, K, N = 3, 128, 192
+    x, xf = q16(rnd(B, rows, K, seed=34), dtype)
+    w, wf = q16(rnd(N, K, seed=35) / K ** 0.5, dtype)
+    vt = ops().linear_t(x, w)
+    assert vt.shape[:2] == (B, N) and vt.shape[2] % 32 == 0 and vt.shape[2] >= rows
+    check("linear_t", vt[:, :, :rows], torch.einsum("nk,brk->bnr", wf, xf), TOL[dtype])
+
+
+# ------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v, H, scale, bias=None):
+    B, nq, Cq = q.shape
+    D = Cq // H
+    qh, kh, vh = (t.reshape(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) * scale
+    if bias is not None:
+        s = s + bias
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, nq, Cq)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 3, 64, 256, 256), (2, 2, 64, 200, 77), (1, 5, 64, 1024, 1024), (2, 4, 32, 128, 320), (1, 2, 32, 96, 50)])
+def test_attention(dtype, cfg):
+    B, H, D, nq, nk = cfg
+    Cq = H * D
+    q, qf = q16(rnd(B, nq, Cq, seed=36), dtype)
+    k, kf = q16(rnd(B, nk, Cq, seed=37), dtype)
+    v, vf = q16(rnd(B, nk, Cq, seed=38), dtype)
+    ld = ((nk + 31) // 32) * 32
+    vt = torch.full((B, Cq, ld), float("nan"), dtype=dtype, device=DEV)     # padding must never be read as data
+    vt[:, :, :nk] = v.transpose(1, 2)
+    out = ops().attention(q, k, vt, B, H, D, nq, nk, q_ld=Cq, k_ld=Cq, vt_ld=ld, q_bs=nq * Cq, k_bs=nk * Cq, vt_bs=Cq * ld)
+    check("attention", out, attn_ref(qf, kf, vf, H, D ** -0.5), 2.5 * TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_fused_qk_buffer_and_bias(dtype):
+    """EPA shape: q and k live in one (q|k) buffer; sparse-flagged additive bias shared over batch/heads."""
+    B, H, D, nq, nk = 2, 2, 32, 128, 256
+    Cq = H * D
+    qk_q, qkf_q = q16(rnd(B * nq, 2 * Cq, seed=39), dtype)
+    qk_k, qkf_k = q16(rnd(B * nk, 2 * Cq, seed=40), dtype)
+    v, vf = q16(rnd(B, nk, Cq, seed=41), dtype)
+    vt = v.transpose(1, 2).contiguous()
+    g = torch.Generator().manual_seed(42)
+    bias = torch.zeros(nq, nk)
+    for (i, j) in [(0, 0), (1, 3), (3, 7), (2, 2)]:                 # a few non-zero 32x32 tiles
+        bias[32 * i:32 * i + 32, 32 * j:32 * j + 32] = torch.rand(32, 32, generator=g) * 2 * (torch.rand(32, 32, generator=g) > 0.7)
+    flags = (bias.reshape(nq // 32, 32, nk // 32, 32).abs().amax((1, 3)) > 0).to(torch.uint8)
+    out = ops().attention(qk_q, qk_k[:, Cq:], vt, B, H, D, nq, nk, q_ld=2 * Cq, k_ld=2 * Cq, vt_ld=nk,
+                          q_bs=nq * 2 * Cq, k_bs=nk * 2 * Cq, vt_bs=Cq * nk, bias=bias.to(DEV), flags=flags.to(DEV))
+    want = attn_ref(qkf_q[:, :Cq].reshape(B, nq, Cq), qkf_k[:, Cq:].reshape(B, nk, Cq), vf, H, D ** -0.5, bias)
+    check("attention+bias", out, want, 2.5 * TOL[dtype])
+    # shift invariance used by the tables: bias and bias - 1 give the same result (models/pano/utils.py:72,76)
+    want2 = attn_ref(qkf_q[:, :Cq].reshape(B, nq, Cq), qkf_k[:, Cq:].reshape(B, nk, Cq), vf, H, D ** -0.5, bias - 1)
+    check("shift invariance", want, want2, 1e-5)
+
+
+def test_attention_online_softmax_rescale_branch():
+    """A key row that dominates late forces the running-max rescale (guide rule 26)."""
+    dtype = torch.float16
+    B, H, D, nq, nk = 1, 1, 64, 32, 256
+    q, qf = q16(rnd(B, nq, D, seed=43), dtype)
+    kk = rnd(B, nk, D, seed=44)
+    kk[0, 200] = qf[0, 5] * 3.0                                    # spike for query 5 at key tile 6
+    k, kf = q16(kk, dtype)
+    v, vf = q16(rnd(B, nk, D, seed=45), dtype)
+    vt = v.transpose(1, 2).contiguous()
+    out = ops().attention(q, k, vt, B, H, D, nq, nk, q_ld=D, k_ld=D, vt_ld=nk, q_bs=nq * D, k_bs=nk * D, vt_bs=D * nk, scale=1.0)
+    check("attention rescale", out, attn_ref(qf, kf, vf, H, 1.0), 2.5 * TOL[dtype])

@@ -1,0 +1,176 @@
+"""End-to-end parity of the HIP denoiser (through the reference's operator API) against the CPU
+oracle and the golden fixtures generated from the reference's own MultiViewBaseModel.
+
+Stated tolerances (rel-L2 on the epsilon outputs, fp32 oracle as truth):
+  * fp16 storage / fp32 accumulate : 4e-3   (the oracle itself, with every layer output rounded to
+    fp16, sits at 1.4e-3 -- DESIGN.md "numerics"; north_star's 1e-3 is the target, not yet met)
+  * bf16 storage / fp32 accumulate : 3e-2   (8 significand bits; same emulation gives 1.2e-2)
+Needs an MI355X: `-m gpu`."""
+import copy
+
+import pytest
+import torch
+
+from conftest import build_tiny_oracle, cam4, golden, rel_l2
+from oracle import ddim as oddim
+from oracle import mvgen as MV
+from oracle import sd2_unet as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = {torch.float16: 4e-3, torch.bfloat16: 3e-2}
+
+
+def hip_model_from(oracle_model, dtype):
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    m = MultiViewBaseModel(oracle_model.unet, oracle_model.pano_unet, None, None, oracle_model.pano_pad,
+                           compute_dtype=dtype)
+    if oracle_model.unet is not None:
+        sd = {k: v for k, v in oracle_model.state_dict().items() if k.startswith("cp_blocks")}
+        missing = m.load_state_dict(sd, strict=False)
+        assert not [k for k in missing.missing_keys if k.startswith("cp_blocks")]
+    return m
+
+
+def tiny_inputs():
+    g = golden("mvgen_tiny.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    return g, t("latents"), t("pano_latent"), t("prompt_embd"), t("pano_prompt_embd")
+
+
+@pytest.fixture(scope="module")
+def oracle_model():
+    return build_tiny_oracle()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_denoiser_vs_reference_golden(oracle_model, dtype):
+    g, lat, pl, pe, ppe = tiny_inputs()
+    model = hip_model_from(oracle_model, dtype)
+    cams = {k: torch.stack([v, v]) for k, v in cam4().items()}
+    t = torch.full((2, 4), 981, dtype=torch.long)
+    s, ps = model(lat.to(DEV), pl.to(DEV), t.to(DEV), pe.to(DEV), ppe.to(DEV), cams)
+    assert s.shape == (2, 4, 4, 16, 16) and ps.shape == (2, 1, 4, 16, 32) and s.dtype == torch.float32
+    es, ep = rel_l2(s.cpu(), torch.from_numpy(g["sample"])), rel_l2(ps.cpu(), torch.from_numpy(g["pano_sample"]))
+    print("rel-L2 %s: views %.3e pano %.3e" % (dtype, es, ep))
+    assert es <= TOL[dtype] and ep <= TOL[dtype], (es, ep)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16])
+def test_pano_only_call_shape(oracle_model, dtype):
+    """PanoOnly.py:13,39-41: unet=None, latents/cameras/prompt None, 1-D timestep."""
+    g, lat, pl, pe, ppe = tiny_inputs()
+    po = MV.DualBranchDenoiser(None, oracle_model.pano_unet)
+    model = hip_model_from(po, dtype)
+    s, ps = model(None, pl.to(DEV), torch.tensor([981, 981], device=DEV), None, ppe.to(DEV), None)
+    assert s is None
+    err = rel_l2(ps.cpu(), torch.from_numpy(golden("panoonly_tiny.npz")["pano_sample"]))
+    assert err <= TOL[dtype], err
+
+
+def test_unpadded_pano_branch(oracle_model):
+    """pano_pad=False (hparam unet_pad=False, PanoGenerator.py:72)."""
+    g, lat, pl, pe, ppe = tiny_inputs()
+    o = MV.DualBranchDenoiser(None, oracle_model.pano_unet, pano_pad=False)
+    with torch.no_grad():
+        _, want = o(None, pl, torch.tensor([981, 981]), None, ppe, None)
+    _, got = hip_model_from(o, torch.float16)(None, pl.to(DEV), torch.tensor([981, 981], device=DEV), None, ppe.to(DEV), None)
+    assert rel_l2(got.cpu(), want) <= TOL[torch.float16]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_warpattn_api_golden(dtype):
+    from panfusion_amd.models.pano import WarpAttn
+    g = golden("warpattn_c64.npz")
+    o = MV.EPABlock(64)
+    U.init_synthetic(o, 21)
+    MV.randomize_epa(o, 22)
+    w = WarpAttn(64, compute_dtype=dtype)
+    w.load_state_dict(o.state_dict())
+    cam8 = {k: torch.cat([v, v]) for k, v in cam4().items()}
+    po, eo = w(torch.from_numpy(g["pers_x"]).to(DEV), torch.from_numpy(g["equi_x"]).to(DEV), cam8)
+    ep, ee = rel_l2(po.cpu(), torch.from_numpy(g["pers_out"])), rel_l2(eo.cpu(), torch.from_numpy(g["equi_out"]))
+    print("WarpAttn rel-L2 %s: %.3e %.3e" % (dtype, ep, ee))
+    assert ep <= TOL[dtype] and ee <= TOL[dtype], (ep, ee)
+
+
+def test_warpattn_identity_at_init_and_per_sample_cameras():
+    from panfusion_amd.models.pano import WarpAttn
+    w = WarpAttn(64, compute_dtype=torch.float16)
+    px, ex = torch.randn(8, 64, 8, 8).half().float(), torch.randn(2, 64, 8, 16).half().float()
+    c = cam4()
+    # different cameras for the two batch elements -> per-sample tables
+    cams = {"FoV": torch.cat([c["FoV"], c["FoV"]]), "theta": torch.cat([c["theta"], c["theta"] + 33.0]),
+            "phi": torch.cat([c["phi"], c["phi"]])}
+    po, eo = w(px.to(DEV), ex.to(DEV), cams)
+    assert torch.equal(po.cpu(), px) and torch.equal(eo.cpu(), ex)        # zero-init projections: exact identity
+    o = MV.EPABlock(64)
+    U.init_synthetic(o, 31)
+    MV.randomize_epa(o, 32)
+    w.load_state_dict(o.state_dict())
+    with torch.no_grad():
+        wp, we = o(px, ex, cams)
+    po, eo = w(px.to(DEV), ex.to(DEV), cams)
+    assert rel_l2(po.cpu(), wp) <= TOL[torch.float16] and rel_l2(eo.cpu(), we) <= TOL[torch.float16]
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_three_ddim_steps_golden(oracle_model, graphs):
+    """The sampling-loop glue (roll, CFG pair/merge, DDIM, camera rotation) + 3 denoiser calls."""
+    from panfusion_amd.pipeline import DenoiseLoop
+    g, lat, pl, pe, ppe = tiny_inputs()
+    gd = golden("ddim3_tiny.npz")
+    model = hip_model_from(oracle_model, torch.float16)
+    cam1 = {k: v[None] for k, v in cam4().items()}
+    loop = DenoiseLoop(model, lat[:1].to(DEV), pl[:1].to(DEV), pe.to(DEV), ppe.to(DEV), cam1, steps=3, use_graphs=graphs)
+    l3, p3 = loop.run()
+    el, ep = rel_l2(l3.cpu(), torch.from_numpy(gd["latents"])), rel_l2(p3.cpu(), torch.from_numpy(gd["pano_latent"]))
+    print("3 DDIM steps rel-L2 (graphs=%s): %.3e %.3e" % (graphs, el, ep))
+    assert el <= 2e-2 and ep <= 2e-2, (el, ep)
+
+
+def test_graph_replay_equals_eager(oracle_model):
+    from panfusion_amd.pipeline import DenoiseLoop
+    g, lat, pl, pe, ppe = tiny_inputs()
+    model = hip_model_from(oracle_model, torch.bfloat16)
+    cam1 = {k: v[None] for k, v in cam4().items()}
+    outs = []
+    for graphs in (False, True):
+        loop = DenoiseLoop(model, lat[:1].to(DEV), pl[:1].to(DEV), pe.to(DEV), ppe.to(DEV), cam1, steps=6, use_graphs=graphs)
+        outs.append([x.cpu() for x in loop.run()])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_mid_size_model_vs_oracle():
+    """Wider than the fixtures (SD-2 head dim 64, 128..512 channels, 8 views of 32x32, 32x64 pano,
+    77 text tokens) -- the oracle runs on the host in a few seconds."""
+    cfg = dict(in_channels=4, out_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+               num_heads=(2, 4, 8, 8), cross_attention_dim=256, norm_num_groups=32,
+               cross_attn_blocks=(True, True, True, False))
+    unet, pano_unet = U.UNet2DConditionModel(**cfg), U.UNet2DConditionModel(**cfg)
+    unet.add_lora(4)
+    pano_unet.add_lora(4)
+    U.init_synthetic(unet, 41)
+    U.init_synthetic(pano_unet, 42)
+    o = MV.DualBranchDenoiser(unet, pano_unet)
+    for i, blk in enumerate([*o.cp_blocks_encoder, o.cp_blocks_mid, *o.cp_blocks_decoder]):
+        U.init_synthetic(blk, 50 + i)
+    MV.randomize_epa(o, 60)
+    gen = torch.Generator().manual_seed(61)
+    b, m = 2, 8
+    lat, pl = torch.randn(b, m, 4, 32, 32, generator=gen), torch.randn(b, 1, 4, 32, 64, generator=gen)
+    pe, ppe = torch.randn(b, m, 77, 256, generator=gen), torch.randn(b, 1, 77, 256, generator=gen)
+    from oracle import geometry as G
+    import numpy as np
+    th, ph = G.horizon_cameras(8)
+    cams = {"FoV": torch.full((b, m), 90), "theta": torch.tensor(np.degrees(th)).repeat(b, 1),
+            "phi": torch.tensor(np.degrees(ph) + 15.0).repeat(b, 1)}
+    t = torch.tensor([[500] * m, [500] * m])
+    with torch.no_grad():
+        ws, wp = o(lat, pl, t, pe, ppe, cams)
+    for dtype in (torch.float16, torch.bfloat16):
+        model = hip_model_from(o, dtype)
+        s, ps = model(lat.to(DEV), pl.to(DEV), t.to(DEV), pe.to(DEV), ppe.to(DEV), cams)
+        es, ep = rel_l2(s.cpu(), ws), rel_l2(ps.cpu(), wp)
+        print("mid-size rel-L2 %s: views %.3e pano %.3e" % (dtype, es, ep))
+        assert es <= TOL[dtype] and ep <= TOL[dtype], (dtype, es, ep)
