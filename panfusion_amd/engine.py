@@ -309,10 +309,66 @@ class EPATables:
         return hit
 
 
-def run_epa(e, tables, xp, xe, m):
+def _epa_tail(e, attn_out, x, Cc):
+    """to_out + residual, then LN2 -> GEGLU FF -> + residual (transformer.py:159-161)."""
+    y = ops.linear(attn_out.view(-1, Cc), e.wo, bias=e.bo, residual=x)
+    ln2 = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps)
+    g = ops.geglu(ops.linear(ln2, e.w_ff1, bias=e.b_ff1))
+    return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y)
+
+
+def run_epa_sharded(e, t, xp, xe, m, shard):
+    """EPA when this rank holds views [v0, v1) of the m (one CFG sample per rank, b == 1).
+    One all-gather of LN1(x_p + PE) inside the CFG half; K / V^T of all views are projected locally;
+    the panorama-query direction is computed redundantly (identical on every rank of the half)."""
+    from . import sharding
+    mloc, ph, pw, Cc = xp.shape
+    b, eh, ew, _ = xe.shape
+    if b != 1:
+        raise ValueError("sharded EPA expects one CFG sample per rank")
+    P, E = ph * pw, eh * ew
+    mP = m * P
+    v0, v1 = shard.views
+    r0, r1 = v0 * P, v1 * P
+    flags_p_loc = t.flags_p[r0 // 32:(r1 + 31) // 32]
+    if r0 % 32:
+        # view-group boundary inside a 32-row flag tile (only at toy sizes, P < 32): re-derive the tile
+        # map of the local rows from the table itself (one-off table preparation, not step arithmetic)
+        key = ("flags_p_loc", r0, r1)
+        if key not in t.__dict__:
+            rows = t.bias_p[r0:r1]
+            pad = torch.nn.functional.pad(rows, (0, (-E) % 32, 0, (-(r1 - r0)) % 32))
+            t.__dict__[key] = (pad.reshape(pad.shape[0] // 32, 32, pad.shape[1] // 32, 32).abs().amax((1, 3)) > 0) \
+                .to(torch.uint8).contiguous()
+        flags_p_loc = t.__dict__[key]
+    tp, te = xp.view(mloc * P, Cc), xe.view(E, Cc)
+    lnp_loc = ops.layernorm(tp, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_p[r0:r1])
+    lne = ops.layernorm(te, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_e)
+    lnp = sharding.gather_view_tokens(lnp_loc, shard)                       # [mP, C]
+    qk_p, qk_e = ops.linear(lnp, e.wqk), ops.linear(lne, e.wqk)
+    vt_p = ops.linear_t(lnp.view(1, mP, Cc), e.wv)
+    vt_e = ops.linear_t(lne.view(1, E, Cc), e.wv)
+    ld = 2 * Cc
+    a_e = ops.attention(qk_e, qk_p[:, Cc:], vt_p, 1, e.heads, 32, E, mP, q_ld=ld, k_ld=ld, vt_ld=vt_p.shape[-1],
+                        q_bs=E * ld, k_bs=mP * ld, vt_bs=vt_p.shape[1] * vt_p.shape[2],
+                        bias=t.bias_e, flags=t.flags_e)
+    out_e = _epa_tail(e, a_e, te, Cc)
+    nq = mloc * P
+    a_p = ops.attention(qk_p[r0:r1], qk_e[:, Cc:], vt_e, 1, e.heads, 32, nq, E, q_ld=ld, k_ld=ld,
+                        vt_ld=vt_e.shape[-1], q_bs=nq * ld, k_bs=E * ld, vt_bs=vt_e.shape[1] * vt_e.shape[2],
+                        bias=t.bias_p[r0:r1], flags=flags_p_loc)
+    out_p = _epa_tail(e, a_p, tp, Cc)
+    return out_p.view(mloc, ph, pw, Cc), out_e.view(1, eh, ew, Cc)
+
+
+def run_epa(e, tables, xp, xe, m, shard=None):
     """EPA fusion (modules.py:15-59) on NHWC activations.
     xp [b*m, ph, pw, C], xe [b, eh, ew, C]; tables: list with one EPATables entry per batch
     element (or a single shared entry)."""
+    if shard is not None:
+        if len(tables) != 1:
+            raise ValueError("sharded EPA needs one camera set")
+        return run_epa_sharded(e, tables[0], xp, xe, m, shard)
     bm, ph, pw, Cc = xp.shape
     b, eh, ew, _ = xe.shape
     P, E = ph * pw, eh * ew

@@ -72,10 +72,13 @@ class MultiViewBaseModel(nn.Module):
         dt = self.compute_dtype
         two = self.unet is not None
         branches = []
-        if two:
+        shard = getattr(self, "shard", None)      # set by sharding.ShardedDenoiseLoop: latents hold only
+        if two:                                   # this rank's views, cameras all m of them
             b, m = latents.shape[:2]
             flat_cams = {k: v.reshape(-1) for k, v in cameras.items()}
-            _, groups = camera_groups(flat_cams, b)
+            m_total, groups = camera_groups(flat_cams, b)
+            if shard is None and m_total != m:
+                raise ValueError("cameras describe %d views but latents hold %d" % (m_total, m))
             pers = engine.Branch(self.packed("unet", dev), latents.flatten(0, 1), timestep.reshape(-1),
                                  prompt_embd.flatten(0, 1).to(dt).contiguous(), pano=False, pad=False)
             pano_t = timestep[:, 0]
@@ -87,7 +90,7 @@ class MultiViewBaseModel(nn.Module):
         branches.append(pano)
 
         def fuse(block):
-            pers.h, pano.h = block.forward_nhwc(pers.h, pano.h, groups, m)
+            pers.h, pano.h = block.forward_nhwc(pers.h, pano.h, groups, m_total, shard=shard)
 
         pu = pano.u
         # encoder (reference :98-152): EPA after each downsample

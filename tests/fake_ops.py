@@ -1,0 +1,243 @@
+"""CPU test double for ``panfusion_amd.ops`` (TEST INFRASTRUCTURE, never shipped).
+
+Implements every entry of the ops front end with plain fp32 torch math on CPU tensors, honouring
+the same calling conventions (views, leading dimensions, out= buffers).  It lets the CPU suite
+exercise the HOST logic of the product -- layer sequencing, skip/pad/crop bookkeeping, weight
+packing, sharding and collectives over gloo -- without a GPU.  It is not a fallback: the product
+never imports it, and nothing here is measured.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import geometry as G
+
+TRACE = None
+
+
+def dt(t):
+    return {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[t.dtype if isinstance(t, torch.Tensor) else t]
+
+
+def _cams(fov, theta, phi):
+    host = lambda v: np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float64).reshape(-1)
+    f, t, p = host(fov), host(theta), host(phi)
+    n = max(len(f), len(t), len(p))
+    return [np.broadcast_to(a, (n,)) for a in (f, t, p)]
+
+
+def e2p_grid(fov, theta, phi, eh, ew, h, w, device, want_lonlat=False):
+    f, t, p = _cams(fov, theta, phi)
+    maps = [G.e2p_grid(eh, ew, f[i], t[i], p[i], h, w) for i in range(len(f))]
+    mx = torch.tensor(np.stack([m[0] for m in maps]), dtype=torch.float32)
+    my = torch.tensor(np.stack([m[1] for m in maps]), dtype=torch.float32)
+    if not want_lonlat:
+        return mx, my
+    ll = [np.stack(G.pers_lonlat(f[i], t[i], p[i], h, w), -1) for i in range(len(f))]
+    return mx, my, torch.tensor(np.stack(ll), dtype=torch.float32)
+
+
+def p2e_grid(fov, theta, phi, ph, pw, h, w, device):
+    f, t, p = _cams(fov, theta, phi)
+    maps = [G.p2e_grid(ph, pw, f[i], t[i], p[i], h, w) for i in range(len(f))]
+    tt = lambda k, d: torch.tensor(np.stack([m[k] for m in maps]), dtype=d)
+    return tt(0, torch.float32), tt(1, torch.float32), tt(2, torch.uint8)
+
+
+def remap(src, map_x, map_y, mode, mask=None):
+    from oracle import third_party as tp
+    out = tp.remap(src.float(), map_x, map_y, align_corners=True, mode=mode)
+    if mask is not None:
+        out = out * mask.unsqueeze(1)
+    return out.to(src.dtype)
+
+
+def equi_coords(H, W, device):
+    lon, lat = np.linspace(-np.pi, np.pi, W), np.linspace(np.pi / 2, -np.pi / 2, H)
+    return torch.tensor(np.stack(np.broadcast_arrays(lon[None, :], lat[:, None]), -1), dtype=torch.float32)
+
+
+def spherical_pe(coords, freq_bands):
+    return G.spherical_pe(coords, freq_bands)
+
+
+def epa_tables(fov, theta, phi, ph, pw, eh, ew, device):
+    f, t, p = _cams(fov, theta, phi)
+    cams = {"FoV": torch.tensor(f), "theta": torch.tensor(t), "phi": torch.tensor(p)}
+    pm, em = G.get_masks(ph, pw, eh, ew, cams)
+    m, E, P = len(f), eh * ew, ph * pw
+    bias_e = (pm.reshape(m, E, P).permute(1, 0, 2).reshape(E, m * P) + 1).contiguous()
+    bias_p = (em.reshape(m * P, E) + 1).contiguous()
+
+    def flags(b):
+        nq, nk = b.shape
+        pad = F.pad(b, (0, (-nk) % 32, 0, (-nq) % 32))
+        return (pad.reshape(pad.shape[0] // 32, 32, pad.shape[1] // 32, 32).abs().amax((1, 3)) > 0).to(torch.uint8)
+    return bias_e, bias_p, flags(bias_e), flags(bias_p)
+
+
+def _cat(x0, x1):
+    return x0 if x1 is None else torch.cat([x0, x1], -1)
+
+
+def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
+    x = _cat(x0, x1).float().reshape(n_img, hw, -1)
+    C = x.shape[-1]
+    xg = x.reshape(n_img, hw, groups, C // groups)
+    mean = xg.mean((1, 3))
+    var = xg.var((1, 3), unbiased=False)
+    rstd = (var + eps).rsqrt()
+    scale = rstd.repeat_interleave(C // groups, 1) * gamma
+    shift = beta - mean.repeat_interleave(C // groups, 1) * scale
+    return scale, shift
+
+
+def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None):
+    x = _cat(x0, x1).float().reshape(n_img, hw, -1)
+    y = x * scale[:, None] + shift[:, None]
+    y = F.silu(y) if act else y
+    return y.to(x0.dtype)
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pe=None, out=None):
+    v = x.float()
+    if pe is not None:
+        v = v + pe.repeat(x.shape[0] // pe.shape[0], 1)
+    y = F.layer_norm(v, (x.shape[-1],), gamma, beta, eps).to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def geglu(x, out=None):
+    a, g = x.float().chunk(2, -1)
+    return (a * F.gelu(g)).to(x.dtype)
+
+
+def timestep_features(t, dim, dtype):
+    half = dim // 2
+    e = (-9.210340371976184 * torch.arange(half, dtype=torch.float32)) / half
+    arg = t.float()[:, None] * torch.exp(e)[None]
+    return torch.cat([torch.cos(arg), torch.sin(arg)], -1).to(dtype)
+
+
+def silu(x, out=None):
+    return F.silu(x.float()).to(x.dtype)
+
+
+def add(a, b, out=None):
+    return a + b
+
+
+def pad_width(x, pad, out=None):
+    return torch.cat([x[:, :, -pad:], x, x[:, :, :pad]], 2).contiguous()
+
+
+def crop_width(x, crop, out=None):
+    return x[:, :, crop:-crop].contiguous()
+
+
+def pad_width_rows(x, pad):
+    return torch.cat([x[..., -pad:], x, x[..., :pad]], -1).contiguous()
+
+
+def roll_width(x, shift, out=None):
+    y = torch.roll(x, shift, -1)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def nchw_to_nhwc(x, dtype, out=None):
+    return x.permute(0, 2, 3, 1).to(dtype).contiguous()
+
+
+def nhwc_to_nchw(x, dtype, out=None):
+    return x.permute(0, 3, 1, 2).to(dtype).contiguous()
+
+
+def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
+    sa, sb, sap, sbp = coef
+    eps = eps_uncond + guidance * (eps_cond - eps_uncond)
+    y = torch.roll(sap * ((x - sb * eps) / sa) + sbp * eps, roll, -1)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
+              bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, **kw):
+    assert batch == 1
+    c0 = a0.shape[-1]
+    x = a0.float().reshape(-1, c0)
+    if a1 is not None:
+        x = torch.cat([x, a1.float().reshape(-1, a1.shape[-1])], -1)
+    C = x.shape[-1]
+    if w_in is None:
+        w_in = x.shape[0]
+    x = x.reshape(n_img, h_in, w_in, C).permute(0, 3, 1, 2)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    wt = w.float().reshape(n_out, ksize, ksize, C).permute(0, 3, 1, 2)
+    y = F.conv2d(x, wt, None if bias is None else bias.float(), stride=stride, padding=pad)
+    ho, wo = y.shape[2:]
+    y = y.permute(0, 2, 3, 1).reshape(n_img * ho * wo, n_out)
+    if rowvec is not None:
+        y = y + rowvec[:, :n_out].float().repeat_interleave(ho * wo, 0)
+    if residual is not None:
+        y = y + residual.float().reshape(-1, residual.shape[-1])[:, :n_out]
+    y = y.to(out_dtype or a0.dtype)
+    if out is not None:
+        out.copy_(y.reshape(out.shape))
+        return out
+    return y
+
+
+def linear(x, w, bias=None, residual=None, out=None, out_dtype=None):
+    return conv_gemm(x, w, w.shape[0], w_in=x.shape[0], bias=bias, residual=residual, out=out, out_dtype=out_dtype)
+
+
+def linear_t(x, w, out=None, ld=None):
+    B, rows, K = x.shape
+    ld = ld or ((rows + 31) // 32) * 32
+    y = torch.full((B, w.shape[0], ld), float("nan"), dtype=x.dtype)     # padding must never be consumed
+    y[:, :, :rows] = torch.einsum("nk,brk->bnr", w.float(), x.float()).to(x.dtype)
+    return y
+
+
+def conv_in(x, wgt, bias, cout, dtype, wrap=False, out=None):
+    w = wgt.permute(3, 2, 0, 1)
+    if wrap:
+        y = F.conv2d(G.pad_pano(x.float(), 1), w, bias, padding=1)[..., 1:-1]
+    else:
+        y = F.conv2d(x.float(), w, bias, padding=1)
+    return y.permute(0, 2, 3, 1).to(dtype).contiguous()
+
+
+def conv_out(x, wgt, bias, cout, wrap=False, out=None):
+    xi = x.float().permute(0, 3, 1, 2)
+    w = wgt.permute(0, 3, 1, 2)
+    if wrap:
+        return F.conv2d(G.pad_pano(xi, 1), w, bias, padding=1)[..., 1:-1].contiguous()
+    return F.conv2d(xi, w, bias, padding=1)
+
+
+def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, k_bs, vt_bs, o_bs=None,
+              scale=None, bias=None, flags=None, out=None):
+    C = H * D
+    qh = q.float().reshape(-1, q.shape[-1])[:B * nq, :C].reshape(B, nq, H, D).transpose(1, 2)
+    kh = k.float().reshape(-1, k.shape[-1])[:B * nk, :C].reshape(B, nk, H, D).transpose(1, 2)
+    v = vt.float().reshape(B, C, -1)[:, :, :nk].reshape(B, H, D, nk).transpose(2, 3)
+    s = qh @ kh.transpose(-1, -2) * (scale if scale is not None else D ** -0.5)
+    if bias is not None:
+        tiles = flags.bool().repeat_interleave(32, 0).repeat_interleave(32, 1)[:nq, :nk]
+        assert not bool((bias[:nq, :nk].ne(0) & ~tiles).any()), "non-zero bias outside flagged tiles"
+        s = s + bias[:nq, :nk]
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, nq, C).to(q.dtype)
+    if out is not None:
+        out.copy_(o.reshape(out.shape))
+        return out
+    return o
