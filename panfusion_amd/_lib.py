@@ -106,6 +106,9 @@ def lib():
         raise PanFusionHipError(
             "HIP extension %s not built; run `make -C panfusion_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+    # Load torch FIRST: the PyTorch-ROCm wheel ships its own HIP runtime (libamdhip64); the library
+    # must resolve to that same runtime instance, or its launches see "no ROCm-capable device".
+    import torch  # noqa: F401
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)      # AttributeError if a declared symbol is missing

@@ -36,6 +36,11 @@ class WarpAttn(nn.Module):
     def repack(self):
         self._packed = None
 
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.repack()                      # packed 16-bit copies are stale now
+        return out
+
     def tables_for(self, groups, ph, pw, eh, ew, device):
         e = self.packed(device)
         uniq = [groups[0]] if all(g == groups[0] for g in groups) else groups

@@ -37,6 +37,7 @@ class _LoRALinear(nn.Linear):
 
 def _resnet(cin, cout, temb, groups):
     r = _Holder()
+    r.in_channels, r.out_channels = cin, cout
     r.norm1 = nn.GroupNorm(groups, cin, eps=1e-5)
     r.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
     r.time_emb_proj = nn.Linear(temb, cout)
