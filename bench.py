@@ -68,7 +68,7 @@ def cpu_baseline(cfg, ctx_dim, lat_hw, flop_per_step):
     SD-2-base UNet (1/40 of the view-branch work of a step), scaled to a whole step by FLOPs."""
     import torch
     from oracle import sd2_unet as U
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     with torch.device("meta"):
         unet = U.UNet2DConditionModel(**cfg)
@@ -76,20 +76,45 @@ def cpu_baseline(cfg, ctx_dim, lat_hw, flop_per_step):
     with torch.no_grad():
         for p in unet.parameters():
             p.normal_(0.0, 0.02)
-        x = torch.randn(1, 4, *lat_hw)
         txt = torch.randn(1, 77, ctx_dim)
         t = torch.tensor([981])
-        unet(x, t, txt)                              # warm-up (thread pools, allocator)
-        t0 = time.perf_counter()
-        unet(x, t, txt)
-        dt = time.perf_counter() - t0
-    sample_flop = 804.3e9 * (lat_hw[0] * lat_hw[1]) / (64 * 64)     # per 64x64 view sample
+
+        def timed(hw):
+            x = torch.randn(1, 4, *hw)
+            t0 = time.perf_counter()
+            unet(x, t, txt)
+            return time.perf_counter() - t0
+
+        small = (lat_hw[0] // 2, lat_hw[1] // 2)
+        timed((8, 8))                                # warm-up (thread pool, allocator, weights paged in)
+        hw, dt = small, timed(small)                 # quarter-size view sample first ...
+        if dt < 6.0:                                 # ... the full one only if it fits the time budget
+            hw, dt = lat_hw, timed(lat_hw)
+    # 804.3 GFLOP per 64x64 view sample; self-attention grows quadratically, the rest
+    # linearly, so the quarter-size sample is priced with its own count (conv+linear 169.6, attention 8.6 GF)
+    sample_flop = 804.3e9 if hw == tuple(lat_hw) else 178.1e9
     est_step_s = dt * flop_per_step / sample_flop
     return {"value": 1.0 / est_step_s, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "oracle SD-2-base UNet forward of 1 of the 40 view samples (%.2f TFLOP) in %.2f s, "
-                      "scaled by FLOPs to one %.2f-TFLOP step; EPA host-side mask building of the "
-                      "reference (~7 s per block on 8 cores, SURVEY.md §3C) not included"
-                      % (sample_flop / 1e12, dt, flop_per_step / 1e12)}
+            "sample": "oracle SD-2-base UNet forward (fp32, %d threads) of ONE view sample at %dx%d latent "
+                      "(%.3f TFLOP) in %.2f s, scaled by FLOPs to one %.2f-TFLOP step; the reference's host-side "
+                      "EPA mask building (~7 s per block on 8 cores, SURVEY.md §3C) is not included"
+                      % (cores, hw[0], hw[1], sample_flop / 1e12, dt, flop_per_step / 1e12)}
+
+
+def usable_cores():
+    """Host cores this process may actually use (affinity mask and cgroup CPU quota), capped at 64:
+    the oracle's small-batch fp32 kernels do not scale past that."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
 
 
 def main():

@@ -19,6 +19,7 @@
 // diffusers AttnProcessor (baddbmm + softmax + bmm) inside unet.*.attentions[j]
 // (models/pano/MVGenModel.py:104,116,185,190,227,241).
 #include "pf_common.h"
+#include <stdlib.h>
 
 namespace pf {
 
@@ -191,6 +192,207 @@ __global__ __launch_bounds__(256) void k_attention(const AttnParams p) {
     }
 }
 
+// ---- LDS-staged variant (default) ----------------------------------------------------------------
+// Same math and register layout as k_attention, but the K tile [64 keys][D] and the V^T tile
+// [D][64 keys] of a step are fetched ONCE per workgroup with coalesced 16-byte loads (a key row /
+// 8 keys of a V^T row per lane), staged through LDS and shared by the 4 wavefronts; double buffered
+// with the next tile's global loads in flight during the MFMAs (one barrier per 64 keys).  The direct
+// variant issues fragment-shaped loads (32 different cache lines per instruction) from every wave.
+//   K rows are 2*D bytes; the 16-B chunk index is XOR-swizzled so ds_read_b128 fragment reads are
+//   conflict free (128-B rows: ^(row>>1)&7, 64-B rows: ^(row>>2)&3).
+//   V^T rows are padded to 136 B (34 banks): the 32 d-rows read by a half-wave with ds_read_b64 hit
+//   distinct bank pairs.
+// One online-softmax update per 64 keys.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_attention_lds(const AttnParams p) {
+    constexpr int KS = D / 16, DB = D / 32, KT = 64;
+    constexpr int KCHUNKS = D / 8;                     // 16-B chunks per K row
+    constexpr int VROW = KT + 4;                       // elements per padded V^T row (136 B)
+    constexpr int K_ELEMS = KT * D, V_ELEMS = D * VROW;
+    constexpr int KCH = KT * KCHUNKS / 256, VCH = D * (KT / 8) / 256;
+    typedef typename Mfma32<T>::frag frag;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (K_ELEMS + V_ELEMS)];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ql = lane & 31, hi = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int h = blockIdx.y;
+    const long b = blockIdx.z;
+    const unsigned short* qp = p.q + b * p.q_bs + h * D;
+    const unsigned short* kp = p.k + b * p.k_bs + h * D;
+    const unsigned short* vp = p.vt + b * p.vt_bs + static_cast<long>(h) * D * p.vt_ld;
+    const int qrow = min(q0 + ql, p.nq - 1);
+
+    frag qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        qf[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(qp + static_cast<long>(qrow) * p.q_ld + 16 * s + 8 * hi));
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    auto k_off = [](int row, int chunk) {
+        const int sw = (KCHUNKS == 8) ? ((row >> 1) & 7) : ((row >> 2) & 3);
+        return row * D + ((chunk ^ sw) << 3);
+    };
+
+    const int nkt = (p.nk + KT - 1) / KT;
+    u16x8 kreg[KCH], vreg[VCH];
+    auto stage_load = [&](int j) {
+        const int k0 = j * KT;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = t + 256 * i, row = c / KCHUNKS, chunk = c % KCHUNKS;
+            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (k0 + row < p.nk) v = *reinterpret_cast<const u16x8*>(kp + static_cast<long>(k0 + row) * p.k_ld + chunk * 8);
+            kreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int c = t + 256 * i, d = c >> 3, key0 = k0 + (c & 7) * 8;
+            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (key0 + 8 <= p.vt_ld) v = *reinterpret_cast<const u16x8*>(vp + static_cast<long>(d) * p.vt_ld + key0);
+            if (k0 + KT > p.nk) {                      // tail tile: padding of V^T may hold anything (0 * NaN = NaN)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (key0 + e >= p.nk) v[e] = 0;
+            }
+            vreg[i] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+        unsigned short* Ks = smem + buf * (K_ELEMS + V_ELEMS);
+        unsigned short* Vs = Ks + K_ELEMS;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = t + 256 * i;
+            *reinterpret_cast<u16x8*>(Ks + k_off(c / KCHUNKS, c % KCHUNKS)) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int c = t + 256 * i;
+            unsigned short* dst = Vs + (c >> 3) * VROW + (c & 7) * 8;     // 8-byte aligned (136-B rows)
+            const u16x8 v = vreg[i];
+            *reinterpret_cast<u16x4*>(dst) = u16x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<u16x4*>(dst + 4) = u16x4{v[4], v[5], v[6], v[7]};
+        }
+    };
+
+    const uint8_t* flag_row = p.flags ? p.flags + static_cast<long>(min(q0, p.nq - 1) >> 5) * p.flags_ld : nullptr;
+    const float* bias_row = p.bias ? p.bias + static_cast<long>(qrow) * p.bias_ld : nullptr;
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int j = 0; j < nkt; ++j) {
+        if (j + 1 < nkt) stage_load(j + 1);
+        const int k0 = j * KT;
+        const unsigned short* Ks = smem + (j & 1) * (K_ELEMS + V_ELEMS);
+        const unsigned short* Vs = Ks + K_ELEMS;
+
+        float sv[2][16];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u16x8 kf = *reinterpret_cast<const u16x8*>(Ks + k_off(hh * 32 + ql, 2 * ks + hi));
+                s = Mfma32<T>::run(__builtin_bit_cast(frag, kf), qf[ks], s);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[hh][r] = s[r] * p.scale_log2e;
+            const int kb = k0 + hh * 32;
+            if (flag_row && kb < p.nk && flag_row[kb >> 5]) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int key = kb + 8 * g + 4 * hi;
+                    if (key + 3 < p.nk) {
+                        const float4 bv = *reinterpret_cast<const float4*>(bias_row + key);
+                        sv[hh][4 * g + 0] += bv.x * 1.44269504088896340736f;
+                        sv[hh][4 * g + 1] += bv.y * 1.44269504088896340736f;
+                        sv[hh][4 * g + 2] += bv.z * 1.44269504088896340736f;
+                        sv[hh][4 * g + 3] += bv.w * 1.44269504088896340736f;
+                    }
+                }
+            }
+            if (kb + 32 > p.nk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.nk) sv[hh][r] = -INFINITY;
+            }
+        }
+        float mt = sv[0][0];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sv[hh][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sv[hh][r] = __builtin_amdgcn_exp2f(sv[hh][r] - m_new);
+                ls += sv[hh][r];
+            }
+        ls += __shfl_xor(ls, 32);
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u16x8 pb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[e] = from_f32<T>(sv[hh][8 * s2 + e]);
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const unsigned short* vrow = Vs + (d * 32 + ql) * VROW + hh * 32 + 16 * s2 + 4 * hi;
+                    const u16x4 lo = *reinterpret_cast<const u16x4*>(vrow);
+                    const u16x4 up = *reinterpret_cast<const u16x4*>(vrow + 8);
+                    const u16x8 vf = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+                    o[d] = Mfma32<T>::run(__builtin_bit_cast(frag, vf), __builtin_bit_cast(frag, pb), o[d]);
+                }
+            }
+
+        if (j + 1 < nkt) stage_store((j + 1) & 1);
+        __syncthreads();
+    }
+
+    if (q0 + ql < p.nq) {
+        const float inv = 1.0f / l_run;
+        unsigned short* op = p.out + b * p.o_bs + static_cast<long>(q0 + ql) * p.o_ld + h * D;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u16x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(o[d][4 * g + e] * inv);
+                *reinterpret_cast<u16x4*>(op + d * 32 + 8 * g + 4 * hi) = w;
+            }
+    }
+}
+
+static bool use_lds_attention() {
+    static int v = -1;                     // PF_ATTENTION_IMPL=direct selects the no-LDS kernel (A/B switch)
+    if (v < 0) { const char* e = getenv("PF_ATTENTION_IMPL"); v = (e && e[0] == 'd') ? 0 : 1; }
+    return v == 1;
+}
+
 }  // namespace pf
 
 using namespace pf;
@@ -220,9 +422,15 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     p.bias = d->bias; p.bias_ld = d->bias_ld; p.flags = d->flags; p.flags_ld = d->flags_ld;
     dim3 grid(cdiv(d->nq, 128), d->H, d->B), block(256);
     hipStream_t st = as_stream(stream);
+    const bool lds = use_lds_attention() && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0;
     PF_DISPATCH_16(d->dtype, "pf_attention",
-        if (d->D == 64) hipLaunchKernelGGL((k_attention<T, 64>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((k_attention<T, 32>), grid, block, 0, st, p));
+        if (lds) {
+            if (d->D == 64) hipLaunchKernelGGL((k_attention_lds<T, 64>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((k_attention_lds<T, 32>), grid, block, 0, st, p);
+        } else {
+            if (d->D == 64) hipLaunchKernelGGL((k_attention<T, 64>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((k_attention<T, 32>), grid, block, 0, st, p);
+        });
     PF_CHECK_LAUNCH("pf_attention");
     return PF_OK;
 }

@@ -53,10 +53,10 @@ template <> __device__ __forceinline__ float to_f32<F16>(unsigned short v) {
 
 template <typename T> __device__ __forceinline__ unsigned short from_f32(float f);
 template <> __device__ __forceinline__ unsigned short from_f32<Bf16>(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);   // round to nearest even
-    return static_cast<unsigned short>(u >> 16);
+    __bf16 b = static_cast<__bf16>(f);   // v_cvt_pk_bf16_f32 on gfx950, round to nearest even
+    unsigned short v;
+    __builtin_memcpy(&v, &b, 2);
+    return v;
 }
 template <> __device__ __forceinline__ unsigned short from_f32<F16>(float f) {
     _Float16 h = static_cast<_Float16>(f);   // v_cvt_f16_f32, RNE

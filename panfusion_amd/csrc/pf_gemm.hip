@@ -19,6 +19,7 @@
 // Replaces cuDNN / cuBLAS behind diffusers Conv2d / Linear (reference call sites
 // models/pano/MVGenModel.py:86-144,174-198,224-294; models/modules/transformer.py:8-74).
 #include "pf_common.h"
+#include <stdlib.h>
 
 namespace pf {
 
@@ -35,6 +36,7 @@ struct GemmParams {
     void* out; int out_ld; int out_f32;
     long a_bs, w_bs, out_bs, res_bs;
     int mtiles, ntiles;
+    const unsigned short* zeros;   // >= 16 zero bytes in global memory (source of padded rows, DMA staging)
 };
 
 template <typename T> struct Mfma;
@@ -55,7 +57,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // in 16-bit elem
     return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-template <typename T, int MREP, int NREP>
+template <typename T, int MREP, int NREP, bool DMA>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -133,6 +135,42 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
             *reinterpret_cast<u16x8*>(Bs + buf * BN * 64 + lds_off(j * 32 + lrow, chunk)) = rb[j];
     };
 
+    // DMA staging: global_load_lds_dwordx4 writes LDS at (wave-uniform base + 16 * lane), i.e. lane l of
+    // wave w fills physical chunk l%8 of row 8w + l/8 of the pass -- exactly the register path's
+    // (lrow, chunk) ownership.  The XOR swizzle therefore moves to the SOURCE address: the lane fetches
+    // the logical chunk that belongs in its physical slot (same 128-B row segment, coalescing intact).
+    // Zero-padded taps / ragged rows read a 16-byte page of zeros.
+    auto dma_stage = [&](int kb, int buf) {
+        const int kg = kb * 64;
+        const int tap = kg / Ctot, cc = kg % Ctot;
+        const int ky = tap / p.ksize, kx = tap % p.ksize;
+        const unsigned short* src;
+        int ld, coff;
+        if (cc < p.c0) { src = a0; ld = p.a0_ld; coff = cc; } else { src = a1; ld = p.a1_ld; coff = cc - p.c0; }
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            const int row = i * 32 + lrow;
+            const int lchunk = chunk ^ ((row >> 1) & 7);
+            const int yi = a_y[i] + ky, xi = a_x[i] + kx;
+            const bool ok = a_ok[i] && yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
+            const long pix = (static_cast<long>(a_img[i]) * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up);
+            const unsigned short* g = ok ? src + pix * ld + coff + lchunk * 8 : p.zeros;
+            unsigned short* dst = As + buf * BM * 64 + (i * 32 + wave * 8) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const int row = j * 32 + lrow;
+            const int lchunk = chunk ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            const unsigned short* g = n < p.N ? wg + static_cast<long>(n) * p.K + kg + lchunk * 8 : p.zeros;
+            unsigned short* dst = Bs + buf * BN * 64 + (j * 32 + wave * 8) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
     f32x4 acc[MREP][NREP];
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
@@ -171,14 +209,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     };
 
     const int nkb = p.K / 64;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kb = 0; kb < nkb; ++kb) {
-        if (kb + 1 < nkb) gload(kb + 1);
-        compute(kb & 1);
-        if (kb + 1 < nkb) lstore((kb + 1) & 1);
+    if constexpr (DMA) {
+        dma_stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int kb = 0; kb < nkb; ++kb) {
+            if (kb + 1 < nkb) dma_stage(kb + 1, (kb + 1) & 1);   // in flight during the MFMAs
+            compute(kb & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's DMA has landed ...
+            __syncthreads();                                      // ... before anyone reads the tile
+        }
+    } else {
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int kb = 0; kb < nkb; ++kb) {
+            if (kb + 1 < nkb) gload(kb + 1);
+            compute(kb & 1);
+            if (kb + 1 < nkb) lstore((kb + 1) & 1);
+            __syncthreads();
+        }
     }
 
     // epilogue: lane holds out[m][n4 .. n4+3], m = lane&15, n4 = 4*(lane>>4)
@@ -220,8 +270,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     }
 }
 
-template <typename T, int MREP, int NREP>
-static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
+static const unsigned short* zero_page() {
+    static unsigned short* z = nullptr;          // 256 zero bytes, created on the first launch (before any capture)
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 256);
+    }
+    return z;
+}
+
+static bool use_dma() {
+    static int v = -1;                           // PF_GEMM_STAGING=reg selects register staging (A/B switch)
+    if (v < 0) { const char* e = getenv("PF_GEMM_STAGING"); v = (e && e[0] == 'r') ? 0 : 1; }
+    return v == 1;
+}
+
+template <typename T, int MREP, int NREP, bool DMA>
+static pf_status launch_impl(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     GemmParams p = gp;
     p.mtiles = static_cast<int>(cdiv(p.M, BM));
@@ -229,13 +294,24 @@ static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     const size_t smem = static_cast<size_t>(2) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP, DMA>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP>), dim3(p.mtiles * p.ntiles, 1, batch), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP, DMA>), dim3(p.mtiles * p.ntiles, 1, batch), dim3(256), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm");
     return PF_OK;
+}
+
+template <typename T, int MREP, int NREP>
+static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
+    if (use_dma()) {
+        GemmParams p = gp;
+        p.zeros = zero_page();
+        PF_REQUIRE(p.zeros, "pf_conv_gemm: zero page allocation failed");
+        return launch_impl<T, MREP, NREP, true>(p, batch, st);
+    }
+    return launch_impl<T, MREP, NREP, false>(gp, batch, st);
 }
 
 }  // namespace pf
@@ -287,6 +363,7 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     p.out = d->out; p.out_ld = d->out_ld; p.out_f32 = d->out_dtype == PF_F32;
     p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;
     p.mtiles = p.ntiles = 0;
+    p.zeros = nullptr;
     hipStream_t st = as_stream(stream);
     // Tile choice: 160-wide N tiles when they divide N exactly (all UNet widths are multiples of
     // 160), 128-wide otherwise; 64-row M tiles when 128-row tiles would not fill the 256 CUs.
