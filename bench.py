@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace-out", default=None, help="write the per-shape table of the instrumented step here")
     ap.add_argument("--small", action="store_true", help="reduced widths/sizes (debug only, not the metric)")
     args = ap.parse_args()
 
@@ -190,11 +191,21 @@ def main():
     torch.cuda.synchronize()
     ops.TRACE = None
     fam = {}
-    for name, flops, e0, e1 in trace:
+    shapes = {}
+    for name, flops, e0, e1, tag in trace:
+        sec = e0.elapsed_time(e1) * 1e-3
         f = fam.setdefault(name, [0.0, 0.0, 0])
         f[0] += flops
-        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[1] += sec
         f[2] += 1
+        g = shapes.setdefault(name + " " + tag, [0.0, 0.0, 0])
+        g[0] += flops
+        g[1] += sec
+        g[2] += 1
+    if args.trace_out and rank == 0:
+        with open(args.trace_out, "w") as fh:
+            for k, (fl, sec, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                fh.write("%-60s launches %3d  ms %8.3f  TF/s %7.1f\n" % (k, n, sec * 1e3, fl / sec / 1e12))
     dom = max(fam, key=lambda k: fam[k][1]) if fam else None
     roofline = None
     if dom:

@@ -19,14 +19,14 @@ _DT = {torch.bfloat16: PF_BF16, torch.float16: PF_F16, torch.float32: PF_F32}
 TRACE = None
 
 
-def _traced(name, flops, launch):
+def _traced(name, flops, launch, tag=""):
     if TRACE is None:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     launch()
     e1.record()
-    TRACE.append((name, float(flops), e0, e1))
+    TRACE.append((name, float(flops), e0, e1, tag))
 
 
 def dt(t):
@@ -298,7 +298,8 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     d.batch = batch
     d.a_bstride, d.w_bstride, d.out_bstride, d.res_bstride = a_bstride, w_bstride, out_bstride, res_bstride
     _traced("k_conv_gemm", 2.0 * M * n_out * ksize * ksize * (c0 + c1) * batch,
-            lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"))
+            lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"),
+            "M%d N%d K%d k%d s%d u%d b%d" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch))
     return out
 
 
@@ -357,5 +358,6 @@ def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, 
     d.bias, d.bias_ld = _p(bias), (_ld(bias) if bias is not None else 0)
     d.flags, d.flags_ld = _p(flags), (_ld(flags) if flags is not None else 0)
     _traced("k_attention", 4.0 * B * H * nq * nk * D,
-            lambda: check(_lib.lib().pf_attention(C.byref(d), _stream()), "pf_attention"))
+            lambda: check(_lib.lib().pf_attention(C.byref(d), _stream()), "pf_attention"),
+            "B%d H%d D%d nq%d nk%d bias%d" % (B, H, D, nq, nk, bias is not None))
     return out
