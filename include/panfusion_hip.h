@@ -182,8 +182,18 @@ typedef struct {
     int dtype;           /* PF_BF16 or PF_F16: A, W, residual                               */
     int batch;           /* >= 1: independent problems, strides below (elements)            */
     long a_bstride, w_bstride, out_bstride, res_bstride;
+    int epilogue;        /* PF_EPILOGUE_NONE, or PF_EPILOGUE_GEGLU: W rows interleaved (value_j, gate_j);
+                          * out [M][n_out/2] = value * gelu(gate) (transformer.py:8-21, erf GELU)    */
+    void* workspace;     /* split-K scratch (may be NULL: no split) of pf_conv_gemm_workspace_size   */
+    size_t workspace_bytes;
 } pf_conv_desc;
 
+enum { PF_EPILOGUE_NONE = 0, PF_EPILOGUE_GEGLU = 1 };
+
+/* Bytes of fp32 scratch that let pf_conv_gemm split the K range of a problem whose output grid alone
+ * cannot fill the 256 CUs (the 8x8 / 16x16 levels and the whole panorama branch); 0 = not wanted.
+ * The slabs are summed in split order by a second kernel: results do not depend on scheduling. */
+size_t pf_conv_gemm_workspace_size(const pf_conv_desc* desc);
 pf_status pf_conv_gemm(const pf_conv_desc* desc, void* stream);
 
 /* 3x3 convolutions with 4 input or 4 output channels at the UNet boundary:

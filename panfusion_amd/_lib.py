@@ -30,6 +30,7 @@ class ConvDesc(C.Structure):
         ("out", c_void_p), ("out_ld", c_int), ("out_dtype", c_int), ("dtype", c_int),
         ("batch", c_int),
         ("a_bstride", c_long), ("w_bstride", c_long), ("out_bstride", c_long), ("res_bstride", c_long),
+        ("epilogue", c_int), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
     ]
 
 
@@ -81,6 +82,7 @@ SIGNATURES = {
     "pf_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,
                                  c_long, c_int, c_int, c_void_p, c_void_p]),
     "pf_conv_gemm": (c_int, [C.POINTER(ConvDesc), c_void_p]),
+    "pf_conv_gemm_workspace_size": (c_size_t, [C.POINTER(ConvDesc)]),
     "pf_conv_in": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                            c_void_p, c_void_p]),
     "pf_conv_out": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,

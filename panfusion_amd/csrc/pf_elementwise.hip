@@ -22,8 +22,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---- GroupNorm statistics ----------------------------------------------------------------------
 // Stage 1: per (image, pixel chunk) block -> per-group (sum, sumsq) partials, deterministic order.
+// Chunks are small (8..64 pixels, >= ~2000 blocks at the benchmark sizes) and every thread keeps
+// four independent 16-byte loads in flight: the pass is HBM-bound, not latency-bound.
 template <typename T>
-__global__ void k_gn_partial(const unsigned short* __restrict__ x0, int c0,
+__global__ __launch_bounds__(256) void k_gn_partial(const unsigned short* __restrict__ x0, int c0,
                              const unsigned short* __restrict__ x1, int c1, int hw, int groups,
                              int pix_per_chunk, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -47,14 +49,23 @@ __global__ void k_gn_partial(const unsigned short* __restrict__ x0, int c0,
             const unsigned short* base;
             int ld, cc;
             if (c < c0) { base = x0; ld = c0; cc = c; } else { base = x1; ld = c1; cc = c - c0; }
-            for (int p = p0 + slot; p < p1; p += pix_par) {
-                u16x8 v = *reinterpret_cast<const u16x8*>(base + (static_cast<long>(img) * hw + p) * ld + cc);
+            base += static_cast<long>(img) * hw * ld + cc;
+            for (int p = p0 + slot; p < p1; p += 4 * pix_par) {
+                u16x8 v[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float f = to_f32<T>(v[j]);
-                    s[j] += f;
-                    q[j] += f * f;
+                for (int u = 0; u < 4; ++u) {
+                    const int pp = p + u * pix_par;
+                    v[u] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (pp < p1) v[u] = *reinterpret_cast<const u16x8*>(base + static_cast<long>(pp) * ld);
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = to_f32<T>(v[u][j]);
+                        s[j] += f;
+                        q[j] += f * f;
+                    }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -77,29 +88,44 @@ __global__ void k_gn_partial(const unsigned short* __restrict__ x0, int c0,
     }
 }
 
-// Stage 2: moments in fp64, folded with gamma/beta into per-(image, channel) scale / shift.
-__global__ void k_gn_finalize(const float* __restrict__ partial, int nchunks, int groups, int C,
+// Stage 2 (one block per image): chunk partials -> fp64 moments per group (256/groups lanes share a
+// group, combined in a fixed order), folded with gamma/beta into per-(image, channel) scale / shift.
+__global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ partial, int nchunks, int groups, int C,
                               int hw, float eps, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* __restrict__ scale,
                               float* __restrict__ shift) {
-    const int img = blockIdx.x;
+    __shared__ double red[2][256];
+    __shared__ float g_mean[64], g_rstd[64];
+    const int img = blockIdx.x, t = threadIdx.x;
     const int cpg = C / groups;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cpg;
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < nchunks; ++k) {
-            long o = ((static_cast<long>(img) * nchunks + k) * groups + g) * 2;
-            s += partial[o];
-            q += partial[o + 1];
+    const int lpg = groups <= 256 ? 256 / groups : 1;
+    const int g = t / lpg, l = t % lpg;
+    double s = 0.0, q = 0.0;
+    if (g < groups) {
+        for (int k = l; k < nchunks; k += lpg) {
+            const float2 v = *reinterpret_cast<const float2*>(partial + ((static_cast<long>(img) * nchunks + k) * groups + g) * 2);
+            s += v.x;
+            q += v.y;
         }
+    }
+    red[0][t] = s;
+    red[1][t] = q;
+    __syncthreads();
+    if (g < groups && l == 0) {
+        for (int j = 1; j < lpg; ++j) { s += red[0][t + j]; q += red[1][t + j]; }
         const double cnt = static_cast<double>(hw) * cpg;
         const double mean = s / cnt;
         double var = q / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
-        const float rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
-        const float sc = rstd * gamma[c];
+        g_mean[g] = static_cast<float>(mean);
+        g_rstd[g] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        const int gg = c / cpg;
+        const float sc = g_rstd[gg] * gamma[c];
         scale[static_cast<long>(img) * C + c] = sc;
-        shift[static_cast<long>(img) * C + c] = beta[c] - static_cast<float>(mean) * sc;
+        shift[static_cast<long>(img) * C + c] = beta[c] - g_mean[gg] * sc;
     }
 }
 
@@ -392,9 +418,20 @@ __global__ void k_conv_out(const unsigned short* __restrict__ x, int n, int cin,
 
 using namespace pf;
 
+// pixels per statistics chunk: ~2048 blocks in flight, 8..64 pixels each, at most 256 chunks per image
+static int gn_pixels_per_chunk(int n_img, int hw) {
+    long ppc = static_cast<long>(n_img) * hw / 2048;
+    if (ppc > 64) ppc = 64;
+    if (ppc < 8) ppc = 8;
+    const long floor_ppc = cdiv(hw, 256);
+    if (ppc < floor_ppc) ppc = floor_ppc;
+    if (ppc > hw) ppc = hw;
+    return static_cast<int>(ppc);
+}
+
 extern "C" size_t pf_groupnorm_workspace_size(int n_img, int hw, int C) {
     (void)C;
-    const int ppc = hw < 256 ? hw : 256;
+    const int ppc = gn_pixels_per_chunk(n_img, hw);
     const long nchunks = cdiv(hw, ppc);
     return static_cast<size_t>(n_img) * nchunks * 64 * 2 * sizeof(float);   // up to 64 groups
 }
@@ -410,7 +447,7 @@ extern "C" pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, 
     PF_REQUIRE(C % 8 == 0 && c0 % 8 == 0 && C % groups == 0, "pf_groupnorm_stats: C=%d must be a multiple of 8 and of groups=%d", C, groups);
     PF_REQUIRE(aligned16(x0) && (!x1 || aligned16(x1)), "pf_groupnorm_stats: inputs must be 16-byte aligned");
     PF_REQUIRE(ws_bytes >= pf_groupnorm_workspace_size(n_img, hw, C), "pf_groupnorm_stats: workspace too small");
-    const int ppc = hw < 256 ? hw : 256;
+    const int ppc = gn_pixels_per_chunk(n_img, hw);
     const int nchunks = static_cast<int>(cdiv(hw, ppc));
     const int OCT = C / 8, OCTB = OCT < 256 ? OCT : 256, pix_par = 256 / OCTB;
     const size_t smem = static_cast<size_t>(2) * pix_par * C * sizeof(float);

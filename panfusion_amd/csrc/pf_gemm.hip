@@ -33,10 +33,13 @@ struct GemmParams {
     int rows_per_img;
     const float* bias; const float* rowvec; int rowvec_ld;
     const unsigned short* residual; int res_ld;
-    void* out; int out_ld; int out_f32;
+    void* out; int out_ld; int out_f32; int geglu;
     long a_bs, w_bs, out_bs, res_bs;
     int mtiles, ntiles;
-    const unsigned short* zeros;   // >= 16 zero bytes in global memory (source of padded rows, DMA staging)
+    const unsigned short* zeros;   // >= 16 zero bytes in global memory (source of padded rows / ragged tiles)
+    int splits, kb_per_split;      // split-K: blockIdx.y walks K-blocks [y*kb_per_split, ...)
+    float* partial;                // [split][batch][M][N] fp32 when splits > 1
+    int batch;
 };
 
 template <typename T> struct Mfma;
@@ -57,7 +60,48 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // in 16-bit elem
     return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-template <typename T, int MREP, int NREP, bool DMA>
+// Epilogue of one output row m, 4 consecutive columns n4..n4+3 (fp32 accumulators v): bias, per-image
+// row vector, residual, then either a plain 16-bit / fp32 store or the GEGLU pairing
+// (columns interleaved (value, gate): out[m][n4/2 + {0,1}] = value * gelu(gate), transformer.py:8-21).
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int m, int n4, float (&v)[4]) {
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n4);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.rowvec) {
+        const int img = m / p.rows_per_img;
+        const float4 b = *reinterpret_cast<const float4*>(p.rowvec + static_cast<long>(img) * p.rowvec_ld + n4);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.residual) {
+        const u16x4 r = *reinterpret_cast<const u16x4*>(p.residual + bz * p.res_bs + static_cast<long>(m) * p.res_ld + n4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(r[e]);
+    }
+    if (p.geglu) {
+        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + (n4 >> 1);
+        typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+        u16x2 w2;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float g = v[2 * e + 1];
+            w2[e] = from_f32<T>(v[2 * e] * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f))));
+        }
+        *reinterpret_cast<u16x2*>(o) = w2;
+    } else if (p.out_f32) {
+        float* o = static_cast<float*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
+        *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
+    } else {
+        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
+        u16x4 w4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w4[e] = from_f32<T>(v[e]);
+        *reinterpret_cast<u16x4*>(o) = w4;
+    }
+}
+
+template <typename T, int MREP, int NREP>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -81,94 +125,76 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int chunk = t & 7, lrow = t >> 3;          // staging: 8 x 16B chunks per 128-B row
+    // staging ownership: global_load_lds_dwordx4 writes LDS at (wave-uniform base + 16 * lane), i.e.
+    // lane l of wave w fills physical chunk l%8 of row 8w + l/8 of a 32-row pass.  The XOR swizzle
+    // therefore moves to the SOURCE address: the lane fetches the logical chunk that belongs in its
+    // physical slot (same 128-B row segment, coalescing intact).  (row>>1)&7 only depends on lrow.
+    const int chunk = t & 7, lrow = t >> 3;
+    const int lchunk8 = (chunk ^ ((lrow >> 1) & 7)) * 8;
 
-    // per-thread staging rows of the activation tile
-    int a_img[MREP], a_y[MREP], a_x[MREP];
-    bool a_ok[MREP];
+    // per-thread staging rows: output pixel -> top-left input coordinate
+    int a_img[MREP], a_y[MREP], a_x[MREP], a_pix[MREP];
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
         const int m = m0 + i * 32 + lrow;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        const int img = mm / p.rows_per_img, rem = mm % p.rows_per_img;
-        a_img[i] = img;
-        a_y[i] = (rem / p.w_out) * p.stride - p.pad;
-        a_x[i] = (rem % p.w_out) * p.stride - p.pad;
+        if (m < p.M) {
+            const int img = m / p.rows_per_img, rem = m - img * p.rows_per_img;
+            const int yo = rem / p.w_out;
+            a_img[i] = img;
+            a_y[i] = yo * p.stride - p.pad;
+            a_x[i] = (rem - yo * p.w_out) * p.stride - p.pad;
+        } else {
+            a_img[i] = 0; a_y[i] = -(1 << 20); a_x[i] = 0;     // never in range
+        }
+    }
+    int w_off[NREP];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+        const int n = n0 + j * 32 + lrow;
+        w_off[j] = n < p.N ? n * p.K + lchunk8 : -1;
     }
     const int Ctot = p.c0 + p.c1;
     const int Hl = p.h_in << p.up, Wl = p.w_in << p.up;
 
-    u16x8 ra[MREP], rb[NREP];
-    auto gload = [&](int kb) {
-        const int kg = kb * 64;
-        const int tap = kg / Ctot, cc = kg % Ctot;
-        const int ky = tap / p.ksize, kx = tap % p.ksize;
-        const unsigned short* src;
-        int ld, coff;
-        if (cc < p.c0) { src = a0; ld = p.a0_ld; coff = cc; } else { src = a1; ld = p.a1_ld; coff = cc - p.c0; }
+    // K walk (wave-uniform state): K-block kb = (tap, 64-channel block cc); no divisions in the loop
+    const int nkb = p.K / 64;
+    const int kb0 = blockIdx.y * p.kb_per_split;
+    const int kb1 = min(nkb, kb0 + p.kb_per_split);
+    int kg = kb0 * 64;
+    int tap = kg / Ctot, cc = kg - tap * Ctot;
+    auto set_tap = [&](int tp) {
+        const int ky = p.ksize == 3 ? tp / 3 : 0, kx = p.ksize == 3 ? tp - 3 * ky : 0;
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
             const int yi = a_y[i] + ky, xi = a_x[i] + kx;
-            const bool ok = a_ok[i] && yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
-            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) {
-                const long pix = (static_cast<long>(a_img[i]) * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up);
-                v = *reinterpret_cast<const u16x8*>(src + pix * ld + coff + chunk * 8);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) {
-            const int n = n0 + j * 32 + lrow;
-            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (n < p.N) v = *reinterpret_cast<const u16x8*>(wg + static_cast<long>(n) * p.K + kg + chunk * 8);
-            rb[j] = v;
+            const bool ok = yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
+            a_pix[i] = ok ? (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up) : -1;
         }
     };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < MREP; ++i)
-            *reinterpret_cast<u16x8*>(As + buf * BM * 64 + lds_off(i * 32 + lrow, chunk)) = ra[i];
-#pragma unroll
-        for (int j = 0; j < NREP; ++j)
-            *reinterpret_cast<u16x8*>(Bs + buf * BN * 64 + lds_off(j * 32 + lrow, chunk)) = rb[j];
-    };
+    set_tap(tap);
 
-    // DMA staging: global_load_lds_dwordx4 writes LDS at (wave-uniform base + 16 * lane), i.e. lane l of
-    // wave w fills physical chunk l%8 of row 8w + l/8 of the pass -- exactly the register path's
-    // (lrow, chunk) ownership.  The XOR swizzle therefore moves to the SOURCE address: the lane fetches
-    // the logical chunk that belongs in its physical slot (same 128-B row segment, coalescing intact).
-    // Zero-padded taps / ragged rows read a 16-byte page of zeros.
-    auto dma_stage = [&](int kb, int buf) {
-        const int kg = kb * 64;
-        const int tap = kg / Ctot, cc = kg % Ctot;
-        const int ky = tap / p.ksize, kx = tap % p.ksize;
+    auto dma_stage = [&](int buf) {
         const unsigned short* src;
         int ld, coff;
         if (cc < p.c0) { src = a0; ld = p.a0_ld; coff = cc; } else { src = a1; ld = p.a1_ld; coff = cc - p.c0; }
+        coff += lchunk8;
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
-            const int row = i * 32 + lrow;
-            const int lchunk = chunk ^ ((row >> 1) & 7);
-            const int yi = a_y[i] + ky, xi = a_x[i] + kx;
-            const bool ok = a_ok[i] && yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
-            const long pix = (static_cast<long>(a_img[i]) * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up);
-            const unsigned short* g = ok ? src + pix * ld + coff + lchunk * 8 : p.zeros;
+            const unsigned short* g = a_pix[i] >= 0 ? src + (static_cast<long>(a_pix[i]) * ld + coff) : p.zeros;
             unsigned short* dst = As + buf * BM * 64 + (i * 32 + wave * 8) * 64;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NREP; ++j) {
-            const int row = j * 32 + lrow;
-            const int lchunk = chunk ^ ((row >> 1) & 7);
-            const int n = n0 + row;
-            const unsigned short* g = n < p.N ? wg + static_cast<long>(n) * p.K + kg + lchunk * 8 : p.zeros;
+            const unsigned short* g = w_off[j] >= 0 ? wg + (static_cast<long>(w_off[j]) + kg) : p.zeros;
             unsigned short* dst = Bs + buf * BN * 64 + (j * 32 + wave * 8) * 64;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
+        kg += 64;
+        cc += 64;
+        if (cc == Ctot) { cc = 0; ++tap; set_tap(tap); }
     };
 
     f32x4 acc[MREP][NREP];
@@ -180,17 +206,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     typedef typename Mfma<T>::frag frag;
     const int frow = lane & 15, fchunk = lane >> 4;
     auto compute = [&](int buf) {
-        const unsigned short* as = As + buf * BM * 64 + (wm * 16 * MREP) * 64;
-        const unsigned short* bs = Bs + buf * BN * 64 + (wn * 16 * NREP) * 64;
 #pragma unroll
         for (int slab = 0; slab < 2; ++slab) {
             frag af[MREP], bf[NREP];
 #pragma unroll
             for (int i = 0; i < MREP; ++i) {
-                const int row = i * 16 + frow;
-                // rows of the wave's sub-tile start at a multiple of 16, so the swizzle term only
-                // depends on the row inside the block tile: add the wave offset back.
-                const int brow = wm * 16 * MREP + row;
+                const int brow = wm * 16 * MREP + i * 16 + frow;
                 u16x8 v = *reinterpret_cast<const u16x8*>(As + buf * BM * 64 + lds_off(brow, slab * 4 + fchunk));
                 af[i] = __builtin_bit_cast(frag, v);
             }
@@ -205,69 +226,57 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < NREP; ++j) acc[i][j] = Mfma<T>::run(bf[j], af[i], acc[i][j]);
         }
-        (void)as; (void)bs;
     };
 
-    const int nkb = p.K / 64;
-    if constexpr (DMA) {
-        dma_stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kb = 0; kb < nkb; ++kb) {
-            if (kb + 1 < nkb) dma_stage(kb + 1, (kb + 1) & 1);   // in flight during the MFMAs
-            compute(kb & 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's DMA has landed ...
-            __syncthreads();                                      // ... before anyone reads the tile
-        }
-    } else {
-        gload(0);
-        lstore(0);
-        __syncthreads();
-        for (int kb = 0; kb < nkb; ++kb) {
-            if (kb + 1 < nkb) gload(kb + 1);
-            compute(kb & 1);
-            if (kb + 1 < nkb) lstore((kb + 1) & 1);
-            __syncthreads();
-        }
+    dma_stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kb = kb0, it = 0; kb < kb1; ++kb, ++it) {
+        if (kb + 1 < kb1) dma_stage((it + 1) & 1);            // in flight during the MFMAs
+        compute(it & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's DMA has landed ...
+        __syncthreads();                                      // ... before anyone reads the tile
     }
 
     // epilogue: lane holds out[m][n4 .. n4+3], m = lane&15, n4 = 4*(lane>>4)
-    const unsigned short* res = p.residual ? p.residual + bz * p.res_bs : nullptr;
-    char* outp = static_cast<char*>(p.out) + bz * p.out_bs * (p.out_f32 ? 4 : 2);
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
         const int m = m0 + wm * 16 * MREP + i * 16 + (lane & 15);
         if (m >= p.M) continue;
-        const int img = m / p.rows_per_img;
 #pragma unroll
         for (int j = 0; j < NREP; ++j) {
             const int n4 = n0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
             if (n4 >= p.N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + n4);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (p.rowvec) {
-                const float4 b = *reinterpret_cast<const float4*>(p.rowvec + static_cast<long>(img) * p.rowvec_ld + n4);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (res) {
-                const u16x4 r = *reinterpret_cast<const u16x4*>(res + static_cast<long>(m) * p.res_ld + n4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(r[e]);
-            }
-            if (p.out_f32) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + static_cast<long>(m) * p.out_ld + n4) =
-                    float4{v[0], v[1], v[2], v[3]};
+            if (p.splits > 1) {
+                float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * p.M + m) * p.N + n4;
+                *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
             } else {
-                u16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
-                *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(outp) + static_cast<long>(m) * p.out_ld + n4) = o;
+                epilogue_store<T>(p, bz, m, n4, v);
             }
         }
     }
+}
+
+// Split-K second pass: sum the fp32 slabs in split order (deterministic) and run the epilogue.
+template <typename T>
+__global__ __launch_bounds__(256) void k_splitk_reduce(const GemmParams p) {
+    const long quads = static_cast<long>(p.N / 4);
+    const long total = static_cast<long>(p.batch) * p.M * quads;
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= total) return;
+    const int n4 = static_cast<int>(i % quads) * 4;
+    const long bm = i / quads;
+    const int m = static_cast<int>(bm % p.M);
+    const long bz = bm / p.M;
+    const long slab = static_cast<long>(p.batch) * p.M * p.N;
+    const float* src = p.partial + (bz * p.M + m) * p.N + n4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.splits; ++s) {
+        const float4 x = *reinterpret_cast<const float4*>(src + s * slab);
+        v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+    }
+    epilogue_store<T>(p, bz, m, n4, v);
 }
 
 static const unsigned short* zero_page() {
@@ -279,39 +288,56 @@ static const unsigned short* zero_page() {
     return z;
 }
 
-static bool use_dma() {
-    static int v = -1;                           // PF_GEMM_STAGING=reg selects register staging (A/B switch)
-    if (v < 0) { const char* e = getenv("PF_GEMM_STAGING"); v = (e && e[0] == 'r') ? 0 : 1; }
-    return v == 1;
-}
-
-template <typename T, int MREP, int NREP, bool DMA>
-static pf_status launch_impl(const GemmParams& gp, int batch, hipStream_t st) {
+template <typename T, int MREP, int NREP>
+static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     GemmParams p = gp;
+    p.zeros = zero_page();
+    PF_REQUIRE(p.zeros, "pf_conv_gemm: zero page allocation failed");
     p.mtiles = static_cast<int>(cdiv(p.M, BM));
     p.ntiles = static_cast<int>(cdiv(p.N, BN));
     const size_t smem = static_cast<size_t>(2) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP, DMA>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP, DMA>), dim3(p.mtiles * p.ntiles, 1, batch), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(256), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm");
+    if (p.splits > 1) {
+        const long total = static_cast<long>(batch) * p.M * (p.N / 4);
+        hipLaunchKernelGGL((k_splitk_reduce<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, p);
+        PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
+    }
     return PF_OK;
 }
 
-template <typename T, int MREP, int NREP>
-static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
-    if (use_dma()) {
-        GemmParams p = gp;
-        p.zeros = zero_page();
-        PF_REQUIRE(p.zeros, "pf_conv_gemm: zero page allocation failed");
-        return launch_impl<T, MREP, NREP, true>(p, batch, st);
+// Tile shape + split-K plan of one problem (shared by the launcher and the workspace query).
+struct GemmPlan { int mrep, nrep, splits, kb_per_split; };
+static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
+    GemmPlan g;
+    // 160-wide N tiles when they divide N exactly (all UNet widths are multiples of 160), 128-wide
+    // otherwise; 64-row M tiles when 128-row tiles would not fill the 256 CUs (2 blocks per CU).
+    g.nrep = (N % 160 == 0) ? 5 : 4;
+    const long ntiles = cdiv(N, 32 * g.nrep);
+    const long tiles128 = cdiv(M, 128) * ntiles * batch;
+    g.mrep = tiles128 < 512 ? 2 : 4;
+    const long tiles = cdiv(M, 32 * g.mrep) * ntiles * batch;
+    const int nkb = K / 64;
+    g.splits = 1;
+    g.kb_per_split = nkb;
+    // split-K when the grid cannot fill the chip and K is long: aim at ~640 blocks, >= 6 K-blocks each
+    if (allow_split && N % 4 == 0 && tiles <= 320 && nkb >= 12) {
+        long s = (640 + tiles - 1) / tiles;
+        if (s > nkb / 6) s = nkb / 6;
+        if (s > 32) s = 32;
+        if (s > 1) {
+            g.kb_per_split = static_cast<int>(cdiv(nkb, s));
+            g.splits = static_cast<int>(cdiv(nkb, g.kb_per_split));
+        }
     }
-    return launch_impl<T, MREP, NREP, false>(gp, batch, st);
+    return g;
 }
 
 }  // namespace pf
@@ -337,13 +363,17 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
                "pf_conv_gemm: n_out=%d must be a multiple of 4 (or no epilogue operands and a padded out_ld)", d->n_out);
     PF_REQUIRE(d->a0_ld >= d->c0 && d->a0_ld % 8 == 0, "pf_conv_gemm: a0_ld must be >= c0 and a multiple of 8");
     PF_REQUIRE(!d->a1 || (d->a1_ld >= c1 && d->a1_ld % 8 == 0), "pf_conv_gemm: a1_ld must be >= c1 and a multiple of 8");
-    PF_REQUIRE(d->out_ld >= d->n_out && d->out_ld % 4 == 0, "pf_conv_gemm: out_ld must be >= n_out and a multiple of 4");
+    PF_REQUIRE(d->epilogue == PF_EPILOGUE_GEGLU || (d->out_ld >= d->n_out && d->out_ld % 4 == 0), "pf_conv_gemm: out_ld must be >= n_out and a multiple of 4");
     PF_REQUIRE(!d->residual || (d->res_ld >= d->n_out && d->res_ld % 4 == 0), "pf_conv_gemm: res_ld must be >= n_out and a multiple of 4");
     PF_REQUIRE(!d->rowvec || (d->rowvec_ld >= d->n_out && d->rowvec_ld % 4 == 0), "pf_conv_gemm: rowvec_ld must be >= n_out and a multiple of 4");
     PF_REQUIRE(aligned16(d->a0) && aligned16(d->w) && aligned16(d->out) && (!d->a1 || aligned16(d->a1)) &&
                (!d->bias || aligned16(d->bias)) && (!d->rowvec || aligned16(d->rowvec)) &&
                (!d->residual || aligned16(d->residual)), "pf_conv_gemm: pointers must be 16-byte aligned");
     PF_REQUIRE(d->batch >= 1, "pf_conv_gemm: batch must be >= 1");
+    PF_REQUIRE(d->epilogue == PF_EPILOGUE_NONE || d->epilogue == PF_EPILOGUE_GEGLU, "pf_conv_gemm: unknown epilogue %d", d->epilogue);
+    if (d->epilogue == PF_EPILOGUE_GEGLU)
+        PF_REQUIRE(d->n_out % 4 == 0 && d->out_dtype == d->dtype && !d->residual && d->out_ld >= d->n_out / 2 && d->out_ld % 2 == 0,
+                   "pf_conv_gemm: GEGLU epilogue needs n_out %% 4 == 0, 16-bit output, no residual, out_ld >= n_out/2");
     {   // the output size must be what the conv arithmetic produces
         const int hl = d->h_in << d->upsample, wl = d->w_in << d->upsample;
         const int ho = (hl + 2 * d->pad - d->ksize) / d->stride + 1, wo = (wl + 2 * d->pad - d->ksize) / d->stride + 1;
@@ -361,17 +391,31 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     p.bias = d->bias; p.rowvec = d->rowvec; p.rowvec_ld = d->rowvec_ld;
     p.residual = static_cast<const unsigned short*>(d->residual); p.res_ld = d->res_ld;
     p.out = d->out; p.out_ld = d->out_ld; p.out_f32 = d->out_dtype == PF_F32;
+    p.geglu = d->epilogue == PF_EPILOGUE_GEGLU;
     p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;
     p.mtiles = p.ntiles = 0;
     p.zeros = nullptr;
+    p.batch = d->batch;
+    const GemmPlan g = plan_gemm(p.M, p.N, p.K, d->batch, d->workspace != nullptr);
+    p.splits = g.splits; p.kb_per_split = g.kb_per_split;
+    p.partial = static_cast<float*>(d->workspace);
+    if (p.splits > 1) {
+        const size_t need = static_cast<size_t>(p.splits) * d->batch * p.M * p.N * sizeof(float);
+        PF_REQUIRE(d->workspace_bytes >= need && aligned16(d->workspace),
+                   "pf_conv_gemm: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, d->workspace_bytes);
+    }
     hipStream_t st = as_stream(stream);
-    // Tile choice: 160-wide N tiles when they divide N exactly (all UNet widths are multiples of
-    // 160), 128-wide otherwise; 64-row M tiles when 128-row tiles would not fill the 256 CUs.
-    const bool n160 = (p.N % 160 == 0);
-    const long tiles128 = cdiv(p.M, 128) * cdiv(p.N, n160 ? 160 : 128) * d->batch;
-    const bool small_m = tiles128 < 512;
     PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
-        if (n160) return small_m ? launch<T, 2, 5>(p, d->batch, st) : launch<T, 4, 5>(p, d->batch, st);
-        else return small_m ? launch<T, 2, 4>(p, d->batch, st) : launch<T, 4, 4>(p, d->batch, st));
+        if (g.nrep == 5) return g.mrep == 2 ? launch<T, 2, 5>(p, d->batch, st) : launch<T, 4, 5>(p, d->batch, st);
+        else return g.mrep == 2 ? launch<T, 2, 4>(p, d->batch, st) : launch<T, 4, 4>(p, d->batch, st));
     return PF_OK;
+}
+
+extern "C" size_t pf_conv_gemm_workspace_size(const pf_conv_desc* d) {
+    if (!d || d->batch < 1 || d->n_out < 1) return 0;
+    const int c1 = d->a1 ? d->c1 : 0;
+    const long M = static_cast<long>(d->n_img) * d->h_out * d->w_out;
+    const int K = d->ksize * d->ksize * (d->c0 + c1);
+    const GemmPlan g = plan_gemm(M, d->n_out, K, d->batch, true);
+    return g.splits > 1 ? static_cast<size_t>(g.splits) * d->batch * M * d->n_out * sizeof(float) : 0;
 }

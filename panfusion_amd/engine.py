@@ -91,7 +91,8 @@ def pack_transformer(tf, dev, dtype):
     t.ln1, t.ln2, t.ln3 = _norm(blk.norm1, dev), _norm(blk.norm2, dev), _norm(blk.norm3, dev)
     t.attn1 = pack_attention(blk.attn1, dev, dtype, True)
     t.attn2 = pack_attention(blk.attn2, dev, dtype, False)
-    t.w_ff1, t.b_ff1 = _w16(blk.ff.net[0].proj.weight, dev, dtype), _bias(blk.ff.net[0].proj, dev)
+    # GEGLU.proj rows interleaved (value_j, gate_j): the gating runs in the GEMM epilogue
+    t.w_ff1, t.b_ff1 = ops.interleave_geglu(_w16(blk.ff.net[0].proj.weight, dev, dtype), _bias(blk.ff.net[0].proj, dev))
     t.w_ff2, t.b_ff2 = _w16(blk.ff.net[2].weight, dev, dtype), _bias(blk.ff.net[2], dev)
     return t
 
@@ -169,7 +170,7 @@ def pack_epa(block, dev, dtype):
     e.wqk = _w16(torch.cat([a.to_q.weight.detach().float(), a.to_k.weight.detach().float()], 0), dev, dtype)
     e.wv = _w16(a.to_v.weight, dev, dtype)
     e.wo, e.bo = _w16(a.to_out.weight, dev, dtype), _bias(a.to_out, dev)
-    e.w_ff1, e.b_ff1 = _w16(tr.ff.net[0].proj.weight, dev, dtype), _bias(tr.ff.net[0].proj, dev)
+    e.w_ff1, e.b_ff1 = ops.interleave_geglu(_w16(tr.ff.net[0].proj.weight, dev, dtype), _bias(tr.ff.net[0].proj, dev))
     e.w_ff2, e.b_ff2 = _w16(tr.ff.net[2].weight, dev, dtype), _bias(tr.ff.net[2], dev)
     e.freq = _f32(block.pe.freq_bands, dev)
     return e
@@ -226,7 +227,7 @@ def run_transformer(t, x, text):
     L = text.shape[1]
     tok = _attend(t.attn2, ln, text.reshape(n * L, -1), n, hw, L, dh, self_attn=False, residual=tok)
     ln = ops.layernorm(tok, t.ln3.g, t.ln3.b, t.ln3.eps)
-    g = ops.geglu(ops.linear(ln, t.w_ff1, bias=t.b_ff1))
+    g = ops.linear(ln, t.w_ff1, bias=t.b_ff1, geglu=True)
     tok = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok)
     out = ops.linear(tok, t.w_out, bias=t.b_out, residual=x.view(n * hw, Cc))
     return out.view(n, h, w, Cc)
@@ -313,7 +314,7 @@ def _epa_tail(e, attn_out, x, Cc):
     """to_out + residual, then LN2 -> GEGLU FF -> + residual (transformer.py:159-161)."""
     y = ops.linear(attn_out.view(-1, Cc), e.wo, bias=e.bo, residual=x)
     ln2 = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps)
-    g = ops.geglu(ops.linear(ln2, e.w_ff1, bias=e.b_ff1))
+    g = ops.linear(ln2, e.w_ff1, bias=e.b_ff1, geglu=True)
     return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y)
 
 
@@ -405,7 +406,7 @@ def run_epa(e, tables, xp, xe, m, shard=None):
     def tail(attn_out, x):
         y = ops.linear(attn_out.view(-1, Cc), e.wo, bias=e.bo, residual=x)
         ln2 = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps)
-        g = ops.geglu(ops.linear(ln2, e.w_ff1, bias=e.b_ff1))
+        g = ops.linear(ln2, e.w_ff1, bias=e.b_ff1, geglu=True)
         return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y)
 
     # panorama pixels query the views (modules.py:43-48), then views query the panorama with the

@@ -268,7 +268,7 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,
               a_bstride=0, w_bstride=0, out_bstride=0, res_bstride=0, a0_ld=None, a1_ld=None, c0=None, c1=None,
-              out_ld=None, res_ld=None):
+              out_ld=None, res_ld=None, geglu=False):
     """out[m, n] = sum_k A[m, k] W[n, k] (+bias +rowvec[img] +residual).  a0/a1 NHWC, the last
     dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out)."""
     c0 = c0 if c0 is not None else a0.shape[-1]
@@ -280,8 +280,9 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     w_out = (wl + 2 * pad - ksize) // stride + 1
     M = n_img * h_out * w_out
     out_dtype = out_dtype or a0.dtype
+    n_store = n_out // 2 if geglu else n_out
     if out is None:
-        out = torch.empty((batch, M, n_out) if batch > 1 else (M, n_out), device=a0.device, dtype=out_dtype)
+        out = torch.empty((batch, M, n_store) if batch > 1 else (M, n_store), device=a0.device, dtype=out_dtype)
     d = ConvDesc()
     d.a0, d.a1, d.c0, d.c1 = _p(a0), _p(a1), c0, c1
     d.a0_ld = a0_ld if a0_ld is not None else _ld(a0)
@@ -297,16 +298,46 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     d.out_dtype, d.dtype = dt(out_dtype), dt(a0)
     d.batch = batch
     d.a_bstride, d.w_bstride, d.out_bstride, d.res_bstride = a_bstride, w_bstride, out_bstride, res_bstride
+    d.epilogue = 1 if geglu else 0
+    nbytes = _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
+    ws = torch.empty(nbytes, device=a0.device, dtype=torch.uint8) if nbytes else None   # split-K slabs
+    d.workspace, d.workspace_bytes = _p(ws), nbytes
     _traced("k_conv_gemm", 2.0 * M * n_out * ksize * ksize * (c0 + c1) * batch,
             lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"),
             "M%d N%d K%d k%d s%d u%d b%d" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch))
     return out
 
 
-def linear(x, w, bias=None, residual=None, out=None, out_dtype=None):
-    """x [rows, K] 16-bit, w [N, K] 16-bit."""
+def gemm_workspace_bytes(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0,
+                         upsample=0, batch=1, **_):
+    """Split-K scratch pf_conv_gemm wants for this problem (0: the K range is not split)."""
+    d = ConvDesc()
+    d.c0, d.c1 = a0.shape[-1], (a1.shape[-1] if a1 is not None else 0)
+    d.a1 = _p(a1)
+    if w_in is None:
+        w_in = a0.numel() // (a0.shape[-1] * max(batch, 1))
+    d.n_img, d.ksize, d.batch, d.n_out = n_img, ksize, batch, n_out
+    d.h_out = ((h_in << upsample) + 2 * pad - ksize) // stride + 1
+    d.w_out = ((w_in << upsample) + 2 * pad - ksize) // stride + 1
+    return _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
+
+
+def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False):
+    """x [rows, K] 16-bit, w [N, K] 16-bit.  geglu: w / bias rows interleaved (value_j, gate_j),
+    returns [rows, N/2] = value * gelu(gate)."""
     rows, K = x.shape
-    return conv_gemm(x, w, w.shape[0], w_in=rows, bias=bias, residual=residual, out=out, out_dtype=out_dtype)
+    return conv_gemm(x, w, w.shape[0], w_in=rows, bias=bias, residual=residual, out=out, out_dtype=out_dtype,
+                     geglu=geglu)
+
+
+def interleave_geglu(w, b=None):
+    """[value rows | gate rows] (diffusers / reference GEGLU.proj, transformer.py:8-21) ->
+    rows interleaved (value_0, gate_0, value_1, gate_1, ...) for the fused epilogue."""
+    inner = w.shape[0] // 2
+    wi = torch.stack([w[:inner], w[inner:]], 1).reshape(w.shape).contiguous()
+    if b is None:
+        return wi
+    return wi, torch.stack([b[:inner], b[inner:]], 1).reshape(b.shape).contiguous()
 
 
 def linear_t(x, w, out=None, ld=None):

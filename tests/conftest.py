@@ -12,8 +12,27 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _usable_cores():
+    """Cores this process may really use: affinity mask and cgroup CPU quota (the GPU box exposes all
+    host cores to os.cpu_count() but grants a fraction; torch's default thread count then
+    oversubscribes the oracle by an order of magnitude)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    workers = int(os.environ.get("PYTEST_XDIST_WORKER_COUNT", "1") or 1)
+    torch.set_num_threads(max(1, min(16, _usable_cores() // max(1, workers))))
 
 
 def pytest_collection_modifyitems(config, items):

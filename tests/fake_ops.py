@@ -169,7 +169,7 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 
 
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
-              bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, **kw):
+              bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, **kw):
     assert batch == 1
     c0 = a0.shape[-1]
     x = a0.float().reshape(-1, c0)
@@ -189,6 +189,8 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
         y = y + rowvec[:, :n_out].float().repeat_interleave(ho * wo, 0)
     if residual is not None:
         y = y + residual.float().reshape(-1, residual.shape[-1])[:, :n_out]
+    if geglu:                                     # rows interleaved (value_j, gate_j)
+        y = y[:, 0::2] * F.gelu(y[:, 1::2])
     y = y.to(out_dtype or a0.dtype)
     if out is not None:
         out.copy_(y.reshape(out.shape))
@@ -196,8 +198,17 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     return y
 
 
-def linear(x, w, bias=None, residual=None, out=None, out_dtype=None):
-    return conv_gemm(x, w, w.shape[0], w_in=x.shape[0], bias=bias, residual=residual, out=out, out_dtype=out_dtype)
+def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False):
+    return conv_gemm(x, w, w.shape[0], w_in=x.shape[0], bias=bias, residual=residual, out=out, out_dtype=out_dtype,
+                     geglu=geglu)
+
+
+def interleave_geglu(w, b=None):
+    inner = w.shape[0] // 2
+    wi = torch.stack([w[:inner], w[inner:]], 1).reshape(w.shape).contiguous()
+    if b is None:
+        return wi
+    return wi, torch.stack([b[:inner], b[inner:]], 1).reshape(b.shape).contiguous()
 
 
 def linear_t(x, w, out=None, ld=None):

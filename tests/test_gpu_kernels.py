@@ -288,6 +288,62 @@ def test_linear(dtype, mnk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mnk", [(300, 640, 320), (64, 2560, 1280)])
+def test_linear_geglu_epilogue(dtype, mnk):
+    """FF1 with the gating fused into the epilogue == geglu(linear) of transformer.py:8-21."""
+    o = ops()
+    M, N, K = mnk
+    x, xf = q16(rnd(M, K, seed=40), dtype)
+    w, wf = q16(rnd(N, K, seed=41) / K ** 0.5, dtype)
+    b = rnd(N, seed=42)
+    wi, bi = o.interleave_geglu(w, b.to(DEV))
+    y = xf @ wf.T + b
+    want = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    got = o.linear(x, wi, bias=bi, geglu=True)
+    assert got.shape == (M, N // 2)
+    check("linear+geglu", got, want, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["linear", "conv", "conv_cat_res"])
+def test_split_k(dtype, case):
+    """Small output grids with a long K are split over K (fp32 slabs + ordered reduce)."""
+    o = ops()
+    if case == "linear":
+        M, N, K = 256, 1280, 5120
+        x, xf = q16(rnd(M, K, seed=43), dtype)
+        w, wf = q16(rnd(N, K, seed=44) / K ** 0.5, dtype)
+        b = rnd(N, seed=45)
+        r, rf = q16(rnd(M, N, seed=46), dtype)
+        d_ws = o.gemm_workspace_bytes(x, w, N, w_in=M)
+        assert d_ws > 0, "this shape is expected to take the split-K path"
+        check("split-K linear", o.linear(x, w, bias=b.to(DEV), residual=r), xf @ wf.T + b + rf, TOL[dtype])
+        return
+    n, h, wd, cin, cout = 2, 8, 20, 640, 320
+    x, xf = q16(rnd(n, h, wd, cin, seed=47), dtype)
+    skip, skipf = q16(rnd(n, h, wd, 640, seed=48), dtype)
+    a1 = skip if case == "conv_cat_res" else None
+    ctot = cin + (640 if a1 is not None else 0)
+    wt = rnd(cout, ctot, 3, 3, seed=49) / (ctot * 9) ** 0.5
+    wq, wqf = q16(wt.permute(0, 2, 3, 1).reshape(cout, -1), dtype)
+    wref = wqf.reshape(cout, 3, 3, ctot).permute(0, 3, 1, 2)
+    b = rnd(cout, seed=50)
+    table = rnd(n, cout, seed=51)
+    xin = xf.permute(0, 3, 1, 2)
+    if a1 is not None:
+        xin = torch.cat([xin, skipf.permute(0, 3, 1, 2)], 1)
+    want = F.conv2d(xin, wref, b, padding=1) + table[:, :, None, None]
+    kw = dict(n_img=n, h_in=h, w_in=wd, ksize=3, pad=1, bias=b.to(DEV), a1=a1, rowvec=table.to(DEV))
+    assert o.gemm_workspace_bytes(x, wq, cout, **{k: v for k, v in kw.items() if k not in ("bias", "rowvec")}) > 0
+    if case == "conv_cat_res":
+        r, rf = q16(rnd(n * h * wd, cout, seed=52), dtype)
+        kw["residual"] = r
+        want = want + rf.view(n, h, wd, cout).permute(0, 3, 1, 2)
+    got = o.conv_gemm(x, wq, cout, **kw)
+    check("split-K conv " + case, got.view(n, h, wd, cout).permute(0, 3, 1, 2), want, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_strided_views_and_rowvec(dtype):
     o = ops()
     M, C = 200, 128
