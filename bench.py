@@ -186,10 +186,16 @@ def main():
 
     # ---- instrumented step: device events around every GEMM / attention launch ------------------
     trace = []
+    serial = getattr(model, "two_streams", None)
+    if serial is not None:
+        model.two_streams = False                     # kernels one at a time: per-launch durations, not overlap
     ops.TRACE = trace
-    loop.step_eager()
+    torch.cuda._sleep(int(0.25 * 2.4e9))              # GPU busy ~0.25 s: the host enqueues the whole eager step
+    loop.step_eager()                                 # ahead of it, so event pairs bracket kernels, not launch gaps
     torch.cuda.synchronize()
     ops.TRACE = None
+    if serial is not None:
+        model.two_streams = serial
     fam = {}
     shapes = {}
     for name, flops, e0, e1, tag in trace:

@@ -194,6 +194,11 @@ enum { PF_EPILOGUE_NONE = 0, PF_EPILOGUE_GEGLU = 1 };
  * cannot fill the 256 CUs (the 8x8 / 16x16 levels and the whole panorama branch); 0 = not wanted.
  * The slabs are summed in split order by a second kernel: results do not depend on scheduling. */
 size_t pf_conv_gemm_workspace_size(const pf_conv_desc* desc);
+/* Diagnostics only: while `device_buffer` (capacity_blocks x 32 uint64) is set, every pf_conv_gemm launch
+ * with at most capacity_blocks workgroups records 4 shader-clock stamps per workgroup (entry, first
+ * operand tile landed, K loop done, exit; the 8-wave kernel adds per-wave K-loop time split into
+ * wait+barrier / DMA issue / ds_read+MFMA at [4 + 3*wave + {0,1,2}]).  NULL switches it off (the default). */
+pf_status pf_debug_gemm_profile(void* device_buffer, long capacity_blocks);
 pf_status pf_conv_gemm(const pf_conv_desc* desc, void* stream);
 
 /* 3x3 convolutions with 4 input or 4 output channels at the UNet boundary:

@@ -83,6 +83,7 @@ SIGNATURES = {
                                  c_long, c_int, c_int, c_void_p, c_void_p]),
     "pf_conv_gemm": (c_int, [C.POINTER(ConvDesc), c_void_p]),
     "pf_conv_gemm_workspace_size": (c_size_t, [C.POINTER(ConvDesc)]),
+    "pf_debug_gemm_profile": (c_int, [c_void_p, c_long]),
     "pf_conv_in": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                            c_void_p, c_void_p]),
     "pf_conv_out": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,

@@ -20,6 +20,7 @@
 // models/pano/MVGenModel.py:86-144,174-198,224-294; models/modules/transformer.py:8-74).
 #include "pf_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace pf {
 
@@ -40,7 +41,17 @@ struct GemmParams {
     int splits, kb_per_split;      // split-K: blockIdx.y walks K-blocks [y*kb_per_split, ...)
     float* partial;                // [split][batch][M][N] fp32 when splits > 1
     int batch;
+    int dbg;                       // diagnostics (PF_GEMM_DEBUG): 1 = skip steady-state DMA, 2 = DMA reads the zero page
+    unsigned long long* prof;      // diagnostics (pf_debug_gemm_profile): 4 s_memtime stamps per block, or NULL
 };
+
+// phase stamp of wave 0 / lane 0 of a block: [block][4] = kernel entry, first tile landed, K loop done, exit
+__device__ __forceinline__ void stamp(const GemmParams& p, int slot) {
+    if (p.prof && threadIdx.x == 0) {
+        const long b = blockIdx.x + static_cast<long>(gridDim.x) * (blockIdx.y + static_cast<long>(gridDim.y) * blockIdx.z);
+        p.prof[b * 32 + slot] = __builtin_amdgcn_s_memtime();
+    }
+}
 
 template <typename T> struct Mfma;
 template <> struct Mfma<Bf16> {
@@ -58,6 +69,20 @@ template <> struct Mfma<F16> {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // in 16-bit elements
     return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one rcp, one exp2, five fma -- the
+// epilogue of the GEGLU projection evaluates it for every second accumulator.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    float y = 1.061405429f;
+    y = y * t - 1.453152027f;
+    y = y * t + 1.421413741f;
+    y = y * t - 0.284496736f;
+    y = y * t + 0.254829592f;
+    y = 1.0f - y * t * __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
+    return copysignf(y, x);
 }
 
 // Epilogue of one output row m, 4 consecutive columns n4..n4+3 (fp32 accumulators v): bias, per-image
@@ -86,7 +111,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const float g = v[2 * e + 1];
-            w2[e] = from_f32<T>(v[2 * e] * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f))));
+            w2[e] = from_f32<T>(v[2 * e] * (0.5f * g * (1.0f + erf_as(g * 0.70710678118654752440f))));
         }
         *reinterpret_cast<u16x2*>(o) = w2;
     } else if (p.out_f32) {
@@ -99,6 +124,97 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
         for (int e = 0; e < 4; ++e) w4[e] = from_f32<T>(v[e]);
         *reinterpret_cast<u16x4*>(o) = w4;
     }
+}
+
+// Block epilogue.  All arithmetic (bias, per-image row vector, residual, GEGLU) runs in the MFMA
+// fragment layout on the fp32 accumulators -- one rounding to 16 bit -- and the finished 16-bit tile is
+// staged through LDS so that it leaves as whole 16-byte row segments (a fragment store touches 16
+// different rows with 8 bytes each).  fp32 output, ragged N or an unaligned out_ld take the direct
+// per-fragment store.  smem16: the block's LDS (the operand ring is dead after the K loop).
+template <typename T, int MREP, int NREP, int NT, int BM, int BN>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, long bz, f32x4 (&acc)[MREP][NREP],
+                                              unsigned short* smem16, int m0, int n0, int row_base, int col_base,
+                                              int lane, int t) {
+    constexpr int SLD = BN + 8;                                   // 16-bit elements per staged row
+    const int n_store = p.geglu ? p.N >> 1 : p.N;
+    const bool staged = !p.out_f32 && (p.out_ld & 7) == 0 && (n_store & 7) == 0;
+    const int cq = 4 * (lane >> 4), rl = lane & 15;
+    float4 bias[NREP];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+        const int n4 = n0 + col_base + j * 16 + cq;
+        bias[j] = (p.bias && n4 < p.N) ? *reinterpret_cast<const float4*>(p.bias + n4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned short* resp = p.residual ? p.residual + bz * p.res_bs : nullptr;
+    __syncthreads();                                              // every wave is done reading the operand ring
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int r = row_base + i * 16 + rl, m = m0 + r;
+        const bool mok = m < p.M;
+        u16x4 res[NREP];
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const int n4 = n0 + col_base + j * 16 + cq;
+            res[j] = u16x4{0, 0, 0, 0};
+            if (resp && mok && n4 < p.N) res[j] = *reinterpret_cast<const u16x4*>(resp + static_cast<long>(m) * p.res_ld + n4);
+        }
+        const float* rv = (p.rowvec && mok) ? p.rowvec + static_cast<long>(m / p.rows_per_img) * p.rowvec_ld : nullptr;
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const int c = col_base + j * 16 + cq, n4 = n0 + c;
+            float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z, acc[i][j][3] + bias[j].w};
+            if (rv && n4 < p.N) {
+                const float4 b = *reinterpret_cast<const float4*>(rv + n4);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(res[j][e]);
+            if (!staged) {
+                if (mok && n4 < p.N) {
+                    if (p.geglu || !p.out_f32) {
+                        // bias / rowvec / residual are already in v: store through the plain path
+                        GemmParams q = p; q.bias = nullptr; q.rowvec = nullptr; q.residual = nullptr;
+                        epilogue_store<T>(q, bz, m, n4, v);
+                    } else {
+                        float* o = static_cast<float*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
+                        *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
+                    }
+                }
+            } else if (p.geglu) {
+                typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+                u16x2 w2;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float g = v[2 * e + 1];
+                    w2[e] = from_f32<T>(v[2 * e] * (0.5f * g * (1.0f + erf_as(g * 0.70710678118654752440f))));
+                }
+                *reinterpret_cast<u16x2*>(smem16 + r * SLD + (c >> 1)) = w2;
+            } else {
+                u16x4 w4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w4[e] = from_f32<T>(v[e]);
+                *reinterpret_cast<u16x4*>(smem16 + r * SLD + c) = w4;
+            }
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    unsigned short* outp = static_cast<unsigned short*>(p.out) + bz * p.out_bs;
+    auto copy_out = [&](auto cpr_tag) {
+        constexpr int CPR = decltype(cpr_tag)::value;             // 16-byte chunks per tile row
+        const int nbase = p.geglu ? n0 >> 1 : n0;
+#pragma unroll
+        for (int k = 0; k < (BM * CPR + NT - 1) / NT; ++k) {
+            const int q = t + k * NT, r = q / CPR, c8 = (q - r * CPR) * 8;
+            const int m = m0 + r;
+            if (q < BM * CPR && m < p.M && nbase + c8 < n_store) {
+                const u16x8 x = *reinterpret_cast<const u16x8*>(smem16 + r * SLD + c8);
+                *reinterpret_cast<u16x8*>(outp + static_cast<long>(m) * p.out_ld + nbase + c8) = x;
+            }
+        }
+    };
+    if (p.geglu) copy_out(std::integral_constant<int, BN / 16>());
+    else copy_out(std::integral_constant<int, BN / 8>());
 }
 
 template <typename T, int MREP, int NREP>
@@ -228,34 +344,270 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
         }
     };
 
+    stamp(p, 0);
     dma_stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(p, 1);
     for (int kb = kb0, it = 0; kb < kb1; ++kb, ++it) {
         if (kb + 1 < kb1) dma_stage((it + 1) & 1);            // in flight during the MFMAs
         compute(it & 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's DMA has landed ...
         __syncthreads();                                      // ... before anyone reads the tile
     }
+    stamp(p, 2);
 
-    // epilogue: lane holds out[m][n4 .. n4+3], m = lane&15, n4 = 4*(lane>>4)
+    if (p.splits > 1) {          // fp32 slab straight from the fragments (64-byte row segments)
 #pragma unroll
-    for (int i = 0; i < MREP; ++i) {
-        const int m = m0 + wm * 16 * MREP + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
+        for (int i = 0; i < MREP; ++i) {
+            const int m = m0 + wm * 16 * MREP + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
 #pragma unroll
-        for (int j = 0; j < NREP; ++j) {
-            const int n4 = n0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
-            if (n4 >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.splits > 1) {
+            for (int j = 0; j < NREP; ++j) {
+                const int n4 = n0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
+                if (n4 >= p.N) continue;
                 float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * p.M + m) * p.N + n4;
-                *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
-            } else {
-                epilogue_store<T>(p, bz, m, n4, v);
+                *reinterpret_cast<float4*>(o) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             }
         }
+        return;
     }
+    epilogue_tile<T, MREP, NREP, 256, BM, BN>(p, bz, acc, smem, m0, n0, wm * 16 * MREP, wn * 16 * NREP, lane, t);
+    stamp(p, 3);
+}
+
+// ---- 8-wave, 3-stage ring variant (the large layers) ---------------------------------------------
+// 512 threads = 8 wavefronts (4 x 2), block tile 256 x (32*NREP) in {256x160, 256x128}, one block per
+// CU (2 waves per SIMD).  Same fragment mapping and LDS image as k_conv_gemm, but the K loop keeps
+// TWO stages of global_load_lds DMA in flight across the barrier: stage it+2 is issued while stage it
+// is multiplied, and stage it is awaited with a COUNTED s_waitcnt vmcnt(L) (L = DMA instructions of
+// one stage) so stage it+1 stays in flight -- one raw s_barrier per K-step, never a full drain.
+// Every wave issues exactly L = 4 + ceil(BN/64) DMA instructions per stage (the ragged half pass of
+// the 160-row weight tile is issued by the lower 32 lanes of all 8 waves), so one immediate serves all.
+// Epilogue: accumulators are staged through LDS (fp32, 128 rows at a time) and leave as whole
+// 16-byte row segments with coalesced residual loads, instead of 8-byte pieces of 16 different rows.
+template <typename T, int NREP>
+__global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
+    constexpr int MREP = 4, BM = 256, BN = 32 * NREP, STAGES = 3;
+    constexpr int STAGE = (BM + BN) * 64;            // 16-bit elements per ring slot
+    constexpr int BFULL = BN / 64;                   // full 64-row DMA passes of the weight tile
+    constexpr bool BHALF = (BN % 64) != 0;           // + one 32-row pass (BN = 160)
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+
+    const int ntile_total = p.mtiles * p.ntiles;
+    int tid_lin = blockIdx.x;
+    {
+        const int q = ntile_total / 8, r = ntile_total % 8;
+        const int xcd = tid_lin % 8, idx = tid_lin / 8;
+        tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = tid_lin % p.ntiles, tile_m = tid_lin / p.ntiles;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long bz = blockIdx.z;
+    const unsigned short* a0 = p.a0 + bz * p.a_bs;
+    const unsigned short* a1 = p.a1 ? p.a1 + bz * p.a_bs : nullptr;
+    const unsigned short* wg = p.w + bz * p.w_bs;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int chunk = t & 7, lrow = t >> 3;                       // 64-row passes: row = pass*64 + lrow
+    const int lchunk8 = (chunk ^ ((lrow >> 1) & 7)) * 8;
+    const int hrow = wave * 4 + (lane >> 3);                      // half pass (lanes 0..31): row = BFULL*64 + hrow
+    const int hchunk8 = (chunk ^ ((hrow >> 1) & 7)) * 8;
+
+    int a_img[MREP], a_y[MREP], a_x[MREP], a_pix[MREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + i * 64 + lrow;
+        if (m < p.M) {
+            const int img = m / p.rows_per_img, rem = m - img * p.rows_per_img;
+            const int yo = rem / p.w_out;
+            a_img[i] = img;
+            a_y[i] = yo * p.stride - p.pad;
+            a_x[i] = (rem - yo * p.w_out) * p.stride - p.pad;
+        } else {
+            a_img[i] = 0; a_y[i] = -(1 << 20); a_x[i] = 0;
+        }
+    }
+    int w_off[BFULL + 1];
+#pragma unroll
+    for (int j = 0; j < BFULL; ++j) {
+        const int n = n0 + j * 64 + lrow;
+        w_off[j] = n < p.N ? n * p.K + lchunk8 : -1;
+    }
+    {
+        const int n = n0 + BFULL * 64 + hrow;
+        w_off[BFULL] = (BHALF && n < p.N) ? n * p.K + hchunk8 : -1;
+    }
+    const int Ctot = p.c0 + p.c1;
+    const int Hl = p.h_in << p.up, Wl = p.w_in << p.up;
+
+    const int nkb = p.K / 64;
+    const int kb0 = blockIdx.y * p.kb_per_split;
+    const int kb1 = min(nkb, kb0 + p.kb_per_split);
+    const int n_it = kb1 - kb0;
+    int kg = kb0 * 64;
+    int tap = kg / Ctot, cc = kg - tap * Ctot;
+    auto set_tap = [&](int tp) {
+        const int ky = p.ksize == 3 ? tp / 3 : 0, kx = p.ksize == 3 ? tp - 3 * ky : 0;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            const int yi = a_y[i] + ky, xi = a_x[i] + kx;
+            const bool ok = yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
+            a_pix[i] = ok ? (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up) : -1;
+        }
+    };
+    set_tap(tap);
+
+    // One stage = NPIECE DMA instructions per wave: pieces 0..3 the activation passes, then the weight
+    // passes.  The pieces are issued one at a time BETWEEN groups of MFMAs: the CU's vector-memory
+    // pipe moves ~64 B/clk, so a burst of 8 waves x 7 KB stalls every wave at issue for ~900 clocks with
+    // the matrix pipe idle (measured, pf_debug_gemm_profile); spread out, the MFMAs cover it.
+    constexpr int NPIECE = MREP + BFULL + (BHALF ? 1 : 0);
+    const unsigned short* st_src = a0;
+    int st_ld = 0, st_coff = 0;
+    auto stage_begin = [&]() {
+        if (cc < p.c0) { st_src = a0; st_ld = p.a0_ld; st_coff = cc + lchunk8; }
+        else { st_src = a1; st_ld = p.a1_ld; st_coff = cc - p.c0 + lchunk8; }
+    };
+    auto stage_end = [&]() {
+        kg += 64;
+        cc += 64;
+        if (cc == Ctot) { cc = 0; ++tap; set_tap(tap); }
+    };
+    auto dma_piece = [&](int slot, int k) {
+        unsigned short* As = smem + slot * STAGE;
+        unsigned short* Bs = As + BM * 64;
+        if (k < MREP) {
+            const unsigned short* g = (a_pix[k] >= 0 && p.dbg != 2) ? st_src + (static_cast<long>(a_pix[k]) * st_ld + st_coff) : p.zeros;
+            unsigned short* dst = As + (k * 64 + wave * 8) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        } else if (k < MREP + BFULL) {
+            const int j = k - MREP;
+            const unsigned short* g = (w_off[j] >= 0 && p.dbg != 2) ? wg + (static_cast<long>(w_off[j]) + kg) : p.zeros;
+            unsigned short* dst = Bs + (j * 64 + wave * 8) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        } else if (BHALF) {
+            if (lane < 32) {
+                const unsigned short* g = w_off[BFULL] >= 0 ? wg + (static_cast<long>(w_off[BFULL]) + kg) : p.zeros;
+                unsigned short* dst = Bs + (BFULL * 64 + wave * 4) * 64;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    auto dma_stage = [&](int slot) {
+        stage_begin();
+#pragma unroll
+        for (int k = 0; k < NPIECE; ++k) dma_piece(slot, k);
+        stage_end();
+    };
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    typedef typename Mfma<T>::frag frag;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    // Fragment registers are double buffered (f0 = first 32 k of a stage, f1 = second) and the barrier
+    // sits BETWEEN the two halves of a step, so the matrix pipe always has 20 MFMAs queued while LDS
+    // reads are in flight (measured: with both halves' reads exposed the K step took 2300 clocks
+    // without any DMA, against 1280 of pure MFMA issue):
+    //   f1 <- LDS(stage it, k 32..63) | MFMA(f0) | wait DMA(it+1), barrier | f0 <- LDS(stage it+1, k 0..31)
+    //   | MFMA(f1) interleaved with the DMA pieces of stage it+2
+    frag fa0[MREP], fb0[NREP], fa1[MREP], fb1[NREP];
+    auto load_frags = [&](int slot, int slab, frag (&fa)[MREP], frag (&fb)[NREP]) {
+        const unsigned short* As = smem + slot * STAGE;
+        const unsigned short* Bs = As + BM * 64;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+            fa[i] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(As + lds_off(wm * 64 + i * 16 + frow, slab * 4 + fchunk)));
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+            fb[j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Bs + lds_off(wn * 16 * NREP + j * 16 + frow, slab * 4 + fchunk)));
+    };
+
+    stamp(p, 0);
+    dma_stage(0);
+    if (n_it > 1) {
+        dma_stage(1);
+        if constexpr (NPIECE == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stamp(p, 1);
+    load_frags(0, 0, fa0, fb0);
+    int cur = 0, nx1 = 1, nx2 = 2;
+    unsigned long long acc_wait = 0, acc_comp = 0, tq = 0;       // diagnostics (p.prof only)
+    for (int it = 0; it < n_it; ++it) {
+        if (p.prof) tq = __builtin_amdgcn_s_memtime();
+        load_frags(cur, 1, fa1, fb1);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc[i][j] = Mfma<T>::run(fb0[j], fa0[i], acc[i][j]);
+        if (p.prof) { asm volatile("s_nop 0" ::: "memory"); const unsigned long long x = __builtin_amdgcn_s_memtime(); acc_comp += x - tq; tq = x; }
+        const bool more = it + 1 < n_it;
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of stage it+1 (a full step in flight)
+            __builtin_amdgcn_s_barrier();                         // stage it+1 complete; stage it-1 no longer read
+            asm volatile("" ::: "memory");
+            if (p.prof) { const unsigned long long x = __builtin_amdgcn_s_memtime(); acc_wait += x - tq; tq = x; }
+            load_frags(nx1, 0, fa0, fb0);
+        }
+        const bool dma = it + 2 < n_it && p.dbg != 1;
+        if (dma) stage_begin();
+#pragma unroll
+        for (int idx = 0; idx < MREP * NREP; ++idx) {
+            const int i = idx / NREP, j = idx % NREP;
+            acc[i][j] = Mfma<T>::run(fb1[j], fa1[i], acc[i][j]);
+            constexpr int GAP = MREP * NREP / NPIECE;             // MFMAs between two DMA pieces
+            if (idx % GAP == GAP - 1 && idx / GAP < NPIECE) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (dma) dma_piece(nx2, idx / GAP);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (dma) stage_end();
+        if (p.prof) { asm volatile("s_nop 0" ::: "memory"); const unsigned long long x = __builtin_amdgcn_s_memtime(); acc_comp += x - tq; tq = x; }
+        cur = cur == STAGES - 1 ? 0 : cur + 1;
+        nx1 = nx1 == STAGES - 1 ? 0 : nx1 + 1;
+        nx2 = nx2 == STAGES - 1 ? 0 : nx2 + 1;
+    }
+    stamp(p, 2);
+    if (p.prof && lane == 0) {
+        const long b = blockIdx.x + static_cast<long>(gridDim.x) * (blockIdx.y + static_cast<long>(gridDim.y) * blockIdx.z);
+        p.prof[b * 32 + 4 + wave * 3 + 0] = acc_wait;
+        p.prof[b * 32 + 4 + wave * 3 + 1] = 0;
+        p.prof[b * 32 + 4 + wave * 3 + 2] = acc_comp;
+    }
+
+    if (p.splits > 1) {          // fp32 slab straight from the fragments (64-byte row segments)
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) {
+                const int n4 = n0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
+                if (n4 >= p.N) continue;
+                float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * p.M + m) * p.N + n4;
+                *reinterpret_cast<float4*>(o) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            }
+        }
+        return;
+    }
+
+    epilogue_tile<T, MREP, NREP, 512, BM, BN>(p, bz, acc, smem, m0, n0, wm * 64, wn * 16 * NREP, lane, t);
+    stamp(p, 3);
 }
 
 // Split-K second pass: sum the fp32 slabs in split order (deterministic) and run the epilogue.
@@ -279,6 +631,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmParams p) {
     epilogue_store<T>(p, bz, m, n4, v);
 }
 
+static unsigned long long* g_prof = nullptr;         // diagnostics buffer (device), see pf_debug_gemm_profile
+static long g_prof_blocks = 0;
+
 static const unsigned short* zero_page() {
     static unsigned short* z = nullptr;          // 256 zero bytes, created on the first launch (before any capture)
     if (!z) {
@@ -296,6 +651,7 @@ static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     PF_REQUIRE(p.zeros, "pf_conv_gemm: zero page allocation failed");
     p.mtiles = static_cast<int>(cdiv(p.M, BM));
     p.ntiles = static_cast<int>(cdiv(p.N, BN));
+    p.prof = (g_prof && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= g_prof_blocks) ? g_prof : nullptr;
     const size_t smem = static_cast<size_t>(2) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
@@ -313,10 +669,51 @@ static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     return PF_OK;
 }
 
+template <typename T, int NREP>
+static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
+    constexpr int BM = 256, BN = 32 * NREP;
+    GemmParams p = gp;
+    p.zeros = zero_page();
+    PF_REQUIRE(p.zeros, "pf_conv_gemm: zero page allocation failed");
+    p.mtiles = static_cast<int>(cdiv(p.M, BM));
+    p.ntiles = static_cast<int>(cdiv(p.N, BN));
+    p.prof = (g_prof && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= g_prof_blocks) ? g_prof : nullptr;
+    const size_t smem = static_cast<size_t>(3) * (BM + BN) * 64 * sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm8<T, NREP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv_gemm8<T, NREP>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(512), smem, st, p);
+    PF_CHECK_LAUNCH("pf_conv_gemm (8-wave)");
+    if (p.splits > 1) {
+        const long total = static_cast<long>(batch) * p.M * (p.N / 4);
+        hipLaunchKernelGGL((k_splitk_reduce<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, p);
+        PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
+    }
+    return PF_OK;
+}
+
+static int tuning(const char* name, int dflt) {     // A/B switches for benchmarking (read once)
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 // Tile shape + split-K plan of one problem (shared by the launcher and the workspace query).
-struct GemmPlan { int mrep, nrep, splits, kb_per_split; };
+struct GemmPlan { int mrep, nrep, splits, kb_per_split; bool big; };
 static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
     GemmPlan g;
+    static const int big_min_tiles = tuning("PF_GEMM8_MIN_TILES", 128);   // 0 disables the 8-wave kernel
+    g.big = false;
+    {
+        const int nrep = (N % 160 == 0) ? 5 : 4;
+        const long tiles256 = cdiv(M, 256) * cdiv(N, 32 * nrep) * batch;
+        if (big_min_tiles > 0 && tiles256 >= big_min_tiles) {
+            g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64;
+            return g;
+        }
+    }
     // 160-wide N tiles when they divide N exactly (all UNet widths are multiples of 160), 128-wide
     // otherwise; 64-row M tiles when 128-row tiles would not fill the 256 CUs (2 blocks per CU).
     g.nrep = (N % 160 == 0) ? 5 : 4;
@@ -395,6 +792,9 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;
     p.mtiles = p.ntiles = 0;
     p.zeros = nullptr;
+    p.prof = nullptr;
+    static const int dbg = tuning("PF_GEMM_DEBUG", 0);
+    p.dbg = dbg;
     p.batch = d->batch;
     const GemmPlan g = plan_gemm(p.M, p.N, p.K, d->batch, d->workspace != nullptr);
     p.splits = g.splits; p.kb_per_split = g.kb_per_split;
@@ -405,9 +805,20 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
                    "pf_conv_gemm: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, d->workspace_bytes);
     }
     hipStream_t st = as_stream(stream);
+    if (g.big) {
+        PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
+            if (g.nrep == 5) return launch8<T, 5>(p, d->batch, st);
+            else return launch8<T, 4>(p, d->batch, st));
+    }
     PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
         if (g.nrep == 5) return g.mrep == 2 ? launch<T, 2, 5>(p, d->batch, st) : launch<T, 4, 5>(p, d->batch, st);
         else return g.mrep == 2 ? launch<T, 2, 4>(p, d->batch, st) : launch<T, 4, 4>(p, d->batch, st));
+    return PF_OK;
+}
+
+extern "C" pf_status pf_debug_gemm_profile(void* device_buffer, long capacity_blocks) {
+    g_prof = static_cast<unsigned long long*>(device_buffer);
+    g_prof_blocks = device_buffer ? capacity_blocks : 0;
     return PF_OK;
 }
 

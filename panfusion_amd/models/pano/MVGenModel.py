@@ -9,6 +9,9 @@ PanoOnly shape, PanoOnly.py:13).  Their weights are repacked once per device
 into kernel layouts; ``forward`` then sequences C-ABI kernel calls and never
 touches the modules' own ``forward``.
 """
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
 
@@ -27,6 +30,10 @@ class MultiViewBaseModel(nn.Module):
         self.pano_pad = pano_pad
         self.compute_dtype = compute_dtype
         self._packed = {}
+        # the panorama branch runs on its own HIP stream between EPA fusions (its layers are too small
+        # to fill 256 CUs; side by side with the view branch they fill each other's tails)
+        self.two_streams = os.environ.get("PF_STREAMS", "2") != "1"
+        self._side = None
 
         if self.unet is not None:      # EPA block widths, reference MVGenModel.py:19-32
             self.cp_blocks_encoder = nn.ModuleList(
@@ -85,17 +92,52 @@ class MultiViewBaseModel(nn.Module):
             branches.append(pers)
         else:
             pano_t = timestep
-        pano = engine.Branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
-                             pano_prompt_embd.flatten(0, 1).to(dt).contiguous(), pano=True, pad=self.pano_pad)
+        main = torch.cuda.current_stream(dev) if pano_latent.is_cuda else None
+        side = None
+        if two and self.two_streams and main is not None:
+            if self._side is None:
+                self._side = torch.cuda.Stream(dev)
+            side = self._side
+        keep = []                                   # tensors produced on one stream and read on the other stay
+                                                    # referenced until the next join (allocator reuse is per stream)
+
+        def on_pano():
+            return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+
+        def fork():
+            if side is not None:
+                side.wait_stream(main)
+
+        def join():
+            if side is not None:
+                main.wait_stream(side)
+                keep.clear()
+
+        fork()
+        with on_pano():
+            pano = engine.Branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
+                                 pano_prompt_embd.flatten(0, 1).to(dt).contiguous(), pano=True, pad=self.pano_pad)
         branches.append(pano)
 
+        def each_branch(fn):
+            for br in branches:
+                if br is pano:
+                    with on_pano():
+                        fn(br)
+                else:
+                    fn(br)
+
         def fuse(block):
+            join()
+            keep.append(pano.h)
             pers.h, pano.h = block.forward_nhwc(pers.h, pano.h, groups, m_total, shard=shard)
+            keep.append(pano.h)
+            fork()
 
         pu = pano.u
         # encoder (reference :98-152): EPA after each downsample
         for i in range(len(pu.down)):
-            for br in branches:
+            def level(br, i=i):
                 blk = br.u.down[i]
                 for j, r in enumerate(blk.resnets):
                     br.resnet(r)
@@ -105,32 +147,38 @@ class MultiViewBaseModel(nn.Module):
                 if blk.down is not None:
                     br.downsample(blk.down)
                     br.push()
+            each_branch(level)
             if pu.down[i].down is not None and two:
                 fuse(self.cp_blocks_encoder[i])
+
         # mid (reference :172-207)
-        for br in branches:
+        def middle(br):
             mid = br.u.mid
             br.resnet(mid.resnets[0])
             for a, r in zip(mid.attns, mid.resnets[1:]):
                 br.attention(a)
                 br.resnet(r)
+        each_branch(middle)
         if two:
             fuse(self.cp_blocks_mid)
         # decoder (reference :210-277): EPA before each upsample
         for i in range(len(pu.up)):
-            for br in branches:
+            def level_up(br, i=i):
                 blk = br.u.up[i]
                 for j, r in enumerate(blk.resnets):
                     br.resnet(r, skip=True)
                     if blk.attns is not None:
                         br.attention(blk.attns[j])
+            each_branch(level_up)
             if pu.up[i].up is not None:
                 if two:
                     fuse(self.cp_blocks_decoder[i])
-                for br in branches:
-                    br.upsample(br.u.up[i].up)
+                each_branch(lambda br, i=i: br.upsample(br.u.up[i].up))
 
+        with on_pano():
+            pano_head = pano.head()
+        join()
         out_dtype = pano_latent.dtype
-        pano_sample = pano.head().to(out_dtype).unflatten(0, (-1, 1))
+        pano_sample = pano_head.to(out_dtype).unflatten(0, (-1, 1))
         sample = pers.head().to(out_dtype).unflatten(0, (b, m)) if two else None
         return sample, pano_sample

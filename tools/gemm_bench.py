@@ -1,0 +1,86 @@
+"""GEMM / conv microbenchmark on the shapes of the benchmark step (one MI355X).
+    python tools/gemm_bench.py [--reps 20] [--shapes conv64,ff1,...]
+Prints TF/s per shape; under rocprofv3 --pmc the per-kernel counters give the stall breakdown."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from panfusion_amd import ops  # noqa: E402
+
+SHAPES = {
+    # name: (n_img, h, w, cin, cout, ksize, extras)
+    "conv64": (40, 64, 64, 320, 320, 3, {}),
+    "conv64cat": (40, 64, 64, 640, 320, 3, {}),
+    "conv32": (40, 32, 32, 640, 640, 3, {}),
+    "conv16": (40, 16, 16, 1280, 1280, 3, {}),
+    "conv8": (40, 8, 8, 1280, 1280, 3, {}),
+    "lin320": (1, 1, 163840, 320, 320, 1, {"res": True}),
+    "qk320": (1, 1, 163840, 320, 640, 1, {}),
+    "ff1_320": (1, 1, 163840, 320, 2560, 1, {"geglu": True}),
+    "ff2_320": (1, 1, 163840, 1280, 320, 1, {"res": True}),
+    "lin640": (1, 1, 40960, 640, 640, 1, {"res": True}),
+    "ff1_640": (1, 1, 40960, 640, 5120, 1, {"geglu": True}),
+    "lin1280": (1, 1, 10240, 1280, 1280, 1, {"res": True}),
+    "ff1_1280": (1, 1, 10240, 1280, 10240, 1, {"geglu": True}),
+    "pano_conv64": (2, 64, 132, 320, 320, 3, {}),
+    "pano_conv8": (2, 8, 20, 1280, 1280, 3, {}),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--phases", action="store_true", help="per-block phase stamps (pf_debug_gemm_profile)")
+    ap.add_argument("--shapes", default=",".join(SHAPES))
+    args = ap.parse_args()
+    dev = "cuda"
+    for name in args.shapes.split(","):
+        n, h, w, cin, cout, ks, ex = SHAPES[name]
+        g = torch.Generator(device=dev).manual_seed(1)
+        x = torch.randn(n, h, w, cin, device=dev, generator=g).to(torch.bfloat16)
+        wt = (torch.randn(cout, ks * ks * cin, device=dev, generator=g) / (ks * ks * cin) ** 0.5).to(torch.bfloat16)
+        b = torch.randn(cout, device=dev, generator=g)
+        M = n * h * w
+        n_store = cout // 2 if ex.get("geglu") else cout
+        res = torch.randn(M, n_store, device=dev, generator=g).to(torch.bfloat16) if ex.get("res") else None
+        out = torch.empty(M, n_store, device=dev, dtype=torch.bfloat16)
+        kw = dict(n_img=n, h_in=h, w_in=w, ksize=ks, pad=ks // 2, bias=b, residual=res, out=out, geglu=bool(ex.get("geglu")))
+        for _ in range(3):
+            ops.conv_gemm(x, wt, cout, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(int(0.02 * 2.4e9))
+        e0.record()
+        for _ in range(args.reps):
+            ops.conv_gemm(x, wt, cout, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.reps
+        fl = 2.0 * M * cout * ks * ks * cin
+        byt = 2.0 * (M * cin + cout * ks * ks * cin + M * n_store * (2 if res is not None else 1))
+        if args.phases:
+            from panfusion_amd import _lib
+            cap = 1 << 16
+            buf = torch.zeros(cap * 32, dtype=torch.int64, device=dev)
+            _lib.lib().pf_debug_gemm_profile(buf.data_ptr(), cap)
+            ops.conv_gemm(x, wt, cout, **kw)
+            torch.cuda.synchronize()
+            _lib.lib().pf_debug_gemm_profile(None, 0)
+            full = buf.view(cap, 32).cpu()
+            full = full[full[:, 3] != 0].double()
+            st = full[:, :4]
+            if float(full[:, 4:28].abs().sum()) > 0:
+                w = full[:, 4:28].view(-1, 8, 3).mean(0)
+                print("   per-wave K-loop clocks [wait+barrier, DMA issue, ds_read+MFMA]:", " ".join("w%d[%.0f %.0f %.0f]" % (i, *w[i]) for i in range(8)))
+            d = (st[:, 1:] - st[:, :-1])
+            span = float(st[:, 3].max() - st[:, 0].min())
+            print("   phases (shader clocks, %d blocks): first tile %.0f  K loop %.0f  epilogue %.0f  | block total %.0f  kernel span %.0f (100 MHz memtime ticks?)"
+                  % (st.shape[0], d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean(), (st[:, 3] - st[:, 0]).mean(), span))
+        print("%-12s M%-7d N%-6d K%-6d  %8.1f us  %7.1f TF/s   algorithmic HBM %6.2f TB/s" % (name, M, cout, ks * ks * cin, us, fl / us / 1e6, byt / us / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+"""Condense rocprofv3 CSV output (too large to keep) into small per-kernel tables.
+
+    python tools/prof_summary.py trace  <kernel_trace.csv>  <out.txt>  [denoiser passes in the run]
+    python tools/prof_summary.py pmc    <counter_collection.csv> <out.txt>
+"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void ", "").replace("pf::", "")
+    cut = name.find("(")
+    return (name[:cut] if cut > 0 else name)[:70]
+
+
+def trace(path, out, passes):
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        key = (short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))
+        a = agg[key]
+        a[0] += 1
+        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+    tot = sum(v[1] for v in agg.values())
+    fam = defaultdict(float)
+    for k, v in agg.items():
+        fam[k[0]] += v[1]
+    with open(out, "w") as fh:
+        fh.write("total kernel time %.2f ms over %d denoiser passes = %.2f ms / pass\n\n" % (tot, passes, tot / passes))
+        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]):
+            fh.write("%-72s %9.3f ms/pass %5.1f %%\n" % (k, v / passes, 100 * v / tot))
+        fh.write("\nper (kernel, grid): calls/pass, ms/pass, us/call\n")
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:120]:
+            fh.write("%-60s grid %8s %4s %4s  calls %6.1f  %8.3f ms  %8.1f us\n" % (k[0][:60], k[1], k[2], k[3], v[0] / passes, v[1] / passes, 1e3 * v[1] / v[0]))
+
+
+def pmc(path, out):
+    agg = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(int)
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        calls[(k, r["Counter_Name"])] += 1
+    with open(out, "w") as fh:
+        for k, cs in sorted(agg.items()):
+            for c, v in sorted(cs.items()):
+                fh.write("%-72s %-28s total %.6g  per-dispatch %.6g  dispatches %d\n" % (k, c, v, v / calls[(k, c)], calls[(k, c)]))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 1)
+    else:
+        pmc(sys.argv[2], sys.argv[3])
