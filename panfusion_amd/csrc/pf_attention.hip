@@ -20,6 +20,7 @@
 // (models/pano/MVGenModel.py:104,116,185,190,227,241).
 #include "pf_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace pf {
 
@@ -204,7 +205,9 @@ __global__ __launch_bounds__(256) void k_attention(const AttnParams p) {
 //   distinct bank pairs.
 // One online-softmax update per 64 keys.
 template <typename T, int D>
-__global__ __launch_bounds__(256) void k_attention_lds(const AttnParams p) {
+__global__ __launch_bounds__(256, D == 64 ? 2 : 4) void k_attention_lds(const AttnParams p) {
+    // (256, 2): at most 256 registers per lane -> the MFMA accumulators live in the VGPR file; with the
+    // default budget the compiler parks S and O in AGPRs and pays ~145 v_accvgpr moves per key tile.
     constexpr int KS = D / 16, DB = D / 32, KT = 64;
     constexpr int KCHUNKS = D / 8;                     // 16-B chunks per K row
     constexpr int VROW = KT + 4;                       // elements per padded V^T row (136 B)
@@ -233,7 +236,8 @@ __global__ __launch_bounds__(256) void k_attention_lds(const AttnParams p) {
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;              // running max of the RAW scores (q.k), running sum
+    const float c2 = p.scale_log2e;                    // softmax(scale * s) = exp2(c2 * s - c2 * max)
 
     auto k_off = [](int row, int chunk) {
         const int sw = (KCHUNKS == 8) ? ((row >> 1) & 7) : ((row >> 2) & 3);
@@ -242,26 +246,33 @@ __global__ __launch_bounds__(256) void k_attention_lds(const AttnParams p) {
 
     const int nkt = (p.nk + KT - 1) / KT;
     u16x8 kreg[KCH], vreg[VCH];
-    auto stage_load = [&](int j) {
+    // staging ownership (fixed per thread): K chunk c = t + 256 i -> (row c / KCHUNKS, chunk c % KCHUNKS);
+    // V^T chunk c -> (d = c >> 3, 8 keys starting at (c & 7) * 8)
+    auto stage_load = [&](int j, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         const int k0 = j * KT;
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             const int c = t + 256 * i, row = c / KCHUNKS, chunk = c % KCHUNKS;
-            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (k0 + row < p.nk) v = *reinterpret_cast<const u16x8*>(kp + static_cast<long>(k0 + row) * p.k_ld + chunk * 8);
-            kreg[i] = v;
+            if (!TAIL || k0 + row < p.nk)
+                kreg[i] = *reinterpret_cast<const u16x8*>(kp + static_cast<long>(k0 + row) * p.k_ld + chunk * 8);
+            else
+                kreg[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
 #pragma unroll
         for (int i = 0; i < VCH; ++i) {
             const int c = t + 256 * i, d = c >> 3, key0 = k0 + (c & 7) * 8;
-            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (key0 + 8 <= p.vt_ld) v = *reinterpret_cast<const u16x8*>(vp + static_cast<long>(d) * p.vt_ld + key0);
-            if (k0 + KT > p.nk) {                      // tail tile: padding of V^T may hold anything (0 * NaN = NaN)
+            if (!TAIL || key0 + 8 <= p.vt_ld) {
+                u16x8 v = *reinterpret_cast<const u16x8*>(vp + static_cast<long>(d) * p.vt_ld + key0);
+                if (TAIL) {                            // padding of V^T may hold anything (0 * NaN = NaN)
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (key0 + e >= p.nk) v[e] = 0;
+                    for (int e = 0; e < 8; ++e)
+                        if (key0 + e >= p.nk) v[e] = 0;
+                }
+                vreg[i] = v;
+            } else {
+                vreg[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
-            vreg[i] = v;
         }
     };
     auto stage_store = [&](int buf) {
@@ -285,43 +296,40 @@ __global__ __launch_bounds__(256) void k_attention_lds(const AttnParams p) {
     const uint8_t* flag_row = p.flags ? p.flags + static_cast<long>(min(q0, p.nq - 1) >> 5) * p.flags_ld : nullptr;
     const float* bias_row = p.bias ? p.bias + static_cast<long>(qrow) * p.bias_ld : nullptr;
 
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    for (int j = 0; j < nkt; ++j) {
-        if (j + 1 < nkt) stage_load(j + 1);
+    // one key tile: S^T = K Q^T (raw scores), online softmax, O^T += V^T P^T
+    auto tile = [&](int j, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         const int k0 = j * KT;
         const unsigned short* Ks = smem + (j & 1) * (K_ELEMS + V_ELEMS);
         const unsigned short* Vs = Ks + K_ELEMS;
-
         float sv[2][16];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const u16x8 kf = *reinterpret_cast<const u16x8*>(Ks + k_off(hh * 32 + ql, 2 * ks + hi));
                 s = Mfma32<T>::run(__builtin_bit_cast(frag, kf), qf[ks], s);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sv[hh][r] = s[r] * p.scale_log2e;
+            for (int r = 0; r < 16; ++r) sv[hh][r] = s[r];
             const int kb = k0 + hh * 32;
-            if (flag_row && kb < p.nk && flag_row[kb >> 5]) {
+            if (flag_row && (!TAIL || kb < p.nk) && flag_row[kb >> 5]) {
+                // additive bias in units of the raw score: bias / scale
+                const float inv_c = 1.44269504088896340736f / c2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int key = kb + 8 * g + 4 * hi;
-                    if (key + 3 < p.nk) {
+                    if (!TAIL || key + 3 < p.nk) {
                         const float4 bv = *reinterpret_cast<const float4*>(bias_row + key);
-                        sv[hh][4 * g + 0] += bv.x * 1.44269504088896340736f;
-                        sv[hh][4 * g + 1] += bv.y * 1.44269504088896340736f;
-                        sv[hh][4 * g + 2] += bv.z * 1.44269504088896340736f;
-                        sv[hh][4 * g + 3] += bv.w * 1.44269504088896340736f;
+                        sv[hh][4 * g + 0] += bv.x * inv_c;
+                        sv[hh][4 * g + 1] += bv.y * inv_c;
+                        sv[hh][4 * g + 2] += bv.z * inv_c;
+                        sv[hh][4 * g + 3] += bv.w * inv_c;
                     }
                 }
             }
-            if (kb + 32 > p.nk) {
+            if (TAIL) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kb + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.nk) sv[hh][r] = -INFINITY;
@@ -333,24 +341,27 @@ __global__ __launch_bounds__(256) void k_attention_lds(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sv[hh][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        if (__any(mt > m_run)) {                       // some row's maximum grew: rescale (exact, no threshold)
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+        const float mc = m_run * c2;
         float ls = 0.f;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sv[hh][r] = __builtin_amdgcn_exp2f(sv[hh][r] - m_new);
+                sv[hh][r] = __builtin_amdgcn_exp2f(sv[hh][r] * c2 - mc);
                 ls += sv[hh][r];
             }
         ls += __shfl_xor(ls, 32);
-        l_run = l_run * alpha + ls;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-
+        l_run += ls;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -367,8 +378,21 @@ __global__ __launch_bounds__(256) void k_attention_lds(const AttnParams p) {
                     o[d] = Mfma32<T>::run(__builtin_bit_cast(frag, vf), __builtin_bit_cast(frag, pb), o[d]);
                 }
             }
+    };
 
-        if (j + 1 < nkt) stage_store((j + 1) & 1);
+    const std::true_type TAILY;
+    const std::false_type FULL;
+    const bool ragged = (p.nk % KT) != 0;              // only the last tile can be partial
+    if (nkt == 1 && ragged) stage_load(0, TAILY); else stage_load(0, FULL);
+    stage_store(0);
+    __syncthreads();
+    for (int j = 0; j < nkt; ++j) {
+        const bool last = j + 1 == nkt;
+        if (!last) {
+            if (j + 2 == nkt && ragged) stage_load(j + 1, TAILY); else stage_load(j + 1, FULL);
+        }
+        if (last && ragged) tile(j, TAILY); else tile(j, FULL);
+        if (!last) stage_store((j + 1) & 1);
         __syncthreads();
     }
 

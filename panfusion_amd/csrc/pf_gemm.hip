@@ -37,11 +37,10 @@ struct GemmParams {
     void* out; int out_ld; int out_f32; int geglu;
     long a_bs, w_bs, out_bs, res_bs;
     int mtiles, ntiles;
-    const unsigned short* zeros;   // >= 16 zero bytes in global memory (source of padded rows / ragged tiles)
     int splits, kb_per_split;      // split-K: blockIdx.y walks K-blocks [y*kb_per_split, ...)
     float* partial;                // [split][batch][M][N] fp32 when splits > 1
     int batch;
-    int dbg;                       // diagnostics (PF_GEMM_DEBUG): 1 = skip steady-state DMA, 2 = DMA reads the zero page
+    unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors of the 8-wave kernel (< 2 GiB)
     unsigned long long* prof;      // diagnostics (pf_debug_gemm_profile): 4 s_memtime stamps per block, or NULL
 };
 
@@ -239,7 +238,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     const unsigned short* a1 = p.a1 ? p.a1 + bz * p.a_bs : nullptr;
     const unsigned short* wg = p.w + bz * p.w_bs;
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     // staging ownership: global_load_lds_dwordx4 writes LDS at (wave-uniform base + 16 * lane), i.e.
     // lane l of wave w fills physical chunk l%8 of row 8w + l/8 of a 32-row pass.  The XOR swizzle
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     const int lchunk8 = (chunk ^ ((lrow >> 1) & 7)) * 8;
 
     // per-thread staging rows: output pixel -> top-left input coordinate
-    int a_img[MREP], a_y[MREP], a_x[MREP], a_pix[MREP];
+    int a_img[MREP], a_y[MREP], a_x[MREP];
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
         const int m = m0 + i * 32 + lrow;
@@ -263,54 +263,69 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
             a_img[i] = 0; a_y[i] = -(1 << 20); a_x[i] = 0;     // never in range
         }
     }
-    int w_off[NREP];
+    // DMA addressing as in k_conv_gemm8: scalar buffer descriptors + per-thread byte offset (VGPR) +
+    // per-stage scalar offset; out-of-range offsets (zero padding, ragged tiles) read as zero.
+    constexpr unsigned OOB = 0x80000000u;
+    auto uniform_ptr = [](const unsigned short* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+        const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+        return reinterpret_cast<unsigned short*>(static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32));
+    };
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(wg), 0, __builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000);
+    unsigned w_off[NREP];                                         // bytes
 #pragma unroll
     for (int j = 0; j < NREP; ++j) {
         const int n = n0 + j * 32 + lrow;
-        w_off[j] = n < p.N ? n * p.K + lchunk8 : -1;
+        w_off[j] = n < p.N ? static_cast<unsigned>(n * p.K + lchunk8) * 2u : OOB;
     }
     const int Ctot = p.c0 + p.c1;
     const int Hl = p.h_in << p.up, Wl = p.w_in << p.up;
 
-    // K walk (wave-uniform state): K-block kb = (tap, 64-channel block cc); no divisions in the loop
+    // K walk (wave-uniform state): K-block kb = (tap, source, 64-channel block); no divisions in the loop
     const int nkb = p.K / 64;
     const int kb0 = blockIdx.y * p.kb_per_split;
     const int kb1 = min(nkb, kb0 + p.kb_per_split);
     int kg = kb0 * 64;
     int tap = kg / Ctot, cc = kg - tap * Ctot;
-    auto set_tap = [&](int tp) {
-        const int ky = p.ksize == 3 ? tp / 3 : 0, kx = p.ksize == 3 ? tp - 3 * ky : 0;
+    unsigned a_off[MREP];                                         // bytes, or OOB
+    bool seg1 = false;
+    auto set_segment = [&]() {
+        const int ky = p.ksize == 3 ? tap / 3 : 0, kx = p.ksize == 3 ? tap - 3 * ky : 0;
+        seg1 = __builtin_amdgcn_readfirstlane(cc >= p.c0 ? 1 : 0) != 0;
+        const int ld = seg1 ? p.a1_ld : p.a0_ld;
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
             const int yi = a_y[i] + ky, xi = a_x[i] + kx;
             const bool ok = yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
-            a_pix[i] = ok ? (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up) : -1;
+            const int pix = (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up);
+            a_off[i] = ok ? static_cast<unsigned>(pix * ld + lchunk8) * 2u : OOB;
         }
     };
-    set_tap(tap);
+    set_segment();
 
+    auto lds_dma = [&](const __amdgpu_buffer_rsrc_t& r, unsigned short* dst, unsigned voff, int soff) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+    };
     auto dma_stage = [&](int buf) {
-        const unsigned short* src;
-        int ld, coff;
-        if (cc < p.c0) { src = a0; ld = p.a0_ld; coff = cc; } else { src = a1; ld = p.a1_ld; coff = cc - p.c0; }
-        coff += lchunk8;
+        const int soff_a = __builtin_amdgcn_readfirstlane((seg1 ? cc - p.c0 : cc) * 2);
+        const int soff_w = __builtin_amdgcn_readfirstlane(kg * 2);
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(seg1 ? a1 : a0), 0, __builtin_amdgcn_readfirstlane(seg1 ? p.a1_bytes : p.a0_bytes), 0x00020000);
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
-            const unsigned short* g = a_pix[i] >= 0 ? src + (static_cast<long>(a_pix[i]) * ld + coff) : p.zeros;
             unsigned short* dst = As + buf * BM * 64 + (i * 32 + wave * 8) * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            lds_dma(rs_a, dst, a_off[i], soff_a);
         }
 #pragma unroll
         for (int j = 0; j < NREP; ++j) {
-            const unsigned short* g = w_off[j] >= 0 ? wg + (static_cast<long>(w_off[j]) + kg) : p.zeros;
             unsigned short* dst = Bs + buf * BN * 64 + (j * 32 + wave * 8) * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            lds_dma(rs_w, dst, w_off[j], soff_w);
         }
         kg += 64;
         cc += 64;
-        if (cc == Ctot) { cc = 0; ++tap; set_tap(tap); }
+        if (cc == Ctot) { cc = 0; ++tap; set_segment(); }
+        else if (cc == p.c0) set_segment();
     };
 
     f32x4 acc[MREP][NREP];
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
     const int hrow = wave * 4 + (lane >> 3);                      // half pass (lanes 0..31): row = BFULL*64 + hrow
     const int hchunk8 = (chunk ^ ((hrow >> 1) & 7)) * 8;
 
-    int a_img[MREP], a_y[MREP], a_x[MREP], a_pix[MREP];
+    int a_img[MREP], a_y[MREP], a_x[MREP];
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
         const int m = m0 + i * 64 + lrow;
@@ -430,79 +445,96 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
             a_img[i] = 0; a_y[i] = -(1 << 20); a_x[i] = 0;
         }
     }
-    int w_off[BFULL + 1];
+    // DMA addressing: buffer descriptors (SGPR) + a per-thread 32-bit byte offset (VGPR) + a per-stage
+    // scalar byte offset (soffset), so that a piece costs no vector ALU work per K step -- the kernel is
+    // bound by instruction issue, not by the matrix pipe (4 issue slots of a SIMD per 16-clock MFMA,
+    // shared by two waves).  Zero padding / ragged tiles: an offset beyond num_records reads as zero.
+    constexpr unsigned OOB = 0x80000000u;                         // launcher guarantees tensors < 2 GiB
+    // descriptors are built from readfirstlane'd words: hipcc otherwise treats a selected descriptor as
+    // divergent and wraps every DMA in a waterfall loop (cdna_hip_programming.md T20)
+    auto uniform_ptr = [](const unsigned short* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+        const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+        return reinterpret_cast<unsigned short*>(static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32));
+    };
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(wg), 0, __builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000);
+    // (the activation descriptor is rebuilt from scalars at the start of every stage: carried across
+    // the loop as a variable it would live in VGPRs again)
+    unsigned w_off[BFULL + 1];                                    // bytes
 #pragma unroll
     for (int j = 0; j < BFULL; ++j) {
         const int n = n0 + j * 64 + lrow;
-        w_off[j] = n < p.N ? n * p.K + lchunk8 : -1;
+        w_off[j] = n < p.N ? static_cast<unsigned>(n * p.K + lchunk8) * 2u : OOB;
     }
     {
         const int n = n0 + BFULL * 64 + hrow;
-        w_off[BFULL] = (BHALF && n < p.N) ? n * p.K + hchunk8 : -1;
+        w_off[BFULL] = (BHALF && n < p.N) ? static_cast<unsigned>(n * p.K + hchunk8) * 2u : OOB;
     }
     const int Ctot = p.c0 + p.c1;
     const int Hl = p.h_in << p.up, Wl = p.w_in << p.up;
 
+    // K walk (wave-uniform): K-block = (tap, source, 64-channel block).  Per-thread activation offsets
+    // change only when the tap or the source changes ("segment"); inside a segment only soffset moves.
     const int nkb = p.K / 64;
     const int kb0 = blockIdx.y * p.kb_per_split;
     const int kb1 = min(nkb, kb0 + p.kb_per_split);
     const int n_it = kb1 - kb0;
     int kg = kb0 * 64;
     int tap = kg / Ctot, cc = kg - tap * Ctot;
-    auto set_tap = [&](int tp) {
-        const int ky = p.ksize == 3 ? tp / 3 : 0, kx = p.ksize == 3 ? tp - 3 * ky : 0;
+    unsigned a_off[MREP];                                         // bytes, or OOB
+    bool seg1 = false;                                            // current source is a1
+    auto set_segment = [&]() {
+        const int ky = p.ksize == 3 ? tap / 3 : 0, kx = p.ksize == 3 ? tap - 3 * ky : 0;
+        seg1 = __builtin_amdgcn_readfirstlane(cc >= p.c0 ? 1 : 0) != 0;
+        const int ld = seg1 ? p.a1_ld : p.a0_ld;
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
             const int yi = a_y[i] + ky, xi = a_x[i] + kx;
             const bool ok = yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
-            a_pix[i] = ok ? (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up) : -1;
+            const int pix = (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up);
+            a_off[i] = ok ? static_cast<unsigned>(pix * ld + lchunk8) * 2u : OOB;
         }
     };
-    set_tap(tap);
+    set_segment();
 
     // One stage = NPIECE DMA instructions per wave: pieces 0..3 the activation passes, then the weight
-    // passes.  The pieces are issued one at a time BETWEEN groups of MFMAs: the CU's vector-memory
-    // pipe moves ~64 B/clk, so a burst of 8 waves x 7 KB stalls every wave at issue for ~900 clocks with
-    // the matrix pipe idle (measured, pf_debug_gemm_profile); spread out, the MFMAs cover it.
+    // passes, issued one at a time between MFMAs (a burst of 8 waves x 7 KB stalls every wave at issue
+    // for ~900 clocks: the CU's vector-memory pipe moves ~64 B/clk).
     constexpr int NPIECE = MREP + BFULL + (BHALF ? 1 : 0);
-    const unsigned short* st_src = a0;
-    int st_ld = 0, st_coff = 0;
+    int st_soff_a = 0, st_soff_w = 0;
     auto stage_begin = [&]() {
-        if (cc < p.c0) { st_src = a0; st_ld = p.a0_ld; st_coff = cc + lchunk8; }
-        else { st_src = a1; st_ld = p.a1_ld; st_coff = cc - p.c0 + lchunk8; }
+        st_soff_a = __builtin_amdgcn_readfirstlane((seg1 ? cc - p.c0 : cc) * 2);
+        st_soff_w = __builtin_amdgcn_readfirstlane(kg * 2);
+        return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(seg1 ? a1 : a0), 0,
+                                                 __builtin_amdgcn_readfirstlane(seg1 ? p.a1_bytes : p.a0_bytes), 0x00020000);
     };
     auto stage_end = [&]() {
         kg += 64;
         cc += 64;
-        if (cc == Ctot) { cc = 0; ++tap; set_tap(tap); }
+        if (cc == Ctot) { cc = 0; ++tap; set_segment(); }
+        else if (cc == p.c0) set_segment();
     };
-    auto dma_piece = [&](int slot, int k) {
+    auto lds_dma = [&](const __amdgpu_buffer_rsrc_t& r, unsigned short* dst, unsigned voff, int soff) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+    };
+    auto dma_piece = [&](const __amdgpu_buffer_rsrc_t& rs_a, int slot, int k) {
         unsigned short* As = smem + slot * STAGE;
         unsigned short* Bs = As + BM * 64;
         if (k < MREP) {
-            const unsigned short* g = (a_pix[k] >= 0 && p.dbg != 2) ? st_src + (static_cast<long>(a_pix[k]) * st_ld + st_coff) : p.zeros;
             unsigned short* dst = As + (k * 64 + wave * 8) * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            lds_dma(rs_a, dst, a_off[k], st_soff_a);
         } else if (k < MREP + BFULL) {
             const int j = k - MREP;
-            const unsigned short* g = (w_off[j] >= 0 && p.dbg != 2) ? wg + (static_cast<long>(w_off[j]) + kg) : p.zeros;
-            unsigned short* dst = Bs + (j * 64 + wave * 8) * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            lds_dma(rs_w, Bs + (j * 64 + wave * 8) * 64, w_off[j], st_soff_w);
         } else if (BHALF) {
-            if (lane < 32) {
-                const unsigned short* g = w_off[BFULL] >= 0 ? wg + (static_cast<long>(w_off[BFULL]) + kg) : p.zeros;
-                unsigned short* dst = Bs + (BFULL * 64 + wave * 4) * 64;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
+            if (lane < 32) lds_dma(rs_w, Bs + (BFULL * 64 + wave * 4) * 64, w_off[BFULL], st_soff_w);
         }
     };
     auto dma_stage = [&](int slot) {
-        stage_begin();
+        const __amdgpu_buffer_rsrc_t rs_a = stage_begin();
 #pragma unroll
-        for (int k = 0; k < NPIECE; ++k) dma_piece(slot, k);
+        for (int k = 0; k < NPIECE; ++k) dma_piece(rs_a, slot, k);
         stage_end();
     };
 
@@ -546,49 +578,61 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
     stamp(p, 1);
     load_frags(0, 0, fa0, fb0);
     int cur = 0, nx1 = 1, nx2 = 2;
-    unsigned long long acc_wait = 0, acc_comp = 0, tq = 0;       // diagnostics (p.prof only)
-    for (int it = 0; it < n_it; ++it) {
-        if (p.prof) tq = __builtin_amdgcn_s_memtime();
-        load_frags(cur, 1, fa1, fb1);
+    // One K step.  MORE: a next stage exists (wait for it, barrier, prefetch its first fragments);
+    // DMA: a stage two ahead exists (issue its pieces between the MFMAs of the second half).  The flags
+    // are compile-time so that the steady-state body is branch free and the compiler's s_waitcnt
+    // insertion sees exact counts (a conditional around the prefetch made it drain lgkmcnt to 0 right
+    // after issuing it, exposing the LDS latency once per step).
+    auto step = [&](auto more_tag, auto dma_tag) {
+        constexpr bool MORE = decltype(more_tag)::value, DMA = decltype(dma_tag)::value;
+        constexpr int NM = MREP * NREP, LEAD = 4;                 // fragment requests go out after LEAD MFMAs:
+        // at every s_waitcnt lgkmcnt the only outstanding LDS reads are then the ones being waited for
+        // (the compiler drains to 0, it does not count), and they were issued >= NM - LEAD MFMAs earlier.
 #pragma unroll
-        for (int i = 0; i < MREP; ++i)
-#pragma unroll
-            for (int j = 0; j < NREP; ++j) acc[i][j] = Mfma<T>::run(fb0[j], fa0[i], acc[i][j]);
-        if (p.prof) { asm volatile("s_nop 0" ::: "memory"); const unsigned long long x = __builtin_amdgcn_s_memtime(); acc_comp += x - tq; tq = x; }
-        const bool more = it + 1 < n_it;
-        if (more) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of stage it+1 (a full step in flight)
-            __builtin_amdgcn_s_barrier();                         // stage it+1 complete; stage it-1 no longer read
-            asm volatile("" ::: "memory");
-            if (p.prof) { const unsigned long long x = __builtin_amdgcn_s_memtime(); acc_wait += x - tq; tq = x; }
-            load_frags(nx1, 0, fa0, fb0);
-        }
-        const bool dma = it + 2 < n_it && p.dbg != 1;
-        if (dma) stage_begin();
-#pragma unroll
-        for (int idx = 0; idx < MREP * NREP; ++idx) {
-            const int i = idx / NREP, j = idx % NREP;
-            acc[i][j] = Mfma<T>::run(fb1[j], fa1[i], acc[i][j]);
-            constexpr int GAP = MREP * NREP / NPIECE;             // MFMAs between two DMA pieces
-            if (idx % GAP == GAP - 1 && idx / GAP < NPIECE) {
+        for (int idx = 0; idx < NM; ++idx) {
+            acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb0[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
+            if (idx == LEAD - 1) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (dma) dma_piece(nx2, idx / GAP);
+                load_frags(cur, 1, fa1, fb1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (dma) stage_end();
-        if (p.prof) { asm volatile("s_nop 0" ::: "memory"); const unsigned long long x = __builtin_amdgcn_s_memtime(); acc_comp += x - tq; tq = x; }
+        if constexpr (MORE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of the next stage (a full step in flight)
+            __builtin_amdgcn_s_barrier();                         // next stage complete; previous stage no longer read
+            asm volatile("" ::: "memory");
+        }
+        __amdgpu_buffer_rsrc_t rs_a = rs_w;
+        if constexpr (DMA) rs_a = stage_begin();
+#pragma unroll
+        for (int idx = 0; idx < NM; ++idx) {
+            acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
+            if (MORE && idx == LEAD - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(nx1, 0, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (DMA) {
+                const int k = idx - LEAD;                         // pieces after MFMA LEAD, LEAD+2, ...
+                if (k >= 0 && (k & 1) == 0 && (k >> 1) < NPIECE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_piece(rs_a, nx2, k >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        static_assert(LEAD + 2 * (NPIECE - 1) < NM, "DMA pieces must fit behind the MFMAs of the second half");
+        if constexpr (DMA) stage_end();
         cur = cur == STAGES - 1 ? 0 : cur + 1;
         nx1 = nx1 == STAGES - 1 ? 0 : nx1 + 1;
         nx2 = nx2 == STAGES - 1 ? 0 : nx2 + 1;
-    }
+    };
+    const std::true_type YES;
+    const std::false_type NO;
+    for (int it = 0; it + 2 < n_it; ++it) step(YES, YES);
+    if (n_it >= 2) step(YES, NO);
+    step(NO, NO);
     stamp(p, 2);
-    if (p.prof && lane == 0) {
-        const long b = blockIdx.x + static_cast<long>(gridDim.x) * (blockIdx.y + static_cast<long>(gridDim.y) * blockIdx.z);
-        p.prof[b * 32 + 4 + wave * 3 + 0] = acc_wait;
-        p.prof[b * 32 + 4 + wave * 3 + 1] = 0;
-        p.prof[b * 32 + 4 + wave * 3 + 2] = acc_comp;
-    }
 
     if (p.splits > 1) {          // fp32 slab straight from the fragments (64-byte row segments)
 #pragma unroll
@@ -647,8 +691,6 @@ template <typename T, int MREP, int NREP>
 static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     GemmParams p = gp;
-    p.zeros = zero_page();
-    PF_REQUIRE(p.zeros, "pf_conv_gemm: zero page allocation failed");
     p.mtiles = static_cast<int>(cdiv(p.M, BM));
     p.ntiles = static_cast<int>(cdiv(p.N, BN));
     p.prof = (g_prof && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= g_prof_blocks) ? g_prof : nullptr;
@@ -673,8 +715,6 @@ template <typename T, int NREP>
 static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 256, BN = 32 * NREP;
     GemmParams p = gp;
-    p.zeros = zero_page();
-    PF_REQUIRE(p.zeros, "pf_conv_gemm: zero page allocation failed");
     p.mtiles = static_cast<int>(cdiv(p.M, BM));
     p.ntiles = static_cast<int>(cdiv(p.N, BN));
     p.prof = (g_prof && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= g_prof_blocks) ? g_prof : nullptr;
@@ -702,18 +742,25 @@ static int tuning(const char* name, int dflt) {     // A/B switches for benchmar
 
 // Tile shape + split-K plan of one problem (shared by the launcher and the workspace query).
 struct GemmPlan { int mrep, nrep, splits, kb_per_split; bool big; };
+static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split);
 static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
-    GemmPlan g;
     static const int big_min_tiles = tuning("PF_GEMM8_MIN_TILES", 128);   // 0 disables the 8-wave kernel
-    g.big = false;
-    {
-        const int nrep = (N % 160 == 0) ? 5 : 4;
-        const long tiles256 = cdiv(M, 256) * cdiv(N, 32 * nrep) * batch;
-        if (big_min_tiles > 0 && tiles256 >= big_min_tiles) {
-            g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64;
-            return g;
-        }
+    const int nrep = (N % 160 == 0) ? 5 : 4;
+    const long tiles256 = cdiv(M, 256) * cdiv(N, 32 * nrep) * batch;
+    // one 8-wave block per CU: take it only when the last round of tiles is well filled (320 tiles on 256
+    // CUs would idle for 37 % of the launch; the 4-wave kernel's 2 blocks per CU degrade more gracefully)
+    const long rounds = cdiv(tiles256, 256);
+    const bool filled = tiles256 * 100 >= rounds * 256 * 88;
+    if (big_min_tiles > 0 && tiles256 >= big_min_tiles && filled) {
+        GemmPlan g;
+        g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64;
+        return g;
     }
+    return plan_gemm_small(M, N, K, batch, allow_split);
+}
+static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split) {
+    GemmPlan g;
+    g.big = false;
     // 160-wide N tiles when they divide N exactly (all UNet widths are multiples of 160), 128-wide
     // otherwise; 64-row M tiles when 128-row tiles would not fill the 256 CUs (2 blocks per CU).
     g.nrep = (N % 160 == 0) ? 5 : 4;
@@ -791,12 +838,17 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     p.geglu = d->epilogue == PF_EPILOGUE_GEGLU;
     p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;
     p.mtiles = p.ntiles = 0;
-    p.zeros = nullptr;
     p.prof = nullptr;
-    static const int dbg = tuning("PF_GEMM_DEBUG", 0);
-    p.dbg = dbg;
     p.batch = d->batch;
-    const GemmPlan g = plan_gemm(p.M, p.N, p.K, d->batch, d->workspace != nullptr);
+    GemmPlan g = plan_gemm(p.M, p.N, p.K, d->batch, d->workspace != nullptr);
+    {   // extents for the buffer descriptors of the 8-wave kernel (32-bit offsets, < 2 GiB)
+        const long npix = static_cast<long>(d->n_img) * d->h_in * d->w_in;
+        const long a0b = ((npix - 1) * p.a0_ld + p.c0) * 2, a1b = p.a1 ? ((npix - 1) * p.a1_ld + p.c1) * 2 : 0;
+        const long wb = static_cast<long>(p.N) * p.K * 2;
+        PF_REQUIRE(a0b < (1L << 31) && a1b < (1L << 31) && wb < (1L << 31),
+                   "pf_conv_gemm: each operand must be smaller than 2 GiB (32-bit buffer offsets)");
+        p.a0_bytes = static_cast<unsigned>(a0b); p.a1_bytes = static_cast<unsigned>(a1b); p.w_bytes = static_cast<unsigned>(wb);
+    }
     p.splits = g.splits; p.kb_per_split = g.kb_per_split;
     p.partial = static_cast<float*>(d->workspace);
     if (p.splits > 1) {

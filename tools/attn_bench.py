@@ -1,0 +1,54 @@
+"""Attention microbenchmark on the shapes of the benchmark step (one MI355X)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from panfusion_amd import ops  # noqa: E402
+
+SHAPES = {  # name: (B, H, D, nq, nk)
+    "self64": (40, 5, 64, 4096, 4096),
+    "self32": (40, 10, 64, 1024, 1024),
+    "self16": (40, 20, 64, 256, 256),
+    "pano64": (2, 5, 64, 8192, 8192),
+    "text64": (40, 5, 64, 4096, 77),
+    "epa_e": (2, 20, 32, 2048, 20480),
+    "epa_p": (2, 20, 32, 20480, 2048),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--shapes", default=",".join(SHAPES))
+    args = ap.parse_args()
+    dev = "cuda"
+    for name in args.shapes.split(","):
+        B, H, D, nq, nk = SHAPES[name]
+        g = torch.Generator(device=dev).manual_seed(1)
+        C = H * D
+        q = torch.randn(B * nq, C, device=dev, generator=g).to(torch.bfloat16)
+        k = torch.randn(B * nk, C, device=dev, generator=g).to(torch.bfloat16)
+        ld = (nk + 31) // 32 * 32
+        vt = torch.randn(B, C, ld, device=dev, generator=g).to(torch.bfloat16)
+        out = torch.empty(B, nq, C, device=dev, dtype=torch.bfloat16)
+        kw = dict(q_ld=C, k_ld=C, vt_ld=ld, q_bs=nq * C, k_bs=nk * C, vt_bs=C * ld, out=out)
+        for _ in range(2):
+            ops.attention(q, k, vt, B, H, D, nq, nk, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(int(0.02 * 2.4e9))
+        e0.record()
+        for _ in range(args.reps):
+            ops.attention(q, k, vt, B, H, D, nq, nk, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.reps
+        fl = 4.0 * B * H * nq * nk * D
+        print("%-8s B%-3d H%-3d D%-3d nq%-6d nk%-6d %9.1f us  %7.1f TF/s" % (name, B, H, D, nq, nk, us, fl / us / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,8 @@
 #!/bin/bash
-# rocprofv3 kernel trace of an eager bench run, condensed to a per-(kernel, grid) table; optional PMC pass.
+# rocprofv3 kernel trace of an eager single-stream bench run, condensed to a per-(kernel, grid) table; optional PMC pass.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+export PF_STREAMS=1
 R=$GRAFT_REPO_ROOT
 TAG=${1:-prof}
 cd /tmp
@@ -9,7 +10,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 T=$(find $R/gpurun_out/$TAG -name '*kernel_trace.csv' | head -1)
 python $R/tools/prof_summary.py trace $T $R/gpurun_out/${TAG}_kernels.txt 10
 find $R/gpurun_out/$TAG -type f -size +2M -delete
-head -n 30 $R/gpurun_out/${TAG}_kernels.txt
+head -n 24 $R/gpurun_out/${TAG}_kernels.txt
 if [ "$2" = "pmc" ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_$C -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graphs > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
