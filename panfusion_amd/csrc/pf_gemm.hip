@@ -756,6 +756,21 @@ static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
         g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64;
         return g;
     }
+    // long-K layers with few output tiles (the 8x8 level, the panorama's inner levels): 256-row tiles
+    // re-read the weight panel 2-4x less often than the 64-row tiles of the small kernel; split K so
+    // that one round of blocks covers the chip
+    const int nkb_all = K / 64;
+    if (big_min_tiles > 0 && allow_split && N % 4 == 0 && tiles256 >= 32 && tiles256 <= 128 && nkb_all >= 32) {
+        long sp = 256 / tiles256;
+        if (sp > nkb_all / 16) sp = nkb_all / 16;
+        if (sp >= 2) {
+            GemmPlan g;
+            g.big = true; g.mrep = 8; g.nrep = nrep;
+            g.kb_per_split = static_cast<int>(cdiv(nkb_all, sp));
+            g.splits = static_cast<int>(cdiv(nkb_all, g.kb_per_split));
+            return g;
+        }
+    }
     return plan_gemm_small(M, N, K, batch, allow_split);
 }
 static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split) {

@@ -27,6 +27,10 @@ SHAPES = {
     "ff1_1280": (1, 1, 10240, 1280, 10240, 1, {"geglu": True}),
     "pano_conv64": (2, 64, 132, 320, 320, 3, {}),
     "pano_conv8": (2, 8, 20, 1280, 1280, 3, {}),
+    "pano_conv16": (2, 16, 36, 1280, 1280, 3, {}),
+    "pano_conv32": (2, 32, 68, 640, 640, 3, {}),
+    "conv8cat": (40, 8, 8, 2560, 1280, 3, {}),
+    "lin_mid": (1, 1, 2560, 1280, 1280, 1, {"res": True}),
 }
 
 
