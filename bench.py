@@ -141,11 +141,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    # PF_DIST_BACKEND=gloo + fewer GPUs than ranks: functional dry run of the sharded path on one GPU
+    backend = os.environ.get("PF_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
     cfg = dict(SD2_BASE)

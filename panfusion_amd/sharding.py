@@ -64,13 +64,101 @@ def make_shard(m):
     return info
 
 
+class SegmentedGraph:
+    """A launch sequence recorded as hipGraph segments separated by eager calls.
+
+    The denoiser of a view-sharded rank contains 7 small collectives (one per EPA block).  Launching
+    its ~1100 kernels eagerly costs more host time than the GPU needs at 4-8 ranks, and capturing RCCL
+    calls inside a graph ties the graph to the communicator's internals; so the kernel stretches BETWEEN
+    collectives are captured (one graph each, one shared memory pool) and the collectives stay ordinary
+    eager calls on the same stream, re-issued on the same tensors at every replay.
+
+        seg = SegmentedGraph()
+        with seg.record():
+            out = fn()              # fn calls seg.eager(callable) (via RECORDER) where it must break
+        seg.replay()                # graphs and eager calls in recorded order; `out` holds the results
+    """
+
+    def __init__(self):
+        self.items = []             # ("graph", CUDAGraph) | ("call", callable)
+        self.pool = None
+        self._cur = None
+        self._stream = None
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()        # one memory pool shared by all segments
+        g.capture_begin(pool=self.pool)
+        self._cur = g
+
+    def _end(self):
+        self._cur.capture_end()
+        self.items.append(("graph", self._cur))
+        self._cur = None
+
+    def record(self):
+        seg = self
+
+        class _Ctx:
+            def __enter__(self_):
+                global RECORDER
+                torch.cuda.synchronize()
+                seg._stream = torch.cuda.Stream()
+                seg._stream.wait_stream(torch.cuda.current_stream())
+                self_.ctx = torch.cuda.stream(seg._stream)
+                self_.ctx.__enter__()
+                RECORDER = seg
+                seg._begin()
+                return seg
+
+            def __exit__(self_, *exc):
+                global RECORDER
+                RECORDER = None
+                if seg._cur is not None:
+                    if exc[0] is None:
+                        seg._end()
+                    else:
+                        try:
+                            seg._cur.capture_end()
+                        except Exception:
+                            pass
+                self_.ctx.__exit__(*exc)
+                torch.cuda.current_stream().wait_stream(seg._stream)
+                return False
+
+        return _Ctx()
+
+    def eager(self, fn):
+        """Called while recording: close the current graph segment, run `fn` eagerly (it is re-run at
+        every replay), open the next segment."""
+        self._end()
+        fn()
+        self.items.append(("call", fn))
+        self._begin()
+
+    def replay(self):
+        for kind, obj in self.items:
+            if kind == "graph":
+                obj.replay()
+            else:
+                obj()
+
+
+RECORDER = None                     # the SegmentedGraph being recorded, if any
+
+
 def gather_view_tokens(x_local, shard):
     """All-gather [rows_local, C] token blocks of the CFG half in view order -> [G * rows_local, C]."""
     if shard.G == 1:
         return x_local
     x_local = x_local.contiguous()
     out = torch.empty(shard.G * x_local.shape[0], x_local.shape[1], dtype=x_local.dtype, device=x_local.device)
-    dist.all_gather_into_tensor(out, x_local, group=shard.group)
+    call = lambda: dist.all_gather_into_tensor(out, x_local, group=shard.group)
+    if RECORDER is not None:
+        RECORDER.eager(call)        # graph break: the collective stays an eager call between two segments
+    else:
+        call()
     return out
 
 
@@ -91,24 +179,41 @@ class ShardedDenoiseLoop(DenoiseLoop):
     """DenoiseLoop whose denoiser call computes only this rank's (CFG sample, view group)."""
 
     def __init__(self, model, shard, *a, **k):
-        k["use_graphs"] = False            # collectives run eagerly between kernels (round 1)
         super().__init__(model, *a, **k)
         self.shard = shard
         self.layout = "cfg2 x viewgroups%d" % shard.G
         model.shard = shard
 
-    def _denoise(self, cams):
+    def _local(self, cams):
         s = self.shard
         v0, v1 = s.views
         c = s.cfg
-        eps, pano_eps = self.model(self.lat[:, v0:v1].contiguous(), self.pano, self.tstep[:1, v0:v1],
-                                   self.prompt[c:c + 1, v0:v1], self.pano_prompt[c:c + 1], cams)
-        return gather_eps(eps, pano_eps, s)
+        return self.model(self.lat[:, v0:v1].contiguous(), self.pano, self.tstep[:1, v0:v1],
+                          self.prompt[c:c + 1, v0:v1], self.pano_prompt[c:c + 1], cams)
+
+    def _denoise(self, cams):
+        return gather_eps(*self._local(cams), self.shard)
+
+    def _denoise_graphed(self, cams):
+        """This rank's share of the denoiser as hipGraph segments between the EPA collectives (one
+        SegmentedGraph per rotation offset); the epsilon all-gather follows eagerly."""
+        key = tuple(float(v) for v in cams["theta"].reshape(-1))
+        g = self.graphs.get(key)
+        if g is None:
+            self._local(cams)                        # warm-up: tables, kernel attributes, communicator
+            torch.cuda.synchronize()
+            seg = SegmentedGraph()
+            with seg.record():
+                out = self._local(cams)
+            g = (seg, out)
+            self.graphs[key] = g
+        g[0].replay()
+        return gather_eps(*g[1], self.shard)
 
 
 def build_sharded(build_model, build_inputs, dev, dtype, cfg, m, lat_hw, pano_hw, cams_deg, steps, use_graphs):
     shard = make_shard(m)
     model = build_model(dev, dtype, cfg)
     inputs = build_inputs(dev, m, lat_hw, pano_hw, cfg["cross_attention_dim"], cams_deg)
-    loop = ShardedDenoiseLoop(model, shard, *inputs, steps=steps)
+    loop = ShardedDenoiseLoop(model, shard, *inputs, steps=steps, use_graphs=use_graphs)
     return model, loop

@@ -174,3 +174,42 @@ def test_mid_size_model_vs_oracle():
         es, ep = rel_l2(s.cpu(), ws), rel_l2(ps.cpu(), wp)
         print("mid-size rel-L2 %s: views %.3e pano %.3e" % (dtype, es, ep))
         assert es <= TOL[dtype] and ep <= TOL[dtype], (dtype, es, ep)
+
+
+def test_segmented_graph_replay_equals_eager(oracle_model):
+    """sharding.SegmentedGraph: kernel stretches captured as hipGraph segments with an eager call in
+    between (the place of the EPA all-gather on a view-sharded rank) replay to the eager result, on new
+    input values."""
+    from panfusion_amd import ops, sharding
+    g, lat, pl, pe, ppe = tiny_inputs()
+    model = hip_model_from(oracle_model, torch.bfloat16)
+    cams = {k: torch.stack([v, v]) for k, v in cam4().items()}
+    t = torch.full((2, 4), 981, dtype=torch.long, device=DEV)
+    lat_d, pl_d, pe_d, ppe_d = lat.to(DEV), pl.to(DEV), pe.to(DEV), ppe.to(DEV)
+    calls = []
+
+    def fn():
+        s, ps = model(lat_d, pl_d, t, pe_d, ppe_d, cams)
+        buf = torch.empty_like(ps)
+        call = lambda: (buf.copy_(ps), calls.append(1))          # stands in for a collective
+        if sharding.RECORDER is not None:
+            sharding.RECORDER.eager(call)
+        else:
+            call()
+        s2, _ = model(lat_d, buf.to(pl_d.dtype), t, pe_d, ppe_d, cams)
+        return s, s2
+
+    fn()
+    torch.cuda.synchronize()
+    seg = sharding.SegmentedGraph()
+    with seg.record():
+        out = fn()
+    assert sum(1 for k, _ in seg.items if k == "graph") == 2 and sum(1 for k, _ in seg.items if k == "call") == 1
+    lat_d.mul_(0.5)                                               # new input values, same storage
+    n_calls = len(calls)
+    seg.replay()
+    torch.cuda.synchronize()
+    got = [x.clone() for x in out]
+    assert len(calls) == n_calls + 1
+    want = fn()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
