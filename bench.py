@@ -220,10 +220,18 @@ def main():
                 fh.write("%-60s launches %3d  ms %8.3f  TF/s %7.1f\n" % (k, n, sec * 1e3, fl / sec / 1e12))
     dom = max(fam, key=lambda k: fam[k][1]) if fam else None
     roofline = None
+    traffic = None                                    # PMC-derived bytes per launch of the dominant kernel (profiles/)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
+            traffic = json.load(fh)
+    except (OSError, ValueError):
+        pass
     if dom:
         fl, sec, n = fam[dom]
         roofline = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS,
-                    "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_DENSE_TFLOPS,
+                    "traffic": traffic["bytes_per_launch"] if traffic and dom in traffic.get("kernel", "") else None,
+                    "traffic_note": "bytes per launch from rocprofv3 PMC passes committed in profiles/r1_traffic.json (not re-measured in this run)",
                     "launches_per_step": n, "avg_launch_us": sec / n * 1e6, "algorithmic_flop_per_launch": fl / n,
                     "share_of_step_time": sec / (elapsed / args.steps),
                     "other": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]}
