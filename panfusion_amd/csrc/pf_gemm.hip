@@ -30,7 +30,8 @@ struct GemmParams {
     int h_in, w_in, h_out, w_out;
     int ksize, stride, pad, up;
     const unsigned short* w;
-    int M, N, K;                 // K = ksize*ksize*(c0+c1)
+    int M, N, K;                 // K = ksize*ksize*(c0+c1); a launch covers output rows [m_begin, M)
+    int m_begin;
     int rows_per_img;
     const float* bias; const float* rowvec; int rowvec_ld;
     const unsigned short* residual; int res_ld;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
         tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tile_n = tid_lin % p.ntiles, tile_m = tid_lin / p.ntiles;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
     const long bz = blockIdx.z;
     const unsigned short* a0 = p.a0 + bz * p.a_bs;
     const unsigned short* a1 = p.a1 ? p.a1 + bz * p.a_bs : nullptr;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
             for (int j = 0; j < NREP; ++j) {
                 const int n4 = n0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
                 if (n4 >= p.N) continue;
-                float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * p.M + m) * p.N + n4;
+                float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * (p.M - p.m_begin) + (m - p.m_begin)) * p.N + n4;
                 *reinterpret_cast<float4*>(o) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             }
         }
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
         tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tile_n = tid_lin % p.ntiles, tile_m = tid_lin / p.ntiles;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
     const long bz = blockIdx.z;
     const unsigned short* a0 = p.a0 + bz * p.a_bs;
     const unsigned short* a1 = p.a1 ? p.a1 + bz * p.a_bs : nullptr;
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
             for (int j = 0; j < NREP; ++j) {
                 const int n4 = n0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
                 if (n4 >= p.N) continue;
-                float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * p.M + m) * p.N + n4;
+                float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * (p.M - p.m_begin) + (m - p.m_begin)) * p.N + n4;
                 *reinterpret_cast<float4*>(o) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             }
         }
@@ -658,15 +659,16 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmParams p) {
     const long quads = static_cast<long>(p.N / 4);
-    const long total = static_cast<long>(p.batch) * p.M * quads;
+    const int Ms = p.M - p.m_begin;
+    const long total = static_cast<long>(p.batch) * Ms * quads;
     const long i = blockIdx.x * 256L + threadIdx.x;
     if (i >= total) return;
     const int n4 = static_cast<int>(i % quads) * 4;
     const long bm = i / quads;
-    const int m = static_cast<int>(bm % p.M);
-    const long bz = bm / p.M;
-    const long slab = static_cast<long>(p.batch) * p.M * p.N;
-    const float* src = p.partial + (bz * p.M + m) * p.N + n4;
+    const int ml = static_cast<int>(bm % Ms), m = p.m_begin + ml;
+    const long bz = bm / Ms;
+    const long slab = static_cast<long>(p.batch) * Ms * p.N;
+    const float* src = p.partial + (bz * Ms + ml) * p.N + n4;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < p.splits; ++s) {
         const float4 x = *reinterpret_cast<const float4*>(src + s * slab);
@@ -691,7 +693,7 @@ template <typename T, int MREP, int NREP>
 static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     GemmParams p = gp;
-    p.mtiles = static_cast<int>(cdiv(p.M, BM));
+    p.mtiles = static_cast<int>(cdiv(p.M - p.m_begin, BM));
     p.ntiles = static_cast<int>(cdiv(p.N, BN));
     p.prof = (g_prof && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= g_prof_blocks) ? g_prof : nullptr;
     const size_t smem = static_cast<size_t>(2) * (BM + BN) * 64 * sizeof(unsigned short);
@@ -704,7 +706,7 @@ static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(256), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm");
     if (p.splits > 1) {
-        const long total = static_cast<long>(batch) * p.M * (p.N / 4);
+        const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
         hipLaunchKernelGGL((k_splitk_reduce<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, p);
         PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
     }
@@ -715,7 +717,7 @@ template <typename T, int NREP>
 static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 256, BN = 32 * NREP;
     GemmParams p = gp;
-    p.mtiles = static_cast<int>(cdiv(p.M, BM));
+    p.mtiles = static_cast<int>(cdiv(p.M - p.m_begin, BM));
     p.ntiles = static_cast<int>(cdiv(p.N, BN));
     p.prof = (g_prof && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= g_prof_blocks) ? g_prof : nullptr;
     const size_t smem = static_cast<size_t>(3) * (BM + BN) * 64 * sizeof(unsigned short);
@@ -728,7 +730,7 @@ static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
     hipLaunchKernelGGL((k_conv_gemm8<T, NREP>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(512), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm (8-wave)");
     if (p.splits > 1) {
-        const long total = static_cast<long>(batch) * p.M * (p.N / 4);
+        const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
         hipLaunchKernelGGL((k_splitk_reduce<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, p);
         PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
     }
@@ -741,7 +743,7 @@ static int tuning(const char* name, int dflt) {     // A/B switches for benchmar
 }
 
 // Tile shape + split-K plan of one problem (shared by the launcher and the workspace query).
-struct GemmPlan { int mrep, nrep, splits, kb_per_split; bool big; };
+struct GemmPlan { int mrep, nrep, splits, kb_per_split; bool big; int m_split; int tail_splits, tail_kb; };
 static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split);
 static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
     static const int big_min_tiles = tuning("PF_GEMM8_MIN_TILES", 128);   // 0 disables the 8-wave kernel
@@ -753,8 +755,27 @@ static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
     const bool filled = tiles256 * 100 >= rounds * 256 * 88;
     if (big_min_tiles > 0 && tiles256 >= big_min_tiles && filled) {
         GemmPlan g;
-        g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64;
+        g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64; g.m_split = 0;
         return g;
+    }
+    // Tail split: whole rounds of 256 tiles run unsplit; the tile rows left over (a badly filled last round)
+    // become a second launch whose K range is split so that it fills the chip once more.  320 tiles then
+    // cost 1.25 rounds instead of 2.
+    static const int tail_on = tuning("PF_GEMM_TAIL_SPLIT", 1);
+    if (big_min_tiles > 0 && tail_on && allow_split && batch == 1 && N % 4 == 0 && tiles256 > 256 && K / 64 >= 40) {
+        const long ntl = cdiv(N, 32 * nrep), mt = cdiv(M, 256);
+        const long rows1 = (tiles256 / 256) * 256 / ntl;            // tile rows of the unsplit launch
+        const long tiles2 = (mt - rows1) * ntl;
+        long sp = tiles2 > 0 ? (256 + tiles2 / 2) / tiles2 : 1;
+        if (sp > (K / 64) / 8) sp = (K / 64) / 8;
+        if (rows1 > 0 && tiles2 > 0 && sp >= 2 && rows1 * ntl * 100 >= (tiles256 / 256) * 256 * 90) {
+            GemmPlan g;
+            g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64;
+            g.m_split = static_cast<int>(rows1 * 256);
+            g.tail_kb = static_cast<int>(cdiv(K / 64, sp));
+            g.tail_splits = static_cast<int>(cdiv(K / 64, g.tail_kb));
+            return g;
+        }
     }
     // long-K layers with few output tiles (the 8x8 level, the panorama's inner levels): 256-row tiles
     // re-read the weight panel 2-4x less often than the 64-row tiles of the small kernel; split K so
@@ -765,7 +786,7 @@ static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
         if (sp > nkb_all / 16) sp = nkb_all / 16;
         if (sp >= 2) {
             GemmPlan g;
-            g.big = true; g.mrep = 8; g.nrep = nrep;
+            g.big = true; g.mrep = 8; g.nrep = nrep; g.m_split = 0;
             g.kb_per_split = static_cast<int>(cdiv(nkb_all, sp));
             g.splits = static_cast<int>(cdiv(nkb_all, g.kb_per_split));
             return g;
@@ -775,7 +796,7 @@ static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
 }
 static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split) {
     GemmPlan g;
-    g.big = false;
+    g.big = false; g.m_split = 0;
     // 160-wide N tiles when they divide N exactly (all UNet widths are multiples of 160), 128-wide
     // otherwise; 64-row M tiles when 128-row tiles would not fill the 256 CUs (2 blocks per CU).
     g.nrep = (N % 160 == 0) ? 5 : 4;
@@ -866,12 +887,24 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     }
     p.splits = g.splits; p.kb_per_split = g.kb_per_split;
     p.partial = static_cast<float*>(d->workspace);
+    p.m_begin = 0;
+    hipStream_t st = as_stream(stream);
+    if (g.big && g.m_split > 0) {           // two launches: full rounds unsplit, then the tail rows with split K
+        const size_t need = static_cast<size_t>(g.tail_splits) * (p.M - g.m_split) * p.N * sizeof(float);
+        PF_REQUIRE(d->workspace_bytes >= need && aligned16(d->workspace),
+                   "pf_conv_gemm: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, d->workspace_bytes);
+        GemmParams p1 = p, p2 = p;
+        p1.M = g.m_split; p1.splits = 1; p1.kb_per_split = p.K / 64;
+        p2.m_begin = g.m_split; p2.splits = g.tail_splits; p2.kb_per_split = g.tail_kb;
+        PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
+            if (g.nrep == 5) { pf_status s1 = launch8<T, 5>(p1, 1, st); if (s1 != PF_OK) return s1; return launch8<T, 5>(p2, 1, st); }
+            else { pf_status s1 = launch8<T, 4>(p1, 1, st); if (s1 != PF_OK) return s1; return launch8<T, 4>(p2, 1, st); });
+    }
     if (p.splits > 1) {
         const size_t need = static_cast<size_t>(p.splits) * d->batch * p.M * p.N * sizeof(float);
         PF_REQUIRE(d->workspace_bytes >= need && aligned16(d->workspace),
                    "pf_conv_gemm: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, d->workspace_bytes);
     }
-    hipStream_t st = as_stream(stream);
     if (g.big) {
         PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
             if (g.nrep == 5) return launch8<T, 5>(p, d->batch, st);
@@ -895,5 +928,6 @@ extern "C" size_t pf_conv_gemm_workspace_size(const pf_conv_desc* d) {
     const long M = static_cast<long>(d->n_img) * d->h_out * d->w_out;
     const int K = d->ksize * d->ksize * (d->c0 + c1);
     const GemmPlan g = plan_gemm(M, d->n_out, K, d->batch, true);
+    if (g.big && g.m_split > 0) return static_cast<size_t>(g.tail_splits) * (M - g.m_split) * d->n_out * sizeof(float);
     return g.splits > 1 ? static_cast<size_t>(g.splits) * d->batch * M * d->n_out * sizeof(float) : 0;
 }

@@ -344,6 +344,20 @@ def test_split_k(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_tail_split_two_phase(dtype):
+    """300 tiles of 256 rows on 256 CUs: 256 tiles run unsplit, the 44 left-over tile rows as a second
+    launch with split K (pf_conv_gemm plans it from the shape); bias + residual epilogue on both parts."""
+    o = ops()
+    M, N, K = 300 * 256 - 37, 160, 2560
+    x, xf = q16(rnd(M, K, seed=60), dtype)
+    w, wf = q16(rnd(N, K, seed=61) / K ** 0.5, dtype)
+    b = rnd(N, seed=62)
+    r, rf = q16(rnd(M, N, seed=63), dtype)
+    assert o.gemm_workspace_bytes(x, w, N, w_in=M) > 0
+    check("tail-split linear", o.linear(x, w, bias=b.to(DEV), residual=r), xf @ wf.T + b + rf, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_strided_views_and_rowvec(dtype):
     o = ops()
     M, C = 200, 128
