@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void k_attention(const AttnParams p) {
 //   V^T rows are padded to 136 B (34 banks): the 32 d-rows read by a half-wave with ds_read_b64 hit
 //   distinct bank pairs.
 // One online-softmax update per 64 keys.
-template <typename T, int D>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 4) void k_attention_lds(const AttnParams p) {
+template <typename T, int D, bool BIAS>
+__global__ __launch_bounds__(256, D == 64 ? 2 : 3) void k_attention_lds(const AttnParams p) {
     // (256, 2): at most 256 registers per lane -> the MFMA accumulators live in the VGPR file; with the
     // default budget the compiler parks S and O in AGPRs and pays ~145 v_accvgpr moves per key tile.
     constexpr int KS = D / 16, DB = D / 32, KT = 64;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 4) void k_attention_lds(const At
     constexpr int K_ELEMS = KT * D, V_ELEMS = D * VROW;
     constexpr int KCH = KT * KCHUNKS / 256, VCH = D * (KT / 8) / 256;
     typedef typename Mfma32<T>::frag frag;
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (K_ELEMS + V_ELEMS)];
+    __shared__ __attribute__((aligned(16))) unsigned short smem[3 * (K_ELEMS + V_ELEMS)];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int ql = lane & 31, hi = lane >> 5;
@@ -293,16 +293,18 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 4) void k_attention_lds(const At
         }
     };
 
-    const uint8_t* flag_row = p.flags ? p.flags + static_cast<long>(min(q0, p.nq - 1) >> 5) * p.flags_ld : nullptr;
-    const float* bias_row = p.bias ? p.bias + static_cast<long>(qrow) * p.bias_ld : nullptr;
+    const uint8_t* flag_row = BIAS ? p.flags + static_cast<long>(min(q0, p.nq - 1) >> 5) * p.flags_ld : nullptr;
+    const float* bias_row = BIAS ? p.bias + static_cast<long>(qrow) * p.bias_ld : nullptr;
 
-    // one key tile: S^T = K Q^T (raw scores), online softmax, O^T += V^T P^T
-    auto tile = [&](int j, auto tail_tag) {
+    // Software pipeline over key tiles (three LDS buffers, tiles j and j+1 resident):
+    //   scores(j+1) = K_{j+1} Q^T  (8 MFMAs)  ||  softmax of scores(j) (vector ALU)  ->  O^T += V_j^T P^T (8 MFMAs)
+    // so the matrix pipe has independent work while the softmax of the previous tile runs; without it
+    // a wave alternates strictly between MFMA and VALU phases and, with two waves per SIMD, both pipes
+    // idle a good part of the time (measured: MFMA 30 %, VALU 55-65 % busy).
+    auto scores = [&](int j, float (&sv)[2][16], auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         const int k0 = j * KT;
-        const unsigned short* Ks = smem + (j & 1) * (K_ELEMS + V_ELEMS);
-        const unsigned short* Vs = Ks + K_ELEMS;
-        float sv[2][16];
+        const unsigned short* Ks = smem + (j % 3) * (K_ELEMS + V_ELEMS);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -314,9 +316,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 4) void k_attention_lds(const At
 #pragma unroll
             for (int r = 0; r < 16; ++r) sv[hh][r] = s[r];
             const int kb = k0 + hh * 32;
-            if (flag_row && (!TAIL || kb < p.nk) && flag_row[kb >> 5]) {
-                // additive bias in units of the raw score: bias / scale
-                const float inv_c = 1.44269504088896340736f / c2;
+            if (BIAS && (!TAIL || kb < p.nk) && flag_row[kb >> 5]) {
+                const float inv_c = 1.44269504088896340736f / c2;      // additive bias in units of the raw score
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int key = kb + 8 * g + 4 * hi;
@@ -335,13 +336,17 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 4) void k_attention_lds(const At
                     if (kb + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.nk) sv[hh][r] = -INFINITY;
             }
         }
+    };
+    auto softmax_pv = [&](int j, float (&sv)[2][16]) {
+        const unsigned short* Vs = smem + (j % 3) * (K_ELEMS + V_ELEMS) + K_ELEMS;
         float mt = sv[0][0];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sv[hh][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32));
-        if (__any(mt > m_run)) {                       // some row's maximum grew: rescale (exact, no threshold)
+        {   // rescale by exp2(c2 * (old max - new max)) -- exactly 1 for rows whose maximum did not grow.
+            // (Unconditional: a branch around it made the compiler copy all of O on the not-taken path.)
             const float m_new = fmaxf(m_run, mt);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
             l_run *= alpha;
@@ -351,15 +356,21 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 4) void k_attention_lds(const At
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         }
-        const float mc = m_run * c2;
-        float ls = 0.f;
+        // p = exp2(c2 * s - c2 * max), two scores per instruction (v_pk_fma_f32), two running sums
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const f32x2 c22 = {c2, c2}, mc2 = {m_run * c2, m_run * c2};
+        f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sv[hh][r] = __builtin_amdgcn_exp2f(sv[hh][r] * c2 - mc);
-                ls += sv[hh][r];
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 x = f32x2{sv[hh][r], sv[hh][r + 1]} * c22 - mc2;
+                const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                sv[hh][r] = e[0];
+                sv[hh][r + 1] = e[1];
+                ls2 += e;
             }
+        float ls = ls2[0] + ls2[1];
         ls += __shfl_xor(ls, 32);
         l_run += ls;
 #pragma unroll
@@ -383,17 +394,46 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 4) void k_attention_lds(const At
     const std::true_type TAILY;
     const std::false_type FULL;
     const bool ragged = (p.nk % KT) != 0;              // only the last tile can be partial
-    if (nkt == 1 && ragged) stage_load(0, TAILY); else stage_load(0, FULL);
+    auto load_tile = [&](int j) { if (j + 1 == nkt && ragged) stage_load(j, TAILY); else stage_load(j, FULL); };
+    auto score_tile = [&](int j, float (&sv)[2][16]) { if (j + 1 == nkt && ragged) scores(j, sv, TAILY); else scores(j, sv, FULL); };
+    load_tile(0);
     stage_store(0);
+    if (nkt > 1) { load_tile(1); stage_store(1); }
     __syncthreads();
-    for (int j = 0; j < nkt; ++j) {
-        const bool last = j + 1 == nkt;
-        if (!last) {
-            if (j + 2 == nkt && ragged) stage_load(j + 1, TAILY); else stage_load(j + 1, FULL);
+    float s_cur[2][16], s_next[2][16];
+    score_tile(0, s_cur);
+    auto rotate = [&]() {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_cur[hh][r] = s_next[hh][r];
+    };
+    int j = 0;
+    // steady state: tiles j+1 and j+2 exist and are full -> a branch-free body whose 8 score MFMAs are
+    // spread over the softmax's vector instructions (sched_group_barrier: 1 MFMA, then ~1/8 of the VALU work)
+    const int n_steady = nkt - 2 - (ragged ? 1 : 0);
+    for (; j < n_steady; ++j) {
+        stage_load(j + 2, FULL);
+        scores(j + 1, s_next, FULL);
+        softmax_pv(j, s_cur);
+        if (!BIAS) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 22, 0);    // 22 VALU
+            }
         }
-        if (last && ragged) tile(j, TAILY); else tile(j, FULL);
-        if (!last) stage_store((j + 1) & 1);
+        stage_store((j + 2) % 3);
         __syncthreads();
+        rotate();
+    }
+    for (; j < nkt; ++j) {
+        if (j + 2 < nkt) load_tile(j + 2);             // global -> registers, written to LDS at the end of the step
+        if (j + 1 < nkt) score_tile(j + 1, s_next);
+        softmax_pv(j, s_cur);
+        if (j + 2 < nkt) stage_store((j + 2) % 3);     // buffer (j+2)%3 held tile j-1: every wave passed the last barrier after using it
+        __syncthreads();
+        rotate();
     }
 
     if (q0 + ql < p.nq) {
@@ -449,8 +489,13 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     const bool lds = use_lds_attention() && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0;
     PF_DISPATCH_16(d->dtype, "pf_attention",
         if (lds) {
-            if (d->D == 64) hipLaunchKernelGGL((k_attention_lds<T, 64>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((k_attention_lds<T, 32>), grid, block, 0, st, p);
+            if (d->D == 64) {
+                if (d->bias) hipLaunchKernelGGL((k_attention_lds<T, 64, true>), grid, block, 0, st, p);
+                else hipLaunchKernelGGL((k_attention_lds<T, 64, false>), grid, block, 0, st, p);
+            } else {
+                if (d->bias) hipLaunchKernelGGL((k_attention_lds<T, 32, true>), grid, block, 0, st, p);
+                else hipLaunchKernelGGL((k_attention_lds<T, 32, false>), grid, block, 0, st, p);
+            }
         } else {
             if (d->D == 64) hipLaunchKernelGGL((k_attention<T, 64>), grid, block, 0, st, p);
             else hipLaunchKernelGGL((k_attention<T, 32>), grid, block, 0, st, p);
