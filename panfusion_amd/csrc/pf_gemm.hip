@@ -59,11 +59,19 @@ template <> struct Mfma<Bf16> {
     static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
+    // accumulate IN PLACE in the AGPR half of the register file (one wave per SIMD, > 256 registers):
+    // with the builtin hipcc copies every AGPR accumulator to a temporary before each MFMA
+    static __device__ __forceinline__ void acc_agpr(frag a, frag b, f32x4& c) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
 };
 template <> struct Mfma<F16> {
     typedef __attribute__((ext_vector_type(8))) _Float16 frag;
     static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void acc_agpr(frag a, frag b, f32x4& c) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
 };
 
@@ -402,12 +410,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
 // the 160-row weight tile is issued by the lower 32 lanes of all 8 waves), so one immediate serves all.
 // Epilogue: accumulators are staged through LDS (fp32, 128 rows at a time) and leave as whole
 // 16-byte row segments with coalesced residual loads, instead of 8-byte pieces of 16 different rows.
-template <typename T, int NREP>
-__global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
-    constexpr int MREP = 4, BM = 256, BN = 32 * NREP, STAGES = 3;
+template <typename T, int NREP, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
+    // NW = 8: 4 x 2 waves, 64x80 per wave, two waves per SIMD.  NW = 4: 2 x 2 waves, 128x80 per wave, ONE wave
+    // per SIMD with the whole register file (160 accumulator + 104 fragment registers): twice the MFMAs per
+    // LDS read / DMA piece / barrier, and no second wave competing for the issue port.
+    constexpr int NT = 64 * NW, WMG = NW / 2, BM = 256, BN = 32 * NREP, MREP = BM / (16 * WMG), STAGES = 3;
+    constexpr int RPP = NT / 8;                      // tile rows staged by one DMA pass of the block
     constexpr int STAGE = (BM + BN) * 64;            // 16-bit elements per ring slot
-    constexpr int BFULL = BN / 64;                   // full 64-row DMA passes of the weight tile
-    constexpr bool BHALF = (BN % 64) != 0;           // + one 32-row pass (BN = 160)
+    constexpr int BFULL = BN / RPP;                  // full DMA passes of the weight tile
+    constexpr bool BHALF = (BN % RPP) != 0;          // + one half pass (BN = 160 with 64-row passes)
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
 
     const int ntile_total = p.mtiles * p.ntiles;
@@ -427,15 +439,16 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int chunk = t & 7, lrow = t >> 3;                       // 64-row passes: row = pass*64 + lrow
+    const int chunk = t & 7, lrow = t >> 3;                       // DMA passes of RPP rows: row = pass*RPP + lrow
     const int lchunk8 = (chunk ^ ((lrow >> 1) & 7)) * 8;
     const int hrow = wave * 4 + (lane >> 3);                      // half pass (lanes 0..31): row = BFULL*64 + hrow
     const int hchunk8 = (chunk ^ ((hrow >> 1) & 7)) * 8;
 
-    int a_img[MREP], a_y[MREP], a_x[MREP];
+    constexpr int APASS = BM / RPP;                  // DMA passes of the activation tile
+    int a_img[APASS], a_y[APASS], a_x[APASS];
 #pragma unroll
-    for (int i = 0; i < MREP; ++i) {
-        const int m = m0 + i * 64 + lrow;
+    for (int i = 0; i < APASS; ++i) {
+        const int m = m0 + i * RPP + lrow;
         if (m < p.M) {
             const int img = m / p.rows_per_img, rem = m - img * p.rows_per_img;
             const int yo = rem / p.w_out;
@@ -465,11 +478,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
     unsigned w_off[BFULL + 1];                                    // bytes
 #pragma unroll
     for (int j = 0; j < BFULL; ++j) {
-        const int n = n0 + j * 64 + lrow;
+        const int n = n0 + j * RPP + lrow;
         w_off[j] = n < p.N ? static_cast<unsigned>(n * p.K + lchunk8) * 2u : OOB;
     }
     {
-        const int n = n0 + BFULL * 64 + hrow;
+        const int n = n0 + BFULL * RPP + hrow;
         w_off[BFULL] = (BHALF && n < p.N) ? static_cast<unsigned>(n * p.K + hchunk8) * 2u : OOB;
     }
     const int Ctot = p.c0 + p.c1;
@@ -483,14 +496,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
     const int n_it = kb1 - kb0;
     int kg = kb0 * 64;
     int tap = kg / Ctot, cc = kg - tap * Ctot;
-    unsigned a_off[MREP];                                         // bytes, or OOB
+    unsigned a_off[APASS];                                        // bytes, or OOB
     bool seg1 = false;                                            // current source is a1
     auto set_segment = [&]() {
         const int ky = p.ksize == 3 ? tap / 3 : 0, kx = p.ksize == 3 ? tap - 3 * ky : 0;
         seg1 = __builtin_amdgcn_readfirstlane(cc >= p.c0 ? 1 : 0) != 0;
         const int ld = seg1 ? p.a1_ld : p.a0_ld;
 #pragma unroll
-        for (int i = 0; i < MREP; ++i) {
+        for (int i = 0; i < APASS; ++i) {
             const int yi = a_y[i] + ky, xi = a_x[i] + kx;
             const bool ok = yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
             const int pix = (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up);
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
     // One stage = NPIECE DMA instructions per wave: pieces 0..3 the activation passes, then the weight
     // passes, issued one at a time between MFMAs (a burst of 8 waves x 7 KB stalls every wave at issue
     // for ~900 clocks: the CU's vector-memory pipe moves ~64 B/clk).
-    constexpr int NPIECE = MREP + BFULL + (BHALF ? 1 : 0);
+    constexpr int NPIECE = APASS + BFULL + (BHALF ? 1 : 0);
     int st_soff_a = 0, st_soff_w = 0;
     auto stage_begin = [&]() {
         st_soff_a = __builtin_amdgcn_readfirstlane((seg1 ? cc - p.c0 : cc) * 2);
@@ -522,14 +535,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
     auto dma_piece = [&](const __amdgpu_buffer_rsrc_t& rs_a, int slot, int k) {
         unsigned short* As = smem + slot * STAGE;
         unsigned short* Bs = As + BM * 64;
-        if (k < MREP) {
-            unsigned short* dst = As + (k * 64 + wave * 8) * 64;
+        if (k < APASS) {
+            unsigned short* dst = As + (k * RPP + wave * 8) * 64;
             lds_dma(rs_a, dst, a_off[k], st_soff_a);
-        } else if (k < MREP + BFULL) {
-            const int j = k - MREP;
-            lds_dma(rs_w, Bs + (j * 64 + wave * 8) * 64, w_off[j], st_soff_w);
+        } else if (k < APASS + BFULL) {
+            const int j = k - APASS;
+            lds_dma(rs_w, Bs + (j * RPP + wave * 8) * 64, w_off[j], st_soff_w);
         } else if (BHALF) {
-            if (lane < 32) lds_dma(rs_w, Bs + (BFULL * 64 + wave * 4) * 64, w_off[BFULL], st_soff_w);
+            if (lane < 32) lds_dma(rs_w, Bs + (BFULL * RPP + wave * 4) * 64, w_off[BFULL], st_soff_w);
         }
     };
     auto dma_stage = [&](int slot) {
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
         const unsigned short* Bs = As + BM * 64;
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
-            fa[i] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(As + lds_off(wm * 64 + i * 16 + frow, slab * 4 + fchunk)));
+            fa[i] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(As + lds_off(wm * 16 * MREP + i * 16 + frow, slab * 4 + fchunk)));
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
             fb[j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Bs + lds_off(wn * 16 * NREP + j * 16 + frow, slab * 4 + fchunk)));
@@ -570,7 +583,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
     if (n_it > 1) {
         dma_stage(1);
         if constexpr (NPIECE == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (NPIECE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (NPIECE == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        else if constexpr (NPIECE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -591,7 +607,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
         // (the compiler drains to 0, it does not count), and they were issued >= NM - LEAD MFMAs earlier.
 #pragma unroll
         for (int idx = 0; idx < NM; ++idx) {
-            acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb0[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
+            if constexpr (NW == 4) Mfma<T>::acc_agpr(fb0[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
+            else acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb0[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
             if (idx == LEAD - 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_frags(cur, 1, fa1, fb1);
@@ -607,7 +624,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
         if constexpr (DMA) rs_a = stage_begin();
 #pragma unroll
         for (int idx = 0; idx < NM; ++idx) {
-            acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
+            if constexpr (NW == 4) Mfma<T>::acc_agpr(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
+            else acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
             if (MORE && idx == LEAD - 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_frags(nx1, 0, fa0, fb0);
@@ -633,12 +651,13 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
     for (int it = 0; it + 2 < n_it; ++it) step(YES, YES);
     if (n_it >= 2) step(YES, NO);
     step(NO, NO);
+    if constexpr (NW == 4) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // inline-asm MFMA results -> vector ALU reads
     stamp(p, 2);
 
     if (p.splits > 1) {          // fp32 slab straight from the fragments (64-byte row segments)
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            const int m = m0 + wm * 16 * MREP + i * 16 + (lane & 15);
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < NREP; ++j) {
@@ -651,7 +670,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm8(const GemmParams p) {
         return;
     }
 
-    epilogue_tile<T, MREP, NREP, 512, BM, BN>(p, bz, acc, smem, m0, n0, wm * 64, wn * 16 * NREP, lane, t);
+    epilogue_tile<T, MREP, NREP, NT, BM, BN>(p, bz, acc, smem, m0, n0, wm * 16 * MREP, wn * 16 * NREP, lane, t);
     stamp(p, 3);
 }
 
@@ -713,8 +732,8 @@ static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     return PF_OK;
 }
 
-template <typename T, int NREP>
-static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
+template <typename T, int NREP, int NW>
+static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 256, BN = 32 * NREP;
     GemmParams p = gp;
     p.mtiles = static_cast<int>(cdiv(p.M - p.m_begin, BM));
@@ -723,11 +742,11 @@ static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
     const size_t smem = static_cast<size_t>(3) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm8<T, NREP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm8<T, NREP, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_gemm8<T, NREP>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(512), smem, st, p);
+    hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(64 * NW), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm (8-wave)");
     if (p.splits > 1) {
         const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
@@ -735,6 +754,14 @@ static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
         PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
     }
     return PF_OK;
+}
+
+static int tuning(const char* name, int dflt);
+template <typename T, int NREP>
+static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
+    // NW = 4 (one 128x80 wave per SIMD, accumulators in AGPRs) is implemented and correct but measured slower
+    // (K step 2520 vs 2222 clocks, epilogue 2x): a lone in-order wave exposes every lgkmcnt / vmcnt / barrier wait
+    return launch8w<T, NREP, 8>(gp, batch, st);
 }
 
 static int tuning(const char* name, int dflt) {     // A/B switches for benchmarking (read once)
