@@ -340,6 +340,115 @@ class UNet2DConditionModel(nn.Module):
         return self.conv_out(self.conv_act(self.conv_norm_out(h)))
 
 
+class ControlNetConditioningEmbedding(nn.Module):
+    """diffusers 0.24 ControlNetConditioningEmbedding: conv_in 3->16, then per level
+    (conv c->c, conv c->c' stride 2) over (16, 32, 96, 256), SiLU after every conv but the last,
+    zero-initialised conv_out 256 -> block_out_channels[0].  512x1024 image -> 64x128 features."""
+
+    def __init__(self, out_channels, cond_channels=3, block_out_channels=(16, 32, 96, 256)):
+        super().__init__()
+        self.conv_in = nn.Conv2d(cond_channels, block_out_channels[0], 3, padding=1)
+        self.blocks = nn.ModuleList()
+        for i in range(len(block_out_channels) - 1):
+            ci, co = block_out_channels[i], block_out_channels[i + 1]
+            self.blocks.append(nn.Conv2d(ci, ci, 3, padding=1))
+            self.blocks.append(nn.Conv2d(ci, co, 3, padding=1, stride=2))
+        self.conv_out = nn.Conv2d(block_out_channels[-1], out_channels, 3, padding=1)
+        nn.init.zeros_(self.conv_out.weight)
+        nn.init.zeros_(self.conv_out.bias)
+
+    def forward(self, cond):
+        h = F.silu(self.conv_in(cond))
+        for blk in self.blocks:
+            h = F.silu(blk(h))
+        return self.conv_out(h)
+
+
+class ControlNetModel(nn.Module):
+    """diffusers==0.24.0 ControlNetModel as the reference uses it (PanoGenerator.py:153-157
+    ``ControlNetModel.from_unet(unet)``; called at MVGenModel.py:68-83 with
+    ``(sample, timestep, encoder_hidden_states=, controlnet_cond=, return_dict=False)``).
+    PARITY UNPINNED (diffusers is not available here): restated from the pinned version's
+    published behaviour: encoder copy of the UNet (conv_in, time embedding,
+    down blocks, mid block), conditioning embedding ADDED to conv_in(sample), one zero-initialised
+    1x1 conv per skip tensor (12) and one for the mid output; conditioning_scale 1.0, no guess mode.
+    Plain zero-padded convolutions on the UN-padded panorama latent (no circular padding)."""
+
+    def __init__(self, in_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                 num_heads=(5, 10, 20, 20), cross_attention_dim=1024, norm_num_groups=32,
+                 cross_attn_blocks=(True, True, True, False), time_embed_dim=None,
+                 conditioning_embedding_out_channels=(16, 32, 96, 256), **_ignored):
+        super().__init__()
+        boc = tuple(block_out_channels)
+        g = norm_num_groups
+        temb = time_embed_dim or boc[0] * 4
+        self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)
+        self.time_proj = Timesteps(boc[0])
+        self.time_embedding = TimestepEmbedding(boc[0], temb)
+        self.controlnet_cond_embedding = ControlNetConditioningEmbedding(
+            boc[0], 3, tuple(conditioning_embedding_out_channels))
+
+        def tfm(ch, heads):
+            return Transformer2DModel(heads, ch // heads, ch, cross_attention_dim, g)
+
+        def zero_conv(ch):
+            c = nn.Conv2d(ch, ch, 1)
+            nn.init.zeros_(c.weight)
+            nn.init.zeros_(c.bias)
+            return c
+
+        self.down_blocks = nn.ModuleList()
+        self.controlnet_down_blocks = nn.ModuleList([zero_conv(boc[0])])
+        ch = boc[0]
+        for i, out_ch in enumerate(boc):
+            blk = _Block(cross_attn_blocks[i])
+            for j in range(layers_per_block):
+                blk.resnets.append(ResnetBlock2D(ch if j == 0 else out_ch, out_ch, temb, g))
+                if blk.has_cross_attention:
+                    blk.attentions.append(tfm(out_ch, num_heads[i]))
+                self.controlnet_down_blocks.append(zero_conv(out_ch))
+            if i != len(boc) - 1:
+                blk.downsamplers = nn.ModuleList([Downsample2D(out_ch)])
+                self.controlnet_down_blocks.append(zero_conv(out_ch))
+            self.down_blocks.append(blk)
+            ch = out_ch
+        self.mid_block = _Block(True)
+        self.mid_block.resnets.append(ResnetBlock2D(boc[-1], boc[-1], temb, g))
+        self.mid_block.attentions.append(tfm(boc[-1], num_heads[-1]))
+        self.mid_block.resnets.append(ResnetBlock2D(boc[-1], boc[-1], temb, g))
+        self.controlnet_mid_block = zero_conv(boc[-1])
+
+    @classmethod
+    def from_unet(cls, unet, conditioning_embedding_out_channels=(16, 32, 96, 256)):
+        cn = cls(conditioning_embedding_out_channels=conditioning_embedding_out_channels, **unet.config)
+        for name in ("conv_in", "time_embedding", "down_blocks", "mid_block"):   # load_weights_from_unet=True
+            getattr(cn, name).load_state_dict(getattr(unet, name).state_dict(), strict=False)
+        return cn
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, controlnet_cond=None, return_dict=False):
+        emb = self.time_embedding(self.time_proj(timestep).to(self.dtype))
+        h = self.conv_in(sample) + self.controlnet_cond_embedding(controlnet_cond)
+        skips = [h]
+        for blk in self.down_blocks:
+            for j, res in enumerate(blk.resnets):
+                h = res(h, emb)
+                if blk.has_cross_attention:
+                    h = blk.attentions[j](h, encoder_hidden_states).sample
+                skips.append(h)
+            if blk.downsamplers is not None:
+                h = blk.downsamplers[0](h)
+                skips.append(h)
+        h = self.mid_block.resnets[0](h, emb)
+        h = self.mid_block.attentions[0](h, encoder_hidden_states).sample
+        h = self.mid_block.resnets[1](h, emb)
+        down = tuple(z(s) for z, s in zip(self.controlnet_down_blocks, skips))
+        return down, self.controlnet_mid_block(h)
+
+
 def tiny_config(width=32, cross_attention_dim=64, heads=(1, 2, 4, 4), groups=8):
     """Same topology as SD-2-base, small widths, for CPU-sized parity cases."""
     return dict(in_channels=4, out_channels=4,

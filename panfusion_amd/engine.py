@@ -105,11 +105,12 @@ def pack_unet(unet, dev, dtype):
     u.cin, u.c0 = ci.weight.shape[1], ci.weight.shape[0]
     u.w_conv_in = _f32(ci.weight.detach().permute(2, 3, 1, 0), dev)           # [3,3,cin,cout]
     u.b_conv_in = _bias(ci, dev)
-    co = unet.conv_out
-    u.cout = co.weight.shape[0]
-    u.w_conv_out = _f32(co.weight.detach().permute(0, 2, 3, 1), dev)          # [cout,3,3,cin]
-    u.b_conv_out = _bias(co, dev)
-    u.norm_out = _norm(unet.conv_norm_out, dev)
+    co = getattr(unet, "conv_out", None)       # a ControlNet has the encoder half only
+    if co is not None:
+        u.cout = co.weight.shape[0]
+        u.w_conv_out = _f32(co.weight.detach().permute(0, 2, 3, 1), dev)      # [cout,3,3,cin]
+        u.b_conv_out = _bias(co, dev)
+        u.norm_out = _norm(unet.conv_norm_out, dev)
     te = unet.time_embedding
     u.t_dim = te.linear_1.weight.shape[1]
     u.w_t1, u.b_t1 = _w16(te.linear_1.weight, dev, dtype), _bias(te.linear_1, dev)
@@ -135,7 +136,7 @@ def pack_unet(unet, dev, dtype):
     u.mid = NS(resnets=[res(r) for r in mid.resnets],
                attns=[pack_transformer(a, dev, dtype) for a in mid.attentions])
     u.up = []
-    for blk in unet.up_blocks:
+    for blk in getattr(unet, "up_blocks", []):
         b = NS(resnets=[res(r) for r in blk.resnets], attns=None, up=None)
         if getattr(blk, "has_cross_attention", False):
             b.attns = [pack_transformer(a, dev, dtype) for a in blk.attentions]
@@ -157,6 +158,93 @@ def pack_unet(unet, dev, dtype):
     u.b_temb = _f32(torch.cat(bs, 0), dev)
     u.temb_total = off
     return u
+
+
+def _pad64(c):
+    return (c + 63) // 64 * 64
+
+
+def pack_controlnet(cn, dev, dtype):
+    """diffusers ControlNetModel (PanoGenerator.py:153-157): the encoder half goes through pack_unet;
+    the conditioning embedding (3 -> 16 -> 16 -> 32 -> 32 -> 96 -> 96 -> 256 -> c0, 3x3, three stride-2
+    steps) runs on the same MFMA conv kernel with channel counts zero-padded to multiples of 64
+    (activation buffers keep the padded stride, the pad columns stay zero); the 13 zero-convs are 1x1."""
+    c = pack_unet(cn, dev, dtype)
+    ce = cn.controlnet_cond_embedding
+    first = ce.conv_in
+    co0 = first.weight.shape[0]
+    w0 = torch.zeros(3, 3, first.weight.shape[1], _pad64(co0))
+    w0[..., :co0] = first.weight.detach().float().permute(2, 3, 1, 0)
+    b0 = torch.zeros(_pad64(co0))
+    b0[:co0] = first.bias.detach().float()
+    c.ce_w0, c.ce_b0, c.ce_c0 = _f32(w0, dev), _f32(b0, dev), _pad64(co0)
+    c.ce_layers = []
+    for conv in [*ce.blocks, ce.conv_out]:
+        co, ci = conv.weight.shape[:2]
+        w = torch.zeros(co, 3, 3, _pad64(ci))
+        w[..., :ci] = conv.weight.detach().float().permute(0, 2, 3, 1)
+        c.ce_layers.append(NS(w=_w16(w.reshape(co, -1), dev, dtype), b=_bias(conv, dev), cout=co,
+                              cin_pad=_pad64(ci), stride=conv.stride[0]))
+    c.ce_bufs = {}
+    zc = lambda m: NS(w=_w16(m.weight.detach().float().reshape(m.weight.shape[0], -1), dev, dtype), b=_bias(m, dev),
+                      c=m.weight.shape[0])
+    c.zero_down = [zc(m) for m in cn.controlnet_down_blocks]
+    c.zero_mid = zc(cn.controlnet_mid_block)
+    return c
+
+
+def run_cond_embedding(c, cond):
+    """cond (n, 3, H, W) -> NHWC [n, H/8, W/8, c0] (diffusers ControlNetConditioningEmbedding.forward)."""
+    n, _, H, W = cond.shape
+    dev = cond.device
+    key = (n, H, W, str(dev))
+    bufs = c.ce_bufs.get(key)
+    if bufs is None:                       # persistent, zero-initialised: the padded channels are never written
+        bufs = [torch.zeros(n, H, W, c.ce_c0, device=dev, dtype=c.dtype)]
+        h, w = H, W
+        for L in c.ce_layers:
+            h, w = (h - 1) // L.stride + 1, (w - 1) // L.stride + 1
+            bufs.append(torch.zeros(n, h, w, _pad64(L.cout), device=dev, dtype=c.dtype))
+        c.ce_bufs[key] = bufs
+    x = ops.conv_in(cond.float(), c.ce_w0, c.ce_b0, c.ce_c0, c.dtype, wrap=False, out=bufs[0])
+    x = ops.silu(x, out=x)
+    h, w = H, W
+    for i, L in enumerate(c.ce_layers):
+        out = bufs[i + 1]
+        ops.conv_gemm(x, L.w, L.cout, n_img=n, h_in=h, w_in=w, ksize=3, stride=L.stride, pad=1, bias=L.b,
+                      c0=L.cin_pad, out=out.view(-1, out.shape[-1]))
+        if i + 1 < len(c.ce_layers):
+            out = ops.silu(out, out=out)
+        x, h, w = out, out.shape[1], out.shape[2]
+    return x
+
+
+def run_controlnet(c, latent, timestep, text, cond):
+    """ControlNetModel.forward(sample, timestep, encoder_hidden_states, controlnet_cond) on NHWC:
+    -> (12 skip residuals [n, h, w, C], mid residual).  Plain zero-padded convolutions (the reference
+    calls it on the un-padded panorama latent, MVGenModel.py:76-83)."""
+    br = Branch(c, latent, timestep, text, pano=False, pad=False)
+    br.h = ops.add(br.h, run_cond_embedding(c, cond))
+    br.skips = [br.h]
+    for blk in c.down:
+        for j, r in enumerate(blk.resnets):
+            br.resnet(r)
+            if blk.attns is not None:
+                br.attention(blk.attns[j])
+            br.push()
+        if blk.down is not None:
+            br.downsample(blk.down)
+            br.push()
+    br.resnet(c.mid.resnets[0])
+    for a, r in zip(c.mid.attns, c.mid.resnets[1:]):
+        br.attention(a)
+        br.resnet(r)
+
+    def zero_conv(z, x):
+        n, h, w, Cc = x.shape
+        return ops.conv_gemm(x, z.w, z.c, n_img=n, h_in=h, w_in=w, ksize=1, bias=z.b).view(n, h, w, z.c)
+
+    return [zero_conv(z, s) for z, s in zip(c.zero_down, br.skips)], zero_conv(c.zero_mid, br.h)
 
 
 def pack_epa(block, dev, dtype):

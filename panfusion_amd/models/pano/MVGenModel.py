@@ -51,7 +51,8 @@ class MultiViewBaseModel(nn.Module):
     def packed(self, which, device):
         key = (which, str(device), self.compute_dtype)
         if key not in self._packed:
-            self._packed[key] = engine.pack_unet(getattr(self, which), device, self.compute_dtype)
+            pack = engine.pack_controlnet if which.endswith("_cn") else engine.pack_unet
+            self._packed[key] = pack(getattr(self, which), device, self.compute_dtype)
         return self._packed[key]
 
     def repack(self):
@@ -71,14 +72,15 @@ class MultiViewBaseModel(nn.Module):
     @torch.no_grad()
     def forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras,
                 pers_layout_cond=None, pano_layout_cond=None):
-        if (self.pers_cn is not None and pers_layout_cond is not None) or \
-                (self.pano_cn is not None and pano_layout_cond is not None):
-            raise NotImplementedError(
-                "ControlNet (layout-conditioned) residuals are not on the HIP path yet (SURVEY.md §8 row a21)")
+        if self.pers_cn is None:
+            pers_layout_cond = None                 # reference MVGenModel.py:62-65
+        if self.pano_cn is None:
+            pano_layout_cond = None
         dev = pano_latent.device
         dt = self.compute_dtype
         two = self.unet is not None
         branches = []
+        cn_res = {}                                 # id(branch) -> (12 skip residuals, mid residual)
         shard = getattr(self, "shard", None)      # set by sharding.ShardedDenoiseLoop: latents hold only
         if two:                                   # this rank's views, cameras all m of them
             b, m = latents.shape[:2]
@@ -90,6 +92,10 @@ class MultiViewBaseModel(nn.Module):
                                  prompt_embd.flatten(0, 1).to(dt).contiguous(), pano=False, pad=False)
             pano_t = timestep[:, 0]
             branches.append(pers)
+            if pers_layout_cond is not None:        # reference :66-74 (ControlNet on the view branch)
+                cn_res[id(pers)] = engine.run_controlnet(
+                    self.packed("pers_cn", dev), latents.flatten(0, 1), timestep.reshape(-1), pers.text,
+                    pers_layout_cond.flatten(0, 1))
         else:
             pano_t = timestep
         main = torch.cuda.current_stream(dev) if pano_latent.is_cuda else None
@@ -117,6 +123,10 @@ class MultiViewBaseModel(nn.Module):
         with on_pano():
             pano = engine.Branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
                                  pano_prompt_embd.flatten(0, 1).to(dt).contiguous(), pano=True, pad=self.pano_pad)
+            if pano_layout_cond is not None:        # reference :75-83: plain convolutions on the un-padded latent
+                cn_res[id(pano)] = engine.run_controlnet(
+                    self.packed("pano_cn", dev), pano_latent.flatten(0, 1), pano_t, pano.text,
+                    pano_layout_cond.flatten(0, 1))
         branches.append(pano)
 
         def each_branch(fn):
@@ -151,6 +161,12 @@ class MultiViewBaseModel(nn.Module):
             if pu.down[i].down is not None and two:
                 fuse(self.cp_blocks_encoder[i])
 
+        # ControlNet residuals onto the skip stack (reference :154-170) and after the mid block (:200-203)
+        def add_skips(br):
+            if id(br) in cn_res:
+                br.skips = [engine.ops.add(sk, r) for sk, r in zip(br.skips, cn_res[id(br)][0])]
+        each_branch(add_skips)
+
         # mid (reference :172-207)
         def middle(br):
             mid = br.u.mid
@@ -158,6 +174,8 @@ class MultiViewBaseModel(nn.Module):
             for a, r in zip(mid.attns, mid.resnets[1:]):
                 br.attention(a)
                 br.resnet(r)
+            if id(br) in cn_res:
+                br.h = engine.ops.add(br.h, cn_res[id(br)][1])
         each_branch(middle)
         if two:
             fuse(self.cp_blocks_mid)

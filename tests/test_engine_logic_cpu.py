@@ -59,6 +59,42 @@ def test_pano_only_and_unpadded(fake_backend, oracle_model):
         assert s is None and rel_l2(got, want) < 2e-5
 
 
+def test_controlnet_residuals(fake_backend, oracle_model):
+    """Layout-conditioned call (reference MVGenModel.py:62-83,154-170,200-203):
+    ControlNet on the panorama branch (the reference's default, PanoGenerator.py:186-191) and on both."""
+    from oracle import sd2_unet as U
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    g = golden("mvgen_tiny.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    cams = {k: torch.stack([v, v]) for k, v in cam4().items()}
+    gen = torch.Generator().manual_seed(7)
+
+    def make_cn(unet, seed):
+        cn = U.ControlNetModel.from_unet(unet)
+        U.init_synthetic(cn.controlnet_cond_embedding, seed)
+        U.init_synthetic(cn.controlnet_down_blocks, seed + 1)       # zero-initialised in diffusers: would test nothing
+        U.init_synthetic(cn.controlnet_mid_block, seed + 2)
+        return cn
+
+    pano_cn, pers_cn = make_cn(oracle_model.pano_unet, 71), make_cn(oracle_model.unet, 75)
+    pano_cond = torch.rand(2, 1, 3, 128, 256, generator=gen) * 2 - 1          # 8x the 16x32 latent
+    pers_cond = torch.rand(2, 4, 3, 128, 128, generator=gen) * 2 - 1
+    for use_pers in (False, True):
+        o = MV.DualBranchDenoiser(oracle_model.unet, oracle_model.pano_unet, pers_cn if use_pers else None, pano_cn)
+        o.load_state_dict({k: v for k, v in oracle_model.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+        args = (t("latents"), t("pano_latent"), torch.full((2, 4), 981), t("prompt_embd"), t("pano_prompt_embd"), cams)
+        with torch.no_grad():
+            ws, wp = o(*args, pers_layout_cond=pers_cond, pano_layout_cond=pano_cond)
+            ws0, wp0 = o(*args)
+        assert rel_l2(wp, wp0) > 1e-3, "the ControlNet must change the output for the test to mean anything"
+        m = MultiViewBaseModel(o.unet, o.pano_unet, o.pers_cn, o.pano_cn, True, compute_dtype=torch.float32)
+        m.load_state_dict({k: v for k, v in o.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+        s, ps = m(*args, pers_layout_cond=pers_cond, pano_layout_cond=pano_cond)
+        assert rel_l2(s, ws) < 2e-5 and rel_l2(ps, wp) < 2e-5, (use_pers, rel_l2(s, ws), rel_l2(ps, wp))
+        s0, ps0 = m(*args)                                                      # no cond -> ControlNet skipped
+        assert rel_l2(s0, ws0) < 2e-5 and rel_l2(ps0, wp0) < 2e-5
+
+
 def test_per_sample_cameras(fake_backend, oracle_model):
     g = golden("mvgen_tiny.npz")
     t = lambda k: torch.from_numpy(g[k])

@@ -213,3 +213,38 @@ def test_segmented_graph_replay_equals_eager(oracle_model):
     assert len(calls) == n_calls + 1
     want = fn()
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_controlnet_layout_condition(oracle_model, dtype):
+    """SURVEY.md §8 row a21 (BASELINE.json configs[4]): ControlNet residuals on the panorama branch
+    (reference default) and on both branches, against the CPU oracle (diffusers semantics restated)."""
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    g, lat, pl, pe, ppe = tiny_inputs()
+    cams = {k: torch.stack([v, v]) for k, v in cam4().items()}
+    gen = torch.Generator().manual_seed(7)
+
+    def make_cn(unet, seed):
+        cn = U.ControlNetModel.from_unet(unet)
+        U.init_synthetic(cn.controlnet_cond_embedding, seed)
+        U.init_synthetic(cn.controlnet_down_blocks, seed + 1)
+        U.init_synthetic(cn.controlnet_mid_block, seed + 2)
+        return cn
+
+    pano_cn, pers_cn = make_cn(oracle_model.pano_unet, 71), make_cn(oracle_model.unet, 75)
+    pano_cond = torch.rand(2, 1, 3, 128, 256, generator=gen) * 2 - 1
+    pers_cond = torch.rand(2, 4, 3, 128, 128, generator=gen) * 2 - 1
+    t = torch.full((2, 4), 981, dtype=torch.long)
+    o = MV.DualBranchDenoiser(oracle_model.unet, oracle_model.pano_unet, pers_cn, pano_cn)
+    o.load_state_dict({k: v for k, v in oracle_model.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    with torch.no_grad():
+        ws, wp = o(lat, pl, t, pe, ppe, cams, pers_layout_cond=pers_cond, pano_layout_cond=pano_cond)
+        ws0, wp0 = o(lat, pl, t, pe, ppe, cams)
+    assert rel_l2(wp, wp0) > 1e-2
+    m = MultiViewBaseModel(o.unet, o.pano_unet, o.pers_cn, o.pano_cn, True, compute_dtype=dtype)
+    m.load_state_dict({k: v for k, v in o.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    s, ps = m(lat.to(DEV), pl.to(DEV), t.to(DEV), pe.to(DEV), ppe.to(DEV), cams,
+              pers_layout_cond=pers_cond.to(DEV), pano_layout_cond=pano_cond.to(DEV))
+    es, ep = rel_l2(s.cpu(), ws), rel_l2(ps.cpu(), wp)
+    print("ControlNet rel-L2 %s: views %.3e pano %.3e" % (dtype, es, ep))
+    assert es <= TOL[dtype] and ep <= TOL[dtype], (es, ep)
