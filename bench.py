@@ -29,17 +29,20 @@ FLOP_PER_STEP_CFG2 = 38.66e12        # SURVEY.md §8d / BASELINE.md §2 (2 FLOPs
 PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
 
 
-def build_model(dev, dtype, cfg):
+def build_model(dev, dtype, cfg, layout_cond=False):
     import torch
     from panfusion_amd.models.pano import MultiViewBaseModel
-    from panfusion_amd.models.sd2_unet_params import UNetParams, fill_synthetic
+    from panfusion_amd.models.sd2_unet_params import ControlNetParams, UNetParams, fill_synthetic
     with torch.device(dev):
         unet, pano_unet = UNetParams(**cfg), UNetParams(**cfg)
         unet.add_lora(4)
         pano_unet.add_lora(4)
+        pano_cn = ControlNetParams(**cfg) if layout_cond else None      # reference default: panorama branch only
     fill_synthetic(unet, 1)
     fill_synthetic(pano_unet, 2)
-    model = MultiViewBaseModel(unet, pano_unet, None, None, True, compute_dtype=dtype).to(dev)
+    if pano_cn is not None:
+        fill_synthetic(pano_cn, 3)          # incl. the zero-convs (zero-initialised in diffusers: would skip no work, but be a no-op)
+    model = MultiViewBaseModel(unet, pano_unet, None, pano_cn, True, compute_dtype=dtype).to(dev)
     for i, blk in enumerate([*model.cp_blocks_encoder, model.cp_blocks_mid, *model.cp_blocks_decoder]):
         fill_synthetic(blk, 10 + i)     # EPA output projections are zero-initialised in the reference
     model.repack()
@@ -127,6 +130,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-out", default=None, help="write the per-shape table of the instrumented step here")
     ap.add_argument("--small", action="store_true", help="reduced widths/sizes (debug only, not the metric)")
+    ap.add_argument("--cfg5", action="store_true",
+                    help="BASELINE.json configs[4]: layout-conditioned (panorama ControlNet, 512x1024 condition image) -- not the metric line")
     ap.add_argument("--cfg4", action="store_true",
                     help="BASELINE.json configs[3]: 1024x2048 panorama (128x256 latent) + 20x512^2 views -- not the metric line")
     args = ap.parse_args()
@@ -159,6 +164,9 @@ def main():
     cfg = dict(SD2_BASE)
     m, lat_hw, pano_hw, flop = 20, (64, 64), (64, 128), FLOP_PER_STEP_CFG2
     workload = "cfg2: 512x1024 pano + 20x512^2 views, CFG pair, SD-2-base UNet shapes"
+    if args.cfg5:
+        flop = FLOP_PER_STEP_CFG2 + 2 * 0.66e12          # + ControlNet encoder + embedding per CFG sample
+        workload = "cfg5: cfg2 + panorama ControlNet on a 512x1024 layout condition (NOT the headline config)"
     if args.cfg4:
         pano_hw, flop = (128, 256), 64.36e12
         workload = "cfg4: 1024x2048 pano + 20x512^2 views, CFG pair, SD-2-base UNet shapes (NOT the headline config)"
@@ -173,9 +181,13 @@ def main():
         model, loop = sharding.build_sharded(build_model, build_inputs, dev, dtype, cfg, m, lat_hw, pano_hw,
                                              cams_deg, args.steps + args.warmup + 1, not args.no_graphs)
     else:
-        model = build_model(dev, dtype, cfg)
+        model = build_model(dev, dtype, cfg, layout_cond=args.cfg5)
         inputs = build_inputs(dev, m, lat_hw, pano_hw, cfg["cross_attention_dim"], cams_deg)
-        loop = DenoiseLoop(model, *inputs, steps=args.steps + args.warmup + 1, use_graphs=not args.no_graphs)
+        layout = None
+        if args.cfg5:
+            layout = (torch.rand(1, 1, 3, pano_hw[0] * 8, pano_hw[1] * 8, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(dev)
+        loop = DenoiseLoop(model, *inputs, steps=args.steps + args.warmup + 1, use_graphs=not args.no_graphs,
+                           pano_layout_cond=layout)
 
     loop.prepare()                                    # tables + one graph per rotation offset, untimed
     for _ in range(args.warmup):
@@ -244,6 +256,7 @@ def main():
 
     if rank == 0:
         metric = ("DDIM denoise steps/sec, 1024x2048 pano + 20x512^2 views (configs[3])" if args.cfg4
+                  else "DDIM denoise steps/sec, layout-conditioned 512x1024 pano + 20x512^2 views (configs[4])" if args.cfg5
                   else "DDIM denoise steps/sec, 512x1024 pano + 20x512^2 views")
         res = {"metric": metric, "value": args.steps / elapsed,
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -146,6 +146,35 @@ class UNetParams(_Holder):
                         lin.set_lora(rank)
 
 
+class ControlNetParams(_Holder):
+    """Parameter tree of diffusers ``ControlNetModel.from_unet(unet)`` (PanoGenerator.py:153-157):
+    encoder half of the UNet + conditioning embedding + 12 + 1 zero-convs, diffusers names."""
+
+    def __init__(self, conditioning_embedding_out_channels=(16, 32, 96, 256), **unet_cfg):
+        super().__init__()
+        enc = UNetParams(**unet_cfg)
+        self.conv_in, self.time_embedding = enc.conv_in, enc.time_embedding
+        self.down_blocks, self.mid_block = enc.down_blocks, enc.mid_block
+        boc = tuple(unet_cfg.get("block_out_channels", SD2_BASE["block_out_channels"]))
+        lpb = unet_cfg.get("layers_per_block", 2)
+        ce = _Holder()
+        coc = tuple(conditioning_embedding_out_channels)
+        ce.conv_in = nn.Conv2d(3, coc[0], 3, padding=1)
+        ce.blocks = nn.ModuleList()
+        for i in range(len(coc) - 1):
+            ce.blocks.append(nn.Conv2d(coc[i], coc[i], 3, padding=1))
+            ce.blocks.append(nn.Conv2d(coc[i], coc[i + 1], 3, padding=1, stride=2))
+        ce.conv_out = nn.Conv2d(coc[-1], boc[0], 3, padding=1)
+        self.controlnet_cond_embedding = ce
+        self.controlnet_down_blocks = nn.ModuleList([nn.Conv2d(boc[0], boc[0], 1)])
+        for i, oc in enumerate(boc):
+            for _ in range(lpb):
+                self.controlnet_down_blocks.append(nn.Conv2d(oc, oc, 1))
+            if i != len(boc) - 1:
+                self.controlnet_down_blocks.append(nn.Conv2d(oc, oc, 1))
+        self.controlnet_mid_block = nn.Conv2d(boc[-1], boc[-1], 1)
+
+
 @torch.no_grad()
 def fill_synthetic(module, seed, device=None):
     """Seeded synthetic weights generated ON the module's device (fan-in scaled normals, norm gains

@@ -58,7 +58,7 @@ class DenoiseLoop:
     """One text-to-panorama sampling run (batch 1 prompt, CFG pair inside)."""
 
     def __init__(self, model, latents, pano_latent, prompt_embd, pano_prompt_embd, cameras,
-                 steps=50, rot_diff=90.0, guidance_scale=9.0, use_graphs=False):
+                 steps=50, rot_diff=90.0, guidance_scale=9.0, use_graphs=False, pano_layout_cond=None):
         """latents (1, m, 4, h, w), pano_latent (1, 1, 4, H, W) fp32 on the GPU;
         prompt_embd (2, m, L, D) / pano_prompt_embd (2, 1, L, D) = [null ; prompt];
         cameras: dict of (1, m) CPU tensors (FoV, theta, phi in degrees)."""
@@ -77,19 +77,37 @@ class DenoiseLoop:
         self.total_rot = 0.0
         self.use_graphs = use_graphs
         self.graphs = {}
+        # layout condition image (1, 1, 3, Hi, Wi) for the panorama ControlNet: rolled with the panorama
+        # every step (PanFusion.py:150-153); one static copy per rotation offset (the loop is 4-periodic)
+        self.layout = None if pano_layout_cond is None else pano_layout_cond.float().contiguous()
+        self._layout_rot = {}
         self.eps = self.pano_eps = None
         # the loop rolls the panorama BEFORE each denoiser call (PanFusion.py:149); afterwards the
         # DDIM kernel writes the next latent already rolled for the following step.
         self._pano_tmp = torch.empty_like(self.pano)
+        self._rot_of = {}                                  # camera-theta key -> accumulated rotation (degrees)
         if rot_diff % 360:
             self.pano.copy_(ops.roll_width(self.pano, self.shift, out=self._pano_tmp))
         self.cameras = rotate_cameras(self.cameras, rot_diff)
         self.total_rot += rot_diff
+        self._rot_of[tuple(float(v) for v in self.cameras["theta"].reshape(-1))] = self.total_rot
+
+    def _layout_for(self, cams):
+        """The condition image rolled by the rotation these cameras carry (PanoGenerator.py:264-269)."""
+        if self.layout is None:
+            return None
+        rot = float(self._rot_of.get(tuple(float(v) for v in cams["theta"].reshape(-1)), self.total_rot)) % 360
+        if rot not in self._layout_rot:
+            shift = int(rot / 360 * self.layout.shape[-1])
+            img = ops.roll_width(self.layout, shift) if shift else self.layout
+            self._layout_rot[rot] = torch.cat([img, img])          # CFG pair (gen_cls_free_guide_pair)
+        return self._layout_rot[rot]
 
     def _denoise(self, cams):
         pair = lambda x: torch.cat([x, x])
         cams2 = {k: torch.cat([v, v]) for k, v in cams.items()}
-        return self.model(pair(self.lat), pair(self.pano), self.tstep, self.prompt, self.pano_prompt, cams2)
+        return self.model(pair(self.lat), pair(self.pano), self.tstep, self.prompt, self.pano_prompt, cams2,
+                          None, self._layout_for(cams))
 
     def _denoise_graphed(self, cams):
         key = tuple(float(v) for v in cams["theta"].reshape(-1))
@@ -110,11 +128,14 @@ class DenoiseLoop:
         offset the loop will visit (4 at rot_diff = 90)."""
         cams, seen = self.cameras, set()
         self.tstep.fill_(self.timesteps[0])
+        rot = self.total_rot
         for _ in range(64):
             key = tuple(float(v) for v in cams["theta"].reshape(-1))
             if key in seen:
                 break
             seen.add(key)
+            self._rot_of.setdefault(key, rot)
+            rot += self.rot_diff
             (self._denoise_graphed if self.use_graphs else self._denoise)(cams)
             cams = rotate_cameras(cams, self.rot_diff)
         torch.cuda.synchronize()
@@ -144,6 +165,7 @@ class DenoiseLoop:
         if not last:
             self.cameras = rotate_cameras(self.cameras, self.rot_diff)
             self.total_rot += self.rot_diff
+            self._rot_of.setdefault(tuple(float(v) for v in self.cameras["theta"].reshape(-1)), self.total_rot)
 
     def run(self):
         while self.i < len(self.timesteps):

@@ -120,6 +120,28 @@ def test_sampling_loop_matches_golden(fake_backend, oracle_model):
     assert rel_l2(p3, torch.from_numpy(gd["pano_latent"])) < 1e-4
 
 
+def test_loop_rolls_layout_condition_with_the_panorama(fake_backend):
+    """PanFusion.py:150-153: the layout condition image is rolled by rot_diff every step, like the panorama."""
+    from panfusion_amd.pipeline import DenoiseLoop
+    seen = []
+
+    class Probe:
+        def __call__(self, lat, pano, t, pe, ppe, cams, pers_cond=None, pano_cond=None):
+            seen.append(pano_cond.clone())
+            return torch.zeros_like(lat), torch.zeros_like(pano)
+
+    gen = torch.Generator().manual_seed(3)
+    cond = torch.rand(1, 1, 3, 16, 64, generator=gen)
+    cam1 = {k: v[None] for k, v in cam4().items()}
+    loop = DenoiseLoop(Probe(), torch.zeros(1, 4, 4, 4, 4), torch.zeros(1, 1, 4, 4, 8), torch.zeros(2, 4, 3, 8),
+                       torch.zeros(2, 1, 3, 8), cam1, steps=6, pano_layout_cond=cond)
+    loop.run()
+    assert len(seen) == 6
+    for i, c in enumerate(seen):
+        want = torch.roll(cond, int(90 / 360 * 64) * (i + 1), -1)
+        assert c.shape[0] == 2 and torch.equal(c[0], want[0]) and torch.equal(c[1], want[0])
+
+
 def test_reference_api_wrappers(fake_backend):
     from panfusion_amd.external.Perspective_and_Equirectangular import e2p, p2e
     from panfusion_amd.models.pano import get_coords, get_masks
