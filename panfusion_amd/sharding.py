@@ -89,7 +89,9 @@ class SegmentedGraph:
         g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()        # one memory pool shared by all segments
-        g.capture_begin(pool=self.pool)
+        # thread_local: the RCCL watchdog thread polls events of the eager collectives issued between
+        # segments; in the default "global" mode such a call from another thread invalidates the capture
+        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
         self._cur = g
 
     def _end(self):
@@ -203,8 +205,15 @@ class ShardedDenoiseLoop(DenoiseLoop):
             self._local(cams)                        # warm-up: tables, kernel attributes, communicator
             torch.cuda.synchronize()
             seg = SegmentedGraph()
-            with seg.record():
-                out = self._local(cams)
+            try:
+                with seg.record():
+                    out = self._local(cams)
+            except RuntimeError as e:                # capture refused (driver / communicator state): the same
+                import sys                           # kernels are launched eagerly instead -- slower host side, same results
+                print("panfusion_amd.sharding: hipGraph capture failed (%s); launching eagerly" % e, file=sys.stderr)
+                torch.cuda.synchronize()
+                self.use_graphs = False
+                return self._denoise(cams)
             g = (seg, out)
             self.graphs[key] = g
         g[0].replay()
