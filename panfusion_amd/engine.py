@@ -406,15 +406,22 @@ def _epa_tail(e, attn_out, x, Cc):
     return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y)
 
 
-def run_epa_sharded(e, t, xp, xe, m, shard):
+def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None):
     """EPA when this rank holds views [v0, v1) of the m (one CFG sample per rank, b == 1).
-    One all-gather of LN1(x_p + PE) inside the CFG half; K / V^T of all views are projected locally;
-    the panorama-query direction is computed redundantly (identical on every rank of the half)."""
+    One all-gather of LN1(x_p + PE) inside the CFG half; K / V^T of all views are projected locally.
+    Replicated layout: every rank holds the panorama and computes the panorama-query direction redundantly.
+    Panorama-rank layout (shard.pano_g): only the owner has xe; it computes the panorama-query direction and
+    broadcasts LN1(x_e + PE), from which every rank projects the panorama K / V^T for its own view queries;
+    the other ranks pass xe = None (equi_hw = its spatial size) and get None back for it."""
     from . import sharding
     mloc, ph, pw, Cc = xp.shape
-    b, eh, ew, _ = xe.shape
-    if b != 1:
-        raise ValueError("sharded EPA expects one CFG sample per rank")
+    owner = xe is not None
+    if owner:
+        b, eh, ew, _ = xe.shape
+        if b != 1:
+            raise ValueError("sharded EPA expects one CFG sample per rank")
+    else:
+        eh, ew = equi_hw
     P, E = ph * pw, eh * ew
     mP = m * P
     v0, v1 = shard.views
@@ -430,34 +437,44 @@ def run_epa_sharded(e, t, xp, xe, m, shard):
             t.__dict__[key] = (pad.reshape(pad.shape[0] // 32, 32, pad.shape[1] // 32, 32).abs().amax((1, 3)) > 0) \
                 .to(torch.uint8).contiguous()
         flags_p_loc = t.__dict__[key]
-    tp, te = xp.view(mloc * P, Cc), xe.view(E, Cc)
+    tp = xp.view(mloc * P, Cc)
     lnp_loc = ops.layernorm(tp, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_p[r0:r1])
-    lne = ops.layernorm(te, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_e)
-    lnp = sharding.gather_view_tokens(lnp_loc, shard)                       # [mP, C]
-    qk_p, qk_e = ops.linear(lnp, e.wqk), ops.linear(lne, e.wqk)
-    vt_p = ops.linear_t(lnp.view(1, mP, Cc), e.wv)
+    lnp = sharding.gather_view_tokens(lnp_loc, shard)                       # [mP, C] (every rank takes part)
+    lne = None
+    if owner:
+        te = xe.view(E, Cc)
+        lne = ops.layernorm(te, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_e)
+    lne = sharding.share_pano_tokens(lne, E, Cc, tp, shard)                 # broadcast in the panorama-rank layout
+    qk_e = ops.linear(lne, e.wqk)
     vt_e = ops.linear_t(lne.view(1, E, Cc), e.wv)
     ld = 2 * Cc
-    a_e = ops.attention(qk_e, qk_p[:, Cc:], vt_p, 1, e.heads, 32, E, mP, q_ld=ld, k_ld=ld, vt_ld=vt_p.shape[-1],
-                        q_bs=E * ld, k_bs=mP * ld, vt_bs=vt_p.shape[1] * vt_p.shape[2],
-                        bias=t.bias_e, flags=t.flags_e)
-    out_e = _epa_tail(e, a_e, te, Cc)
+    out_e = None
+    if owner:
+        qk_p = ops.linear(lnp, e.wqk)
+        vt_p = ops.linear_t(lnp.view(1, mP, Cc), e.wv)
+        a_e = ops.attention(qk_e, qk_p[:, Cc:], vt_p, 1, e.heads, 32, E, mP, q_ld=ld, k_ld=ld, vt_ld=vt_p.shape[-1],
+                            q_bs=E * ld, k_bs=mP * ld, vt_bs=vt_p.shape[1] * vt_p.shape[2],
+                            bias=t.bias_e, flags=t.flags_e)
+        out_e = _epa_tail(e, a_e, te, Cc).view(1, eh, ew, Cc)
+        q_loc = qk_p[r0:r1]
+    else:
+        q_loc = ops.linear(lnp_loc, e.wqk)                                  # only the local queries are needed
     nq = mloc * P
-    a_p = ops.attention(qk_p[r0:r1], qk_e[:, Cc:], vt_e, 1, e.heads, 32, nq, E, q_ld=ld, k_ld=ld,
+    a_p = ops.attention(q_loc, qk_e[:, Cc:], vt_e, 1, e.heads, 32, nq, E, q_ld=ld, k_ld=ld,
                         vt_ld=vt_e.shape[-1], q_bs=nq * ld, k_bs=E * ld, vt_bs=vt_e.shape[1] * vt_e.shape[2],
                         bias=t.bias_p[r0:r1], flags=flags_p_loc)
     out_p = _epa_tail(e, a_p, tp, Cc)
-    return out_p.view(mloc, ph, pw, Cc), out_e.view(1, eh, ew, Cc)
+    return out_p.view(mloc, ph, pw, Cc), out_e
 
 
-def run_epa(e, tables, xp, xe, m, shard=None):
+def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None):
     """EPA fusion (modules.py:15-59) on NHWC activations.
     xp [b*m, ph, pw, C], xe [b, eh, ew, C]; tables: list with one EPATables entry per batch
     element (or a single shared entry)."""
     if shard is not None:
         if len(tables) != 1:
             raise ValueError("sharded EPA needs one camera set")
-        return run_epa_sharded(e, tables[0], xp, xe, m, shard)
+        return run_epa_sharded(e, tables[0], xp, xe, m, shard, equi_hw)
     bm, ph, pw, Cc = xp.shape
     b, eh, ew, _ = xe.shape
     P, E = ph * pw, eh * ew

@@ -98,9 +98,12 @@ class MultiViewBaseModel(nn.Module):
                     pers_layout_cond.flatten(0, 1))
         else:
             pano_t = timestep
+        # view-sharded rank without the panorama branch (sharding layout "pano_rank"): the view branch only;
+        # the panorama tokens arrive by broadcast inside every EPA block
+        view_only = two and shard is not None and not shard.has_pano
         main = torch.cuda.current_stream(dev) if pano_latent.is_cuda else None
         side = None
-        if two and self.two_streams and main is not None:
+        if two and self.two_streams and main is not None and not view_only:
             if self._side is None:
                 self._side = torch.cuda.Stream(dev)
             side = self._side
@@ -120,14 +123,16 @@ class MultiViewBaseModel(nn.Module):
                 keep.clear()
 
         fork()
-        with on_pano():
-            pano = engine.Branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
-                                 pano_prompt_embd.flatten(0, 1).to(dt).contiguous(), pano=True, pad=self.pano_pad)
-            if pano_layout_cond is not None:        # reference :75-83: plain convolutions on the un-padded latent
-                cn_res[id(pano)] = engine.run_controlnet(
-                    self.packed("pano_cn", dev), pano_latent.flatten(0, 1), pano_t, pano.text,
-                    pano_layout_cond.flatten(0, 1))
-        branches.append(pano)
+        pano = None
+        if not view_only:
+            with on_pano():
+                pano = engine.Branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
+                                     pano_prompt_embd.flatten(0, 1).to(dt).contiguous(), pano=True, pad=self.pano_pad)
+                if pano_layout_cond is not None:    # reference :75-83: plain convolutions on the un-padded latent
+                    cn_res[id(pano)] = engine.run_controlnet(
+                        self.packed("pano_cn", dev), pano_latent.flatten(0, 1), pano_t, pano.text,
+                        pano_layout_cond.flatten(0, 1))
+            branches.append(pano)
 
         def each_branch(fn):
             for br in branches:
@@ -138,13 +143,18 @@ class MultiViewBaseModel(nn.Module):
                     fn(br)
 
         def fuse(block):
+            if view_only:                           # panorama feature map size at this level, from the latents' ratio
+                sc = latents.shape[-2] // pers.h.shape[1]
+                hw = (pano_latent.shape[-2] // sc, pano_latent.shape[-1] // sc)
+                pers.h, _ = block.forward_nhwc(pers.h, None, groups, m_total, shard=shard, equi_hw=hw)
+                return
             join()
             keep.append(pano.h)
             pers.h, pano.h = block.forward_nhwc(pers.h, pano.h, groups, m_total, shard=shard)
             keep.append(pano.h)
             fork()
 
-        pu = pano.u
+        pu = branches[-1].u
         # encoder (reference :98-152): EPA after each downsample
         for i in range(len(pu.down)):
             def level(br, i=i):
@@ -193,10 +203,12 @@ class MultiViewBaseModel(nn.Module):
                     fuse(self.cp_blocks_decoder[i])
                 each_branch(lambda br, i=i: br.upsample(br.u.up[i].up))
 
-        with on_pano():
-            pano_head = pano.head()
+        pano_head = None
+        if pano is not None:
+            with on_pano():
+                pano_head = pano.head()
         join()
         out_dtype = pano_latent.dtype
-        pano_sample = pano_head.to(out_dtype).unflatten(0, (-1, 1))
+        pano_sample = pano_head.to(out_dtype).unflatten(0, (-1, 1)) if pano_head is not None else None
         sample = pers.head().to(out_dtype).unflatten(0, (b, m)) if two else None
         return sample, pano_sample

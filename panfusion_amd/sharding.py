@@ -6,7 +6,9 @@ The reference has no intra-step parallelism (views are a batch dimension on one 
   * the two classifier-free-guidance samples (independent everywhere, EPA included);
   * the m perspective views (independent everywhere except inside EPA).
 Layout for N ranks (N even): 2 CFG halves x G = N/2 view groups; rank r -> (c, g) = (r // G, r % G),
-views [g*m/G, (g+1)*m/G).  N = 2 is the pure CFG split: no traffic inside the step.
+views [g*m/G, (g+1)*m/G) ("even"), or -- from G >= 4 -- the "pano_rank" layout of plan(): group 0 of a half owns
+the panorama branch and fewer views, the others run the view branch only.  N = 2 is the pure CFG split: no traffic
+inside the step.
 
 Exchanges per step:
   * per EPA block (7x), only when G > 1: ONE all-gather inside the CFG half of the layer-normed view
@@ -36,28 +38,83 @@ class ShardInfo:
     G: int              # view groups per CFG half
     m: int              # total number of views
     group: object = None      # process group of the CFG half (None when G == 1)
+    split: tuple = None       # views per group (None: m / G each)
+    pano_g: int = None        # the group that computes the panorama branch (None: every rank does, replicated)
+
+    @property
+    def counts(self):
+        return tuple(self.split) if self.split is not None else (self.m // self.G,) * self.G
 
     @property
     def views(self):
-        per = self.m // self.G
-        return self.g * per, (self.g + 1) * per
+        c = self.counts
+        v0 = sum(c[:self.g])
+        return v0, v0 + c[self.g]
+
+    @property
+    def vmax(self):
+        return max(self.counts)
+
+    @property
+    def has_pano(self):
+        return self.pano_g is None or self.pano_g == self.g
+
+    @property
+    def pano_src(self):
+        """Global rank of the panorama owner of this CFG half."""
+        return self.cfg * self.G + (self.pano_g or 0)
 
 
-def plan(world, rank, m):
-    """(cfg, g, G) layout of `rank`; world must be even (CFG pair) and m divisible by G."""
+# cost of the panorama branch + its EPA side in units of one view (SURVEY.md §8e: 1.918 / 0.804 TFLOP, + EPA)
+PANO_VIEW_EQUIV = 2.7
+
+
+def pano_rank_split(m, G):
+    """Views per group when group 0 owns the panorama branch: the largest m0 with m0 + pano <= share of the
+    others and (m - m0) divisible by G - 1; None if there is no such split (or it leaves group 0 without views)."""
+    best = None
+    for m0 in range(1, m):
+        if (m - m0) % (G - 1):
+            continue
+        if m0 + PANO_VIEW_EQUIV <= (m - m0) / (G - 1) + 1e-9:
+            best = m0
+    return None if best is None else (best,) + ((m - best) // (G - 1),) * (G - 1)
+
+
+def plan(world, rank, m, layout="auto", split=None):
+    """Layout of `rank`: 2 CFG halves x G = world/2 view groups.
+    layout "even": m/G views per group, the panorama branch replicated inside a CFG half (ceiling 6.06x at
+    8 ranks).  layout "pano_rank" (chosen by "auto" from G >= 4): group 0 of a half owns the panorama branch
+    and fewer views (2, 6, 6, 6 for m = 20, G = 4: ceiling 7.7x); the other groups run the view branch only
+    and receive the layer-normed panorama tokens by a broadcast at every EPA block."""
     if world < 2 or world % 2:
         raise ValueError("sharded step needs an even number of ranks (CFG pair x view groups), got %d" % world)
     G = world // 2
+    info = ShardInfo(rank=rank, world=world, cfg=rank // G, g=rank % G, G=G, m=m)
+    if split is not None:
+        if len(split) != G or sum(split) != m or min(split) < 1:
+            raise ValueError("split %r does not distribute %d views over %d groups" % (split, m, G))
+        info.split, info.pano_g = tuple(split), 0
+        return info
+    if layout == "auto":
+        layout = "pano_rank" if G >= 4 and pano_rank_split(m, G) is not None else "even"
+    if layout == "pano_rank":
+        sp = pano_rank_split(m, G) if G >= 2 else None
+        if sp is None:
+            raise ValueError("no panorama-rank split of %d views over %d groups" % (m, G))
+        info.split, info.pano_g = sp, 0
+        return info
     if m % G:
         raise ValueError("%d views do not divide over %d view groups" % (m, G))
-    return ShardInfo(rank=rank, world=world, cfg=rank // G, g=rank % G, G=G, m=m)
+    return info
 
 
-def make_shard(m):
+def make_shard(m, layout=None, split=None):
     """Build this process' ShardInfo and the process group of its CFG half (collective call:
     every rank creates every group, in the same order)."""
+    import os
     world, rank = dist.get_world_size(), dist.get_rank()
-    info = plan(world, rank, m)
+    info = plan(world, rank, m, layout or os.environ.get("PF_SHARD_LAYOUT", "auto"), split)
     if info.G > 1:
         groups = [dist.new_group(list(range(c * info.G, (c + 1) * info.G))) for c in range(2)]
         info.group = groups[info.cfg]
@@ -150,30 +207,64 @@ class SegmentedGraph:
 RECORDER = None                     # the SegmentedGraph being recorded, if any
 
 
-def gather_view_tokens(x_local, shard):
-    """All-gather [rows_local, C] token blocks of the CFG half in view order -> [G * rows_local, C]."""
-    if shard.G == 1:
-        return x_local
-    x_local = x_local.contiguous()
-    out = torch.empty(shard.G * x_local.shape[0], x_local.shape[1], dtype=x_local.dtype, device=x_local.device)
-    call = lambda: dist.all_gather_into_tensor(out, x_local, group=shard.group)
+def _collective(call):
     if RECORDER is not None:
         RECORDER.eager(call)        # graph break: the collective stays an eager call between two segments
     else:
         call()
-    return out
 
 
-def gather_eps(eps_local, pano_eps_local, shard):
-    """-> eps [2, m, ...] and pano_eps [2, 1, ...] on every rank (rank order == (cfg, view group))."""
-    e = eps_local.contiguous()                            # [1, m/G, 4, h, w]
-    out = torch.empty(shard.world * e.shape[0], *e.shape[1:], dtype=e.dtype, device=e.device)
+def gather_view_tokens(x_local, shard):
+    """All-gather [views_local * P, C] token blocks of the CFG half in view order -> [m * P, C].
+    Unequal view counts (panorama-rank layout) travel padded to the largest group and are compacted."""
+    if shard.G == 1:
+        return x_local
+    x_local = x_local.contiguous()
+    counts = shard.counts
+    P = x_local.shape[0] // counts[shard.g]
+    rows = shard.vmax * P
+    if x_local.shape[0] != rows:
+        padded = torch.empty(rows, x_local.shape[1], dtype=x_local.dtype, device=x_local.device)
+        padded[:x_local.shape[0]] = x_local
+        x_local = padded
+    out = torch.empty(shard.G * rows, x_local.shape[1], dtype=x_local.dtype, device=x_local.device)
+    _collective(lambda: dist.all_gather_into_tensor(out, x_local, group=shard.group))
+    if len(set(counts)) == 1:
+        return out
+    return torch.cat([out[g * rows:g * rows + counts[g] * P] for g in range(shard.G)])
+
+
+def share_pano_tokens(x, rows, cols, like, shard):
+    """The panorama owner's [rows, cols] tensor on every rank of the CFG half (x is None elsewhere)."""
+    if shard.pano_g is None or shard.G == 1:
+        return x
+    buf = x.contiguous() if x is not None else torch.empty(rows, cols, dtype=like.dtype, device=like.device)
+    _collective(lambda: dist.broadcast(buf, src=shard.pano_src, group=shard.group))
+    return buf
+
+
+def gather_eps(eps_local, pano_eps_local, shard, pano_shape=None):
+    """-> eps [2, m, ...] and pano_eps [2, 1, ...] on every rank (rank order == (cfg, view group)).
+    pano_eps_local is None on ranks without the panorama branch (pano_shape = its shape there)."""
+    e = eps_local.contiguous()                            # [1, views_local, 4, h, w]
+    counts = shard.counts
+    if e.shape[1] != shard.vmax:                          # unequal groups travel padded to the largest
+        pad = torch.zeros(1, shard.vmax, *e.shape[2:], dtype=e.dtype, device=e.device)
+        pad[:, :e.shape[1]] = e
+        e = pad
+    out = torch.empty(shard.world, *e.shape[1:], dtype=e.dtype, device=e.device)
     dist.all_gather_into_tensor(out, e)                   # concatenated along dim 0 in rank order
-    eps = out.view(2, shard.m, *e.shape[2:])              # [(c, g), m/G, ...] is [2, m, ...] in memory
-    p = pano_eps_local.contiguous()                       # [1, 1, 4, H, W]
+    if len(set(counts)) == 1:
+        eps = out.view(2, shard.m, *e.shape[2:])          # [(c, g), m/G, ...] is [2, m, ...] in memory
+    else:
+        eps = torch.stack([torch.cat([out[c * shard.G + g, :counts[g]] for g in range(shard.G)]) for c in range(2)])
+    if pano_eps_local is None:
+        p = torch.zeros(*pano_shape, dtype=e.dtype, device=e.device)
+    else:
+        p = pano_eps_local.contiguous()                   # [1, 1, 4, H, W]
     pout = torch.empty(shard.world * p.shape[0], *p.shape[1:], dtype=p.dtype, device=p.device)
     dist.all_gather_into_tensor(pout, p)
-    pano_eps = pout[::shard.G].contiguous()               # replicas inside a CFG half are identical
+    pano_eps = pout[(shard.pano_g or 0)::shard.G].contiguous()    # the owner's (replicas are identical otherwise)
     return eps, pano_eps
 
 
@@ -183,7 +274,8 @@ class ShardedDenoiseLoop(DenoiseLoop):
     def __init__(self, model, shard, *a, **k):
         super().__init__(model, *a, **k)
         self.shard = shard
-        self.layout = "cfg2 x viewgroups%d" % shard.G
+        self.layout = "cfg2 x viewgroups%d %s" % (shard.G, "views " + "/".join(map(str, shard.counts)) +
+                                                  (" (group 0 owns the panorama)" if shard.pano_g is not None else ""))
         model.shard = shard
 
     def _local(self, cams):
@@ -193,8 +285,11 @@ class ShardedDenoiseLoop(DenoiseLoop):
         return self.model(self.lat[:, v0:v1].contiguous(), self.pano, self.tstep[:1, v0:v1],
                           self.prompt[c:c + 1, v0:v1], self.pano_prompt[c:c + 1], cams)
 
+    def _gather(self, out):
+        return gather_eps(out[0], out[1], self.shard, pano_shape=(1,) + tuple(self.pano.shape[1:]))
+
     def _denoise(self, cams):
-        return gather_eps(*self._local(cams), self.shard)
+        return self._gather(self._local(cams))
 
     def _denoise_graphed(self, cams):
         """This rank's share of the denoiser as hipGraph segments between the EPA collectives (one
@@ -217,7 +312,7 @@ class ShardedDenoiseLoop(DenoiseLoop):
             g = (seg, out)
             self.graphs[key] = g
         g[0].replay()
-        return gather_eps(*g[1], self.shard)
+        return self._gather(g[1])
 
 
 def build_sharded(build_model, build_inputs, dev, dtype, cfg, m, lat_hw, pano_hw, cams_deg, steps, use_graphs):

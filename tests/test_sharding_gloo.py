@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_loop(sharded, steps=2):
+def _run_loop(sharded, steps=2, split=None):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import fake_ops
@@ -37,18 +37,18 @@ def _run_loop(sharded, steps=2):
     cam1 = {k: v[None] for k, v in cam4().items()}
     args = (t("latents")[:1], t("pano_latent")[:1], t("prompt_embd"), t("pano_prompt_embd"), cam1)
     if sharded:
-        loop = sharding.ShardedDenoiseLoop(model, sharding.make_shard(4), *args, steps=steps)
+        loop = sharding.ShardedDenoiseLoop(model, sharding.make_shard(4, split=split), *args, steps=steps)
     else:
         loop = DenoiseLoop(model, *args, steps=steps)
     return loop.run()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, split=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        lat, pano = _run_loop(True)
+        lat, pano = _run_loop(True, split=split)
         torch.save((lat, pano), os.path.join(out, "r%d.pt" % rank))
     finally:
         dist.destroy_process_group()
@@ -59,19 +59,28 @@ def test_plan_layout():
     for world, want in ((2, [(0, 0, 1), (1, 0, 1)]), (4, [(0, 0, 2), (0, 1, 2), (1, 0, 2), (1, 1, 2)])):
         got = [(s.cfg, s.g, s.G) for s in (sharding.plan(world, r, 20) for r in range(world))]
         assert got == want
-    s = sharding.plan(8, 6, 20)
+    s = sharding.plan(8, 6, 20, layout="even")
     assert (s.cfg, s.g, s.G, s.views) == (1, 2, 4, (10, 15))
     with pytest.raises(ValueError):
         sharding.plan(3, 0, 20)
     with pytest.raises(ValueError):
-        sharding.plan(16, 0, 20)          # 20 views do not split into 8 groups
+        sharding.plan(16, 0, 20, layout="even")          # 20 views do not split into 8 groups
+    # panorama-rank layout: group 0 of a CFG half owns the panorama branch and fewer views
+    assert sharding.pano_rank_split(20, 4) == (2, 6, 6, 6)
+    s = sharding.plan(8, 5, 20)                           # "auto" picks it from G >= 4
+    assert (s.cfg, s.g, s.counts, s.views, s.has_pano, s.pano_src, s.vmax) == (1, 1, (2, 6, 6, 6), (2, 8), False, 4, 6)
+    s = sharding.plan(8, 4, 20)
+    assert s.has_pano and s.views == (0, 2)
+    assert sharding.plan(4, 1, 20).pano_g is None and sharding.plan(8, 1, 20, layout="even").views == (5, 10)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_loop_equals_single_process(world):
+@pytest.mark.parametrize("world,split", [(2, None), (4, None), (6, (2, 1, 1))])
+def test_sharded_loop_equals_single_process(world, split):
+    """(6, (2, 1, 1)): the panorama-rank layout -- rank 0 / 3 own the panorama branch and two views, the other
+    ranks run the view branch only and receive the panorama tokens by broadcast (unequal, padded gathers)."""
     want = _run_loop(False)
     with tempfile.TemporaryDirectory() as out:
-        mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), out, split), nprocs=world, join=True)
         res = [torch.load(os.path.join(out, "r%d.pt" % r)) for r in range(world)]
     for lat, pano in res:                       # every rank holds the full, identical latents
         rel = lambda a, b: float((a - b).norm() / b.norm())       # fp32 round-off of differently batched convs
