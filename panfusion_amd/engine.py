@@ -467,7 +467,7 @@ def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None):
     return out_p.view(mloc, ph, pw, Cc), out_e
 
 
-def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None):
+def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None, side=None):
     """EPA fusion (modules.py:15-59) on NHWC activations.
     xp [b*m, ph, pw, C], xe [b, eh, ew, C]; tables: list with one EPATables entry per batch
     element (or a single shared entry)."""
@@ -515,7 +515,16 @@ def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None):
         return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y)
 
     # panorama pixels query the views (modules.py:43-48), then views query the panorama with the
-    # ORIGINAL view activations (modules.py:50-55)
-    out_e = tail(attend(qk_e, qk_p[:, Cc:], vt_p, E, mP, "e"), te)
-    out_p = tail(attend(qk_p, qk_e[:, Cc:], vt_e, mP, E, "p"), tp)
+    # ORIGINAL view activations (modules.py:50-55): the two directions are independent -- with a side stream
+    # the (small, latency-bound) panorama side runs next to the view side
+    if side is not None:
+        main = torch.cuda.current_stream(xp.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out_e = tail(attend(qk_e, qk_p[:, Cc:], vt_p, E, mP, "e"), te)
+        out_p = tail(attend(qk_p, qk_e[:, Cc:], vt_e, mP, E, "p"), tp)
+        main.wait_stream(side)
+    else:
+        out_e = tail(attend(qk_e, qk_p[:, Cc:], vt_p, E, mP, "e"), te)
+        out_p = tail(attend(qk_p, qk_e[:, Cc:], vt_e, mP, E, "p"), tp)
     return out_p.view(bm, ph, pw, Cc), out_e.view(b, eh, ew, Cc)

@@ -150,7 +150,8 @@ class MultiViewBaseModel(nn.Module):
                 return
             join()
             keep.append(pano.h)
-            pers.h, pano.h = block.forward_nhwc(pers.h, pano.h, groups, m_total, shard=shard)
+            epa_side = side if os.environ.get("PF_EPA_STREAMS", "2") != "1" else None
+            pers.h, pano.h = block.forward_nhwc(pers.h, pano.h, groups, m_total, shard=shard, side=epa_side)
             keep.append(pano.h)
             fork()
 
