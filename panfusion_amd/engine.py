@@ -285,24 +285,37 @@ def run_resnet(r, x, skip, temb_all, groups_eps=None):
     return out.view(n, h, w, r.cout)
 
 
-def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual):
-    """q_src [n*nq, C] already layer-normed; kv_tokens [n*nk, Ckv]."""
+def text_kv(a, text):
+    """K and V^T of the text tokens for one cross-attention (attn2): text [n, L, Dt] -> (k [n*L, C], vt [n, C, ld])."""
+    n, L = text.shape[:2]
+    return ops.linear(text.reshape(n * L, -1), a.wk), ops.linear_t(text, a.wv)
+
+
+def all_transformers(u):
+    for blk in [*u.down, u.mid, *u.up]:
+        for t in (blk.attns or []):
+            yield t
+
+
+def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv=None):
+    """q_src [n*nq, C] already layer-normed; kv_tokens [n*nk, Ckv] (or kv = precomputed (k, vt))."""
     Cq = a.dim
     if self_attn:
         qk = ops.linear(q_src, a.wqk)                         # [rows, 2C]  (q | k)
         q, k, ld = qk, qk[:, Cq:], 2 * Cq
     else:
         q, ld = ops.linear(q_src, a.wq), Cq
-        k = ops.linear(kv_tokens, a.wk)
-    vt = ops.linear_t(kv_tokens.view(n, nk, -1), a.wv)        # [n, C, ld_v] keys contiguous
+        k = kv[0] if kv is not None else ops.linear(kv_tokens, a.wk)
+    vt = kv[1] if kv is not None else ops.linear_t(kv_tokens.view(n, nk, -1), a.wv)   # [n, C, ld_v] keys contiguous
     o = ops.attention(q, k, vt, n, a.heads, head_dim, nq, nk,
                       q_ld=ld, k_ld=(ld if self_attn else Cq), vt_ld=vt.shape[-1],
                       q_bs=nq * ld, k_bs=nk * (ld if self_attn else Cq), vt_bs=vt.shape[1] * vt.shape[2])
     return ops.linear(o.view(n * nq, Cq), a.wo, bias=a.bo, residual=residual)
 
 
-def run_transformer(t, x, text):
-    """diffusers Transformer2DModel (linear projections) on x [n, h, w, C]; text [n, L, Dt]."""
+def run_transformer(t, x, text, kv=None):
+    """diffusers Transformer2DModel (linear projections) on x [n, h, w, C]; text [n, L, Dt]
+    (kv: the text K / V^T of this block computed ahead of time, text_kv)."""
     n, h, w, Cc = x.shape
     hw = h * w
     sc, sh = ops.groupnorm_scale_shift(x, None, n, hw, t.norm.groups, t.norm.eps, t.norm.g, t.norm.b)
@@ -313,7 +326,7 @@ def run_transformer(t, x, text):
     tok = _attend(t.attn1, ln, ln, n, hw, hw, dh, self_attn=True, residual=tok)
     ln = ops.layernorm(tok, t.ln2.g, t.ln2.b, t.ln2.eps)
     L = text.shape[1]
-    tok = _attend(t.attn2, ln, text.reshape(n * L, -1), n, hw, L, dh, self_attn=False, residual=tok)
+    tok = _attend(t.attn2, ln, text.reshape(n * L, -1), n, hw, L, dh, self_attn=False, residual=tok, kv=kv)
     ln = ops.layernorm(tok, t.ln3.g, t.ln3.b, t.ln3.eps)
     g = ops.linear(ln, t.w_ff1, bias=t.b_ff1, geglu=True)
     tok = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok)
@@ -336,6 +349,14 @@ class Branch:
         # pano: pad 1 / conv / crop 1 (MVGenModel.py:87-91) == circular-width convolution
         self.h = ops.conv_in(latent.float(), u.w_conv_in, u.b_conv_in, u.c0, u.dtype, wrap=self.pad)
         self.skips = [self.h]
+        self.text_kv = {}               # id(transformer pack) -> (k, vt) of the text tokens, if computed ahead
+        self.text_ready = None          # event to wait for before the first use (computed on another stream)
+
+    def precompute_text_kv(self):
+        """All 16 cross-attentions' K / V^T of the (step-constant) text tokens in one go: 32 tiny GEMMs that would
+        otherwise sit between the big layers of the critical path."""
+        for t in all_transformers(self.u):
+            self.text_kv[id(t)] = text_kv(t.attn2, self.text)
 
     def _padded(self, t, p):
         return ops.pad_width(t, p) if (self.pad and t is not None) else t
@@ -349,7 +370,10 @@ class Branch:
             self.h = run_resnet(r, self.h, s, self.temb)
 
     def attention(self, t):
-        self.h = run_transformer(t, self.h, self.text)
+        if self.text_ready is not None:
+            torch.cuda.current_stream(self.h.device).wait_event(self.text_ready)
+            self.text_ready = None
+        self.h = run_transformer(t, self.h, self.text, self.text_kv.get(id(t)))
 
     def push(self):
         self.skips.append(self.h)

@@ -123,6 +123,11 @@ class MultiViewBaseModel(nn.Module):
                 keep.clear()
 
         fork()
+        if side is not None:                        # the view branch's text K / V^T: 32 tiny GEMMs, off the critical path
+            with on_pano():
+                pers.precompute_text_kv()
+                pers.text_ready = torch.cuda.Event()
+                pers.text_ready.record(side)
         pano = None
         if not view_only:
             with on_pano():
