@@ -41,3 +41,63 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.ConvDesc) == 8 + 8 + 4 * 4 + 5 * 4 + 4 * 4 + 4 + 8 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 4 * 3 + 4 + 4 * 8 \
         or C.sizeof(_lib.ConvDesc) % 8 == 0
     assert C.sizeof(_lib.AttnDesc) % 8 == 0
+
+
+def _conv_desc(**kw):
+    """A structurally valid 1x1 problem on fake (never dereferenced) device addresses; kw overrides fields."""
+    d = _lib.ConvDesc()
+    d.a0, d.w, d.out = 0x10000, 0x20000, 0x30000
+    d.c0, d.a0_ld = 64, 64
+    d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = 1, 1, 128, 1, 128
+    d.ksize, d.stride, d.pad, d.upsample = 1, 1, 0, 0
+    d.n_out, d.out_ld = 64, 64
+    d.out_dtype = d.dtype = _lib.PF_BF16
+    d.batch = 1
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_conv_gemm_rejects_bad_arguments_before_any_launch():
+    """Every rule of include/panfusion_hip.h's pf_conv_desc is checked on the host, before a launch (so this runs
+    without a GPU): status PF_ERR_ARG and a message naming the problem."""
+    lib = _lib.lib()
+    bad = [
+        (dict(c0=48), b"multiples of 64"),
+        (dict(ksize=5), b"ksize"),
+        (dict(stride=3), b"stride"),
+        (dict(dtype=_lib.PF_F32), b"dtype"),
+        (dict(out_dtype=_lib.PF_F16), b"out_dtype"),
+        (dict(a0=0x10008), b"16-byte aligned"),
+        (dict(out_ld=60), b"out_ld"),
+        (dict(n_out=62, bias=0x50000), b"n_out"),
+        (dict(h_out=2), b"output size"),
+        (dict(batch=0), b"batch"),
+        (dict(epilogue=7), b"epilogue"),
+        (dict(epilogue=1, residual=0x40000, res_ld=64), b"GEGLU"),
+        (dict(n_img=1, w_in=1 << 26, w_out=1 << 26, a0_ld=64), b"2 GiB"),
+    ]
+    for kw, needle in bad:
+        assert lib.pf_conv_gemm(C.byref(_conv_desc(**kw)), None) == 1, kw
+        assert needle in lib.pf_last_error_string(), (kw, lib.pf_last_error_string())
+    # the split-K scratch query is pure host arithmetic: long K + few tiles wants scratch, a big grid does not
+    assert lib.pf_conv_gemm_workspace_size(C.byref(_conv_desc(c0=5120, a0_ld=5120, w_in=256, w_out=256, n_out=1280, out_ld=1280))) > 0
+    assert lib.pf_conv_gemm_workspace_size(C.byref(_conv_desc(w_in=163840, w_out=163840, n_out=320, out_ld=320))) == 0
+
+
+def test_attention_and_norm_reject_bad_arguments():
+    lib = _lib.lib()
+    a = _lib.AttnDesc()
+    a.q, a.k, a.vt, a.out = 0x10000, 0x20000, 0x30000, 0x40000
+    a.dtype, a.B, a.H, a.D, a.nq, a.nk = _lib.PF_F16, 1, 1, 48, 64, 64
+    a.q_ld = a.k_ld = a.o_ld = 64
+    a.vt_ld = 64
+    assert lib.pf_attention(C.byref(a), None) == 1 and b"head dim" in lib.pf_last_error_string()
+    a.D, a.vt_ld = 64, 32
+    assert lib.pf_attention(C.byref(a), None) == 1 and b"vt_ld" in lib.pf_last_error_string()
+    a.vt_ld, a.bias = 64, 0x50000                                  # bias without flags
+    assert lib.pf_attention(C.byref(a), None) == 1 and b"bias and flags" in lib.pf_last_error_string()
+    assert lib.pf_layernorm(0x10000, None, 0, _lib.PF_F16, 4, 4100, 0x20000, 0x30000, 1e-5, 0x40000, None) == 1
+    assert lib.pf_groupnorm_stats(0x10000, 60, None, 0, _lib.PF_F16, 1, 16, 32, 1e-5, 0x20000, 0x30000, 0x40000, 0x50000,
+                                  0x60000, 1 << 20, None) == 1
+    assert lib.pf_geglu(0x10000, _lib.PF_F16, 4, 12, 0x20000, None) == 1
