@@ -130,85 +130,113 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ p
 }
 
 template <typename T>
-__global__ void k_scale_shift_act(const unsigned short* __restrict__ x0, int c0,
-                                  const unsigned short* __restrict__ x1, int c1, int hw, long total_oct,
+__global__ __launch_bounds__(256) void k_scale_shift_act(const unsigned short* __restrict__ x0, int c0,
+                                  const unsigned short* __restrict__ x1, int c1, int hw,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   int act, unsigned short* __restrict__ y) {
-    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
-    if (i >= total_oct) return;
-    const int C = c0 + c1, OCT = C / 8;
-    const int oct = i % OCT;
-    const long pix = i / OCT;           // img*hw + p
-    const int img = pix / hw;
-    const int c = oct * 8;
-    const unsigned short* src = (c < c0) ? x0 + pix * c0 + c : x1 + pix * c1 + (c - c0);
-    u16x8 v = *reinterpret_cast<const u16x8*>(src);
-    const float4* sc = reinterpret_cast<const float4*>(scale + static_cast<long>(img) * C + c);
-    const float4* sh = reinterpret_cast<const float4*>(shift + static_cast<long>(img) * C + c);
-    float4 s0 = sc[0], s1 = sc[1], h0 = sh[0], h1 = sh[1];
-    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    float f[8];
+    // grid (octet pairs of one image, image): 32-bit index arithmetic only, two 16-byte loads in flight per thread
+    const unsigned C = c0 + c1, OCT = C / 8, per_img = static_cast<unsigned>(hw) * OCT;
+    const unsigned img = blockIdx.y;
+    const unsigned j0 = (blockIdx.x * 256u + threadIdx.x) * 2u;
+    if (j0 >= per_img) return;
+    u16x8 v[2];
+    unsigned cc[2];
+    long pix[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float r = to_f32<T>(v[j]) * sv[j] + hv[j];
-        f[j] = act ? r / (1.0f + expf(-r)) : r;
+    for (int u = 0; u < 2; ++u) {
+        const unsigned j = min(j0 + u, per_img - 1);
+        const unsigned p = j / OCT, c = (j - p * OCT) * 8;
+        cc[u] = c;
+        pix[u] = static_cast<long>(img) * hw + p;
+        const unsigned short* src = (c < static_cast<unsigned>(c0)) ? x0 + pix[u] * c0 + c : x1 + pix[u] * c1 + (c - c0);
+        v[u] = *reinterpret_cast<const u16x8*>(src);
     }
-    *reinterpret_cast<u16x8*>(y + pix * C + c) = pack8<T>(f);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (j0 + u >= per_img) break;
+        const float4* sc = reinterpret_cast<const float4*>(scale + static_cast<long>(img) * C + cc[u]);
+        const float4* sh = reinterpret_cast<const float4*>(shift + static_cast<long>(img) * C + cc[u]);
+        float4 s0 = sc[0], s1 = sc[1], h0 = sh[0], h1 = sh[1];
+        const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float r = to_f32<T>(v[u][j]) * sv[j] + hv[j];
+            f[j] = act ? r / (1.0f + expf(-r)) : r;
+        }
+        *reinterpret_cast<u16x8*>(y + pix[u] * C + cc[u]) = pack8<T>(f);
+    }
 }
 
 // ---- LayerNorm (+ PE) ------------------------------------------------------------------------
-// One wavefront per row; the row lives in registers (<= 4 octets per lane, C <= 2048).
-template <typename T>
-__global__ void k_layernorm(const unsigned short* __restrict__ x, const float* __restrict__ pe,
+// One wavefront normalises ROWS rows at a time; all their 16-byte loads are issued before the first
+// reduction (a 640-byte row per wave in flight is too little to cover HBM latency: 2.9 TB/s measured with
+// one row per wave).  A row lives in registers (<= 4 octets per lane, C <= 2048).
+template <typename T, int ROWS>
+__global__ __launch_bounds__(256) void k_layernorm(const unsigned short* __restrict__ x, const float* __restrict__ pe,
                             long pe_rows, long rows, int C, const float* __restrict__ gamma,
                             const float* __restrict__ beta, float eps, unsigned short* __restrict__ y) {
     const int lane = threadIdx.x & 63;
-    const long row = blockIdx.x * static_cast<long>(blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long row0 = (blockIdx.x * static_cast<long>(blockDim.x >> 6) + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= rows) return;
     const int OCT = C / 8;
-    float v[4][8];
-    float s = 0.f;
+    constexpr int KMAX = ROWS == 1 ? 4 : 1;            // octets per lane per row (the multi-row form: C <= 512)
+    u16x8 raw[ROWS][KMAX];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int oct = lane + 64 * k;
-        if (oct < OCT) {
-            u16x8 r = *reinterpret_cast<const u16x8*>(x + row * C + oct * 8);
-            unpack8<T>(r, v[k]);
-            if (pe) {
-                const float4* pp = reinterpret_cast<const float4*>(pe + (row % pe_rows) * C + oct * 8);
-                float4 a = pp[0], b = pp[1];
-                v[k][0] += a.x; v[k][1] += a.y; v[k][2] += a.z; v[k][3] += a.w;
-                v[k][4] += b.x; v[k][5] += b.y; v[k][6] += b.z; v[k][7] += b.w;
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int oct = lane + 64 * k;
+            raw[r][k] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (oct < OCT && row0 + r < rows) raw[r][k] = *reinterpret_cast<const u16x8*>(x + (row0 + r) * C + oct * 8);
+        }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const long row = row0 + r;
+        if (row >= rows) break;
+        float v[KMAX][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int oct = lane + 64 * k;
+            if (oct < OCT) {
+                unpack8<T>(raw[r][k], v[k]);
+                if (pe) {
+                    const float4* pp = reinterpret_cast<const float4*>(pe + (row % pe_rows) * C + oct * 8);
+                    float4 a = pp[0], b = pp[1];
+                    v[k][0] += a.x; v[k][1] += a.y; v[k][2] += a.z; v[k][3] += a.w;
+                    v[k][4] += b.x; v[k][5] += b.y; v[k][6] += b.z; v[k][7] += b.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[k][j];
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[k][j];
         }
-    }
-    const float mean = wave_sum(s) / static_cast<float>(C);
-    float q = 0.f;
+        const float mean = wave_sum(s) / static_cast<float>(C);
+        float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int oct = lane + 64 * k;
-        if (oct < OCT) {
+        for (int k = 0; k < KMAX; ++k) {
+            const int oct = lane + 64 * k;
+            if (oct < OCT) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { float d = v[k][j] - mean; q += d * d; }
+                for (int j = 0; j < 8; ++j) { float d = v[k][j] - mean; q += d * d; }
+            }
         }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / static_cast<float>(C) + eps);
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / static_cast<float>(C) + eps);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int oct = lane + 64 * k;
-        if (oct < OCT) {
-            const float4* gp = reinterpret_cast<const float4*>(gamma + oct * 8);
-            const float4* bp = reinterpret_cast<const float4*>(beta + oct * 8);
-            float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
-            const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            float f[8];
+        for (int k = 0; k < KMAX; ++k) {
+            const int oct = lane + 64 * k;
+            if (oct < OCT) {
+                const float4* gp = reinterpret_cast<const float4*>(gamma + oct * 8);
+                const float4* bp = reinterpret_cast<const float4*>(beta + oct * 8);
+                float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
+                const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float f[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = (v[k][j] - mean) * rstd * gv[j] + bv[j];
-            *reinterpret_cast<u16x8*>(y + row * C + oct * 8) = pack8<T>(f);
+                for (int j = 0; j < 8; ++j) f[j] = (v[k][j] - mean) * rstd * gv[j] + bv[j];
+                *reinterpret_cast<u16x8*>(y + row * C + oct * 8) = pack8<T>(f);
+            }
         }
     }
 }
@@ -473,11 +501,12 @@ extern "C" pf_status pf_scale_shift_act(const void* x0, int c0, const void* x1, 
     PF_REQUIRE(C % 8 == 0 && c0 % 8 == 0 && n_img > 0 && hw > 0, "pf_scale_shift_act: bad sizes");
     PF_REQUIRE(aligned16(x0) && aligned16(y) && (!x1 || aligned16(x1)) && aligned16(scale) && aligned16(shift),
                "pf_scale_shift_act: pointers must be 16-byte aligned");
-    const long total = static_cast<long>(n_img) * hw * (C / 8);
+    const long per_img = static_cast<long>(hw) * (C / 8);
+    PF_REQUIRE(per_img < (1L << 31) && n_img <= 65535, "pf_scale_shift_act: image too large / too many images");
     PF_DISPATCH_16(dtype, "pf_scale_shift_act",
-        hipLaunchKernelGGL(k_scale_shift_act<T>, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+        hipLaunchKernelGGL(k_scale_shift_act<T>, dim3(cdiv(per_img, 512), n_img), dim3(256), 0, as_stream(stream),
                            static_cast<const unsigned short*>(x0), c0, static_cast<const unsigned short*>(x1), c1,
-                           hw, total, scale, shift, act, static_cast<unsigned short*>(y)));
+                           hw, scale, shift, act, static_cast<unsigned short*>(y)));
     PF_CHECK_LAUNCH("pf_scale_shift_act");
     return PF_OK;
 }
@@ -491,9 +520,14 @@ extern "C" pf_status pf_layernorm(const void* x, const float* pe, long pe_rows, 
     PF_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!pe || aligned16(pe)),
                "pf_layernorm: pointers must be 16-byte aligned");
     PF_DISPATCH_16(dtype, "pf_layernorm",
-        hipLaunchKernelGGL(k_layernorm<T>, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream),
-                           static_cast<const unsigned short*>(x), pe, pe_rows, rows, C, gamma, beta, eps,
-                           static_cast<unsigned short*>(y)));
+        if (C <= 512 && rows >= 4096)      // narrow rows: 4 rows per wavefront in flight
+            hipLaunchKernelGGL((k_layernorm<T, 4>), dim3(cdiv(rows, 16)), dim3(256), 0, as_stream(stream),
+                               static_cast<const unsigned short*>(x), pe, pe_rows, rows, C, gamma, beta, eps,
+                               static_cast<unsigned short*>(y));
+        else
+            hipLaunchKernelGGL((k_layernorm<T, 1>), dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream),
+                               static_cast<const unsigned short*>(x), pe, pe_rows, rows, C, gamma, beta, eps,
+                               static_cast<unsigned short*>(y)));
     PF_CHECK_LAUNCH("pf_layernorm");
     return PF_OK;
 }
