@@ -699,14 +699,6 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmParams p) {
 static unsigned long long* g_prof = nullptr;         // diagnostics buffer (device), see pf_debug_gemm_profile
 static long g_prof_blocks = 0;
 
-static const unsigned short* zero_page() {
-    static unsigned short* z = nullptr;          // 256 zero bytes, created on the first launch (before any capture)
-    if (!z) {
-        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
-        (void)hipMemset(z, 0, 256);
-    }
-    return z;
-}
 
 template <typename T, int MREP, int NREP>
 static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
