@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpanfusion_hip.so")
+LIB_PATH = os.environ.get("PF_HIP_LIB") or os.path.join(_HERE, "libpanfusion_hip.so")   # PF_HIP_LIB: A/B another build
 
 PF_OK = 0
 PF_BF16, PF_F16, PF_F32 = 0, 1, 2

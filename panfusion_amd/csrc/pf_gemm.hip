@@ -42,6 +42,7 @@ struct GemmParams {
     float* partial;                // [split][batch][M][N] fp32 when splits > 1
     int batch;
     unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors of the 8-wave kernel (< 2 GiB)
+    int adv_img, adv_y, adv_x;              // (image, row, column) advance of one DMA pass of output rows (8-wave kernel)
     unsigned long long* prof;      // diagnostics (pf_debug_gemm_profile): 4 s_memtime stamps per block, or NULL
 };
 
@@ -139,90 +140,174 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
 // staged through LDS so that it leaves as whole 16-byte row segments (a fragment store touches 16
 // different rows with 8 bytes each).  fp32 output, ragged N or an unaligned out_ld take the direct
 // per-fragment store.  smem16: the block's LDS (the operand ring is dead after the K loop).
-template <typename T, int MREP, int NREP, int NT, int BM, int BN>
-__device__ __forceinline__ void epilogue_tile(const GemmParams& p, long bz, f32x4 (&acc)[MREP][NREP],
-                                              unsigned short* smem16, int m0, int n0, int row_base, int col_base,
-                                              int lane, int t) {
+struct NoOp { __device__ void operator()() const {} };
+
+// Staged block epilogue, specialised at compile time for the operand mix of the layer (MODE):
+//   0 bias | 1 bias + per-image row vector (time embedding) | 2 bias + residual | 3 bias + GEGLU pairing.
+// Straight-line code: rows beyond M / quads beyond N are CLAMPED to the last valid one instead of being
+// predicated (their results are dropped by the bounds check of the copy-out), the operands of two
+// 16-row fragment groups are requested one group ahead of the arithmetic, and nothing in the loop
+// waits for memory more than once per group.  The finished 16-bit tile goes through LDS in HALVES row
+// slices (every wave stages MREP / HALVES of its fragment rows per slice) and leaves as 16-byte row segments.
+template <typename T, int MREP, int NREP, int NT, int BM, int BN, int HALVES, int MODE>
+__device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x4 (&acc)[MREP][NREP], unsigned short* smem16,
+                                              int m0, int n0, int row_base, int col_base, int lane, int t) {
     constexpr int SLD = BN + 8;                                   // 16-bit elements per staged row
-    const int n_store = p.geglu ? p.N >> 1 : p.N;
-    const bool staged = !p.out_f32 && (p.out_ld & 7) == 0 && (n_store & 7) == 0;
+    constexpr int BMH = BM / HALVES;                              // staged rows per slice
+    constexpr int WR = 16 * MREP, WRH = WR / HALVES, IH = MREP / HALVES;
+    constexpr int G = 2, NG = MREP / G;                           // fragment rows per operand group
+    static_assert(MREP % HALVES == 0 && IH % G == 0, "slices are whole operand groups");
     const int cq = 4 * (lane >> 4), rl = lane & 15;
+    const int n_store = MODE == 3 ? p.N >> 1 : p.N;
+    int ncl[NREP];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) ncl[j] = min(n0 + col_base + j * 16 + cq, p.N - 4);
     float4 bias[NREP];
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) {
-        const int n4 = n0 + col_base + j * 16 + cq;
-        bias[j] = (p.bias && n4 < p.N) ? *reinterpret_cast<const float4*>(p.bias + n4) : float4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NREP; ++j) bias[j] = float4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) bias[j] = *reinterpret_cast<const float4*>(p.bias + ncl[j]);
     }
-    const unsigned short* resp = p.residual ? p.residual + bz * p.res_bs : nullptr;
-    __syncthreads();                                              // every wave is done reading the operand ring
-#pragma unroll
-    for (int i = 0; i < MREP; ++i) {
-        const int r = row_base + i * 16 + rl, m = m0 + r;
-        const bool mok = m < p.M;
-        u16x4 res[NREP];
+    const unsigned short* resp = MODE == 2 ? p.residual + bz * p.res_bs : nullptr;
+    // MODE 1 (requires rows_per_img >= BM: the tile touches two images at most): both candidate row
+    // vectors are fetched up front, a row picks one by comparing its offset with the image boundary
+    float4 rv0[NREP], rv1[NREP];
+    int boundary = 0;                                             // first tile row of the second image
+    if (MODE == 1) {
+        const int img0 = m0 / p.rows_per_img, img_last = (p.M - 1) / p.rows_per_img;
+        boundary = (img0 + 1) * p.rows_per_img - m0;
+        const float* r0 = p.rowvec + static_cast<long>(img0) * p.rowvec_ld;
+        const float* r1 = p.rowvec + static_cast<long>(min(img0 + 1, img_last)) * p.rowvec_ld;
 #pragma unroll
         for (int j = 0; j < NREP; ++j) {
-            const int n4 = n0 + col_base + j * 16 + cq;
-            res[j] = u16x4{0, 0, 0, 0};
-            if (resp && mok && n4 < p.N) res[j] = *reinterpret_cast<const u16x4*>(resp + static_cast<long>(m) * p.res_ld + n4);
+            rv0[j] = *reinterpret_cast<const float4*>(r0 + ncl[j]);
+            rv1[j] = *reinterpret_cast<const float4*>(r1 + ncl[j]);
         }
-        const float* rv = (p.rowvec && mok) ? p.rowvec + static_cast<long>(m / p.rows_per_img) * p.rowvec_ld : nullptr;
+    }
+    u16x4 res[2][G][NREP];                                        // residual, requested one group ahead (MODE 2)
+    auto request = [&](auto g_tag, auto buf_tag) {
+        constexpr int g = decltype(g_tag)::value, bf = decltype(buf_tag)::value;
+        if (MODE != 2) return;
 #pragma unroll
-        for (int j = 0; j < NREP; ++j) {
-            const int c = col_base + j * 16 + cq, n4 = n0 + c;
-            float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z, acc[i][j][3] + bias[j].w};
-            if (rv && n4 < p.N) {
-                const float4 b = *reinterpret_cast<const float4*>(rv + n4);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
+        for (int ii = 0; ii < G; ++ii) {
+            const int mc = min(m0 + row_base + (g * G + ii) * 16 + rl, p.M - 1);
+            const unsigned short* rp = resp + static_cast<long>(mc) * p.res_ld;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(res[j][e]);
-            if (!staged) {
-                if (mok && n4 < p.N) {
-                    if (p.geglu || !p.out_f32) {
-                        // bias / rowvec / residual are already in v: store through the plain path
-                        GemmParams q = p; q.bias = nullptr; q.rowvec = nullptr; q.residual = nullptr;
-                        epilogue_store<T>(q, bz, m, n4, v);
-                    } else {
-                        float* o = static_cast<float*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
-                        *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
+            for (int j = 0; j < NREP; ++j) res[bf][ii][j] = *reinterpret_cast<const u16x4*>(rp + ncl[j]);
+        }
+    };
+    auto arithmetic = [&](auto g_tag, auto buf_tag) {
+        constexpr int g = decltype(g_tag)::value, bf = decltype(buf_tag)::value;
+#pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            constexpr int i0 = g * G;
+            const int i = i0 + ii, h = i0 / IH;
+            const int r = row_base / HALVES + (i - h * IH) * 16 + rl;         // staged row <-> tile row row_base + i*16 + rl
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) {
+                const int c = col_base + j * 16 + cq;
+                float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z, acc[i][j][3] + bias[j].w};
+                if (MODE == 1) {
+                    const bool second = row_base + i * 16 + rl >= boundary;
+                    v[0] += second ? rv1[j].x : rv0[j].x; v[1] += second ? rv1[j].y : rv0[j].y;
+                    v[2] += second ? rv1[j].z : rv0[j].z; v[3] += second ? rv1[j].w : rv0[j].w;
+                }
+                if (MODE == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(res[bf][ii][j][e]);
+                }
+                if (MODE == 3) {
+                    typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+                    u16x2 w2;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float gt = v[2 * e + 1];
+                        w2[e] = from_f32<T>(v[2 * e] * (0.5f * gt * (1.0f + erf_as(gt * 0.70710678118654752440f))));
                     }
-                }
-            } else if (p.geglu) {
-                typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
-                u16x2 w2;
+                    *reinterpret_cast<u16x2*>(smem16 + r * SLD + (c >> 1)) = w2;
+                } else {
+                    u16x4 w4;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float g = v[2 * e + 1];
-                    w2[e] = from_f32<T>(v[2 * e] * (0.5f * g * (1.0f + erf_as(g * 0.70710678118654752440f))));
+                    for (int e = 0; e < 4; ++e) w4[e] = from_f32<T>(v[e]);
+                    *reinterpret_cast<u16x4*>(smem16 + r * SLD + c) = w4;
                 }
-                *reinterpret_cast<u16x2*>(smem16 + r * SLD + (c >> 1)) = w2;
-            } else {
-                u16x4 w4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w4[e] = from_f32<T>(v[e]);
-                *reinterpret_cast<u16x4*>(smem16 + r * SLD + c) = w4;
             }
         }
-    }
-    if (!staged) return;
-    __syncthreads();
+    };
     unsigned short* outp = static_cast<unsigned short*>(p.out) + bz * p.out_bs;
-    auto copy_out = [&](auto cpr_tag) {
-        constexpr int CPR = decltype(cpr_tag)::value;             // 16-byte chunks per tile row
-        const int nbase = p.geglu ? n0 >> 1 : n0;
+    auto copy_out = [&](int h) {
+        constexpr int CPR = MODE == 3 ? BN / 16 : BN / 8;         // 16-byte chunks per tile row
+        const int nbase = MODE == 3 ? n0 >> 1 : n0;
 #pragma unroll
-        for (int k = 0; k < (BM * CPR + NT - 1) / NT; ++k) {
+        for (int k = 0; k < (BMH * CPR + NT - 1) / NT; ++k) {
             const int q = t + k * NT, r = q / CPR, c8 = (q - r * CPR) * 8;
-            const int m = m0 + r;
-            if (q < BM * CPR && m < p.M && nbase + c8 < n_store) {
+            const int m = m0 + (r / WRH) * WR + h * WRH + r % WRH;
+            if (q < BMH * CPR && m < p.M && nbase + c8 < n_store) {
                 const u16x8 x = *reinterpret_cast<const u16x8*>(smem16 + r * SLD + c8);
                 *reinterpret_cast<u16x8*>(outp + static_cast<long>(m) * p.out_ld + nbase + c8) = x;
             }
         }
     };
-    if (p.geglu) copy_out(std::integral_constant<int, BN / 16>());
-    else copy_out(std::integral_constant<int, BN / 8>());
+    auto group = [&](auto g_tag) {
+        constexpr int g = decltype(g_tag)::value;
+        if constexpr (g + 1 < NG) request(std::integral_constant<int, g + 1>(), std::integral_constant<int, (g + 1) & 1>());
+        arithmetic(g_tag, std::integral_constant<int, g & 1>());
+        if constexpr (((g + 1) * G) % IH == 0) {                  // slice complete
+            constexpr int h = (g * G) / IH;
+            stamp(p, 6 + 3 * h);
+            __syncthreads();
+            stamp(p, 7 + 3 * h);
+            copy_out(h);
+            stamp(p, 8 + 3 * h);
+            if constexpr (h + 1 < HALVES) __syncthreads();        // slice read out before the next one is staged
+        }
+    };
+    request(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+    group(std::integral_constant<int, 0>());
+    if constexpr (NG > 1) group(std::integral_constant<int, 1>());
+    if constexpr (NG > 2) group(std::integral_constant<int, 2>());
+    if constexpr (NG > 3) group(std::integral_constant<int, 3>());
+    static_assert(NG <= 4, "unrolled by hand");
+}
+
+// Block epilogue.  All arithmetic (bias, per-image row vector, residual, GEGLU) runs in the MFMA
+// fragment layout on the fp32 accumulators -- one rounding to 16 bit.  16-bit outputs with 16-byte
+// aligned rows take one of the staged specialisations above; everything else (fp32 output, ragged or
+// unaligned rows, row vector AND residual together) takes the per-fragment store.  smem16: the LDS
+// region the staged tile may use.  HALVES > 1: staged in row slices through a smaller region;
+// after_ring() runs right after the barrier that retires the operand ring -- the persistent kernel
+// requests the next tile's first stages there, into ring slots the staging region does not overlap.
+template <typename T, int MREP, int NREP, int NT, int BM, int BN, int HALVES = 1, typename F = NoOp>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, long bz, f32x4 (&acc)[MREP][NREP],
+                                              unsigned short* smem16, int m0, int n0, int row_base, int col_base,
+                                              int lane, int t, F after_ring = F()) {
+    __syncthreads();                                              // every wave is done reading the operand ring
+    stamp(p, 4);
+    after_ring();
+    stamp(p, 5);
+    const int n_store = p.geglu ? p.N >> 1 : p.N;
+    const bool staged = !p.out_f32 && (p.out_ld & 7) == 0 && (n_store & 7) == 0 && (p.N & 3) == 0;
+    if (staged && !(p.rowvec && p.residual) && !(p.geglu && (p.rowvec || p.residual))) {
+        if (p.geglu) epilogue_fast<T, MREP, NREP, NT, BM, BN, HALVES, 3>(p, bz, acc, smem16, m0, n0, row_base, col_base, lane, t);
+        else if (p.rowvec && p.rows_per_img < BM) goto generic;
+        else if (p.rowvec) epilogue_fast<T, MREP, NREP, NT, BM, BN, HALVES, 1>(p, bz, acc, smem16, m0, n0, row_base, col_base, lane, t);
+        else if (p.residual) epilogue_fast<T, MREP, NREP, NT, BM, BN, HALVES, 2>(p, bz, acc, smem16, m0, n0, row_base, col_base, lane, t);
+        else epilogue_fast<T, MREP, NREP, NT, BM, BN, HALVES, 0>(p, bz, acc, smem16, m0, n0, row_base, col_base, lane, t);
+        return;
+    }
+generic:
+    const int cq = 4 * (lane >> 4), rl = lane & 15;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + row_base + i * 16 + rl;
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const int n4 = n0 + col_base + j * 16 + cq;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (m < p.M && n4 < p.N) epilogue_store<T>(p, bz, m, n4, v);
+        }
+    }
 }
 
 template <typename T, int MREP, int NREP>
@@ -423,18 +508,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
 
     const int ntile_total = p.mtiles * p.ntiles;
-    int tid_lin = blockIdx.x;
-    {
-        const int q = ntile_total / 8, r = ntile_total % 8;
-        const int xcd = tid_lin % 8, idx = tid_lin / 8;
-        tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_n = tid_lin % p.ntiles, tile_m = tid_lin / p.ntiles;
-    const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
     const long bz = blockIdx.z;
     const unsigned short* a0 = p.a0 + bz * p.a_bs;
     const unsigned short* a1 = p.a1 ? p.a1 + bz * p.a_bs : nullptr;
     const unsigned short* wg = p.w + bz * p.w_bs;
+    int m0 = 0, n0 = 0;                              // origin of the tile being multiplied (set_tile)
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -446,19 +524,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
 
     constexpr int APASS = BM / RPP;                  // DMA passes of the activation tile
     int a_img[APASS], a_y[APASS], a_x[APASS];
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-        const int m = m0 + i * RPP + lrow;
-        if (m < p.M) {
-            const int img = m / p.rows_per_img, rem = m - img * p.rows_per_img;
-            const int yo = rem / p.w_out;
-            a_img[i] = img;
-            a_y[i] = yo * p.stride - p.pad;
-            a_x[i] = (rem - yo * p.w_out) * p.stride - p.pad;
-        } else {
-            a_img[i] = 0; a_y[i] = -(1 << 20); a_x[i] = 0;
-        }
-    }
     // DMA addressing: buffer descriptors (SGPR) + a per-thread 32-bit byte offset (VGPR) + a per-stage
     // scalar byte offset (soffset), so that a piece costs no vector ALU work per K step -- the kernel is
     // bound by instruction issue, not by the matrix pipe (4 issue slots of a SIMD per 16-clock MFMA,
@@ -476,15 +541,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // (the activation descriptor is rebuilt from scalars at the start of every stage: carried across
     // the loop as a variable it would live in VGPRs again)
     unsigned w_off[BFULL + 1];                                    // bytes
-#pragma unroll
-    for (int j = 0; j < BFULL; ++j) {
-        const int n = n0 + j * RPP + lrow;
-        w_off[j] = n < p.N ? static_cast<unsigned>(n * p.K + lchunk8) * 2u : OOB;
-    }
-    {
-        const int n = n0 + BFULL * RPP + hrow;
-        w_off[BFULL] = (BHALF && n < p.N) ? static_cast<unsigned>(n * p.K + hchunk8) * 2u : OOB;
-    }
     const int Ctot = p.c0 + p.c1;
     const int Hl = p.h_in << p.up, Wl = p.w_in << p.up;
 
@@ -494,8 +550,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     const int kb0 = blockIdx.y * p.kb_per_split;
     const int kb1 = min(nkb, kb0 + p.kb_per_split);
     const int n_it = kb1 - kb0;
-    int kg = kb0 * 64;
-    int tap = kg / Ctot, cc = kg - tap * Ctot;
+    int kg = 0, tap = 0, cc = 0;
     unsigned a_off[APASS];                                        // bytes, or OOB
     bool seg1 = false;                                            // current source is a1
     auto set_segment = [&]() {
@@ -510,7 +565,53 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             a_off[i] = ok ? static_cast<unsigned>(pix * ld + lchunk8) * 2u : OOB;
         }
     };
-    set_segment();
+    // Persistent over tiles: a block walks tiles blockIdx.x, + gridDim.x, ...; all per-tile state is set here.
+    // (XCD-aware, bijective remap of the tile id: block b and all its tiles live on XCD b % 8.)
+    auto set_tile = [&](int tile) {
+        int tid_lin = tile;
+        {
+            const int q = ntile_total >> 3, r = ntile_total & 7;
+            const int xcd = tid_lin & 7, idx = tid_lin >> 3;
+            tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        const int tile_m = static_cast<unsigned>(tid_lin) / static_cast<unsigned>(p.ntiles), tile_n = tid_lin - tile_m * p.ntiles;
+        m0 = p.m_begin + tile_m * BM;
+        n0 = tile_n * BN;
+        {
+            // output row -> (image, y, x): two divisions for the first DMA pass, then the host-computed
+            // advance of RPP rows with one carry per level (this runs once per tile on every thread)
+            const unsigned m = static_cast<unsigned>(m0 + lrow);
+            int img = static_cast<int>(m / static_cast<unsigned>(p.rows_per_img));
+            const unsigned rem = m - static_cast<unsigned>(img) * static_cast<unsigned>(p.rows_per_img);
+            int yo = static_cast<int>(rem / static_cast<unsigned>(p.w_out));
+            int xo = static_cast<int>(rem) - yo * p.w_out;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const bool ok = m0 + i * RPP + lrow < p.M;
+                a_img[i] = ok ? img : 0;
+                a_y[i] = ok ? yo * p.stride - p.pad : -(1 << 20);
+                a_x[i] = xo * p.stride - p.pad;
+                xo += p.adv_x;
+                if (xo >= p.w_out) { xo -= p.w_out; ++yo; }
+                yo += p.adv_y;
+                if (yo >= p.h_out) { yo -= p.h_out; ++img; }
+                img += p.adv_img;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BFULL; ++j) {
+            const int n = n0 + j * RPP + lrow;
+            w_off[j] = n < p.N ? static_cast<unsigned>(n * p.K + lchunk8) * 2u : OOB;
+        }
+        {
+            const int n = n0 + BFULL * RPP + hrow;
+            w_off[BFULL] = (BHALF && n < p.N) ? static_cast<unsigned>(n * p.K + hchunk8) * 2u : OOB;
+        }
+        kg = kb0 * 64;
+        tap = kg / Ctot;
+        cc = kg - tap * Ctot;
+        set_segment();
+    };
 
     // One stage = NPIECE DMA instructions per wave: pieces 0..3 the activation passes, then the weight
     // passes, issued one at a time between MFMAs (a burst of 8 waves x 7 KB stalls every wave at issue
@@ -553,10 +654,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     };
 
     f32x4 acc[MREP][NREP];
-#pragma unroll
-    for (int i = 0; i < MREP; ++i)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     typedef typename Mfma<T>::frag frag;
     const int frow = lane & 15, fchunk = lane >> 4;
@@ -578,22 +675,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             fb[j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Bs + lds_off(wn * 16 * NREP + j * 16 + frow, slab * 4 + fchunk)));
     };
 
-    stamp(p, 0);
-    dma_stage(0);
-    if (n_it > 1) {
-        dma_stage(1);
-        if constexpr (NPIECE == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else if constexpr (NPIECE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if constexpr (NPIECE == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-        else if constexpr (NPIECE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    stamp(p, 1);
-    load_frags(0, 0, fa0, fb0);
+    auto issue_prologue = [&]() {
+        dma_stage(0);
+        if (n_it > 1) dma_stage(1);
+    };
+    const std::true_type YES;
+    const std::false_type NO;
     int cur = 0, nx1 = 1, nx2 = 2;
     // One K step.  MORE: a next stage exists (wait for it, barrier, prefetch its first fragments);
     // DMA: a stage two ahead exists (issue its pieces between the MFMAs of the second half).  The flags
@@ -646,31 +733,72 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         nx1 = nx1 == STAGES - 1 ? 0 : nx1 + 1;
         nx2 = nx2 == STAGES - 1 ? 0 : nx2 + 1;
     };
-    const std::true_type YES;
-    const std::false_type NO;
-    for (int it = 0; it + 2 < n_it; ++it) step(YES, YES);
-    if (n_it >= 2) step(YES, NO);
-    step(NO, NO);
-    if constexpr (NW == 4) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // inline-asm MFMA results -> vector ALU reads
-    stamp(p, 2);
 
-    if (p.splits > 1) {          // fp32 slab straight from the fragments (64-byte row segments)
+    stamp(p, 0);
+    int tile = blockIdx.x;
+    set_tile(tile);
+    issue_prologue();
+    bool first = true;
+    for (;;) {
 #pragma unroll
-        for (int i = 0; i < MREP; ++i) {
-            const int m = m0 + wm * 16 * MREP + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
+        for (int i = 0; i < MREP; ++i)
 #pragma unroll
-            for (int j = 0; j < NREP; ++j) {
-                const int n4 = n0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
-                if (n4 >= p.N) continue;
-                float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * (p.M - p.m_begin) + (m - p.m_begin)) * p.N + n4;
-                *reinterpret_cast<float4*>(o) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            }
+            for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (first && n_it > 1) {                          // stage 0 landed, stage 1 may still fly
+            if constexpr (NPIECE == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if constexpr (NPIECE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (NPIECE == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            else if constexpr (NPIECE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {                                          // later tiles: the epilogue's stores sit behind the DMAs in vmcnt
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        return;
-    }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (first) stamp(p, 1);
+        first = false;
+        load_frags(0, 0, fa0, fb0);
+        cur = 0; nx1 = 1; nx2 = 2;
+        for (int it = 0; it + 2 < n_it; ++it) step(YES, YES);
+        if (n_it >= 2) step(YES, NO);
+        step(NO, NO);
+        if constexpr (NW == 4) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // inline-asm MFMA results -> vector ALU reads
+        stamp(p, 2);
 
-    epilogue_tile<T, MREP, NREP, NT, BM, BN>(p, bz, acc, smem, m0, n0, wm * 16 * MREP, wn * 16 * NREP, lane, t);
+        const int em0 = m0, en0 = n0;
+        const int next = tile + static_cast<int>(gridDim.x);
+        const bool has_next = next < ntile_total;
+        if (p.splits > 1) {          // fp32 slab straight from the fragments (64-byte row segments)
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) {
+                const int m = em0 + wm * 16 * MREP + i * 16 + (lane & 15);
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) {
+                    const int n4 = en0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
+                    if (n4 >= p.N) continue;
+                    float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * (p.M - p.m_begin) + (m - p.m_begin)) * p.N + n4;
+                    *reinterpret_cast<float4*>(o) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                }
+            }
+            if (!has_next) break;
+            __syncthreads();                              // every wave is done reading the operand ring
+            set_tile(next);
+            issue_prologue();
+        } else {
+            // epilogue in two 128-row halves through ring slot 2; the next tile's first two stages are
+            // requested into slots 0 / 1 right after the barrier that frees the ring, so their latency
+            // hides behind the epilogue
+            // (laundered lane / thread ids: the epilogue's per-thread addressing would otherwise be hoisted out
+            // of the tile loop and stay live -- in registers the K loop has none to spare of)
+            int e_lane = lane, e_t = t;
+            asm volatile("" : "+v"(e_lane), "+v"(e_t));
+            epilogue_tile<T, MREP, NREP, NT, BM, BN, 2>(p, bz, acc, smem + 2 * STAGE, em0, en0, wm * 16 * MREP, wn * 16 * NREP,
+                                                        e_lane, e_t, [&]() { if (has_next) { set_tile(next); issue_prologue(); } });
+            if (!has_next) break;
+        }
+        tile = next;
+    }
     stamp(p, 3);
 }
 
@@ -724,12 +852,19 @@ static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     return PF_OK;
 }
 
+static int tuning(const char* name, int dflt);
 template <typename T, int NREP, int NW>
 static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 256, BN = 32 * NREP;
     GemmParams p = gp;
     p.mtiles = static_cast<int>(cdiv(p.M - p.m_begin, BM));
     p.ntiles = static_cast<int>(cdiv(p.N, BN));
+    {
+        const int rpp = 8 * NW, rem = rpp % p.rows_per_img;       // rows of one DMA pass, as (images, rows, columns)
+        p.adv_img = rpp / p.rows_per_img;
+        p.adv_y = rem / p.w_out;
+        p.adv_x = rem % p.w_out;
+    }
     p.prof = (g_prof && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= g_prof_blocks) ? g_prof : nullptr;
     const size_t smem = static_cast<size_t>(3) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
@@ -738,7 +873,12 @@ static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(64 * NW), smem, st, p);
+    // persistent over tiles: one block per CU walks tiles b, b + grid, ... (a multiple of 8 keeps a tile on
+    // the XCD its id maps to); PF_GEMM8_PERSIST=0 launches one block per tile
+    static const int cap = tuning("PF_GEMM8_PERSIST", 256);
+    int grid = p.mtiles * p.ntiles;
+    if (cap > 0) grid = std::min(grid, std::max(8, cap / (p.splits * batch) / 8 * 8));
+    hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW>), dim3(grid, p.splits, batch), dim3(64 * NW), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm (8-wave)");
     if (p.splits > 1) {
         const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);

@@ -76,9 +76,15 @@ def main():
             full = buf.view(cap, 32).cpu()
             full = full[full[:, 3] != 0].double()
             st = full[:, :4]
-            if float(full[:, 4:28].abs().sum()) > 0:
+            if float(full[:, 12:28].abs().sum()) > 0:
                 w = full[:, 4:28].view(-1, 8, 3).mean(0)
                 print("   per-wave K-loop clocks [wait+barrier, DMA issue, ds_read+MFMA]:", " ".join("w%d[%.0f %.0f %.0f]" % (i, *w[i]) for i in range(8)))
+            if float(full[:, 4].abs().sum()) > 0 and float(full[:, 12:28].abs().sum()) == 0:     # epilogue sub-stamps
+                e = full[:, 2:12]
+                seq = [2, 4, 5, 6, 7, 8, 9, 10, 11]
+                names = ["ring barrier", "next-tile setup+DMA issue", "fragments->LDS (slice 0)", "barrier", "copy-out issue",
+                         "fragments->LDS (slice 1)", "barrier", "copy-out issue"]
+                print("   epilogue: " + "  ".join("%s %.0f" % (n, (full[:, b] - full[:, a]).mean()) for n, a, b in zip(names, seq[:-1], seq[1:])))
             d = (st[:, 1:] - st[:, :-1])
             span = float(st[:, 3].max() - st[:, 0].min())
             print("   phases (shader clocks, %d blocks): first tile %.0f  K loop %.0f  epilogue %.0f  | block total %.0f  kernel span %.0f (100 MHz memtime ticks?)"
