@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_attention(const AttnParams p) {
 //   distinct bank pairs.
 // One online-softmax update per 64 keys.
 template <typename T, int D, bool BIAS>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 3) void k_attention_lds(const AttnParams p) {
+__global__ __launch_bounds__(256, 3) void k_attention_lds(const AttnParams p) {
     // (256, 2): at most 256 registers per lane -> the MFMA accumulators live in the VGPR file; with the
     // default budget the compiler parks S and O in AGPRs and pays ~145 v_accvgpr moves per key tile.
     constexpr int KS = D / 16, DB = D / 32, KT = 64;

@@ -877,7 +877,11 @@ static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
     // the XCD its id maps to); PF_GEMM8_PERSIST=0 launches one block per tile
     static const int cap = tuning("PF_GEMM8_PERSIST", 256);
     int grid = p.mtiles * p.ntiles;
-    if (cap > 0) grid = std::min(grid, std::max(8, cap / (p.splits * batch) / 8 * 8));
+    if (cap > 0) {
+        int gx = std::max(1, cap / (p.splits * batch));           // blockIdx.y / z multiply the resident blocks
+        if (gx >= 8) gx = gx / 8 * 8;
+        grid = std::min(grid, gx);
+    }
     hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW>), dim3(grid, p.splits, batch), dim3(64 * NW), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm (8-wave)");
     if (p.splits > 1) {

@@ -29,3 +29,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   find $R/gpurun_out/${TAG}_pmc_$C -type f -size +1M -delete
   grep -E "k_conv_gemm|k_attention" $R/gpurun_out/${TAG}_pmc_$C.txt | cut -c1-200
 done
+cd $R
+echo "== microbenchmarks"
+python tools/gemm_bench.py --reps 20 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_gemm_microbench.txt
+PF_GEMM8_PERSIST=0 python tools/gemm_bench.py --reps 5 --phases --shapes conv64,lin320,ff1_320 2>&1 | grep -v amdgpu.ids | grep -v per-wave > gpurun_out/${TAG}_gemm_phases.txt
+python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_attn_microbench.txt
+tail -n 4 gpurun_out/${TAG}_gemm_microbench.txt

@@ -47,8 +47,37 @@ def pmc(path, out):
                 fh.write("%-72s %-28s total %.6g  per-dispatch %.6g  dispatches %d\n" % (k, c, v, v / calls[(k, c)], calls[(k, c)]))
 
 
+def traffic(fetch_txt, write_txt, out, family="k_conv_gemm"):
+    """profiles/r1_traffic.json (read by bench.py for roofline.traffic) from the two PMC summaries."""
+    import json
+    tot, n = {}, {}
+    for path in (fetch_txt, write_txt):
+        for line in open(path):
+            f = line.split()
+            if not line.startswith(family) or "total" not in f:
+                continue
+            c = f[f.index("total") - 1]
+            tot[c] = tot.get(c, 0.0) + float(f[f.index("total") + 1])
+            n[c] = n.get(c, 0) + int(f[f.index("dispatches") + 1])
+    assert n["FETCH_SIZE"] == n["WRITE_SIZE"], n
+    doc = {
+        "kernel": family + " (all tile variants)",
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, PF_STREAMS=1 bench.py --steps 1 --warmup 0 --no-graphs",
+        "launches": n["FETCH_SIZE"],
+        "fetch_size_kb_total": tot["FETCH_SIZE"],
+        "write_size_kb_total": tot["WRITE_SIZE"],
+        "correction": "FETCH_SIZE x2 (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
+                      "WRITE_SIZE uncorrected; Infinity-Cache hits are counted, so this is L2<->fabric traffic, an upper bound on HBM bytes",
+        "bytes_per_launch": (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / n["FETCH_SIZE"],
+    }
+    json.dump(doc, open(out, "w"), indent=1)
+    print(doc["launches"], "launches,", round(doc["bytes_per_launch"] / 1e6, 1), "MB per launch")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "trace":
+    if sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     else:
         pmc(sys.argv[2], sys.argv[3])
