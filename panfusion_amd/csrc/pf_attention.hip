@@ -204,8 +204,11 @@ __global__ __launch_bounds__(256) void k_attention(const AttnParams p) {
 //   V^T rows are padded to 136 B (34 banks): the 32 d-rows read by a half-wave with ds_read_b64 hit
 //   distinct bank pairs.
 // One online-softmax update per 64 keys.
-template <typename T, int D, bool BIAS>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 3) void k_attention_lds(const AttnParams p) {
+// PIPE: scores of tile j+1 held in registers while the softmax of tile j runs (three LDS buffers, two
+// waves per SIMD at D = 64).  !PIPE: one score array, two LDS buffers, OCC waves per SIMD -- the
+// MFMA / vector-ALU overlap then comes from the other waves of the SIMD instead of from inside a wave.
+template <typename T, int D, bool BIAS, bool PIPE = true, int OCC = (D == 64 ? 2 : 3)>
+__global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) {
     // (256, 2): at most 256 registers per lane -> the MFMA accumulators live in the VGPR file; with the
     // default budget the compiler parks S and O in AGPRs and pays ~145 v_accvgpr moves per key tile.
     constexpr int KS = D / 16, DB = D / 32, KT = 64;
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 3) void k_attention_lds(const At
     constexpr int K_ELEMS = KT * D, V_ELEMS = D * VROW;
     constexpr int KCH = KT * KCHUNKS / 256, VCH = D * (KT / 8) / 256;
     typedef typename Mfma32<T>::frag frag;
-    __shared__ __attribute__((aligned(16))) unsigned short smem[3 * (K_ELEMS + V_ELEMS)];
+    constexpr int NBUF = PIPE ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[NBUF * (K_ELEMS + V_ELEMS)];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int ql = lane & 31, hi = lane >> 5;
@@ -398,6 +402,17 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 3) void k_attention_lds(const At
     auto score_tile = [&](int j, float (&sv)[2][16]) { if (j + 1 == nkt && ragged) scores(j, j % 3, sv, TAILY); else scores(j, j % 3, sv, FULL); };
     load_tile(0);
     stage_store(0);
+    if constexpr (!PIPE) {
+        __syncthreads();
+        float sv[2][16];
+        for (int j = 0; j < nkt; ++j) {
+            if (j + 1 < nkt) load_tile(j + 1);          // global -> registers while this tile is processed
+            if (j + 1 == nkt && ragged) scores(j, j & 1, sv, TAILY); else scores(j, j & 1, sv, FULL);
+            softmax_pv(j & 1, sv);
+            if (j + 1 < nkt) stage_store((j + 1) & 1);  // held tile j-1: every wave passed the last barrier after using it
+            __syncthreads();
+        }
+    } else {
     if (nkt > 1) { load_tile(1); stage_store(1); }
     __syncthreads();
     float s_cur[2][16], s_next[2][16];
@@ -452,6 +467,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 3) void k_attention_lds(const At
         __syncthreads();
         rotate();
     }
+    }
 
     if (q0 + ql < p.nq) {
         const float inv = 1.0f / l_run;
@@ -472,6 +488,13 @@ static bool use_lds_attention() {
     static int v = -1;                     // PF_ATTENTION_IMPL=direct selects the no-LDS kernel (A/B switch)
     if (v < 0) { const char* e = getenv("PF_ATTENTION_IMPL"); v = (e && e[0] == 'd') ? 0 : 1; }
     return v == 1;
+}
+
+// A/B switches.  PF_ATTENTION_OCC (D = 64): 3 = one score array, three waves per SIMD (default), 2 = register-pipelined
+// scores, two waves per SIMD.  PF_ATTENTION_OCC32 (D = 32): 3 = pipelined (default), 4 | 5 = not pipelined at that occupancy.
+static int attention_occupancy(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 }  // namespace pf
@@ -506,12 +529,24 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     const bool lds = use_lds_attention() && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0;
     PF_DISPATCH_16(d->dtype, "pf_attention",
         if (lds) {
+            static const int occ64 = attention_occupancy("PF_ATTENTION_OCC", 3), occ32 = attention_occupancy("PF_ATTENTION_OCC32", 3);
             if (d->D == 64) {
-                if (d->bias) hipLaunchKernelGGL((k_attention_lds<T, 64, true>), grid, block, 0, st, p);
-                else hipLaunchKernelGGL((k_attention_lds<T, 64, false>), grid, block, 0, st, p);
+                if (d->bias) {                 // (not pipelined it needs 169 registers at three waves per SIMD)
+                    hipLaunchKernelGGL((k_attention_lds<T, 64, true>), grid, block, 0, st, p);
+                } else {
+                    if (occ64 == 2) hipLaunchKernelGGL((k_attention_lds<T, 64, false>), grid, block, 0, st, p);
+                    else hipLaunchKernelGGL((k_attention_lds<T, 64, false, false, 3>), grid, block, 0, st, p);
+                }
             } else {
-                if (d->bias) hipLaunchKernelGGL((k_attention_lds<T, 32, true>), grid, block, 0, st, p);
-                else hipLaunchKernelGGL((k_attention_lds<T, 32, false>), grid, block, 0, st, p);
+                if (d->bias) {
+                    if (occ32 == 4) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 4>), grid, block, 0, st, p);
+                    else if (occ32 == 5) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 5>), grid, block, 0, st, p);
+                    else hipLaunchKernelGGL((k_attention_lds<T, 32, true>), grid, block, 0, st, p);
+                } else {
+                    if (occ32 == 4) hipLaunchKernelGGL((k_attention_lds<T, 32, false, false, 4>), grid, block, 0, st, p);
+                    else if (occ32 == 5) hipLaunchKernelGGL((k_attention_lds<T, 32, false, false, 5>), grid, block, 0, st, p);
+                    else hipLaunchKernelGGL((k_attention_lds<T, 32, false>), grid, block, 0, st, p);
+                }
             }
         } else {
             if (d->D == 64) hipLaunchKernelGGL((k_attention<T, 64>), grid, block, 0, st, p);
