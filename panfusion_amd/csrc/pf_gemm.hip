@@ -683,12 +683,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     const std::false_type NO;
     int cur = 0, nx1 = 1, nx2 = 2;
     // One K step.  MORE: a next stage exists (wait for it, barrier, prefetch its first fragments);
-    // DMA: a stage two ahead exists (issue its pieces between the MFMAs of the second half).  The flags
+    // DMA: a stage three ahead exists (issue its pieces between the MFMAs of the second half).  The flags
     // are compile-time so that the steady-state body is branch free and the compiler's s_waitcnt
     // insertion sees exact counts (a conditional around the prefetch made it drain lgkmcnt to 0 right
     // after issuing it, exposing the LDS latency once per step).
-    auto step = [&](auto more_tag, auto dma_tag) {
+    auto step = [&](auto more_tag, auto dma_tag, auto wait_tag) {
         constexpr bool MORE = decltype(more_tag)::value, DMA = decltype(dma_tag)::value;
+        constexpr int WAIT = decltype(wait_tag)::value;           // DMA instructions that may stay in flight at the mid-step wait
         constexpr int NM = MREP * NREP, LEAD = 4;                 // fragment requests go out after LEAD MFMAs:
         // at every s_waitcnt lgkmcnt the only outstanding LDS reads are then the ones being waited for
         // (the compiler drains to 0, it does not count), and they were issued >= NM - LEAD MFMAs earlier.
@@ -703,8 +704,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             }
         }
         if constexpr (MORE) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of the next stage (a full step in flight)
-            __builtin_amdgcn_s_barrier();                         // next stage complete; previous stage no longer read
+            // my pieces of the next stage have landed (the stage after it may still be in flight: WAIT), and my
+            // reads of the current slot have returned -- it is refilled right after the barrier
+            if constexpr (WAIT == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if constexpr (WAIT == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if constexpr (WAIT == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+            else if constexpr (WAIT == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+            else if constexpr (WAIT == 13) asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");
+            else static_assert(WAIT == 0, "add the immediate");
+            __builtin_amdgcn_s_barrier();                         // next stage complete; the current slot no longer read
             asm volatile("" ::: "memory");
         }
         __amdgpu_buffer_rsrc_t rs_a = rs_w;
@@ -722,7 +730,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
                 const int k = idx - LEAD;                         // pieces after MFMA LEAD, LEAD+2, ...
                 if (k >= 0 && (k & 1) == 0 && (k >> 1) < NPIECE) {
                     __builtin_amdgcn_sched_barrier(0);
-                    dma_piece(rs_a, nx2, k >> 1);
+                    dma_piece(rs_a, cur, k >> 1);                 // stage it+3 into the slot retired at this step's barrier
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -757,11 +765,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         asm volatile("" ::: "memory");
         if (first) stamp(p, 1);
         first = false;
+        if (n_it > 2) dma_stage(2);                       // third stage in flight (slot 2 staged the previous tile's epilogue)
         load_frags(0, 0, fa0, fb0);
         cur = 0; nx1 = 1; nx2 = 2;
-        for (int it = 0; it + 2 < n_it; ++it) step(YES, YES);
-        if (n_it >= 2) step(YES, NO);
-        step(NO, NO);
+        // The slot of stage `it` is retired at the mid-step barrier of step `it` (its last fragments are
+        // requested in the first half), and stage it+3 is requested into it right behind that barrier: with
+        // three slots a stage has TWO K steps to arrive, the mid-step wait leaves the younger one in flight.
+        const std::integral_constant<int, NPIECE> W1;
+        const std::integral_constant<int, 0> W0;
+        for (int it = 0; it + 3 < n_it; ++it) step(YES, YES, W1);
+        if (n_it >= 3) step(YES, NO, W1);
+        if (n_it >= 2) step(YES, NO, W0);
+        step(NO, NO, W0);
         if constexpr (NW == 4) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // inline-asm MFMA results -> vector ALU reads
         stamp(p, 2);
 
