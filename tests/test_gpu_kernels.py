@@ -358,6 +358,42 @@ def test_tail_split_two_phase(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 448])
+def test_persistent_8wave_kernel_short_k_and_epilogue_modes(dtype, K):
+    """Shapes that the plan gives to k_conv_gemm8 (>= 256 full-ish 256x160 tiles, so every block walks
+    several tiles): 1..7 K steps exercise every prologue / tail combination of the three-slot ring
+    (stage it+3 requested into the slot retired at the mid-step barrier), a ragged last row tile and
+    each staged epilogue specialisation (bias, + residual, + per-image row vector incl. tiles that
+    straddle an image boundary, GEGLU) plus the fp32 per-fragment path."""
+    o = ops()
+    n_img, hw = 130, 500                                           # rows_per_img = 500 >= 256: tiles cross image boundaries
+    M, N = n_img * hw - 0, 320                                     # 65000 rows: 254 row tiles, the last one ragged
+    x, xf = q16(rnd(M, K, seed=60 + K), dtype)
+    w, wf = q16(rnd(N, K, seed=61) / K ** 0.5, dtype)
+    b = rnd(N, seed=62)
+    r, rf = q16(rnd(M, N, seed=63), dtype)
+    base = xf @ wf.T + b
+
+    def check_all(name, got, want, tol):
+        check(name, got, want, tol)
+        check(name + " (ragged last row tile)", got[-232:], want[-232:], tol)      # 65000 = 253 * 256 + 232
+        check(name + " (first tile)", got[:256], want[:256], tol)
+
+    check_all("bias", o.linear(x, w, bias=b.to(DEV)), base, TOL[dtype])
+    check_all("bias+res", o.linear(x, w, bias=b.to(DEV), residual=r), base + rf, TOL[dtype])
+    table = rnd(n_img, N, seed=64)
+    got = o.conv_gemm(x, w, N, n_img=n_img, h_in=20, w_in=25, bias=b.to(DEV), rowvec=table.to(DEV))
+    check_all("bias+rowvec", got, base + table.repeat_interleave(hw, 0), TOL[dtype])
+    got = o.linear(x, w, bias=b.to(DEV), out_dtype=torch.float32)
+    check_all("fp32 out", got, base, 2e-5)
+    w2, w2f = q16(rnd(2 * N, K, seed=65) / K ** 0.5, dtype)
+    b2 = rnd(2 * N, seed=66)
+    wi, bi = o.interleave_geglu(w2, b2.to(DEV))
+    y = xf @ w2f.T + b2
+    check_all("geglu", o.linear(x, wi, bias=bi, geglu=True), y[:, :N] * F.gelu(y[:, N:]), TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_strided_views_and_rowvec(dtype):
     o = ops()
     M, C = 200, 128
