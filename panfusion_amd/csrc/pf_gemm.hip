@@ -927,10 +927,12 @@ static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
     static const int big_min_tiles = tuning("PF_GEMM8_MIN_TILES", 128);   // 0 disables the 8-wave kernel
     const int nrep = (N % 160 == 0) ? 5 : 4;
     const long tiles256 = cdiv(M, 256) * cdiv(N, 32 * nrep) * batch;
-    // one 8-wave block per CU: take it only when the last round of tiles is well filled (320 tiles on 256
-    // CUs would idle for 37 % of the launch; the 4-wave kernel's 2 blocks per CU degrade more gracefully)
+    // one 8-wave block per CU: take it only when the tiles fill their rounds of 256 CUs to >= 60 % overall (320
+    // tiles would idle for 37 % of the launch; the 4-wave kernel's 2 blocks per CU degrade more gracefully).
+    // The threshold is flat at the single-GPU sizes (17.4-17.5 steps/s from 50 to 95 %) and was set on the smaller
+    // per-rank GEMMs of 2 / 4 / 8 ranks (tools/sim_rank.py: 37.1 -> 33.9 ms per step at 2 ranks from 88 to 60 %).
     const long rounds = cdiv(tiles256, 256);
-    static const int fill_pct = tuning("PF_GEMM8_FILL", 88);
+    static const int fill_pct = tuning("PF_GEMM8_FILL", 60);
     const bool filled = tiles256 * 100 >= rounds * 256 * fill_pct;
     if (big_min_tiles > 0 && tiles256 >= big_min_tiles && filled) {
         GemmPlan g;

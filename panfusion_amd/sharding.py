@@ -65,28 +65,43 @@ class ShardInfo:
         return self.cfg * self.G + (self.pano_g or 0)
 
 
-# cost of the panorama branch + its EPA side in units of one view (1.918 / 0.804 TFLOP, + EPA)
-PANO_VIEW_EQUIV = 2.7
+# Cost of the panorama branch + its EPA side in units of one view, in TIME on one MI355X (tools/sim_rank.py:
+# a rank's step takes 7.5 ms + 0.88 ms per view + 6.9 ms for the panorama branch).  By FLOPs it is only 2.7
+# (1.918 / 0.804 TFLOP + EPA): the panorama branch runs 2 samples through layers too small to
+# fill 256 CUs.
+PANO_VIEW_EQUIV = 7.8
 
 
 def pano_rank_split(m, G):
-    """Views per group when group 0 owns the panorama branch: the largest m0 with m0 + pano <= share of the
-    others and (m - m0) divisible by G - 1; None if there is no such split (or it leaves group 0 without views)."""
-    best = None
-    for m0 in range(1, m):
-        if (m - m0) % (G - 1):
-            continue
-        if m0 + PANO_VIEW_EQUIV <= (m - m0) / (G - 1) + 1e-9:
-            best = m0
-    return None if best is None else (best,) + ((m - best) // (G - 1),) * (G - 1)
+    """Views per group when group 0 owns the panorama branch: (m0, ...rest spread as evenly as possible) for
+    the m0 >= 1 that minimises the slowest group, max(m0 + PANO_VIEW_EQUIV, ceil((m - m0) / (G - 1)));
+    None if G < 2 or the views do not leave every group at least one."""
+    if G < 2 or m < G:
+        return None
+    best, best_cost = None, None
+    for m0 in range(1, m - (G - 1) + 1):
+        rest = m - m0
+        cost = max(m0 + PANO_VIEW_EQUIV, -(-rest // (G - 1)))
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = m0, cost
+    rest, q, r = m - best, (m - best) // (G - 1), (m - best) % (G - 1)
+    return (best,) + tuple(q + (1 if i < r else 0) for i in range(G - 1))
+
+
+def split_cost(split, pano_replicated):
+    """Slowest group of a layout in view units (the model above)."""
+    if pano_replicated:
+        return max(split) + PANO_VIEW_EQUIV
+    return max(split[0] + PANO_VIEW_EQUIV, max(split[1:]))
 
 
 def plan(world, rank, m, layout="auto", split=None):
     """Layout of `rank`: 2 CFG halves x G = world/2 view groups.
-    layout "even": m/G views per group, the panorama branch replicated inside a CFG half (ceiling 6.06x at
-    8 ranks).  layout "pano_rank" (chosen by "auto" from G >= 4): group 0 of a half owns the panorama branch
-    and fewer views (2, 6, 6, 6 for m = 20, G = 4: ceiling 7.7x); the other groups run the view branch only
-    and receive the layer-normed panorama tokens by a broadcast at every EPA block."""
+    layout "even": m/G views per group, the panorama branch replicated inside a CFG half.  layout "pano_rank"
+    (chosen by "auto" whenever its slowest group is faster by the time model above, i.e. from G >= 2): group 0
+    of a half owns the panorama branch and fewer views (6 / 14 for m = 20, G = 2; 1 / 7 / 6 / 6 for G = 4); the
+    other groups run the view branch only and receive the layer-normed panorama tokens by a broadcast at every
+    EPA block.  PF_SHARD_SPLIT=a,b,... overrides the split."""
     if world < 2 or world % 2:
         raise ValueError("sharded step needs an even number of ranks (CFG pair x view groups), got %d" % world)
     G = world // 2
@@ -96,10 +111,15 @@ def plan(world, rank, m, layout="auto", split=None):
             raise ValueError("split %r does not distribute %d views over %d groups" % (split, m, G))
         info.split, info.pano_g = tuple(split), 0
         return info
-    if layout == "auto":
-        layout = "pano_rank" if G >= 4 and pano_rank_split(m, G) is not None else "even"
+    if layout == "auto":                                  # whichever the time model says is faster
+        sp = pano_rank_split(m, G)
+        even_ok = m % G == 0
+        if sp is not None and (not even_ok or split_cost(sp, False) < split_cost((m // G,) * G, True)):
+            layout = "pano_rank"
+        else:
+            layout = "even"
     if layout == "pano_rank":
-        sp = pano_rank_split(m, G) if G >= 2 else None
+        sp = pano_rank_split(m, G)
         if sp is None:
             raise ValueError("no panorama-rank split of %d views over %d groups" % (m, G))
         info.split, info.pano_g = sp, 0
@@ -114,6 +134,8 @@ def make_shard(m, layout=None, split=None):
     every rank creates every group, in the same order)."""
     import os
     world, rank = dist.get_world_size(), dist.get_rank()
+    if split is None and os.environ.get("PF_SHARD_SPLIT"):
+        split = tuple(int(v) for v in os.environ["PF_SHARD_SPLIT"].split(","))
     info = plan(world, rank, m, layout or os.environ.get("PF_SHARD_LAYOUT", "auto"), split)
     if info.G > 1:
         groups = [dist.new_group(list(range(c * info.G, (c + 1) * info.G))) for c in range(2)]

@@ -1,0 +1,72 @@
+"""Per-rank compute time of the sharded step, measured in ONE process on one MI355X.
+
+    python tools/sim_rank.py --world 8 --ranks 0,1 [--steps 6]
+
+torch.distributed is replaced by local stand-ins (an all-gather fills every slot with this rank's
+block, a broadcast is a no-op), so the timing is the rank's kernels + the graph-segment structure
+without any wire time: an upper bound on what N GPUs can deliver, and the workload on which the tile
+plan can be tuned for the smaller per-rank GEMMs of 4 and 8 ranks.  Results are NOT parity-checked
+(the gathered tensors are fake); functional coverage of the sharded path is tests/test_sharding_gloo.py
+and tools/gpu_dist_dry.sh."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def fake_dist(world, rank):
+    dist.get_world_size = lambda group=None: world
+    dist.get_rank = lambda group=None: rank
+    dist.new_group = lambda ranks=None, **k: tuple(ranks)
+
+    def all_gather_into_tensor(out, x, group=None):
+        n = out.numel() // x.numel()
+        out.view(n, -1).copy_(x.reshape(1, -1).expand(n, -1))
+
+    dist.all_gather_into_tensor = all_gather_into_tensor
+    dist.broadcast = lambda t, src=0, group=None: None
+    dist.barrier = lambda *a, **k: None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--ranks", default="0")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    args = ap.parse_args()
+    import bench
+    from panfusion_amd import sharding
+    from panfusion_amd.models.sd2_unet_params import SD2_BASE
+    from panfusion_amd.utils.pano import icosahedron_sample_camera
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    th, ph = icosahedron_sample_camera()
+    cams_deg = (np.degrees(th), np.degrees(ph))
+    cfg = dict(SD2_BASE)
+    for rank in [int(r) for r in args.ranks.split(",")]:
+        fake_dist(args.world, rank)
+        model, loop = sharding.build_sharded(bench.build_model, bench.build_inputs, dev, torch.bfloat16, cfg, 20, (64, 64), (64, 128),
+                                             cams_deg, args.steps + args.warmup + 1, True)
+        loop.prepare()
+        for _ in range(args.warmup):
+            loop.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loop.step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / args.steps
+        print("world %d rank %d  %-60s %7.2f ms/step  (graphs %s)" % (args.world, rank, loop.layout, ms, loop.use_graphs), flush=True)
+        del model, loop
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
