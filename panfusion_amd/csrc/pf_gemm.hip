@@ -6,15 +6,18 @@
 // channels) address 128 contiguous bytes of the NHWC activation (zero padding, optional nearest
 // x2 upsampling, optional channel concat of two sources are folded into the address).
 //
-// Structure: 256 threads = 4 wavefronts (2 x 2), block tile (32*MREP) x (32*NREP), K-step 64,
-// v_mfma_f32_16x16x32 (bf16 or f16) with fp32 accumulation.  The weight tile is the MFMA "A"
-// operand and the activation tile the "B" operand, so every lane ends up with 4 CONSECUTIVE
-// output channels of one output row (8-byte stores, float4 bias loads).  Global -> registers ->
-// LDS staging, double buffered (one barrier per K-step, next tile's loads in flight during the
-// MFMAs).  LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row>>1)&7 which
-// makes the ds_read_b128 fragment reads and the ds_write_b128 staging writes conflict free.
-// Workgroup ids are remapped so that the tiles sharing an activation row-panel run on one XCD
-// (private L2 per XCD).
+// Two tile kernels share the fragment mapping, the LDS image and the block epilogue:
+//   k_conv_gemm   256 threads = 4 wavefronts (2 x 2), tile (32*MREP) x (32*NREP), two LDS slots, 2 blocks per CU;
+//   k_conv_gemm8  512 threads = 8 wavefronts (4 x 2), tile 256 x (32*NREP), three LDS slots, persistent over tiles.
+// K-step 64, v_mfma_f32_16x16x32 (bf16 or f16) with fp32 accumulation.  The weight tile is the MFMA "A"
+// operand and the activation tile the "B" operand, so every lane ends up with 4 CONSECUTIVE output channels
+// of one output row (float4 bias loads, 8-byte LDS staging writes).  Operands go global -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds) through scalar buffer descriptors: zero padding and ragged tiles are offsets
+// beyond num_records.  LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row>>1)&7 (applied to
+// the per-lane SOURCE offset, the DMA writes lane-linear), which makes the ds_read_b128 fragment reads conflict
+// free.  Tile ids are remapped so that the tiles sharing an activation row-panel run on one XCD (private L2).
+// Epilogue (epilogue_fast): bias / per-image row vector / residual / GEGLU on the fp32 accumulators, one
+// rounding, 16-bit tile staged through LDS and written as whole 16-byte row segments.
 //
 // Replaces cuDNN / cuBLAS behind diffusers Conv2d / Linear (reference call sites
 // models/pano/MVGenModel.py:86-144,174-198,224-294; models/modules/transformer.py:8-74).
@@ -487,14 +490,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
 
 // ---- 8-wave, 3-stage ring variant (the large layers) ---------------------------------------------
 // 512 threads = 8 wavefronts (4 x 2), block tile 256 x (32*NREP) in {256x160, 256x128}, one block per
-// CU (2 waves per SIMD).  Same fragment mapping and LDS image as k_conv_gemm, but the K loop keeps
-// TWO stages of global_load_lds DMA in flight across the barrier: stage it+2 is issued while stage it
-// is multiplied, and stage it is awaited with a COUNTED s_waitcnt vmcnt(L) (L = DMA instructions of
-// one stage) so stage it+1 stays in flight -- one raw s_barrier per K-step, never a full drain.
-// Every wave issues exactly L = 4 + ceil(BN/64) DMA instructions per stage (the ragged half pass of
-// the 160-row weight tile is issued by the lower 32 lanes of all 8 waves), so one immediate serves all.
-// Epilogue: accumulators are staged through LDS (fp32, 128 rows at a time) and leave as whole
-// 16-byte row segments with coalesced residual loads, instead of 8-byte pieces of 16 different rows.
+// CU (2 waves per SIMD), persistent: a block walks tiles blockIdx.x, + gridDim.x, ...
+// K loop: fragment registers are double buffered and the single raw s_barrier of a K step sits between its
+// two 32-k halves.  The last fragments of stage `it` are requested in the first half, so its slot is retired by
+// that barrier and stage it+3 is requested into it right behind the barrier: TWO K steps of DMA look-ahead with
+// three slots.  Stage it+1 is awaited with a COUNTED s_waitcnt vmcnt(L) (L = DMA instructions of one stage) so
+// that stage it+2 stays in flight -- never a full drain inside a tile.  Every wave issues exactly
+// L = 4 + ceil(BN/64) DMA instructions per stage (the 32-row remainder pass of the 160-row weight tile is issued
+// by the lower 32 lanes of all 8 waves), so one immediate serves all.
+// Tile boundary: right after the barrier that retires the ring the block decodes its next tile and requests
+// that tile's first two stages into slots 0 / 1; the epilogue runs meanwhile in two row slices through slot 2.
 template <typename T, int NREP, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // NW = 8: 4 x 2 waves, 64x80 per wave, two waves per SIMD.  NW = 4: 2 x 2 waves, 128x80 per wave, ONE wave
