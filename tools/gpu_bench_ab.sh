@@ -12,5 +12,5 @@ except Exception as e:
 "; }
 timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_default.log 2>&1; summ gpurun_out/bench_default.log default
 for kv in "$@"; do
-  timeout 600 env $kv python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$kv.log 2>&1; summ gpurun_out/bench_$kv.log $kv
+  timeout 600 env $kv python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "gpurun_out/bench_${kv//\//_}.log" 2>&1; summ "gpurun_out/bench_${kv//\//_}.log" $kv
 done
