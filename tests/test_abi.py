@@ -101,3 +101,21 @@ def test_attention_and_norm_reject_bad_arguments():
     assert lib.pf_groupnorm_stats(0x10000, 60, None, 0, _lib.PF_F16, 1, 16, 32, 1e-5, 0x20000, 0x30000, 0x40000, 0x50000,
                                   0x60000, 1 << 20, None) == 1
     assert lib.pf_geglu(0x10000, _lib.PF_F16, 4, 12, 0x20000, None) == 1
+
+
+def test_pf_hip_lib_selects_another_build(tmp_path):
+    """PF_HIP_LIB (same-box A/B of kernel builds, tools/gpu_lib_ab.sh) replaces the in-tree library path;
+    a missing file must fail loudly -- there is no fallback."""
+    import shutil
+    import subprocess
+    import sys
+    other = tmp_path / "libpf_other.so"
+    shutil.copy(_lib.LIB_PATH, other)
+    code = "from panfusion_amd import _lib; print(_lib.LIB_PATH); print(_lib.lib().pf_version())"
+    env = dict(os.environ, PF_HIP_LIB=str(other), PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] == str(other) and int(out.stdout.split()[1]) >= 100
+    env["PF_HIP_LIB"] = str(tmp_path / "nope.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
