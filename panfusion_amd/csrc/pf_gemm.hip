@@ -994,7 +994,8 @@ static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_spli
     g.splits = 1;
     g.kb_per_split = nkb;
     // split-K when the grid cannot fill the chip and K is long: aim at ~640 blocks, >= 6 K-blocks each
-    if (allow_split && N % 4 == 0 && tiles <= 320 && nkb >= 12) {
+    static const int split_min_kb = tuning("PF_GEMM_SPLIT_MINKB", 12);   // least K depth (64-blocks) for split-K on the 4-wave kernel
+    if (allow_split && N % 4 == 0 && tiles <= 320 && nkb >= split_min_kb) {
         long s = (640 + tiles - 1) / tiles;
         if (s > nkb / 6) s = nkb / 6;
         if (s > 32) s = 32;
