@@ -430,16 +430,23 @@ def _epa_tail(e, attn_out, x, Cc):
     return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y)
 
 
-def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None):
+def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None, pers_hw=None):
     """EPA when this rank holds views [v0, v1) of the m (one CFG sample per rank, b == 1).
     One all-gather of LN1(x_p + PE) inside the CFG half; K / V^T of all views are projected locally.
     Replicated layout: every rank holds the panorama and computes the panorama-query direction redundantly.
     Panorama-rank layout (shard.pano_g): only the owner has xe; it computes the panorama-query direction and
     broadcasts LN1(x_e + PE), from which every rank projects the panorama K / V^T for its own view queries;
-    the other ranks pass xe = None (equi_hw = its spatial size) and get None back for it."""
+    the other ranks pass xe = None (equi_hw = its spatial size) and get None back for it.  An owner without
+    views (explicit split 0, ...) passes xp = None and pers_hw = (ph, pw): it contributes an empty block to the
+    gather, computes the panorama-query direction only and gets None back for the views."""
     from . import sharding
-    mloc, ph, pw, Cc = xp.shape
     owner = xe is not None
+    if xp is None:
+        if not owner:
+            raise ValueError("a rank without views must own the panorama branch")
+        (ph, pw), mloc, Cc = pers_hw, 0, xe.shape[-1]
+    else:
+        mloc, ph, pw, Cc = xp.shape
     if owner:
         b, eh, ew, _ = xe.shape
         if b != 1:
@@ -461,9 +468,12 @@ def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None):
             t.__dict__[key] = (pad.reshape(pad.shape[0] // 32, 32, pad.shape[1] // 32, 32).abs().amax((1, 3)) > 0) \
                 .to(torch.uint8).contiguous()
         flags_p_loc = t.__dict__[key]
-    tp = xp.view(mloc * P, Cc)
-    lnp_loc = ops.layernorm(tp, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_p[r0:r1])
-    lnp = sharding.gather_view_tokens(lnp_loc, shard)                       # [mP, C] (every rank takes part)
+    if mloc:
+        tp = xp.view(mloc * P, Cc)
+        lnp_loc = ops.layernorm(tp, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_p[r0:r1])
+    else:
+        tp = lnp_loc = xe.new_empty(0, Cc)
+    lnp = sharding.gather_view_tokens(lnp_loc, shard, P=P)                  # [mP, C] (every rank takes part)
     lne = None
     if owner:
         te = xe.view(E, Cc)
@@ -480,6 +490,8 @@ def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None):
                             q_bs=E * ld, k_bs=mP * ld, vt_bs=vt_p.shape[1] * vt_p.shape[2],
                             bias=t.bias_e, flags=t.flags_e)
         out_e = _epa_tail(e, a_e, te, Cc).view(1, eh, ew, Cc)
+        if not mloc:
+            return None, out_e
         q_loc = qk_p[r0:r1]
     else:
         q_loc = ops.linear(lnp_loc, e.wqk)                                  # only the local queries are needed
@@ -491,14 +503,14 @@ def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None):
     return out_p.view(mloc, ph, pw, Cc), out_e
 
 
-def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None, side=None):
+def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None, side=None, pers_hw=None):
     """EPA fusion (modules.py:15-59) on NHWC activations.
     xp [b*m, ph, pw, C], xe [b, eh, ew, C]; tables: list with one EPATables entry per batch
     element (or a single shared entry)."""
     if shard is not None:
         if len(tables) != 1:
             raise ValueError("sharded EPA needs one camera set")
-        return run_epa_sharded(e, tables[0], xp, xe, m, shard, equi_hw)
+        return run_epa_sharded(e, tables[0], xp, xe, m, shard, equi_hw, pers_hw)
     bm, ph, pw, Cc = xp.shape
     b, eh, ew, _ = xe.shape
     P, E = ph * pw, eh * ew

@@ -88,9 +88,14 @@ class MultiViewBaseModel(nn.Module):
             m_total, groups = camera_groups(flat_cams, b)
             if shard is None and m_total != m:
                 raise ValueError("cameras describe %d views but latents hold %d" % (m_total, m))
+            pano_t = timestep[:, 0]
+        # panorama owner that was given no views (sharding split 0, ...): no view branch at all, the EPA blocks
+        # compute their panorama-query half from the gathered view tokens
+        pano_only = two and shard is not None and m == 0
+        pers = None
+        if two and not pano_only:
             pers = engine.Branch(self.packed("unet", dev), latents.flatten(0, 1), timestep.reshape(-1),
                                  prompt_embd.flatten(0, 1).to(dt).contiguous(), pano=False, pad=False)
-            pano_t = timestep[:, 0]
             branches.append(pers)
             if pers_layout_cond is not None:        # reference :66-74 (ControlNet on the view branch)
                 cn_res[id(pers)] = engine.run_controlnet(
@@ -103,7 +108,7 @@ class MultiViewBaseModel(nn.Module):
         view_only = two and shard is not None and not shard.has_pano
         main = torch.cuda.current_stream(dev) if pano_latent.is_cuda else None
         side = None
-        if two and self.two_streams and main is not None and not view_only:
+        if two and self.two_streams and main is not None and not view_only and not pano_only:
             if self._side is None:
                 self._side = torch.cuda.Stream(dev)
             side = self._side
@@ -148,6 +153,11 @@ class MultiViewBaseModel(nn.Module):
                     fn(br)
 
         def fuse(block):
+            if pano_only:                           # view feature map size at this level, from the latents' ratio
+                sc = pano_latent.shape[-2] // (pano.h.shape[1])
+                hw = (latents.shape[-2] // sc, latents.shape[-1] // sc)
+                _, pano.h = block.forward_nhwc(None, pano.h, groups, m_total, shard=shard, pers_hw=hw)
+                return
             if view_only:                           # panorama feature map size at this level, from the latents' ratio
                 sc = latents.shape[-2] // pers.h.shape[1]
                 hw = (pano_latent.shape[-2] // sc, pano_latent.shape[-1] // sc)
@@ -216,5 +226,8 @@ class MultiViewBaseModel(nn.Module):
         join()
         out_dtype = pano_latent.dtype
         pano_sample = pano_head.to(out_dtype).unflatten(0, (-1, 1)) if pano_head is not None else None
-        sample = pers.head().to(out_dtype).unflatten(0, (b, m)) if two else None
+        if pano_only:
+            sample = latents.new_zeros(b, 0, *latents.shape[2:]).to(out_dtype)
+        else:
+            sample = pers.head().to(out_dtype).unflatten(0, (b, m)) if two else None
         return sample, pano_sample

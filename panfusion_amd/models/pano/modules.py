@@ -47,14 +47,17 @@ class WarpAttn(nn.Module):
         return [self._tables.get(f, t, p, ph, pw, eh, ew, e.freq, device) for f, t, p in uniq]
 
     @torch.no_grad()
-    def forward_nhwc(self, xp, xe, groups, m, shard=None, equi_hw=None, side=None):
+    def forward_nhwc(self, xp, xe, groups, m, shard=None, equi_hw=None, side=None, pers_hw=None):
         """xp [b*m, ph, pw, C], xe [b, eh, ew, C] 16-bit NHWC (the denoiser's internal layout).
         With ``shard`` (sharding.ShardInfo) xp holds only this rank's views of the m; on a rank without the
-        panorama branch xe is None and equi_hw = (eh, ew)."""
-        e = self.packed(xp.device)
+        panorama branch xe is None and equi_hw = (eh, ew); on a panorama owner without views xp is None and
+        pers_hw = (ph, pw)."""
+        dev = xp.device if xp is not None else xe.device
+        e = self.packed(dev)
         eh, ew = (xe.shape[1], xe.shape[2]) if xe is not None else equi_hw
-        tabs = self.tables_for(groups, xp.shape[1], xp.shape[2], eh, ew, xp.device)
-        return engine.run_epa(e, tabs, xp, xe, m, shard=shard, equi_hw=(eh, ew), side=side)
+        ph, pw = (xp.shape[1], xp.shape[2]) if xp is not None else pers_hw
+        tabs = self.tables_for(groups, ph, pw, eh, ew, dev)
+        return engine.run_epa(e, tabs, xp, xe, m, shard=shard, equi_hw=(eh, ew), side=side, pers_hw=(ph, pw))
 
     @torch.no_grad()
     def forward(self, pers_x, equi_x, cameras):

@@ -60,6 +60,11 @@ class ShardInfo:
         return self.pano_g is None or self.pano_g == self.g
 
     @property
+    def has_views(self):
+        """False on a panorama-only owner (explicit split with 0 views for group 0)."""
+        return self.counts[self.g] > 0
+
+    @property
     def pano_src(self):
         """Global rank of the panorama owner of this CFG half."""
         return self.cfg * self.G + (self.pano_g or 0)
@@ -68,20 +73,26 @@ class ShardInfo:
 # Cost of the panorama branch + its EPA side in units of one view, in TIME on one MI355X (tools/sim_rank.py:
 # a rank's step takes 7.5 ms + 0.88 ms per view + 6.9 ms for the panorama branch).  By FLOPs it is only 2.7
 # (1.918 / 0.804 TFLOP + EPA): the panorama branch runs 2 samples through layers too small to
-# fill 256 CUs.
+# fill 256 CUs.  An owner WITHOUT views is cheaper than that (12.0 ms instead of 14.4 + 0.88 per view: no second
+# chain of ~600 latency-bound kernels competing with the panorama branch's ~1400).
 PANO_VIEW_EQUIV = 7.8
+PANO_ONLY_EQUIV = 5.1
+
+
+def owner_cost(m0):
+    return PANO_ONLY_EQUIV if m0 == 0 else m0 + PANO_VIEW_EQUIV
 
 
 def pano_rank_split(m, G):
     """Views per group when group 0 owns the panorama branch: (m0, ...rest spread as evenly as possible) for
-    the m0 >= 1 that minimises the slowest group, max(m0 + PANO_VIEW_EQUIV, ceil((m - m0) / (G - 1)));
-    None if G < 2 or the views do not leave every group at least one."""
-    if G < 2 or m < G:
+    the m0 >= 0 that minimises the slowest group, max(owner_cost(m0), ceil((m - m0) / (G - 1))); m0 = 0 is a
+    panorama-only owner.  None if G < 2 or the views do not give every other group at least one."""
+    if G < 2 or m < G - 1:
         return None
     best, best_cost = None, None
-    for m0 in range(1, m - (G - 1) + 1):
+    for m0 in range(0, m - (G - 1) + 1):
         rest = m - m0
-        cost = max(m0 + PANO_VIEW_EQUIV, -(-rest // (G - 1)))
+        cost = max(owner_cost(m0), -(-rest // (G - 1)))
         if best_cost is None or cost < best_cost - 1e-9:
             best, best_cost = m0, cost
     rest, q, r = m - best, (m - best) // (G - 1), (m - best) % (G - 1)
@@ -92,14 +103,14 @@ def split_cost(split, pano_replicated):
     """Slowest group of a layout in view units (the model above)."""
     if pano_replicated:
         return max(split) + PANO_VIEW_EQUIV
-    return max(split[0] + PANO_VIEW_EQUIV, max(split[1:]))
+    return max(owner_cost(split[0]), max(split[1:]))
 
 
 def plan(world, rank, m, layout="auto", split=None):
     """Layout of `rank`: 2 CFG halves x G = world/2 view groups.
     layout "even": m/G views per group, the panorama branch replicated inside a CFG half.  layout "pano_rank"
     (chosen by "auto" whenever its slowest group is faster by the time model above, i.e. from G >= 2): group 0
-    of a half owns the panorama branch and fewer views (6 / 14 for m = 20, G = 2; 1 / 7 / 6 / 6 for G = 4); the
+    of a half owns the panorama branch and fewer views (6 / 14 for m = 20, G = 2; none at all, 0 / 7 / 7 / 6, for G = 4); the
     other groups run the view branch only and receive the layer-normed panorama tokens by a broadcast at every
     EPA block.  PF_SHARD_SPLIT=a,b,... overrides the split."""
     if world < 2 or world % 2:
@@ -107,7 +118,9 @@ def plan(world, rank, m, layout="auto", split=None):
     G = world // 2
     info = ShardInfo(rank=rank, world=world, cfg=rank // G, g=rank % G, G=G, m=m)
     if split is not None:
-        if len(split) != G or sum(split) != m or min(split) < 1:
+        # group 0 (the panorama owner) may be given no views at all: it then runs the panorama branch and the
+        # panorama-query half of every EPA block only
+        if len(split) != G or sum(split) != m or min(split) < 0 or (G > 1 and min(split[1:]) < 1) or (G == 1 and split[0] < 1):
             raise ValueError("split %r does not distribute %d views over %d groups" % (split, m, G))
         info.split, info.pano_g = tuple(split), 0
         return info
@@ -236,14 +249,16 @@ def _collective(call):
         call()
 
 
-def gather_view_tokens(x_local, shard):
+def gather_view_tokens(x_local, shard, P=None):
     """All-gather [views_local * P, C] token blocks of the CFG half in view order -> [m * P, C].
-    Unequal view counts (panorama-rank layout) travel padded to the largest group and are compacted."""
+    Unequal view counts (panorama-rank layout) travel padded to the largest group and are compacted.
+    P (tokens per view) must be given by a rank without views (x_local is then an empty [0, C] tensor)."""
     if shard.G == 1:
         return x_local
     x_local = x_local.contiguous()
     counts = shard.counts
-    P = x_local.shape[0] // counts[shard.g]
+    if P is None:
+        P = x_local.shape[0] // counts[shard.g]
     rows = shard.vmax * P
     if x_local.shape[0] != rows:
         padded = torch.empty(rows, x_local.shape[1], dtype=x_local.dtype, device=x_local.device)
@@ -304,7 +319,8 @@ class ShardedDenoiseLoop(DenoiseLoop):
         s = self.shard
         v0, v1 = s.views
         c = s.cfg
-        return self.model(self.lat[:, v0:v1].contiguous(), self.pano, self.tstep[:1, v0:v1],
+        ts = self.tstep[:1, v0:v1] if v1 > v0 else self.tstep[:1, :1]     # a panorama-only owner still needs t
+        return self.model(self.lat[:, v0:v1].contiguous(), self.pano, ts,
                           self.prompt[c:c + 1, v0:v1], self.pano_prompt[c:c + 1], cams)
 
     def _gather(self, out):

@@ -69,24 +69,30 @@ def test_plan_layout():
     # panorama-rank layout: group 0 of a CFG half owns the panorama branch and fewer views; the split
     # minimises the slowest group under the measured time model (panorama branch = 7.8 views)
     assert sharding.pano_rank_split(20, 2) == (6, 14)
-    assert sharding.pano_rank_split(20, 4) == (1, 7, 6, 6)
+    assert sharding.pano_rank_split(20, 4) == (0, 7, 7, 6)      # a panorama-only owner is cheaper than one with a view
     assert sharding.pano_rank_split(20, 1) is None
     s = sharding.plan(8, 5, 20)                           # "auto" picks it whenever it is faster than replicating
-    assert (s.cfg, s.g, s.counts, s.views, s.has_pano, s.pano_src, s.vmax) == (1, 1, (1, 7, 6, 6), (1, 8), False, 4, 7)
+    assert (s.cfg, s.g, s.counts, s.views, s.has_pano, s.pano_src, s.vmax) == (1, 1, (0, 7, 7, 6), (0, 7), False, 4, 7)
     s = sharding.plan(8, 4, 20)
-    assert s.has_pano and s.views == (0, 1)
+    assert s.has_pano and s.views == (0, 0) and not s.has_views
     s = sharding.plan(4, 1, 20)
     assert s.pano_g == 0 and s.views == (6, 20) and not s.has_pano
     assert sharding.plan(4, 1, 20, layout="even").pano_g is None and sharding.plan(8, 1, 20, layout="even").views == (5, 10)
-    s = sharding.plan(16, 3, 20)                          # 8 groups: 1 / 3 3 3 3 3 2 2
-    assert sum(s.counts) == 20 and s.counts[0] == 1 and max(s.counts[1:]) - min(s.counts[1:]) <= 1
+    s = sharding.plan(8, 0, 20, split=(0, 7, 7, 6))      # explicit split only: a panorama-only owner
+    assert s.has_pano and not s.has_views and s.views == (0, 0) and sharding.plan(8, 1, 20, split=(0, 7, 7, 6)).views == (0, 7)
+    with pytest.raises(ValueError):
+        sharding.plan(8, 0, 20, split=(7, 0, 7, 6))      # only the owner may go without views
+    s = sharding.plan(16, 3, 20)                          # 8 groups: 0 / 3 3 3 3 3 3 2
+    assert sum(s.counts) == 20 and s.counts[0] == 0 and max(s.counts[1:]) - min(s.counts[1:]) <= 1
 
 
-@pytest.mark.parametrize("world,split,layout", [(2, None, None), (4, None, "even"), (4, None, None), (6, (2, 1, 1), None)])
+@pytest.mark.parametrize("world,split,layout", [(2, None, None), (4, None, "even"), (4, None, None), (6, (2, 1, 1), None),
+                                                (6, (0, 2, 2), None), (6, None, None)])
 def test_sharded_loop_equals_single_process(world, split, layout):
-    """(4, auto) and (6, (2, 1, 1)): the panorama-rank layout -- group 0 of a CFG half owns the panorama branch and
+    """(4, auto) = (0, 4), (6, auto) = (0, 2, 2) and (6, (2, 1, 1)): the panorama-rank layout -- group 0 of a CFG half owns the panorama branch and
     fewer views, the other ranks run the view branch only and receive the panorama tokens by broadcast (unequal,
-    padded gathers).  (4, "even"): views split evenly, panorama branch replicated."""
+    padded gathers).  (4, "even"): views split evenly, panorama branch replicated.  (6, (0, 2, 2)): a panorama-only
+    owner -- no view branch on ranks 0 / 3, they contribute empty blocks to the gathers."""
     want = _run_loop(False)
     with tempfile.TemporaryDirectory() as out:
         mp.spawn(_worker, args=(world, _free_port(), out, split, layout), nprocs=world, join=True)
