@@ -87,9 +87,9 @@ def test_plan_layout():
 
 
 @pytest.mark.parametrize("world,split,layout", [(2, None, None), (4, None, "even"), (4, None, None), (6, (2, 1, 1), None),
-                                                (6, (0, 2, 2), None), (6, None, None)])
+                                                (6, (0, 2, 2), None), (6, None, None), (8, None, None)])
 def test_sharded_loop_equals_single_process(world, split, layout):
-    """(4, auto) = (0, 4), (6, auto) = (0, 2, 2) and (6, (2, 1, 1)): the panorama-rank layout -- group 0 of a CFG half owns the panorama branch and
+    """(4, auto) = (0, 4), (6, auto) = (0, 2, 2), (8, auto) = (0, 2, 1, 1) and (6, (2, 1, 1)): the panorama-rank layout -- group 0 of a CFG half owns the panorama branch and
     fewer views, the other ranks run the view branch only and receive the panorama tokens by broadcast (unequal,
     padded gathers).  (4, "even"): views split evenly, panorama branch replicated.  (6, (0, 2, 2)): a panorama-only
     owner -- no view branch on ranks 0 / 3, they contribute empty blocks to the gathers."""
