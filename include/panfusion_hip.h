@@ -95,7 +95,8 @@ pf_status pf_epa_tables_build(const double* host_fov, const double* host_theta,
 
 /* GroupNorm statistics folded with the affine: for x [n_img][hw][C] (C = c0+c1 when two
  * sources are concatenated along channels, MVGenModel.py:231-233) writes scale/shift
- * [n_img][C] fp32 such that GN(x) = x*scale + shift.  workspace: pf_groupnorm_workspace_size. */
+ * [n_img][C] fp32 such that GN(x) = x*scale + shift.  workspace: pf_groupnorm_workspace_size.
+ * dtype (both sources): PF_BF16 / PF_F16, or PF_F32 for the fp32 residual stream of the mixed scheme. */
 size_t pf_groupnorm_workspace_size(int n_img, int hw, int C);
 pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, int c1, int dtype,
                              int n_img, int hw, int groups, float eps,
@@ -103,15 +104,22 @@ pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, int c1, int
                              float* scale, float* shift, void* workspace, size_t workspace_bytes,
                              void* stream);
 
-/* y = act(x*scale + shift), act 0 = identity, 1 = SiLU.  Same concat convention; y [n_img][hw][C]. */
+/* y = act(x*scale + shift), act 0 = identity, 1 = SiLU (scale = shift = NULL: y = act(x)).  Same concat
+ * convention.  dtype = type of the sources (16-bit or PF_F32).  Output:
+ *   out_dtype 16-bit, out_split 0:  y [n_img][hw][C]
+ *   out_dtype 16-bit, out_split 1:  y [n_img][hw][2C] = [hi | lo], hi = round16(v), lo = round16(v - hi):
+ *                                   the A operand of a split-precision GEMM (3 MFMA passes reproduce the
+ *                                   fp32 product to ~2^-22: A_hi W_hi + A_lo W_hi + A_hi W_lo)
+ *   out_dtype PF_F32:               y [n_img][hw][C] fp32. */
 pf_status pf_scale_shift_act(const void* x0, int c0, const void* x1, int c1, int dtype,
                              int n_img, int hw, const float* scale, const float* shift, int act,
-                             void* y, void* stream);
+                             int out_dtype, int out_split, void* y, void* stream);
 
 /* y = LayerNorm(x + pe) * gamma + beta over the last dim; x,y [rows][C]; pe (optional) fp32
- * [pe_rows][C], row r uses pe row (r % pe_rows) (transformer.py:155-158; eps 1e-5). */
+ * [pe_rows][C], row r uses pe row (r % pe_rows) (transformer.py:155-158; eps 1e-5).
+ * dtype: type of x (16-bit == out_dtype, or PF_F32); out_dtype: 16-bit type of y. */
 pf_status pf_layernorm(const void* x, const float* pe, long pe_rows, int dtype, long rows, int C,
-                       const float* gamma, const float* beta, float eps, void* y, void* stream);
+                       const float* gamma, const float* beta, float eps, int out_dtype, void* y, void* stream);
 
 /* GEGLU: in [rows][2*inner] = [a | gate] -> out [rows][inner] = a * gelu(gate) (erf GELU). */
 pf_status pf_geglu(const void* in, int dtype, long rows, int inner, void* out, void* stream);
@@ -123,7 +131,7 @@ pf_status pf_timestep_features(const int64_t* t, int n, int dim, int out_dtype, 
 /* y = silu(x) element-wise, n elements. */
 pf_status pf_silu(const void* x, int dtype, long n, void* y, void* stream);
 
-/* Circular width pad (utils/pano.py:74-99) and crop (:102-105) on NHWC: x [n][h][w][C]. */
+/* Circular width pad (utils/pano.py:74-99) and crop (:102-105) on NHWC: x [n][h][w][C], 16-bit or PF_F32. */
 pf_status pf_pad_width(const void* x, int dtype, int n, int h, int w, int C, int pad, void* y, void* stream);
 pf_status pf_crop_width(const void* x, int dtype, int n, int h, int w, int C, int crop, void* y, void* stream);
 
@@ -137,8 +145,9 @@ pf_status pf_roll_width_rows(const void* x, int elem_bytes, long rows, int w, in
 pf_status pf_nchw_to_nhwc(const void* x, int src_dtype, int n, int C, int h, int w, int dst_dtype, void* y, void* stream);
 pf_status pf_nhwc_to_nchw(const void* x, int src_dtype, int n, int C, int h, int w, int dst_dtype, void* y, void* stream);
 
-/* y = a + b element-wise (ControlNet residual adds, MVGenModel.py:154-170,200-203). */
-pf_status pf_add(const void* a, const void* b, int dtype, long n, void* y, void* stream);
+/* y = a + b element-wise (ControlNet residual adds, MVGenModel.py:154-170,200-203); a and y of type
+ * dtype_a, b of type dtype_b (any of PF_BF16 / PF_F16 / PF_F32). */
+pf_status pf_add(const void* a, int dtype_a, const void* b, int dtype_b, long n, void* y, void* stream);
 
 /* Fused classifier-free-guidance merge + DDIM update (+ optional width roll of the result):
  * eps = eps_uncond + g*(eps_cond - eps_uncond)                (PanoGenerator.py:253-262)
@@ -174,8 +183,9 @@ typedef struct {
     const float* bias;   /* [n_out] or NULL                                                 */
     const float* rowvec; /* [n_img][rowvec_ld] added per image (time embedding) or NULL     */
     int rowvec_ld;
-    const void* residual;/* [M][res_ld] 16-bit or NULL                                      */
+    const void* residual;/* [M][res_ld] (res_dtype) or NULL                                 */
     int res_ld;
+    int res_dtype;       /* == dtype, or PF_F32: the fp32 residual stream of the mixed scheme */
     void* out;           /* [M][out_ld]                                                     */
     int out_ld;
     int out_dtype;       /* PF_BF16 / PF_F16 (== dtype) or PF_F32                           */
@@ -202,10 +212,10 @@ pf_status pf_debug_gemm_profile(void* device_buffer, long capacity_blocks);
 pf_status pf_conv_gemm(const pf_conv_desc* desc, void* stream);
 
 /* 3x3 convolutions with 4 input or 4 output channels at the UNet boundary:
- * conv_in  (MVGenModel.py:86,89): x fp32 NCHW [n][cin][h][w] -> y NHWC 16-bit [n][h][w][cout],
- *          weights fp32 [3][3][cin][cout];
- * conv_out (MVGenModel.py:283,292): x NHWC 16-bit [n][h][w][cin] -> y fp32 NCHW [n][cout][h][w],
- *          weights fp32 [cout][3][3][cin], cout <= 8.
+ * conv_in  (MVGenModel.py:86,89): x fp32 NCHW [n][cin][h][w] -> y NHWC [n][h][w][cout] (out_dtype 16-bit
+ *          or PF_F32), weights fp32 [3][3][cin][cout];
+ * conv_out (MVGenModel.py:283,292): x NHWC [n][h][w][cin] (dtype 16-bit or PF_F32) -> y fp32 NCHW
+ *          [n][cout][h][w], weights fp32 [cout][3][3][cin], cout <= 8.
  * bias fp32 [cout]; zero padding 1 in y.  wrap = 1: the width axis is circular, which is exactly
  * pad_pano(x,1) -> conv(zero pad) -> unpad_pano(.,1) of the pano branch (MVGenModel.py:87-91,
  * 290-294); wrap = 0: zero padding in x. */

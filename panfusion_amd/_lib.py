@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
         ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int),
         ("w", c_void_p), ("n_out", c_int),
         ("bias", c_void_p), ("rowvec", c_void_p), ("rowvec_ld", c_int),
-        ("residual", c_void_p), ("res_ld", c_int),
+        ("residual", c_void_p), ("res_ld", c_int), ("res_dtype", c_int),
         ("out", c_void_p), ("out_ld", c_int), ("out_dtype", c_int), ("dtype", c_int),
         ("batch", c_int),
         ("a_bstride", c_long), ("w_bstride", c_long), ("out_bstride", c_long), ("res_bstride", c_long),
@@ -66,9 +66,9 @@ SIGNATURES = {
     "pf_groupnorm_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pf_scale_shift_act": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
-                                   c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_layernorm": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_int, c_void_p, c_void_p,
-                             c_float, c_void_p, c_void_p]),
+                             c_float, c_int, c_void_p, c_void_p]),
     "pf_geglu": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p]),
     "pf_timestep_features": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_silu": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p]),
@@ -78,7 +78,7 @@ SIGNATURES = {
     "pf_roll_width_rows": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p]),
     "pf_nchw_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_nhwc_to_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "pf_add": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "pf_add": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "pf_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,
                                  c_long, c_int, c_int, c_void_p, c_void_p]),
     "pf_conv_gemm": (c_int, [C.POINTER(ConvDesc), c_void_p]),

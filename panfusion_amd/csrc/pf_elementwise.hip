@@ -20,14 +20,36 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// 8 consecutive channels of a 16-bit (T = Bf16 / F16) or fp32 (F32In) tensor as floats.  `ptr` is typed
+// in units of the element, the octet must be 16-byte (16-bit) / 32-byte (fp32) aligned.
+struct F32In {};
+template <typename TI> struct In8 {
+    typedef unsigned short elem;
+    static __device__ __forceinline__ void load(const elem* ptr, float (&f)[8]) {
+        unpack8<TI>(*reinterpret_cast<const u16x8*>(ptr), f);
+    }
+};
+template <> struct In8<F32In> {
+    typedef float elem;
+    static __device__ __forceinline__ void load(const elem* ptr, float (&f)[8]) {
+        const float4 a = reinterpret_cast<const float4*>(ptr)[0], b = reinterpret_cast<const float4*>(ptr)[1];
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+};
+__device__ __forceinline__ void store8_f32(float* ptr, const float (&f)[8]) {
+    reinterpret_cast<float4*>(ptr)[0] = float4{f[0], f[1], f[2], f[3]};
+    reinterpret_cast<float4*>(ptr)[1] = float4{f[4], f[5], f[6], f[7]};
+}
+
 // ---- GroupNorm statistics ----------------------------------------------------------------------
 // Stage 1: per (image, pixel chunk) block -> per-group (sum, sumsq) partials, deterministic order.
 // Chunks are small (8..64 pixels, >= ~2000 blocks at the benchmark sizes) and every thread keeps
 // four independent 16-byte loads in flight: the pass is HBM-bound, not latency-bound.
-template <typename T>
-__global__ __launch_bounds__(256) void k_gn_partial(const unsigned short* __restrict__ x0, int c0,
-                             const unsigned short* __restrict__ x1, int c1, int hw, int groups,
+template <typename TI>
+__global__ __launch_bounds__(256) void k_gn_partial(const typename In8<TI>::elem* __restrict__ x0, int c0,
+                             const typename In8<TI>::elem* __restrict__ x1, int c1, int hw, int groups,
                              int pix_per_chunk, float* __restrict__ partial) {
+    typedef typename In8<TI>::elem elem;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = c0 + c1, OCT = C / 8, cpg = C / groups;
     const int OCTB = OCT < 256 ? OCT : 256;
@@ -46,23 +68,24 @@ __global__ __launch_bounds__(256) void k_gn_partial(const unsigned short* __rest
         for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
         if (slot < pix_par && oct < OCT) {
             const int c = oct * 8;
-            const unsigned short* base;
+            const elem* base;
             int ld, cc;
             if (c < c0) { base = x0; ld = c0; cc = c; } else { base = x1; ld = c1; cc = c - c0; }
             base += static_cast<long>(img) * hw * ld + cc;
             for (int p = p0 + slot; p < p1; p += 4 * pix_par) {
-                u16x8 v[4];
+                float v[4][8];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int pp = p + u * pix_par;
-                    v[u] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                    if (pp < p1) v[u] = *reinterpret_cast<const u16x8*>(base + static_cast<long>(pp) * ld);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[u][j] = 0.f;
+                    if (pp < p1) In8<TI>::load(base + static_cast<long>(pp) * ld, v[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float f = to_f32<T>(v[u][j]);
+                        const float f = v[u][j];
                         s[j] += f;
                         q[j] += f * f;
                     }
@@ -129,17 +152,21 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ p
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_scale_shift_act(const unsigned short* __restrict__ x0, int c0,
-                                  const unsigned short* __restrict__ x1, int c1, int hw,
+// y = act(x * scale + shift) (scale == nullptr: identity), x = channel concat of two sources, 16-bit or fp32.
+// OUT 0: 16-bit T [pix][C];  OUT 1: split pair [pix][hi(C) | lo(C)] with hi = round16(v), lo = round16(v - hi)
+// (the A operand of a split-precision GEMM, engine.py);  OUT 2: fp32 [pix][C].
+template <typename TI, typename T, int OUT>
+__global__ __launch_bounds__(256) void k_scale_shift_act(const typename In8<TI>::elem* __restrict__ x0, int c0,
+                                  const typename In8<TI>::elem* __restrict__ x1, int c1, int hw,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                  int act, unsigned short* __restrict__ y) {
-    // grid (octet pairs of one image, image): 32-bit index arithmetic only, two 16-byte loads in flight per thread
+                                  int act, void* __restrict__ yv) {
+    typedef typename In8<TI>::elem elem;
+    // grid (octet pairs of one image, image): 32-bit index arithmetic only, two octet loads in flight per thread
     const unsigned C = c0 + c1, OCT = C / 8, per_img = static_cast<unsigned>(hw) * OCT;
     const unsigned img = blockIdx.y;
     const unsigned j0 = (blockIdx.x * 256u + threadIdx.x) * 2u;
     if (j0 >= per_img) return;
-    u16x8 v[2];
+    float v[2][8];
     unsigned cc[2];
     long pix[2];
 #pragma unroll
@@ -148,24 +175,42 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const unsigned short* _
         const unsigned p = j / OCT, c = (j - p * OCT) * 8;
         cc[u] = c;
         pix[u] = static_cast<long>(img) * hw + p;
-        const unsigned short* src = (c < static_cast<unsigned>(c0)) ? x0 + pix[u] * c0 + c : x1 + pix[u] * c1 + (c - c0);
-        v[u] = *reinterpret_cast<const u16x8*>(src);
+        const elem* src = (c < static_cast<unsigned>(c0)) ? x0 + pix[u] * c0 + c : x1 + pix[u] * c1 + (c - c0);
+        In8<TI>::load(src, v[u]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         if (j0 + u >= per_img) break;
-        const float4* sc = reinterpret_cast<const float4*>(scale + static_cast<long>(img) * C + cc[u]);
-        const float4* sh = reinterpret_cast<const float4*>(shift + static_cast<long>(img) * C + cc[u]);
-        float4 s0 = sc[0], s1 = sc[1], h0 = sh[0], h1 = sh[1];
-        const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
         float f[8];
+        if (scale) {
+            const float4* sc = reinterpret_cast<const float4*>(scale + static_cast<long>(img) * C + cc[u]);
+            const float4* sh = reinterpret_cast<const float4*>(shift + static_cast<long>(img) * C + cc[u]);
+            float4 s0 = sc[0], s1 = sc[1], h0 = sh[0], h1 = sh[1];
+            const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float r = to_f32<T>(v[u][j]) * sv[j] + hv[j];
-            f[j] = act ? r / (1.0f + expf(-r)) : r;
+            for (int j = 0; j < 8; ++j) f[j] = v[u][j] * sv[j] + hv[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = v[u][j];
         }
-        *reinterpret_cast<u16x8*>(y + pix[u] * C + cc[u]) = pack8<T>(f);
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = f[j] / (1.0f + expf(-f[j]));
+        }
+        if (OUT == 0) {
+            *reinterpret_cast<u16x8*>(static_cast<unsigned short*>(yv) + pix[u] * C + cc[u]) = pack8<T>(f);
+        } else if (OUT == 1) {
+            unsigned short* y = static_cast<unsigned short*>(yv) + pix[u] * (2 * C) + cc[u];
+            const u16x8 hi = pack8<T>(f);
+            float lo[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo[j] = f[j] - to_f32<T>(hi[j]);
+            *reinterpret_cast<u16x8*>(y) = hi;
+            *reinterpret_cast<u16x8*>(y + C) = pack8<T>(lo);
+        } else {
+            store8_f32(static_cast<float*>(yv) + pix[u] * C + cc[u], f);
+        }
     }
 }
 
@@ -173,8 +218,8 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const unsigned short* _
 // One wavefront normalises ROWS rows at a time; all their 16-byte loads are issued before the first
 // reduction (a 640-byte row per wave in flight is too little to cover HBM latency: 2.9 TB/s measured with
 // one row per wave).  A row lives in registers (<= 4 octets per lane, C <= 2048).
-template <typename T, int ROWS>
-__global__ __launch_bounds__(256) void k_layernorm(const unsigned short* __restrict__ x, const float* __restrict__ pe,
+template <typename TI, typename T, int ROWS>
+__global__ __launch_bounds__(256) void k_layernorm(const typename In8<TI>::elem* __restrict__ x, const float* __restrict__ pe,
                             long pe_rows, long rows, int C, const float* __restrict__ gamma,
                             const float* __restrict__ beta, float eps, unsigned short* __restrict__ y) {
     const int lane = threadIdx.x & 63;
@@ -182,26 +227,26 @@ __global__ __launch_bounds__(256) void k_layernorm(const unsigned short* __restr
     if (row0 >= rows) return;
     const int OCT = C / 8;
     constexpr int KMAX = ROWS == 1 ? 4 : 1;            // octets per lane per row (the multi-row form: C <= 512)
-    u16x8 raw[ROWS][KMAX];
+    float raw[ROWS][KMAX][8];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int oct = lane + 64 * k;
-            raw[r][k] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (oct < OCT && row0 + r < rows) raw[r][k] = *reinterpret_cast<const u16x8*>(x + (row0 + r) * C + oct * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[r][k][j] = 0.f;
+            if (oct < OCT && row0 + r < rows) In8<TI>::load(x + (row0 + r) * C + oct * 8, raw[r][k]);
         }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const long row = row0 + r;
         if (row >= rows) break;
-        float v[KMAX][8];
+        float (&v)[KMAX][8] = raw[r];
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int oct = lane + 64 * k;
             if (oct < OCT) {
-                unpack8<T>(raw[r][k], v[k]);
                 if (pe) {
                     const float4* pp = reinterpret_cast<const float4*>(pe + (row % pe_rows) * C + oct * 8);
                     float4 a = pp[0], b = pp[1];
@@ -270,13 +315,6 @@ __global__ void k_silu(const unsigned short* __restrict__ x, long n, unsigned sh
     y[i] = from_f32<T>(v / (1.0f + expf(-v)));
 }
 
-template <typename T>
-__global__ void k_add(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b, long n,
-                      unsigned short* __restrict__ y) {
-    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
-    if (i >= n) return;
-    y[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[i]));
-}
 
 // diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0): [cos(t f_i) | sin(t f_i)], fp32 math.
 template <typename T>
@@ -331,6 +369,14 @@ template <> __device__ __forceinline__ void st_any<AnyF32>(void* p, long i, floa
 template <> __device__ __forceinline__ void st_any<AnyBf16>(void* p, long i, float v) { static_cast<unsigned short*>(p)[i] = from_f32<Bf16>(v); }
 template <> __device__ __forceinline__ void st_any<AnyF16>(void* p, long i, float v) { static_cast<unsigned short*>(p)[i] = from_f32<F16>(v); }
 
+// y = a + b element-wise; a / y of type SA, b of type SB (fp32 stream + 16-bit ControlNet residual, ...)
+template <typename SA, typename SB>
+__global__ void k_add(const void* __restrict__ a, const void* __restrict__ b, long n, void* __restrict__ y) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    st_any<SA>(y, i, ld_any<SA>(a, i) + ld_any<SB>(b, i));
+}
+
 // out index enumerates the DESTINATION (coalesced writes).
 template <typename SI, typename SO, bool TO_NHWC>
 __global__ void k_permute(const void* x, int n, int C, long hw, void* y) {
@@ -367,10 +413,10 @@ __global__ void k_cfg_ddim(const float* __restrict__ x, const float* __restrict_
 
 // ---- boundary convolutions ---------------------------------------------------------------------
 // conv_in: x fp32 NCHW [n][cin][h][w] -> y NHWC 16-bit; weights fp32 [3][3][cin][cout].
-template <typename T>
+template <typename T, bool OUT_F32>
 __global__ void k_conv_in(const float* __restrict__ x, int n, int cin, int h, int w,
                           const float* __restrict__ wgt, const float* __restrict__ bias, int cout,
-                          int wrap, unsigned short* __restrict__ y) {
+                          int wrap, void* __restrict__ y) {
     long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
     const int OCT = cout / 8;
     long total = static_cast<long>(n) * h * w * OCT;
@@ -397,13 +443,14 @@ __global__ void k_conv_in(const float* __restrict__ x, int n, int cin, int h, in
             }
         }
     }
-    *reinterpret_cast<u16x8*>(y + pix * cout + oct * 8) = pack8<T>(acc);
+    if (OUT_F32) store8_f32(static_cast<float*>(y) + pix * cout + oct * 8, acc);
+    else *reinterpret_cast<u16x8*>(static_cast<unsigned short*>(y) + pix * cout + oct * 8) = pack8<T>(acc);
 }
 
 // conv_out: x NHWC 16-bit [n][h][w][cin] -> y fp32 NCHW [n][cout<=8][h][w]; weights fp32
 // [cout][3][3][cin].  One wavefront per output pixel, lanes over the channel octets of each tap.
-template <typename T>
-__global__ void k_conv_out(const unsigned short* __restrict__ x, int n, int cin, int h, int w,
+template <typename TI>
+__global__ void k_conv_out(const typename In8<TI>::elem* __restrict__ x, int n, int cin, int h, int w,
                            const float* __restrict__ wgt, const float* __restrict__ bias, int cout,
                            int wrap, float* __restrict__ y) {
     const int lane = threadIdx.x & 63;
@@ -420,10 +467,10 @@ __global__ void k_conv_out(const unsigned short* __restrict__ x, int n, int cin,
         int xi = xx + tap % 3 - 1;
         if (wrap) xi = (xi + w) % w;
         if (yi < 0 || yi >= h || xi < 0 || xi >= w) continue;   // wave-uniform
-        const unsigned short* src = x + ((static_cast<long>(b) * h + yi) * w + xi) * cin;
+        const typename In8<TI>::elem* src = x + ((static_cast<long>(b) * h + yi) * w + xi) * cin;
         for (int oct = lane; oct < OCT; oct += 64) {
             float f[8];
-            unpack8<T>(*reinterpret_cast<const u16x8*>(src + oct * 8), f);
+            In8<TI>::load(src + oct * 8, f);
 #pragma unroll
             for (int co = 0; co < 8; ++co) {
                 if (co >= cout) break;
@@ -445,6 +492,15 @@ __global__ void k_conv_out(const unsigned short* __restrict__ x, int n, int cin,
 }  // namespace pf
 
 using namespace pf;
+
+// Dispatch an INPUT dtype (16-bit or fp32) to the loader tag TI.
+#define PF_DISPATCH_IN(dtype, name, ...)                                          \
+    do {                                                                          \
+        if ((dtype) == PF_BF16) { using TI = pf::Bf16; __VA_ARGS__; }             \
+        else if ((dtype) == PF_F16) { using TI = pf::F16; __VA_ARGS__; }          \
+        else if ((dtype) == PF_F32) { using TI = pf::F32In; __VA_ARGS__; }        \
+        else { pf::set_error("%s: dtype must be PF_BF16, PF_F16 or PF_F32", name); return PF_ERR_ARG; } \
+    } while (0)
 
 // pixels per statistics chunk: ~2048 blocks in flight, 8..64 pixels each, at most 256 chunks per image
 static int gn_pixels_per_chunk(int n_img, int hw) {
@@ -474,6 +530,7 @@ extern "C" pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, 
     PF_REQUIRE(n_img > 0 && hw > 0 && groups > 0 && groups <= 64, "pf_groupnorm_stats: bad sizes");
     PF_REQUIRE(C % 8 == 0 && c0 % 8 == 0 && C % groups == 0, "pf_groupnorm_stats: C=%d must be a multiple of 8 and of groups=%d", C, groups);
     PF_REQUIRE(aligned16(x0) && (!x1 || aligned16(x1)), "pf_groupnorm_stats: inputs must be 16-byte aligned");
+    PF_REQUIRE(dtype != PF_F32 || (c0 % 4 == 0 && c1 % 4 == 0), "pf_groupnorm_stats: fp32 sources need c0, c1 %% 4 == 0");
     PF_REQUIRE(ws_bytes >= pf_groupnorm_workspace_size(n_img, hw, C), "pf_groupnorm_stats: workspace too small");
     const int ppc = gn_pixels_per_chunk(n_img, hw);
     const int nchunks = static_cast<int>(cdiv(hw, ppc));
@@ -482,9 +539,9 @@ extern "C" pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, 
     PF_REQUIRE(smem <= 64 * 1024, "pf_groupnorm_stats: C=%d too large", C);
     hipStream_t st = as_stream(stream);
     float* partial = static_cast<float*>(workspace);
-    PF_DISPATCH_16(dtype, "pf_groupnorm_stats",
-        hipLaunchKernelGGL(k_gn_partial<T>, dim3(nchunks, n_img), dim3(256), smem, st,
-                           static_cast<const unsigned short*>(x0), c0, static_cast<const unsigned short*>(x1), c1,
+    PF_DISPATCH_IN(dtype, "pf_groupnorm_stats",
+        hipLaunchKernelGGL(k_gn_partial<TI>, dim3(nchunks, n_img), dim3(256), smem, st,
+                           static_cast<const In8<TI>::elem*>(x0), c0, static_cast<const In8<TI>::elem*>(x1), c1,
                            hw, groups, ppc, partial));
     hipLaunchKernelGGL(k_gn_finalize, dim3(n_img), dim3(256), 0, st, partial, nchunks, groups, C, hw, eps,
                        gamma, beta, scale, shift);
@@ -494,40 +551,60 @@ extern "C" pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, 
 
 extern "C" pf_status pf_scale_shift_act(const void* x0, int c0, const void* x1, int c1, int dtype,
                                         int n_img, int hw, const float* scale, const float* shift,
-                                        int act, void* y, void* stream) {
+                                        int act, int out_dtype, int out_split, void* y, void* stream) {
     if (!x1) c1 = 0;
     const int C = c0 + c1;
-    PF_REQUIRE(x0 && scale && shift && y, "pf_scale_shift_act: null pointer");
+    PF_REQUIRE(x0 && y, "pf_scale_shift_act: null pointer");
+    PF_REQUIRE((scale == nullptr) == (shift == nullptr), "pf_scale_shift_act: scale and shift must both be given or both be NULL");
     PF_REQUIRE(C % 8 == 0 && c0 % 8 == 0 && n_img > 0 && hw > 0, "pf_scale_shift_act: bad sizes");
-    PF_REQUIRE(aligned16(x0) && aligned16(y) && (!x1 || aligned16(x1)) && aligned16(scale) && aligned16(shift),
+    PF_REQUIRE(aligned16(x0) && aligned16(y) && (!x1 || aligned16(x1)) && (!scale || (aligned16(scale) && aligned16(shift))),
                "pf_scale_shift_act: pointers must be 16-byte aligned");
+    PF_REQUIRE(out_dtype == PF_BF16 || out_dtype == PF_F16 || (out_dtype == PF_F32 && !out_split),
+               "pf_scale_shift_act: out_dtype must be 16-bit (optionally split) or PF_F32");
+    PF_REQUIRE(dtype == PF_F32 || out_dtype == PF_F32 || dtype == out_dtype, "pf_scale_shift_act: 16-bit input and output types must agree");
     const long per_img = static_cast<long>(hw) * (C / 8);
     PF_REQUIRE(per_img < (1L << 31) && n_img <= 65535, "pf_scale_shift_act: image too large / too many images");
-    PF_DISPATCH_16(dtype, "pf_scale_shift_act",
-        hipLaunchKernelGGL(k_scale_shift_act<T>, dim3(cdiv(per_img, 512), n_img), dim3(256), 0, as_stream(stream),
-                           static_cast<const unsigned short*>(x0), c0, static_cast<const unsigned short*>(x1), c1,
-                           hw, scale, shift, act, static_cast<unsigned short*>(y)));
+    const dim3 grid(cdiv(per_img, 512), n_img), block(256);
+    hipStream_t st = as_stream(stream);
+#define PF_SSA(TI, T, OUT) hipLaunchKernelGGL((k_scale_shift_act<TI, T, OUT>), grid, block, 0, st,                      \
+                                              static_cast<const In8<TI>::elem*>(x0), c0,                                \
+                                              static_cast<const In8<TI>::elem*>(x1), c1, hw, scale, shift, act, y)
+    const int out_kind = out_dtype == PF_F32 ? 2 : (out_split ? 1 : 0);
+    // T = the 16-bit type on whichever side has one (bf16 when both sides are fp32: unused)
+    const int t16 = out_dtype != PF_F32 ? out_dtype : (dtype != PF_F32 ? dtype : PF_BF16);
+    PF_DISPATCH_16(t16, "pf_scale_shift_act",
+        if (dtype == PF_F32) {
+            if (out_kind == 0) PF_SSA(F32In, T, 0); else if (out_kind == 1) PF_SSA(F32In, T, 1); else PF_SSA(F32In, T, 2);
+        } else {
+            if (out_kind == 0) PF_SSA(T, T, 0); else if (out_kind == 1) PF_SSA(T, T, 1); else PF_SSA(T, T, 2);
+        });
+#undef PF_SSA
     PF_CHECK_LAUNCH("pf_scale_shift_act");
     return PF_OK;
 }
 
 extern "C" pf_status pf_layernorm(const void* x, const float* pe, long pe_rows, int dtype, long rows,
-                                  int C, const float* gamma, const float* beta, float eps, void* y,
+                                  int C, const float* gamma, const float* beta, float eps, int out_dtype, void* y,
                                   void* stream) {
     PF_REQUIRE(x && gamma && beta && y && rows > 0, "pf_layernorm: bad arguments");
     PF_REQUIRE(C % 8 == 0 && C <= 2048, "pf_layernorm: C=%d must be a multiple of 8 and <= 2048", C);
     PF_REQUIRE(!pe || pe_rows > 0, "pf_layernorm: pe_rows must be > 0 with pe");
     PF_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!pe || aligned16(pe)),
                "pf_layernorm: pointers must be 16-byte aligned");
-    PF_DISPATCH_16(dtype, "pf_layernorm",
-        if (C <= 512 && rows >= 4096)      // narrow rows: 4 rows per wavefront in flight
-            hipLaunchKernelGGL((k_layernorm<T, 4>), dim3(cdiv(rows, 16)), dim3(256), 0, as_stream(stream),
-                               static_cast<const unsigned short*>(x), pe, pe_rows, rows, C, gamma, beta, eps,
-                               static_cast<unsigned short*>(y));
-        else
-            hipLaunchKernelGGL((k_layernorm<T, 1>), dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream),
-                               static_cast<const unsigned short*>(x), pe, pe_rows, rows, C, gamma, beta, eps,
-                               static_cast<unsigned short*>(y)));
+    PF_REQUIRE(dtype == PF_F32 || dtype == out_dtype, "pf_layernorm: a 16-bit input must have the output's type");
+    hipStream_t st = as_stream(stream);
+    unsigned short* yo = static_cast<unsigned short*>(y);
+#define PF_LN(TI, T) do {                                                                                                \
+        if (C <= 512 && rows >= 4096)      /* narrow rows: 4 rows per wavefront in flight */                             \
+            hipLaunchKernelGGL((k_layernorm<TI, T, 4>), dim3(cdiv(rows, 16)), dim3(256), 0, st,                          \
+                               static_cast<const In8<TI>::elem*>(x), pe, pe_rows, rows, C, gamma, beta, eps, yo);        \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_layernorm<TI, T, 1>), dim3(cdiv(rows, 4)), dim3(256), 0, st,                           \
+                               static_cast<const In8<TI>::elem*>(x), pe, pe_rows, rows, C, gamma, beta, eps, yo);        \
+    } while (0)
+    PF_DISPATCH_16(out_dtype, "pf_layernorm",
+        if (dtype == PF_F32) PF_LN(F32In, T); else PF_LN(T, T));
+#undef PF_LN
     PF_CHECK_LAUNCH("pf_layernorm");
     return PF_OK;
 }
@@ -562,12 +639,24 @@ extern "C" pf_status pf_silu(const void* x, int dtype, long n, void* y, void* st
     return PF_OK;
 }
 
-extern "C" pf_status pf_add(const void* a, const void* b, int dtype, long n, void* y, void* stream) {
+extern "C" pf_status pf_add(const void* a, int dtype_a, const void* b, int dtype_b, long n, void* y, void* stream) {
     PF_REQUIRE(a && b && y && n > 0, "pf_add: bad arguments");
-    PF_DISPATCH_16(dtype, "pf_add",
-        hipLaunchKernelGGL(k_add<T>, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream),
-                           static_cast<const unsigned short*>(a), static_cast<const unsigned short*>(b), n,
-                           static_cast<unsigned short*>(y)));
+    const dim3 grid(cdiv(n, 256)), block(256);
+    hipStream_t st = as_stream(stream);
+#define PF_ADD(SA, SB) hipLaunchKernelGGL((k_add<SA, SB>), grid, block, 0, st, a, b, n, y)
+#define PF_ADD_B(SA)                                                                  \
+    do {                                                                              \
+        if (dtype_b == PF_F32) PF_ADD(SA, AnyF32);                                    \
+        else if (dtype_b == PF_BF16) PF_ADD(SA, AnyBf16);                             \
+        else if (dtype_b == PF_F16) PF_ADD(SA, AnyF16);                               \
+        else PF_REQUIRE(false, "pf_add: unknown dtype_b %d", dtype_b);               \
+    } while (0)
+    if (dtype_a == PF_F32) PF_ADD_B(AnyF32);
+    else if (dtype_a == PF_BF16) PF_ADD_B(AnyBf16);
+    else if (dtype_a == PF_F16) PF_ADD_B(AnyF16);
+    else PF_REQUIRE(false, "pf_add: unknown dtype_a %d", dtype_a);
+#undef PF_ADD_B
+#undef PF_ADD
     PF_CHECK_LAUNCH("pf_add");
     return PF_OK;
 }
@@ -575,8 +664,9 @@ extern "C" pf_status pf_add(const void* a, const void* b, int dtype, long n, voi
 static pf_status shift_width(const void* x, int dtype, int n, int h, int w_in, int w_out, int C, int offset,
                              void* y, void* stream, const char* who) {
     PF_REQUIRE(x && y && n > 0 && h > 0 && w_in > 0 && w_out > 0, "%s: bad sizes", who);
-    PF_REQUIRE(dtype == PF_BF16 || dtype == PF_F16, "%s: dtype must be 16-bit", who);
-    PF_REQUIRE(C % 8 == 0 && aligned16(x) && aligned16(y), "%s: C %% 8 and 16-byte alignment required", who);
+    PF_REQUIRE(dtype == PF_BF16 || dtype == PF_F16 || dtype == PF_F32, "%s: unknown dtype", who);
+    if (dtype == PF_F32) C *= 2;                         // whole pixels are moved: an fp32 channel = two 16-bit words
+    PF_REQUIRE(C % 8 == 0 && aligned16(x) && aligned16(y), "%s: 16-byte pixels and alignment required", who);
     const long total = static_cast<long>(n) * h * w_out * (C / 8);
     hipLaunchKernelGGL(k_shift_width, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
                        static_cast<const u16x8*>(x), n * h, w_in, w_out, C / 8, offset, static_cast<u16x8*>(y));
@@ -663,9 +753,13 @@ extern "C" pf_status pf_conv_in(const float* x, int n, int cin, int h, int w, co
     PF_REQUIRE(x && wgt && y && n > 0 && cin > 0 && h > 0 && w > 0, "pf_conv_in: bad arguments");
     PF_REQUIRE(cout % 8 == 0 && aligned16(wgt) && aligned16(y), "pf_conv_in: cout %% 8 and 16-byte alignment required");
     const long total = static_cast<long>(n) * h * w * (cout / 8);
-    PF_DISPATCH_16(out_dtype, "pf_conv_in",
-        hipLaunchKernelGGL(k_conv_in<T>, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), x, n, cin, h, w,
-                           wgt, bias, cout, wrap, static_cast<unsigned short*>(y)));
+    if (out_dtype == PF_F32)
+        hipLaunchKernelGGL((k_conv_in<Bf16, true>), dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), x, n, cin, h, w,
+                           wgt, bias, cout, wrap, y);
+    else
+        PF_DISPATCH_16(out_dtype, "pf_conv_in",
+            hipLaunchKernelGGL((k_conv_in<T, false>), dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), x, n, cin, h, w,
+                               wgt, bias, cout, wrap, y));
     PF_CHECK_LAUNCH("pf_conv_in");
     return PF_OK;
 }
@@ -676,9 +770,9 @@ extern "C" pf_status pf_conv_out(const void* x, int dtype, int n, int cin, int h
     PF_REQUIRE(cin % 8 == 0 && cout > 0 && cout <= 8, "pf_conv_out: cin %% 8 == 0 and cout <= 8 required");
     PF_REQUIRE(aligned16(x) && aligned16(wgt), "pf_conv_out: 16-byte alignment required");
     const long npix = static_cast<long>(n) * h * w;
-    PF_DISPATCH_16(dtype, "pf_conv_out",
-        hipLaunchKernelGGL(k_conv_out<T>, dim3(cdiv(npix, 4)), dim3(256), 0, as_stream(stream),
-                           static_cast<const unsigned short*>(x), n, cin, h, w, wgt, bias, cout, wrap, y));
+    PF_DISPATCH_IN(dtype, "pf_conv_out",
+        hipLaunchKernelGGL(k_conv_out<TI>, dim3(cdiv(npix, 4)), dim3(256), 0, as_stream(stream),
+                           static_cast<const In8<TI>::elem*>(x), n, cin, h, w, wgt, bias, cout, wrap, y));
     PF_CHECK_LAUNCH("pf_conv_out");
     return PF_OK;
 }

@@ -37,7 +37,7 @@ struct GemmParams {
     int m_begin;
     int rows_per_img;
     const float* bias; const float* rowvec; int rowvec_ld;
-    const unsigned short* residual; int res_ld;
+    const void* residual; int res_ld; int res_f32;   // residual: 16-bit T, or fp32 (the fp32 residual stream)
     void* out; int out_ld; int out_f32; int geglu;
     long a_bs, w_bs, out_bs, res_bs;
     int mtiles, ntiles;
@@ -111,8 +111,11 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
         const float4 b = *reinterpret_cast<const float4*>(p.rowvec + static_cast<long>(img) * p.rowvec_ld + n4);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    if (p.residual) {
-        const u16x4 r = *reinterpret_cast<const u16x4*>(p.residual + bz * p.res_bs + static_cast<long>(m) * p.res_ld + n4);
+    if (p.residual && p.res_f32) {
+        const float4 r = *reinterpret_cast<const float4*>(static_cast<const float*>(p.residual) + bz * p.res_bs + static_cast<long>(m) * p.res_ld + n4);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    } else if (p.residual) {
+        const u16x4 r = *reinterpret_cast<const u16x4*>(static_cast<const unsigned short*>(p.residual) + bz * p.res_bs + static_cast<long>(m) * p.res_ld + n4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(r[e]);
     }
@@ -172,7 +175,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x
 #pragma unroll
         for (int j = 0; j < NREP; ++j) bias[j] = *reinterpret_cast<const float4*>(p.bias + ncl[j]);
     }
-    const unsigned short* resp = MODE == 2 ? p.residual + bz * p.res_bs : nullptr;
+    const unsigned short* resp = MODE == 2 ? static_cast<const unsigned short*>(p.residual) + bz * p.res_bs : nullptr;
     // MODE 1 (requires rows_per_img >= BM: the tile touches two images at most): both candidate row
     // vectors are fetched up front, a row picks one by comparing its offset with the image boundary
     float4 rv0[NREP], rv1[NREP];
@@ -274,6 +277,66 @@ __device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x
     static_assert(NG <= 4, "unrolled by hand");
 }
 
+// fp32 block epilogue of the mixed-precision scheme (the residual stream is fp32): bias (+ fp32 residual)
+// on the accumulators, stored straight from the fragments -- a lane owns 4 consecutive fp32 columns
+// (16 bytes), the four column groups of a fragment make a 64-byte row segment, so no LDS staging is
+// needed.  Straight-line like epilogue_fast: rows / quads beyond the edge are clamped for the loads and
+// only the store is predicated; the residual of a group of two fragment rows is requested one group ahead.
+template <typename T, int MREP, int NREP, bool RES>
+__device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4 (&acc)[MREP][NREP],
+                                             int m0, int n0, int row_base, int col_base, int lane) {
+    constexpr int G = 1, NG = MREP / G;                           // (two fp32 row groups in flight would spill)
+    const int cq = 4 * (lane >> 4), rl = lane & 15;
+    int ncl[NREP];
+    bool nok[NREP];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+        const int n4 = n0 + col_base + j * 16 + cq;
+        nok[j] = n4 < p.N;
+        ncl[j] = min(n4, p.N - 4);
+    }
+    float4 bias[NREP];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) bias[j] = float4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) bias[j] = *reinterpret_cast<const float4*>(p.bias + ncl[j]);
+    }
+    const float* resp = RES ? static_cast<const float*>(p.residual) + bz * p.res_bs : nullptr;
+    float* outp = static_cast<float*>(p.out) + bz * p.out_bs;
+    float4 res[2][G][NREP];
+    auto request = [&](int g, int bf) {
+        if (!RES) return;
+#pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            const int mc = min(m0 + row_base + (g * G + ii) * 16 + rl, p.M - 1);
+            const float* rp = resp + static_cast<long>(mc) * p.res_ld;
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) res[bf][ii][j] = *reinterpret_cast<const float4*>(rp + ncl[j]);
+        }
+    };
+    request(0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) request(g + 1, (g + 1) & 1);
+#pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            const int i = g * G + ii;
+            const int m = m0 + row_base + i * 16 + rl;
+            float* op = outp + static_cast<long>(min(m, p.M - 1)) * p.out_ld;
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) {
+                float4 v = float4{acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z, acc[i][j][3] + bias[j].w};
+                if (RES) {
+                    const float4 r = res[g & 1][ii][j];
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (m < p.M && nok[j]) *reinterpret_cast<float4*>(op + ncl[j]) = v;
+            }
+        }
+    }
+}
+
 // Block epilogue.  All arithmetic (bias, per-image row vector, residual, GEGLU) runs in the MFMA
 // fragment layout on the fp32 accumulators -- one rounding to 16 bit.  16-bit outputs with 16-byte
 // aligned rows take one of the staged specialisations above; everything else (fp32 output, ragged or
@@ -290,7 +353,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, long bz, f32x
     after_ring();
     stamp(p, 5);
     const int n_store = p.geglu ? p.N >> 1 : p.N;
-    const bool staged = !p.out_f32 && (p.out_ld & 7) == 0 && (n_store & 7) == 0 && (p.N & 3) == 0;
+    if (p.out_f32 && !p.geglu && !p.rowvec && (p.N & 3) == 0 && (p.out_ld & 3) == 0 && p.N >= 4) {
+        if (!p.residual) { epilogue_f32<T, MREP, NREP, false>(p, bz, acc, m0, n0, row_base, col_base, lane); return; }
+        if (p.res_f32 && (p.res_ld & 3) == 0) { epilogue_f32<T, MREP, NREP, true>(p, bz, acc, m0, n0, row_base, col_base, lane); return; }
+    }
+    const bool staged = !p.out_f32 && !p.res_f32 && (p.out_ld & 7) == 0 && (n_store & 7) == 0 && (p.N & 3) == 0;
     if (staged && !(p.rowvec && p.residual) && !(p.geglu && (p.rowvec || p.residual))) {
         if (p.geglu) epilogue_fast<T, MREP, NREP, NT, BM, BN, HALVES, 3>(p, bz, acc, smem16, m0, n0, row_base, col_base, lane, t);
         else if (p.rowvec && p.rows_per_img < BM) goto generic;
@@ -1016,6 +1083,7 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     PF_REQUIRE(d->a0 && d->w && d->out, "pf_conv_gemm: null pointer");
     PF_REQUIRE(d->dtype == PF_BF16 || d->dtype == PF_F16, "pf_conv_gemm: dtype must be PF_BF16 or PF_F16");
     PF_REQUIRE(d->out_dtype == d->dtype || d->out_dtype == PF_F32, "pf_conv_gemm: out_dtype must equal dtype or be PF_F32");
+    PF_REQUIRE(!d->residual || d->res_dtype == d->dtype || d->res_dtype == PF_F32, "pf_conv_gemm: res_dtype must equal dtype or be PF_F32");
     const int c1 = d->a1 ? d->c1 : 0;
     const int Ctot = d->c0 + c1;
     PF_REQUIRE(d->c0 > 0 && d->c0 % 64 == 0 && c1 % 64 == 0, "pf_conv_gemm: channel counts (%d,%d) must be multiples of 64", d->c0, c1);
@@ -1056,7 +1124,8 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     p.rows_per_img = d->h_out * d->w_out;
     p.M = d->n_img * p.rows_per_img; p.N = d->n_out; p.K = d->ksize * d->ksize * Ctot;
     p.bias = d->bias; p.rowvec = d->rowvec; p.rowvec_ld = d->rowvec_ld;
-    p.residual = static_cast<const unsigned short*>(d->residual); p.res_ld = d->res_ld;
+    p.residual = d->residual; p.res_ld = d->res_ld;
+    p.res_f32 = d->residual != nullptr && d->res_dtype == PF_F32;
     p.out = d->out; p.out_ld = d->out_ld; p.out_f32 = d->out_dtype == PF_F32;
     p.geglu = d->epilogue == PF_EPILOGUE_GEGLU;
     p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;

@@ -5,14 +5,39 @@ Takes module trees with the diffusers SD-2 UNet attribute layout (what
 and the EPA blocks, repacks their weights ONCE into the kernel layouts
 (16-bit, K-contiguous, LoRA folded, q|k projections fused, all time-embedding
 projections of a UNet concatenated), and runs the forward as a sequence of
-C-ABI calls on the current stream.  Activations stay NHWC / token-major 16-bit
+C-ABI calls on the current stream.  Activations stay NHWC / token-major
 between kernels; nothing here computes on the host.
+
+Two storage schemes (``precision``):
+  * ``"fast"``  -- every activation 16-bit (bf16 / fp16), fp32 accumulation: the round-1 path.
+  * ``"mixed"`` -- the scheme that meets north_star's 1e-3 rel-L2 with fp16 operands (error budget:
+    tools/precision_study.py, profiles/r2_precision_budget.txt).  MFMA operands stay 16-bit; the residual
+    streams (block outputs, the token stream inside a transformer block, the shortcut) are fp32; and the few
+    GEMMs that map the stream linearly onto itself -- resnet shortcut 1x1, proj_in, proj_out, the
+    downsampling conv -- run as SPLIT-PRECISION GEMMs: A = A_hi + A_lo, W = W_hi + W_lo (16-bit each),
+    A_hi W_hi + A_lo W_hi + A_hi W_lo in one launch of the same kernel with K' = 3K (the operand is stored
+    as [hi | lo], the kernel's two-source channel concat reads it as [hi | lo] + [hi], the weights are
+    packed [W_hi | W_hi | W_lo] per tap): ~2^-22 relative, 8 % of the step's FLOPs.
 """
+import os
 from types import SimpleNamespace as NS
 
 import torch
 
 from . import ops
+
+
+def default_precision(dtype):
+    """PF_PRECISION=mixed|fast overrides; otherwise fp16 runs the mixed scheme (the one that passes the
+    1e-3 parity bar), bf16 / the fp32 CPU test double the plain 16-bit one."""
+    env = os.environ.get("PF_PRECISION")
+    if env in ("mixed", "fast"):
+        return env
+    return "mixed" if dtype == torch.float16 else "fast"
+
+
+def stream_dtype(dtype, precision):
+    return torch.float32 if precision == "mixed" else dtype
 
 
 # ---------------------------------------------------------------------------- packing helpers
@@ -43,6 +68,42 @@ def _conv3_weight(conv, dev, dtype):
     return _w16(conv.weight.detach().float().permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1), dev, dtype)
 
 
+def _split_weight(w, taps, dev, dtype):
+    """Split-precision packing of an fp32 weight [N, taps * C] (tap-major): per tap [W_hi | W_hi | W_lo],
+    the partner of the A operand [hi | lo] + [hi] (see exact_gemm)."""
+    w = w.detach().to(device=dev, dtype=torch.float32).reshape(w.shape[0], taps, -1)
+    hi = w.to(dtype)
+    lo = (w - hi.float()).to(dtype)
+    return torch.cat([hi, hi, lo], -1).reshape(w.shape[0], -1).contiguous()
+
+
+def split_operand(x0, x1=None, scale=None, shift=None, act=0, dtype=None):
+    """[.., C] stream tensor(s) (channel concat of x0 | x1, optionally GroupNorm-applied) -> [rows, 2C]
+    16-bit pair [hi | lo]."""
+    c = x0.shape[-1]
+    n_img = scale.shape[0] if scale is not None else 1
+    hw = x0.numel() // (c * n_img)
+    return ops.scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out_dtype=dtype, split=True)
+
+
+def exact_gemm(a_split, w3, n_out, **kw):
+    """Split-precision GEMM / conv: a_split [.., 2C] = [A_hi | A_lo], w3 per tap [W_hi | W_hi | W_lo].
+    The kernel's channel concat takes source 0 = the whole pair (2C channels) and source 1 = its hi half
+    again (C channels, same row stride): sum_k A_hi W_hi + A_lo W_hi + A_hi W_lo."""
+    C2 = a_split.shape[-1]
+    C = C2 // 2
+    k = kw.get("ksize", 1)
+    return ops.conv_gemm(a_split, w3, n_out, a1=a_split, c0=C2, c1=C, a0_ld=C2, a1_ld=C2, algo_k=k * k * C, **kw)
+
+
+def to16(x, dtype):
+    """Stream tensor -> 16-bit MFMA operand (no-op when the stream is 16-bit already)."""
+    if x.dtype == dtype:
+        return x
+    c = x.shape[-1]
+    return ops.scale_shift_act(x, None, 1, x.numel() // c, None, None, 0, out_dtype=dtype).view(x.shape)
+
+
 def _norm(n, dev):
     return NS(g=_f32(n.weight, dev), b=_f32(n.bias, dev), eps=float(n.eps),
               groups=getattr(n, "num_groups", None))
@@ -52,16 +113,20 @@ def _bias(m, dev):
     return None if m.bias is None else _f32(m.bias, dev)
 
 
-def pack_resnet(res, dev, dtype):
+def pack_resnet(res, dev, dtype, mixed=False):
     r = NS()
+    r.dtype, r.stream = dtype, (torch.float32 if mixed else dtype)
     r.cin, r.cout = res.conv1.weight.shape[1], res.conv1.weight.shape[0]
     r.norm1, r.norm2 = _norm(res.norm1, dev), _norm(res.norm2, dev)
     r.w1, r.b1 = _conv3_weight(res.conv1, dev, dtype), _bias(res.conv1, dev)
     r.w2, r.b2 = _conv3_weight(res.conv2, dev, dtype), _bias(res.conv2, dev)
     sc = getattr(res, "conv_shortcut", None)
+    r.ws3 = None
     if sc is not None:
         r.ws = _w16(sc.weight.detach().float().reshape(r.cout, r.cin), dev, dtype)
         r.bs = _bias(sc, dev)
+        if mixed:
+            r.ws3 = _split_weight(sc.weight.detach().float().reshape(r.cout, r.cin), 1, dev, dtype)
     else:
         r.ws = r.bs = None
     r.temb = res.time_emb_proj      # consumed by pack_unet (concatenated projection)
@@ -82,8 +147,13 @@ def pack_attention(attn, dev, dtype, self_attn):
     return a
 
 
-def pack_transformer(tf, dev, dtype):
+def pack_transformer(tf, dev, dtype, mixed=False):
     t = NS()
+    t.dtype, t.stream = dtype, (torch.float32 if mixed else dtype)
+    t.w_in3 = t.w_out3 = None
+    if mixed:
+        t.w_in3 = _split_weight(tf.proj_in.weight, 1, dev, dtype)
+        t.w_out3 = _split_weight(tf.proj_out.weight, 1, dev, dtype)
     blk = tf.transformer_blocks[0]
     t.norm = _norm(tf.norm, dev)
     t.w_in, t.b_in = _w16(tf.proj_in.weight, dev, dtype), _bias(tf.proj_in, dev)
@@ -97,10 +167,11 @@ def pack_transformer(tf, dev, dtype):
     return t
 
 
-def pack_unet(unet, dev, dtype):
+def pack_unet(unet, dev, dtype, mixed=False):
     """Walks the diffusers attribute tree exactly as MVGenModel.py does."""
     u = NS()
-    u.dtype = dtype
+    u.dtype, u.mixed = dtype, mixed
+    u.stream = torch.float32 if mixed else dtype
     ci = unet.conv_in
     u.cin, u.c0 = ci.weight.shape[1], ci.weight.shape[0]
     u.w_conv_in = _f32(ci.weight.detach().permute(2, 3, 1, 0), dev)           # [3,3,cin,cout]
@@ -119,7 +190,7 @@ def pack_unet(unet, dev, dtype):
     resnets = []
 
     def res(r):
-        p = pack_resnet(r, dev, dtype)
+        p = pack_resnet(r, dev, dtype, mixed)
         resnets.append(p)
         return p
 
@@ -127,19 +198,22 @@ def pack_unet(unet, dev, dtype):
     for blk in unet.down_blocks:
         b = NS(resnets=[res(r) for r in blk.resnets], attns=None, down=None)
         if getattr(blk, "has_cross_attention", False):
-            b.attns = [pack_transformer(a, dev, dtype) for a in blk.attentions]
+            b.attns = [pack_transformer(a, dev, dtype, mixed) for a in blk.attentions]
         if blk.downsamplers is not None:
             c = blk.downsamplers[0].conv
-            b.down = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0])
+            b.down = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0], w3=None)
+            if mixed:
+                b.down.w3 = _split_weight(c.weight.detach().float().permute(0, 2, 3, 1).reshape(c.weight.shape[0], -1),
+                                          9, dev, dtype)
         u.down.append(b)
     mid = unet.mid_block
     u.mid = NS(resnets=[res(r) for r in mid.resnets],
-               attns=[pack_transformer(a, dev, dtype) for a in mid.attentions])
+               attns=[pack_transformer(a, dev, dtype, mixed) for a in mid.attentions])
     u.up = []
     for blk in getattr(unet, "up_blocks", []):
         b = NS(resnets=[res(r) for r in blk.resnets], attns=None, up=None)
         if getattr(blk, "has_cross_attention", False):
-            b.attns = [pack_transformer(a, dev, dtype) for a in blk.attentions]
+            b.attns = [pack_transformer(a, dev, dtype, mixed) for a in blk.attentions]
         if blk.upsamplers is not None:
             c = blk.upsamplers[0].conv
             b.up = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0])
@@ -164,12 +238,12 @@ def _pad64(c):
     return (c + 63) // 64 * 64
 
 
-def pack_controlnet(cn, dev, dtype):
+def pack_controlnet(cn, dev, dtype, mixed=False):
     """diffusers ControlNetModel (PanoGenerator.py:153-157): the encoder half goes through pack_unet;
     the conditioning embedding (3 -> 16 -> 16 -> 32 -> 32 -> 96 -> 96 -> 256 -> c0, 3x3, three stride-2
     steps) runs on the same MFMA conv kernel with channel counts zero-padded to multiples of 64
     (activation buffers keep the padded stride, the pad columns stay zero); the 13 zero-convs are 1x1."""
-    c = pack_unet(cn, dev, dtype)
+    c = pack_unet(cn, dev, dtype, mixed)
     ce = cn.controlnet_cond_embedding
     first = ce.conv_in
     co0 = first.weight.shape[0]
@@ -242,15 +316,16 @@ def run_controlnet(c, latent, timestep, text, cond):
 
     def zero_conv(z, x):
         n, h, w, Cc = x.shape
-        return ops.conv_gemm(x, z.w, z.c, n_img=n, h_in=h, w_in=w, ksize=1, bias=z.b).view(n, h, w, z.c)
+        return ops.conv_gemm(to16(x, c.dtype), z.w, z.c, n_img=n, h_in=h, w_in=w, ksize=1, bias=z.b).view(n, h, w, z.c)
 
     return [zero_conv(z, s) for z, s in zip(c.zero_down, br.skips)], zero_conv(c.zero_mid, br.h)
 
 
-def pack_epa(block, dev, dtype):
+def pack_epa(block, dev, dtype, mixed=False):
     """block: module with the reference WarpAttn parameter names (modules.py:8-13)."""
     tr = block.transformer
     e = NS()
+    e.cdtype, e.stream = dtype, (torch.float32 if mixed else dtype)
     e.dim = tr.norm1.weight.shape[0]
     e.heads = e.dim // 32
     e.ln1, e.ln2 = _norm(tr.norm1, dev), _norm(tr.norm2, dev)
@@ -266,18 +341,21 @@ def pack_epa(block, dev, dtype):
 
 # ---------------------------------------------------------------------------- layer runners
 def run_resnet(r, x, skip, temb_all, groups_eps=None):
-    """x [n, h, w, C] (+ skip concatenated along channels) -> [n, h, w, cout].
+    """x [n, h, w, C] (+ skip concatenated along channels) -> [n, h, w, cout], stream dtype in and out.
     GN -> SiLU -> conv3x3 (+bias +temb) -> GN -> SiLU -> conv3x3 (+bias) + shortcut(x)."""
     n, h, w, _ = x.shape
     hw = h * w
     sc, sh = ops.groupnorm_scale_shift(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, r.norm1.b)
-    y = ops.scale_shift_act(x, skip, n, hw, sc, sh, 1)
+    y = ops.scale_shift_act(x, skip, n, hw, sc, sh, 1, out_dtype=r.dtype)
     rowvec = temb_all[:, r.temb_off:]
     h1 = ops.conv_gemm(y, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec)
     h1 = h1.view(n, hw, r.cout)
     sc, sh = ops.groupnorm_scale_shift(h1, None, n, hw, r.norm2.groups, r.norm2.eps, r.norm2.g, r.norm2.b)
-    y2 = ops.scale_shift_act(h1, None, n, hw, sc, sh, 1)
-    if r.ws is not None:
+    y2 = ops.scale_shift_act(h1, None, n, hw, sc, sh, 1, out_dtype=r.dtype)
+    if r.ws3 is not None:         # mixed scheme: the shortcut maps the stream linearly -> split precision, fp32 out
+        short = exact_gemm(split_operand(x, skip, dtype=r.dtype), r.ws3, r.cout, w_in=n * hw, bias=r.bs,
+                           out_dtype=r.stream)
+    elif r.ws is not None:
         short = ops.conv_gemm(x, r.ws, r.cout, a1=skip, n_img=n, h_in=h, w_in=w, ksize=1, bias=r.bs)
     else:
         short = x.view(n * hw, r.cout)
@@ -314,23 +392,31 @@ def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv
 
 
 def run_transformer(t, x, text, kv=None):
-    """diffusers Transformer2DModel (linear projections) on x [n, h, w, C]; text [n, L, Dt]
+    """diffusers Transformer2DModel (linear projections) on x [n, h, w, C] (stream dtype); text [n, L, Dt]
     (kv: the text K / V^T of this block computed ahead of time, text_kv)."""
     n, h, w, Cc = x.shape
     hw = h * w
     sc, sh = ops.groupnorm_scale_shift(x, None, n, hw, t.norm.groups, t.norm.eps, t.norm.g, t.norm.b)
-    y = ops.scale_shift_act(x, None, n, hw, sc, sh, 0)
-    tok = ops.linear(y.view(n * hw, Cc), t.w_in, bias=t.b_in)
+    if t.w_in3 is not None:       # mixed scheme: proj_in / proj_out carry the stream -> split precision
+        tok = exact_gemm(split_operand(x, None, sc, sh, 0, dtype=t.dtype), t.w_in3, Cc, w_in=n * hw, bias=t.b_in,
+                         out_dtype=t.stream)
+    else:
+        y = ops.scale_shift_act(x, None, n, hw, sc, sh, 0)
+        tok = ops.linear(y.view(n * hw, Cc), t.w_in, bias=t.b_in)
     dh = t.attn1.dim // t.attn1.heads
-    ln = ops.layernorm(tok, t.ln1.g, t.ln1.b, t.ln1.eps)
+    ln = ops.layernorm(tok, t.ln1.g, t.ln1.b, t.ln1.eps, out_dtype=t.dtype)
     tok = _attend(t.attn1, ln, ln, n, hw, hw, dh, self_attn=True, residual=tok)
-    ln = ops.layernorm(tok, t.ln2.g, t.ln2.b, t.ln2.eps)
+    ln = ops.layernorm(tok, t.ln2.g, t.ln2.b, t.ln2.eps, out_dtype=t.dtype)
     L = text.shape[1]
     tok = _attend(t.attn2, ln, text.reshape(n * L, -1), n, hw, L, dh, self_attn=False, residual=tok, kv=kv)
-    ln = ops.layernorm(tok, t.ln3.g, t.ln3.b, t.ln3.eps)
+    ln = ops.layernorm(tok, t.ln3.g, t.ln3.b, t.ln3.eps, out_dtype=t.dtype)
     g = ops.linear(ln, t.w_ff1, bias=t.b_ff1, geglu=True)
     tok = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok)
-    out = ops.linear(tok, t.w_out, bias=t.b_out, residual=x.view(n * hw, Cc))
+    if t.w_out3 is not None:
+        out = exact_gemm(split_operand(tok, dtype=t.dtype), t.w_out3, Cc, w_in=n * hw, bias=t.b_out,
+                         residual=x.view(n * hw, Cc))
+    else:
+        out = ops.linear(tok, t.w_out, bias=t.b_out, residual=x.view(n * hw, Cc))
     return out.view(n, h, w, Cc)
 
 
@@ -347,7 +433,7 @@ class Branch:
         e = ops.linear(ops.silu(e), u.w_t2, bias=u.b_t2)                       # emb [n, 1280]
         self.temb = ops.linear(ops.silu(e), u.w_temb, bias=u.b_temb, out_dtype=torch.float32)
         # pano: pad 1 / conv / crop 1 (MVGenModel.py:87-91) == circular-width convolution
-        self.h = ops.conv_in(latent.float(), u.w_conv_in, u.b_conv_in, u.c0, u.dtype, wrap=self.pad)
+        self.h = ops.conv_in(latent.float(), u.w_conv_in, u.b_conv_in, u.c0, u.stream, wrap=self.pad)
         self.skips = [self.h]
         self.text_kv = {}               # id(transformer pack) -> (k, vt) of the text tokens, if computed ahead
         self.text_ready = None          # event to wait for before the first use (computed on another stream)
@@ -381,14 +467,19 @@ class Branch:
     def downsample(self, d):            # pano: pad 2, conv s2, crop 1   (MVGenModel.py:138-144)
         x = self._padded(self.h, 2)
         n, h, w, Cc = x.shape
-        y = ops.conv_gemm(x, d.w, d.c, n_img=n, h_in=h, w_in=w, ksize=3, stride=2, pad=1, bias=d.b)
+        if d.w3 is not None:            # mixed scheme: stream -> stream linear map, split precision
+            y = exact_gemm(split_operand(x, dtype=self.u.dtype), d.w3, d.c, n_img=n, h_in=h, w_in=w, ksize=3, stride=2,
+                           pad=1, bias=d.b, out_dtype=self.u.stream)
+        else:
+            y = ops.conv_gemm(x, d.w, d.c, n_img=n, h_in=h, w_in=w, ksize=3, stride=2, pad=1, bias=d.b)
         y = y.view(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, d.c)
         self.h = ops.crop_width(y, 1) if self.pad else y
 
     def upsample(self, up):             # pano: pad 1, nearest x2 + conv, crop 2   (:272-277)
-        x = self._padded(self.h, 1)
+        x = to16(self._padded(self.h, 1), self.u.dtype)
         n, h, w, Cc = x.shape
-        y = ops.conv_gemm(x, up.w, up.c, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1, bias=up.b)
+        y = ops.conv_gemm(x, up.w, up.c, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1, bias=up.b,
+                          out_dtype=self.u.stream)
         y = y.view(n, 2 * h, 2 * w, up.c)
         self.h = ops.crop_width(y, 2) if self.pad else y
 
@@ -397,7 +488,8 @@ class Branch:
         n, h, w, Cc = self.h.shape
         sc, sh = ops.groupnorm_scale_shift(self.h, None, n, h * w, u.norm_out.groups, u.norm_out.eps,
                                            u.norm_out.g, u.norm_out.b)
-        y = ops.scale_shift_act(self.h, None, n, h * w, sc, sh, 1).view(n, h, w, Cc)
+        # (mixed scheme: the 4-channel output conv reads the normalised activation in fp32 -- it is not an MFMA GEMM)
+        y = ops.scale_shift_act(self.h, None, n, h * w, sc, sh, 1, out_dtype=u.stream).view(n, h, w, Cc)
         return ops.conv_out(y, u.w_conv_out, u.b_conv_out, u.cout, wrap=self.pad)      # fp32 NCHW
 
 
@@ -425,7 +517,7 @@ class EPATables:
 def _epa_tail(e, attn_out, x, Cc):
     """to_out + residual, then LN2 -> GEGLU FF -> + residual (transformer.py:159-161)."""
     y = ops.linear(attn_out.view(-1, Cc), e.wo, bias=e.bo, residual=x)
-    ln2 = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps)
+    ln2 = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps, out_dtype=e.cdtype)
     g = ops.linear(ln2, e.w_ff1, bias=e.b_ff1, geglu=True)
     return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y)
 
@@ -470,15 +562,16 @@ def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None, pers_hw=None):
         flags_p_loc = t.__dict__[key]
     if mloc:
         tp = xp.view(mloc * P, Cc)
-        lnp_loc = ops.layernorm(tp, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_p[r0:r1])
+        lnp_loc = ops.layernorm(tp, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_p[r0:r1], out_dtype=e.cdtype)
     else:
-        tp = lnp_loc = xe.new_empty(0, Cc)
+        tp = xe.new_empty(0, Cc)
+        lnp_loc = torch.empty(0, Cc, device=xe.device, dtype=e.cdtype)
     lnp = sharding.gather_view_tokens(lnp_loc, shard, P=P)                  # [mP, C] (every rank takes part)
     lne = None
     if owner:
         te = xe.view(E, Cc)
-        lne = ops.layernorm(te, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_e)
-    lne = sharding.share_pano_tokens(lne, E, Cc, tp, shard)                 # broadcast in the panorama-rank layout
+        lne = ops.layernorm(te, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_e, out_dtype=e.cdtype)
+    lne = sharding.share_pano_tokens(lne, E, Cc, lnp_loc, shard)                 # broadcast in the panorama-rank layout
     qk_e = ops.linear(lne, e.wqk)
     vt_e = ops.linear_t(lne.view(1, E, Cc), e.wv)
     ld = 2 * Cc
@@ -518,10 +611,10 @@ def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None, side=None, pers_hw=N
     tp, te = xp.view(b * mP, Cc), xe.view(b * E, Cc)
     shared = len(tables) == 1
     if shared:
-        lnp = ops.layernorm(tp, e.ln1.g, e.ln1.b, e.ln1.eps, pe=tables[0].pe_p)
-        lne = ops.layernorm(te, e.ln1.g, e.ln1.b, e.ln1.eps, pe=tables[0].pe_e)
+        lnp = ops.layernorm(tp, e.ln1.g, e.ln1.b, e.ln1.eps, pe=tables[0].pe_p, out_dtype=e.cdtype)
+        lne = ops.layernorm(te, e.ln1.g, e.ln1.b, e.ln1.eps, pe=tables[0].pe_e, out_dtype=e.cdtype)
     else:
-        lnp, lne = torch.empty_like(tp), torch.empty_like(te)
+        lnp, lne = torch.empty_like(tp, dtype=e.cdtype), torch.empty_like(te, dtype=e.cdtype)
         for i, t in enumerate(tables):
             ops.layernorm(tp[i * mP:(i + 1) * mP], e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_p, out=lnp[i * mP:(i + 1) * mP])
             ops.layernorm(te[i * E:(i + 1) * E], e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_e, out=lne[i * E:(i + 1) * E])
@@ -545,10 +638,7 @@ def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None, side=None, pers_hw=N
         return out
 
     def tail(attn_out, x):
-        y = ops.linear(attn_out.view(-1, Cc), e.wo, bias=e.bo, residual=x)
-        ln2 = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps)
-        g = ops.linear(ln2, e.w_ff1, bias=e.b_ff1, geglu=True)
-        return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y)
+        return _epa_tail(e, attn_out, x, Cc)
 
     # panorama pixels query the views (modules.py:43-48), then views query the panorama with the
     # ORIGINAL view activations (modules.py:50-55): the two directions are independent -- with a side stream

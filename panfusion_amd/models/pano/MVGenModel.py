@@ -21,8 +21,12 @@ from .modules import WarpAttn, camera_groups
 
 class MultiViewBaseModel(nn.Module):
     def __init__(self, unet, pano_unet, pers_cn=None, pano_cn=None, pano_pad=True,
-                 compute_dtype=torch.bfloat16):
+                 compute_dtype=torch.float16, precision=None):
+        """compute_dtype: the 16-bit MFMA operand type; precision: "mixed" (fp32 residual streams +
+        split-precision stream-path GEMMs: the scheme that meets the 1e-3 parity bar, default for fp16)
+        or "fast" (everything 16-bit); None -> engine.default_precision (PF_PRECISION overrides)."""
         super().__init__()
+        self.precision = precision or engine.default_precision(compute_dtype)
         self.unet = unet
         self.pano_unet = pano_unet
         self.pers_cn = pers_cn
@@ -37,11 +41,11 @@ class MultiViewBaseModel(nn.Module):
 
         if self.unet is not None:      # EPA block widths, reference MVGenModel.py:19-32
             self.cp_blocks_encoder = nn.ModuleList(
-                [WarpAttn(blk.downsamplers[-1].out_channels, compute_dtype)
+                [WarpAttn(blk.downsamplers[-1].out_channels, compute_dtype, self.precision)
                  for blk in self.unet.down_blocks if blk.downsamplers is not None])
-            self.cp_blocks_mid = WarpAttn(self.unet.mid_block.resnets[-1].out_channels, compute_dtype)
+            self.cp_blocks_mid = WarpAttn(self.unet.mid_block.resnets[-1].out_channels, compute_dtype, self.precision)
             self.cp_blocks_decoder = nn.ModuleList(
-                [WarpAttn(blk.upsamplers[0].channels, compute_dtype)
+                [WarpAttn(blk.upsamplers[0].channels, compute_dtype, self.precision)
                  for blk in self.unet.up_blocks if blk.upsamplers is not None])
             self.trainable_parameters = [(list(self.cp_blocks_mid.parameters())
                                           + list(self.cp_blocks_decoder.parameters())
@@ -49,10 +53,10 @@ class MultiViewBaseModel(nn.Module):
 
     # ------------------------------------------------------------------ weights
     def packed(self, which, device):
-        key = (which, str(device), self.compute_dtype)
+        key = (which, str(device), self.compute_dtype, self.precision)
         if key not in self._packed:
             pack = engine.pack_controlnet if which.endswith("_cn") else engine.pack_unet
-            self._packed[key] = pack(getattr(self, which), device, self.compute_dtype)
+            self._packed[key] = pack(getattr(self, which), device, self.compute_dtype, self.precision == "mixed")
         return self._packed[key]
 
     def repack(self):
@@ -60,7 +64,7 @@ class MultiViewBaseModel(nn.Module):
         self._packed.clear()
         if self.unet is not None:
             for blk in [*self.cp_blocks_encoder, self.cp_blocks_mid, *self.cp_blocks_decoder]:
-                blk.compute_dtype = self.compute_dtype
+                blk.compute_dtype, blk.precision = self.compute_dtype, self.precision
                 blk.repack()
 
     def load_state_dict(self, *a, **k):

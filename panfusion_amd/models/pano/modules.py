@@ -19,8 +19,9 @@ def camera_groups(cameras, b):
 
 
 class WarpAttn(nn.Module):
-    def __init__(self, dim, compute_dtype=torch.bfloat16):
+    def __init__(self, dim, compute_dtype=torch.float16, precision=None):
         super().__init__()
+        self.precision = precision or engine.default_precision(compute_dtype)
         self.transformer = BasicTransformerBlock(dim, dim // 32, 32, context_dim=dim)
         self.pe = SphericalPE(dim // 4)
         self.compute_dtype = compute_dtype
@@ -28,9 +29,10 @@ class WarpAttn(nn.Module):
         self._tables = engine.EPATables()
 
     def packed(self, device):
-        if self._packed is None or self._packed.device != device or self._packed.dtype != self.compute_dtype:
-            self._packed = engine.pack_epa(self, device, self.compute_dtype)
-            self._packed.device, self._packed.dtype = device, self.compute_dtype
+        key = (device, self.compute_dtype, self.precision)
+        if self._packed is None or self._packed.key != key:
+            self._packed = engine.pack_epa(self, device, self.compute_dtype, self.precision == "mixed")
+            self._packed.key = key
         return self._packed
 
     def repack(self):
@@ -48,7 +50,8 @@ class WarpAttn(nn.Module):
 
     @torch.no_grad()
     def forward_nhwc(self, xp, xe, groups, m, shard=None, equi_hw=None, side=None, pers_hw=None):
-        """xp [b*m, ph, pw, C], xe [b, eh, ew, C] 16-bit NHWC (the denoiser's internal layout).
+        """xp [b*m, ph, pw, C], xe [b, eh, ew, C] NHWC in the stream dtype (the denoiser's internal layout:
+        16-bit, or fp32 in the mixed scheme).
         With ``shard`` (sharding.ShardInfo) xp holds only this rank's views of the m; on a rank without the
         panorama branch xe is None and equi_hw = (eh, ew); on a panorama owner without views xp is None and
         pers_hw = (ph, pw)."""
@@ -63,7 +66,7 @@ class WarpAttn(nn.Module):
     def forward(self, pers_x, equi_x, cameras):
         b = equi_x.shape[0]
         m, groups = camera_groups(cameras, b)
-        dt = self.compute_dtype
+        dt = engine.stream_dtype(self.compute_dtype, self.precision)
         xp = ops.nchw_to_nhwc(pers_x.float(), dt)
         xe = ops.nchw_to_nhwc(equi_x.float(), dt)
         op, oe = self.forward_nhwc(xp, xe, groups, m)

@@ -145,23 +145,28 @@ def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
     return scale, shift
 
 
-def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None):
+def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None, out_dtype=None, split=False):
+    """y = act(x * scale + shift) over the channel concat (x0 | x1); scale = shift = None: y = act(x).
+    Sources 16-bit or fp32.  out_dtype: 16-bit type (default: the sources') or fp32; split=True: the
+    16-bit pair [.., hi(C) | lo(C)] (A operand of a split-precision GEMM, engine.exact_gemm)."""
     c0 = x0.shape[-1]
     c1 = x1.shape[-1] if x1 is not None else 0
+    out_dtype = out_dtype or x0.dtype
     if out is None:
-        out = torch.empty(n_img, hw, c0 + c1, device=x0.device, dtype=x0.dtype)
+        out = torch.empty(n_img, hw, (c0 + c1) * (2 if split else 1), device=x0.device, dtype=out_dtype)
     check(_lib.lib().pf_scale_shift_act(_p(x0), c0, _p(x1), c1, dt(x0), n_img, hw, _p(scale), _p(shift),
-                                        int(act), _p(out), _stream()), "pf_scale_shift_act")
+                                        int(act), dt(out_dtype), int(split), _p(out), _stream()), "pf_scale_shift_act")
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-5, pe=None, out=None):
-    """x [rows, C] 16-bit; pe optional fp32 [pe_rows, C] (row r uses pe[r % pe_rows])."""
+def layernorm(x, gamma, beta, eps=1e-5, pe=None, out=None, out_dtype=None):
+    """x [rows, C] 16-bit or fp32 -> 16-bit (out_dtype, default x.dtype); pe optional fp32 [pe_rows, C]
+    (row r uses pe[r % pe_rows])."""
     rows, Cc = x.shape
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty(rows, Cc, device=x.device, dtype=out_dtype or x.dtype)
     check(_lib.lib().pf_layernorm(_p(x), _p(pe), 0 if pe is None else pe.shape[0], dt(x), rows, Cc,
-                                  _p(gamma), _p(beta), eps, _p(out), _stream()), "pf_layernorm")
+                                  _p(gamma), _p(beta), eps, dt(out), _p(out), _stream()), "pf_layernorm")
     return out
 
 
@@ -190,9 +195,10 @@ def silu(x, out=None):
 
 
 def add(a, b, out=None):
+    """a + b in a's dtype (b may have another one: fp32 stream + 16-bit ControlNet residual)."""
     if out is None:
         out = torch.empty_like(a)
-    check(_lib.lib().pf_add(_p(a), _p(b), dt(a), a.numel(), _p(out), _stream()), "pf_add")
+    check(_lib.lib().pf_add(_p(a), dt(a), _p(b), dt(b), a.numel(), _p(out), _stream()), "pf_add")
     return out
 
 
@@ -268,9 +274,11 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,
               a_bstride=0, w_bstride=0, out_bstride=0, res_bstride=0, a0_ld=None, a1_ld=None, c0=None, c1=None,
-              out_ld=None, res_ld=None, geglu=False):
+              out_ld=None, res_ld=None, geglu=False, algo_k=None):
     """out[m, n] = sum_k A[m, k] W[n, k] (+bias +rowvec[img] +residual).  a0/a1 NHWC, the last
-    dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out)."""
+    dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out).  The output takes the
+    residual's dtype unless out_dtype says otherwise (fp32 residual stream in, fp32 out).
+    algo_k: K of the layer for the FLOP count when the launched K carries split-precision passes."""
     c0 = c0 if c0 is not None else a0.shape[-1]
     c1 = (c1 if c1 is not None else a1.shape[-1]) if a1 is not None else 0
     if w_in is None:
@@ -279,7 +287,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     h_out = (hl + 2 * pad - ksize) // stride + 1
     w_out = (wl + 2 * pad - ksize) // stride + 1
     M = n_img * h_out * w_out
-    out_dtype = out_dtype or a0.dtype
+    out_dtype = out_dtype or (residual.dtype if residual is not None else a0.dtype)
     n_store = n_out // 2 if geglu else n_out
     if out is None:
         out = torch.empty((batch, M, n_store) if batch > 1 else (M, n_store), device=a0.device, dtype=out_dtype)
@@ -294,6 +302,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     d.rowvec, d.rowvec_ld = _p(rowvec), (_ld(rowvec) if rowvec is not None else 0)
     d.residual = _p(residual)
     d.res_ld = (res_ld if res_ld is not None else _ld(residual)) if residual is not None else 0
+    d.res_dtype = dt(residual) if residual is not None else dt(a0)
     d.out, d.out_ld = _p(out), (out_ld if out_ld is not None else _ld(out))
     d.out_dtype, d.dtype = dt(out_dtype), dt(a0)
     d.batch = batch
@@ -302,7 +311,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     nbytes = _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
     ws = torch.empty(nbytes, device=a0.device, dtype=torch.uint8) if nbytes else None   # split-K slabs
     d.workspace, d.workspace_bytes = _p(ws), nbytes
-    _traced("k_conv_gemm", 2.0 * M * n_out * ksize * ksize * (c0 + c1) * batch,
+    _traced("k_conv_gemm", 2.0 * M * n_out * (algo_k or ksize * ksize * (c0 + c1)) * batch,
             lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"),
             "M%d N%d K%d k%d s%d u%d b%d" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch))
     return out

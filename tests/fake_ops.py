@@ -92,18 +92,22 @@ def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
     return scale, shift
 
 
-def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None):
+def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None, out_dtype=None, split=False):
     x = _cat(x0, x1).float().reshape(n_img, hw, -1)
-    y = x * scale[:, None] + shift[:, None]
+    y = x if scale is None else x * scale[:, None] + shift[:, None]
     y = F.silu(y) if act else y
-    return y.to(x0.dtype)
+    out_dtype = out_dtype or x0.dtype
+    if split:
+        hi = y.to(out_dtype)
+        return torch.cat([hi, (y - hi.float()).to(out_dtype)], -1)
+    return y.to(out_dtype)
 
 
-def layernorm(x, gamma, beta, eps=1e-5, pe=None, out=None):
+def layernorm(x, gamma, beta, eps=1e-5, pe=None, out=None, out_dtype=None):
     v = x.float()
     if pe is not None:
         v = v + pe.repeat(x.shape[0] // pe.shape[0], 1)
-    y = F.layer_norm(v, (x.shape[-1],), gamma, beta, eps).to(x.dtype)
+    y = F.layer_norm(v, (x.shape[-1],), gamma, beta, eps).to(out.dtype if out is not None else (out_dtype or x.dtype))
     if out is not None:
         out.copy_(y)
         return out
@@ -131,10 +135,11 @@ def silu(x, out=None):
 
 
 def add(a, b, out=None):
+    y = (a.float() + b.float()).to(a.dtype)
     if out is not None:
-        out.copy_(a + b)
+        out.copy_(y)
         return out
-    return a + b
+    return y
 
 
 def pad_width(x, pad, out=None):
@@ -176,13 +181,14 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 
 
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
-              bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, **kw):
+              bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, c1=None,
+              a0_ld=None, a1_ld=None, algo_k=None, **kw):
     assert batch == 1
-    assert c0 is None or c0 == a0.shape[-1], "the test double takes whole (padded) channel rows"
-    c0 = a0.shape[-1]
-    x = a0.float().reshape(-1, c0)
+    # [pixel][ld] rows of which the first c channels are taken (the split-precision GEMM passes the [hi | lo]
+    # pair as source 0 and its hi half again as source 1: same storage, c1 = ld / 2)
+    x = a0.float().reshape(-1, a0_ld or a0.shape[-1])[:, :(c0 or a0.shape[-1])]
     if a1 is not None:
-        x = torch.cat([x, a1.float().reshape(-1, a1.shape[-1])], -1)
+        x = torch.cat([x, a1.float().reshape(-1, a1_ld or a1.shape[-1])[:, :(c1 or a1.shape[-1])]], -1)
     C = x.shape[-1]
     if w_in is None:
         w_in = x.shape[0]
@@ -199,7 +205,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
         y = y + residual.float().reshape(-1, residual.shape[-1])[:, :n_out]
     if geglu:                                     # rows interleaved (value_j, gate_j)
         y = y[:, 0::2] * F.gelu(y[:, 1::2])
-    y = y.to(out_dtype or a0.dtype)
+    y = y.to(out_dtype or (residual.dtype if residual is not None else a0.dtype))
     if out is not None:
         if out.shape[-1] != y.shape[-1] and out.numel() != y.numel():   # wider row stride: pad columns untouched
             out.view(-1, out.shape[-1])[:, :y.shape[-1]] = y
@@ -236,7 +242,11 @@ def conv_in(x, wgt, bias, cout, dtype, wrap=False, out=None):
         y = F.conv2d(G.pad_pano(x.float(), 1), w, bias, padding=1)[..., 1:-1]
     else:
         y = F.conv2d(x.float(), w, bias, padding=1)
-    return y.permute(0, 2, 3, 1).to(dtype).contiguous()
+    y = y.permute(0, 2, 3, 1).to(dtype).contiguous()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def conv_out(x, wgt, bias, cout, wrap=False, out=None):

@@ -36,11 +36,39 @@ def test_version_and_error_plumbing():
     assert lib.pf_attention(C.byref(a), None) == 1
 
 
-def test_struct_layouts_match_header():
-    # field counts / sizes of the two descriptors (the C side is plain ints, longs, pointers)
-    assert C.sizeof(_lib.ConvDesc) == 8 + 8 + 4 * 4 + 5 * 4 + 4 * 4 + 4 + 8 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 4 * 3 + 4 + 4 * 8 \
-        or C.sizeof(_lib.ConvDesc) % 8 == 0
-    assert C.sizeof(_lib.AttnDesc) % 8 == 0
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors of pf_conv_desc / pf_attn_desc are pinned to the C header: a probe compiled by gcc
+    against include/panfusion_hip.h prints sizeof and offsetof of every field; they must equal ctypes'."""
+    import subprocess
+    structs = {"pf_conv_desc": _lib.ConvDesc, "pf_attn_desc": _lib.AttnDesc}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "panfusion_hip.h"\nint main(void) {\n%s\nreturn 0; }\n'
+                   % "\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True, capture_output=True, timeout=120)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=60).stdout.split("\n")
+    seen = 0
+    for line in filter(None, out):
+        cname, field, value = line.split()
+        cls = structs[cname]
+        want = C.sizeof(cls) if field == "sizeof" else getattr(cls, field).offset
+        assert int(value) == want, "%s.%s: header %s, ctypes %d" % (cname, field, value, want)
+        seen += 1
+    # every ctypes field exists in the header (the probe would not compile otherwise) and nothing was skipped
+    assert seen == sum(len(c._fields_) + 1 for c in structs.values())
+    # and the header has no field the binding misses: the sizes agree, so a missing trailing field would show
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "panfusion_hip.h")).read(), flags=re.S)
+    for cname, cls in structs.items():
+        end = hdr.index("} %s;" % cname)
+        body = hdr[hdr.rindex("typedef struct {", 0, end):end]
+        names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*(?:,|;)", body)
+        assert sorted(names) == sorted(f for f, _ in cls._fields_), (cname, names)
 
 
 def _conv_desc(**kw):
@@ -68,6 +96,7 @@ def test_conv_gemm_rejects_bad_arguments_before_any_launch():
         (dict(stride=3), b"stride"),
         (dict(dtype=_lib.PF_F32), b"dtype"),
         (dict(out_dtype=_lib.PF_F16), b"out_dtype"),
+        (dict(residual=0x40000, res_ld=64, res_dtype=_lib.PF_F16), b"res_dtype"),
         (dict(a0=0x10008), b"16-byte aligned"),
         (dict(out_ld=60), b"out_ld"),
         (dict(n_out=62, bias=0x50000), b"n_out"),
@@ -97,7 +126,12 @@ def test_attention_and_norm_reject_bad_arguments():
     assert lib.pf_attention(C.byref(a), None) == 1 and b"vt_ld" in lib.pf_last_error_string()
     a.vt_ld, a.bias = 64, 0x50000                                  # bias without flags
     assert lib.pf_attention(C.byref(a), None) == 1 and b"bias and flags" in lib.pf_last_error_string()
-    assert lib.pf_layernorm(0x10000, None, 0, _lib.PF_F16, 4, 4100, 0x20000, 0x30000, 1e-5, 0x40000, None) == 1
+    assert lib.pf_layernorm(0x10000, None, 0, _lib.PF_F16, 4, 4100, 0x20000, 0x30000, 1e-5, _lib.PF_F16, 0x40000, None) == 1
+    assert lib.pf_layernorm(0x10000, None, 0, _lib.PF_F16, 4, 64, 0x20000, 0x30000, 1e-5, _lib.PF_BF16, 0x40000, None) == 1   # 16-bit in != out
+    # scale without shift; fp32 output cannot be a split pair
+    assert lib.pf_scale_shift_act(0x10000, 64, None, 0, _lib.PF_F32, 1, 16, 0x20000, None, 0, _lib.PF_F16, 0, 0x40000, None) == 1
+    assert lib.pf_scale_shift_act(0x10000, 64, None, 0, _lib.PF_F32, 1, 16, None, None, 0, _lib.PF_F32, 1, 0x40000, None) == 1
+    assert lib.pf_add(0x10000, 7, 0x20000, _lib.PF_F16, 16, 0x30000, None) == 1
     assert lib.pf_groupnorm_stats(0x10000, 60, None, 0, _lib.PF_F16, 1, 16, 32, 1e-5, 0x20000, 0x30000, 0x40000, 0x50000,
                                   0x60000, 1 << 20, None) == 1
     assert lib.pf_geglu(0x10000, _lib.PF_F16, 4, 12, 0x20000, None) == 1
