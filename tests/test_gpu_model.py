@@ -2,9 +2,10 @@
 oracle and the golden fixtures generated from the reference's own MultiViewBaseModel.
 
 Stated tolerances (rel-L2 on the epsilon outputs, fp32 oracle as truth):
-  * fp16 storage / fp32 accumulate : 4e-3   (the oracle itself, with every layer output rounded to
-    fp16, sits at 1.4e-3 -- DESIGN.md "numerics"; north_star's 1e-3 is the target, not yet met)
-  * bf16 storage / fp32 accumulate : 3e-2   (8 significand bits; same emulation gives 1.2e-2)
+  * fp16 operands, MIXED scheme (fp32 residual streams + split-precision stream-path GEMMs; the default for
+    fp16 and the benchmarked configuration): 1e-3 = north_star's bar (emulated on the oracle: 6.8e-4,
+    profiles/r2_precision_budget.txt)
+  * bf16 storage / fp32 accumulate, FAST scheme (everything 16-bit): 3e-2 (8 significand bits; emulation 1.2e-2)
 Needs an MI355X: `-m gpu`."""
 import copy
 
@@ -18,7 +19,7 @@ from oracle import sd2_unet as U
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-TOL = {torch.float16: 4e-3, torch.bfloat16: 3e-2}
+TOL = {torch.float16: 1e-3, torch.bfloat16: 3e-2}
 
 
 def hip_model_from(oracle_model, dtype):
