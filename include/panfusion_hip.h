@@ -10,11 +10,13 @@
  * Conventions
  *   - extern "C", plain pointers + sizes, no C++/torch types.  All data pointers are DEVICE
  *     pointers owned by the caller unless the name says `host_`.  Scratch is passed in
- *     (`workspace`, size from the matching *_workspace_size); the only device memory the library
- *     owns is a few-KB buffer of per-camera constants created on the first geometry call.
- *   - All work is enqueued on `stream` (a hipStream_t passed as void*); no implicit device sync.
- *   - Activations are 16-bit (PF_BF16 or PF_F16), token-major / NHWC: [image][y][x][channel].
- *     Statistics, biases, tables and accumulators are fp32.
+ *     (`workspace`, size from the matching *_workspace_size); the library owns NO device memory
+ *     (per-camera constants of the geometry calls travel by value in the kernel arguments).
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*); no implicit device sync,
+ *     no allocation, host arrays (`host_*`) are consumed before the call returns.
+ *   - Activations are token-major / NHWC: [image][y][x][channel]; MFMA operands are 16-bit (PF_BF16 or
+ *     PF_F16); in the mixed scheme the residual-stream tensors are PF_F32 (the entry points that take a
+ *     stream tensor say so).  Statistics, biases, tables and accumulators are fp32.
  *   - Every function returns pf_status; on failure pf_last_error_string() describes the problem
  *     (thread-local).  Arguments are validated before any launch.  Nothing throws or aborts.
  */

@@ -23,6 +23,7 @@
 // models/pano/MVGenModel.py:86-144,174-198,224-294; models/modules/transformer.py:8-74).
 #include "pf_common.h"
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 namespace pf {
@@ -911,8 +912,14 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmParams p) {
     epilogue_store<T>(p, bz, m, n4, v);
 }
 
-static unsigned long long* g_prof = nullptr;         // diagnostics buffer (device), see pf_debug_gemm_profile
-static long g_prof_blocks = 0;
+// diagnostics buffer (device) + its capacity, see pf_debug_gemm_profile: published / read as ONE atomic
+// snapshot so that concurrent launches from other host threads see either the old or the new pair
+struct ProfState { unsigned long long* buf; long blocks; };
+static std::atomic<const ProfState*> g_prof_state{nullptr};
+static inline ProfState prof_snapshot() {
+    const ProfState* s = g_prof_state.load(std::memory_order_acquire);
+    return s ? *s : ProfState{nullptr, 0};
+}
 
 
 template <typename T, int MREP, int NREP>
@@ -921,7 +928,8 @@ static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     GemmParams p = gp;
     p.mtiles = static_cast<int>(cdiv(p.M - p.m_begin, BM));
     p.ntiles = static_cast<int>(cdiv(p.N, BN));
-    p.prof = (g_prof && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= g_prof_blocks) ? g_prof : nullptr;
+    const ProfState ps = prof_snapshot();
+    p.prof = (ps.buf && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= ps.blocks) ? ps.buf : nullptr;
     const size_t smem = static_cast<size_t>(2) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
@@ -952,7 +960,8 @@ static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
         p.adv_y = rem / p.w_out;
         p.adv_x = rem % p.w_out;
     }
-    p.prof = (g_prof && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= g_prof_blocks) ? g_prof : nullptr;
+    const ProfState ps = prof_snapshot();
+    p.prof = (ps.buf && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= ps.blocks) ? ps.buf : nullptr;
     const size_t smem = static_cast<size_t>(3) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1173,8 +1182,9 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
 }
 
 extern "C" pf_status pf_debug_gemm_profile(void* device_buffer, long capacity_blocks) {
-    g_prof = static_cast<unsigned long long*>(device_buffer);
-    g_prof_blocks = device_buffer ? capacity_blocks : 0;
+    // (states are leaked on purpose: a few bytes per call of a diagnostics switch, never freed under a reader)
+    const ProfState* s = device_buffer ? new ProfState{static_cast<unsigned long long*>(device_buffer), capacity_blocks} : nullptr;
+    g_prof_state.store(s, std::memory_order_release);
     return PF_OK;
 }
 

@@ -42,14 +42,31 @@ static void rodrigues_f32(const float rvec[3], double R[9]) {
 }
 
 static void inverse_f32(const double A[9], double Ai[9]) {
-    // np.linalg.inv on a float32 matrix returns float32 (LAPACK sgesv).  We return the correctly
-    // rounded float32 inverse computed in double; it differs from LAPACK's by a few float32 ulp.
-    double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5], g = A[6], h = A[7], i = A[8];
-    double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
-    double inv[9] = {(e * i - f * h), -(b * i - c * h), (b * f - c * e),
-                     -(d * i - f * g), (a * i - c * g), -(a * f - c * d),
-                     (d * h - e * g), -(a * h - b * g), (a * e - b * d)};
-    for (int k = 0; k < 9; ++k) Ai[k] = static_cast<double>(static_cast<float>(inv[k] / det));
+    // np.linalg.inv on a float32 matrix (p2e.py:28-29): numpy's `inv` always computes in DOUBLE (gufunc
+    // signature 'd->d': LAPACK dgesv, LU with partial pivoting on [A | I]) and casts the result to the input
+    // type.  Same here: LU with partial pivoting in double, then one rounding to float32 -- the double result
+    // is ~1e-16 from the exact inverse, so the float32 value is the correctly rounded inverse in all but
+    // measure-zero cases, whatever the operation order inside LAPACK.
+    double M[3][6];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) { M[r][c] = A[3 * r + c]; M[r][3 + c] = (r == c) ? 1.0 : 0.0; }
+    for (int j = 0; j < 3; ++j) {
+        int p = j;
+        for (int r = j + 1; r < 3; ++r) if (fabs(M[r][j]) > fabs(M[p][j])) p = r;
+        if (p != j) for (int c = 0; c < 6; ++c) { double t = M[j][c]; M[j][c] = M[p][c]; M[p][c] = t; }
+        for (int r = j + 1; r < 3; ++r) {
+            const double l = M[r][j] / M[j][j];
+            for (int c = j; c < 6; ++c) M[r][c] -= l * M[j][c];
+        }
+    }
+    for (int c = 3; c < 6; ++c)
+        for (int r = 2; r >= 0; --r) {
+            double v = M[r][c];
+            for (int k = r + 1; k < 3; ++k) v -= M[r][k] * M[k][c];
+            M[r][c] = v / M[r][r];
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Ai[3 * r + c] = static_cast<double>(static_cast<float>(M[r][3 + c]));
 }
 
 static void make_cam(double fov, double theta, double phi, int vh, int vw, CamParams* cp) {
@@ -136,14 +153,26 @@ __device__ __forceinline__ float sample_position(float coord, int size) {
 }
 
 // ---- grids -----------------------------------------------------------------------------------
-__global__ void k_e2p_grid(const CamParams* cams, int ncam, int eh, int ew, int h, int w,
+// Camera constants travel BY VALUE in the kernel arguments (<= CAM_BATCH cameras per launch, 3.6 KB of the
+// 4 KB argument block): no host-to-device copy of a host temporary, hence no stream synchronisation and no
+// library-owned device scratch (include/panfusion_hip.h: "no implicit device sync").
+constexpr int CAM_BATCH = 12;
+struct CamBatch { CamParams c[CAM_BATCH]; };
+
+__global__ void k_store_cams(const CamBatch batch, int n, CamParams* dst) {      // workspace copy for the table builder
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int WORDS = sizeof(CamParams) / sizeof(double);
+    if (i < n * WORDS) reinterpret_cast<double*>(dst)[i] = reinterpret_cast<const double*>(batch.c)[i];
+}
+
+__global__ void k_e2p_grid(const CamBatch cams, int ncam, int eh, int ew, int h, int w,
                            float* map_x, float* map_y, float* lonlat) {
     long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
     long total = static_cast<long>(ncam) * h * w;
     if (i >= total) return;
     int x = i % w, y = (i / w) % h, c = i / (static_cast<long>(w) * h);
     double px, py, lon, lat;
-    e2p_position(cams[c], eh, ew, h, w, y, x, px, py, lon, lat);
+    e2p_position(cams.c[c], eh, ew, h, w, y, x, px, py, lon, lat);
     if (map_x) map_x[i] = static_cast<float>(px);
     if (map_y) map_y[i] = static_cast<float>(py);
     if (lonlat) {
@@ -152,7 +181,7 @@ __global__ void k_e2p_grid(const CamParams* cams, int ncam, int eh, int ew, int 
     }
 }
 
-__global__ void k_p2e_grid(const CamParams* cams, int ncam, int ph, int pw, int h, int w,
+__global__ void k_p2e_grid(const CamBatch cams, int ncam, int ph, int pw, int h, int w,
                            float* map_u, float* map_v, uint8_t* mask) {
     long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
     long total = static_cast<long>(ncam) * h * w;
@@ -160,7 +189,7 @@ __global__ void k_p2e_grid(const CamParams* cams, int ncam, int ph, int pw, int 
     int x = i % w, y = (i / w) % h, c = i / (static_cast<long>(w) * h);
     double u, v;
     bool vis;
-    p2e_position(cams[c], ph, pw, h, w, y, x, u, v, vis);
+    p2e_position(cams.c[c], ph, pw, h, w, y, x, u, v, vis);
     map_u[i] = static_cast<float>(u);
     map_v[i] = static_cast<float>(v);
     mask[i] = vis ? 1 : 0;
@@ -397,35 +426,11 @@ __global__ void k_blur_normalise(const float* src, int rows_per_view, int h, int
     }
 }
 
-static pf_status upload_cams(const double* fov, const double* theta, const double* phi, int ncam,
-                             int vh, int vw, CamParams* dev, hipStream_t st, const char* who) {
-    std::vector<CamParams> host(ncam);
-    for (int i = 0; i < ncam; ++i) make_cam(fov[i], theta[i], phi[i], vh, vw, &host[i]);
-    hipError_t e = hipMemcpyAsync(dev, host.data(), sizeof(CamParams) * ncam, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) {
-        set_error("%s: camera upload failed: %s", who, hipGetErrorString(e));
-        return PF_ERR_LAUNCH;
-    }
-    // The source is a pageable host temporary: wait until the bytes have left it.  Geometry is built
-    // once per (camera set, size) outside the steady-state loop, so this sync is off the hot path.
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        set_error("%s: stream sync failed: %s", who, hipGetErrorString(e));
-        return PF_ERR_LAUNCH;
-    }
-    return PF_OK;
-}
-
-// Small persistent device scratch for camera constants of the stand-alone grid calls.
-static CamParams* cam_scratch(int ncam) {
-    static thread_local CamParams* buf = nullptr;
-    static thread_local int cap = 0;
-    if (ncam > cap) {
-        if (buf) hipFree(buf);
-        cap = ncam < 64 ? 64 : ncam;
-        if (hipMalloc(&buf, sizeof(CamParams) * cap) != hipSuccess) { buf = nullptr; cap = 0; }
-    }
-    return buf;
+// Host side of the by-value camera batches: cameras [c0, c0 + n) of the call.
+static void fill_batch(const double* fov, const double* theta, const double* phi, int c0, int n, int vh, int vw,
+                       CamBatch* b) {
+    for (int i = 0; i < n; ++i) make_cam(fov[c0 + i], theta[c0 + i], phi[c0 + i], vh, vw, &b->c[i]);
+    for (int i = n; i < CAM_BATCH; ++i) b->c[i] = b->c[0];
 }
 
 }  // namespace pf
@@ -437,14 +442,16 @@ extern "C" pf_status pf_e2p_grid(const double* fov, const double* theta, const d
                                  float* lonlat, void* stream) {
     PF_REQUIRE(fov && theta && phi && ncam > 0, "pf_e2p_grid: cameras missing");
     PF_REQUIRE(eh > 1 && ew > 1 && h > 1 && w > 1, "pf_e2p_grid: sizes must be > 1");
-    CamParams* d = cam_scratch(ncam);
-    PF_REQUIRE(d, "pf_e2p_grid: camera scratch allocation failed");
     hipStream_t st = as_stream(stream);
-    pf_status s = upload_cams(fov, theta, phi, ncam, h, w, d, st, "pf_e2p_grid");
-    if (s != PF_OK) return s;
-    long total = static_cast<long>(ncam) * h * w;
-    hipLaunchKernelGGL(k_e2p_grid, dim3(cdiv(total, 256)), dim3(256), 0, st, d, ncam, eh, ew, h, w,
-                       map_x, map_y, lonlat);
+    const long per = static_cast<long>(h) * w;
+    for (int c0 = 0; c0 < ncam; c0 += CAM_BATCH) {
+        const int n = ncam - c0 < CAM_BATCH ? ncam - c0 : CAM_BATCH;
+        CamBatch batch;
+        fill_batch(fov, theta, phi, c0, n, h, w, &batch);
+        hipLaunchKernelGGL(k_e2p_grid, dim3(cdiv(n * per, 256)), dim3(256), 0, st, batch, n, eh, ew, h, w,
+                           map_x ? map_x + c0 * per : nullptr, map_y ? map_y + c0 * per : nullptr,
+                           lonlat ? lonlat + 2 * c0 * per : nullptr);
+    }
     PF_CHECK_LAUNCH("pf_e2p_grid");
     return PF_OK;
 }
@@ -455,14 +462,15 @@ extern "C" pf_status pf_p2e_grid(const double* fov, const double* theta, const d
     PF_REQUIRE(fov && theta && phi && ncam > 0, "pf_p2e_grid: cameras missing");
     PF_REQUIRE(ph > 1 && pw > 1 && h > 1 && w > 1, "pf_p2e_grid: sizes must be > 1");
     PF_REQUIRE(map_u && map_v && mask, "pf_p2e_grid: outputs missing");
-    CamParams* d = cam_scratch(ncam);
-    PF_REQUIRE(d, "pf_p2e_grid: camera scratch allocation failed");
     hipStream_t st = as_stream(stream);
-    pf_status s = upload_cams(fov, theta, phi, ncam, ph, pw, d, st, "pf_p2e_grid");
-    if (s != PF_OK) return s;
-    long total = static_cast<long>(ncam) * h * w;
-    hipLaunchKernelGGL(k_p2e_grid, dim3(cdiv(total, 256)), dim3(256), 0, st, d, ncam, ph, pw, h, w,
-                       map_u, map_v, mask);
+    const long per = static_cast<long>(h) * w;
+    for (int c0 = 0; c0 < ncam; c0 += CAM_BATCH) {
+        const int n = ncam - c0 < CAM_BATCH ? ncam - c0 : CAM_BATCH;
+        CamBatch batch;
+        fill_batch(fov, theta, phi, c0, n, ph, pw, &batch);
+        hipLaunchKernelGGL(k_p2e_grid, dim3(cdiv(n * per, 256)), dim3(256), 0, st, batch, n, ph, pw, h, w,
+                           map_u + c0 * per, map_v + c0 * per, mask + c0 * per);
+    }
     PF_CHECK_LAUNCH("pf_p2e_grid");
     return PF_OK;
 }
@@ -546,8 +554,13 @@ extern "C" pf_status pf_epa_tables_build(const double* fov, const double* theta,
     float* W2 = reinterpret_cast<float*>(ws + dense);
     float* Bt = reinterpret_cast<float*>(ws + 2 * dense);
     CamParams* cams = reinterpret_cast<CamParams*>(ws + 3 * dense);
-    pf_status s = upload_cams(fov, theta, phi, m, ph, pw, cams, st, "pf_epa_tables_build");
-    if (s != PF_OK) return s;
+    for (int c0 = 0; c0 < m; c0 += CAM_BATCH) {            // camera constants into the caller's workspace, by value
+        const int n = m - c0 < CAM_BATCH ? m - c0 : CAM_BATCH;
+        CamBatch batch;
+        fill_batch(fov, theta, phi, c0, n, ph, pw, &batch);
+        constexpr int WORDS = sizeof(CamParams) / sizeof(double);
+        hipLaunchKernelGGL(k_store_cams, dim3(cdiv(n * WORDS, 256)), dim3(256), 0, st, batch, n, cams + c0);
+    }
     const int fe_ld = static_cast<int>(cdiv(mP, 32)), fp_ld = static_cast<int>(cdiv(E, 32));
     hipMemsetAsync(ws, 0, 3 * dense, st);
     hipMemsetAsync(bias_e, 0, sizeof(float) * E * mP, st);

@@ -60,6 +60,45 @@ def test_e2p_nearest_indices_bit_exact(rot):
         assert np.array_equal(idx, want), "%d index mismatches at %s rot %d" % ((idx != want).sum(), name, rot)
 
 
+def _sha(t):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).digest(), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("rot", [0, 90, 180, 270])
+def test_p2e_grid_and_indices_bit_exact(rot):
+    """north_star: the p2e grid computation is bit-exact too -- mask, float32 (u, v) maps (SHA-256 of the
+    reference's maps, p2e.py:9-49,66-67) and the nearest-neighbour gather indices, 20 benchmark cameras x 4
+    rotation offsets at 64x64 -> 64x128 and 8x8 -> 8x16 (fixture: tools/make_golden_grids.py)."""
+    g = golden("grids_r2.npz")
+    thd, phd = g["theta"], g["phi"]
+    for name, (vh, vw, H, W) in {"64": (64, 64, 64, 128), "8": (8, 8, 8, 16)}.items():
+        key = "%s_rot%d" % (name, rot)
+        mu, mv, mask = ops().p2e_grid([90] * 20, (thd + rot) % 360, phd, vh, vw, H, W, DEV)
+        want_mask = np.unpackbits(g["p2e_mask_" + key])[:20 * H * W].reshape(20, H, W).astype(bool)
+        assert np.array_equal(mask.cpu().numpy().astype(bool), want_mask), key
+        if name == "8":
+            assert np.array_equal(mu.cpu().numpy(), g["p2e_u_" + key]) and np.array_equal(mv.cpu().numpy(), g["p2e_v_" + key])
+        if not (np.array_equal(_sha(mu), g["p2e_u_sha_" + key]) and np.array_equal(_sha(mv), g["p2e_v_sha_" + key])):
+            wu = np.stack([G.p2e_grid(vh, vw, 90, (thd[i] + rot) % 360, phd[i], H, W)[0] for i in range(20)]).astype(np.float32)
+            bad = mu.cpu().numpy() != wu
+            raise AssertionError("%s: %d of %d u values differ from the oracle's (max abs %.3e)"
+                                 % (key, bad.sum(), bad.size, np.abs(mu.cpu().numpy() - wu).max()))
+        idx = ops().nearest_indices(mu, mv, vh, vw).cpu().numpy()
+        assert np.array_equal(idx, g["p2e_idx_" + key].astype(np.int32)), "%d p2e index mismatches at %s" % (
+            (idx != g["p2e_idx_" + key]).sum(), key)
+
+
+@pytest.mark.parametrize("rot", [0, 90, 180, 270])
+def test_e2p_nearest_indices_bit_exact_cfg4(rot):
+    """BASELINE.json configs[3]: 128x256 panorama latent -> 64x64 views, all 20 cameras."""
+    g = golden("grids_r2.npz")
+    mx, my = ops().e2p_grid([90] * 20, (g["theta"] + rot) % 360, g["phi"], 128, 256, 64, 64, DEV)
+    idx = ops().nearest_indices(mx, my, 128, 256).cpu().numpy()
+    want = g["e2p_idx_cfg4_rot%d" % rot]
+    assert np.array_equal(idx, want), "%d index mismatches at rot %d" % ((idx != want).sum(), rot)
+
+
 def test_e2p_p2e_grids_vs_oracle():
     thd, phd = ico()
     th = (thd + 90) % 360
@@ -69,8 +108,8 @@ def test_e2p_p2e_grids_vs_oracle():
     assert float((mx.cpu() - want[:, 0]).abs().max()) <= 4e-6 and float((my.cpu() - want[:, 1]).abs().max()) <= 4e-6
     mu, mv, mask = ops().p2e_grid([90] * 20, th, phd, 16, 16, 16, 32, DEV)
     assert np.array_equal(mask.cpu().numpy().astype(bool), g["p2e_mask_16"])
-    assert float((mu.cpu() - torch.from_numpy(g["p2e_u_16"]).float()).abs().max()) <= 2e-5
-    assert float((mv.cpu() - torch.from_numpy(g["p2e_v_16"]).float()).abs().max()) <= 2e-5
+    assert torch.equal(mu.cpu(), torch.from_numpy(g["p2e_u_16"]).float())      # bit-exact (see the test above)
+    assert torch.equal(mv.cpu(), torch.from_numpy(g["p2e_v_16"]).float())
     cams = {"FoV": torch.full((20,), 90), "theta": torch.tensor(th), "phi": torch.tensor(phd)}
     pc, ec = G.get_coords(16, 16, 16, 32, cams)
     assert float((ll.cpu() - pc).abs().max()) <= 1e-6
@@ -93,7 +132,10 @@ def test_remap_e2p_p2e_vs_oracle(mode):
     ge, gm = p2e(y.to(DEV), *cams, (16, 32), mode=mode)
     we, wm = G.p2e(y, *cams, (16, 32), mode=mode)
     assert torch.equal(gm.cpu(), wm)
-    check("p2e " + mode, ge, we, 1e-5)
+    if mode == "nearest":
+        assert torch.equal(ge.cpu(), we)                     # pure gather * mask: exact
+    else:
+        check("p2e " + mode, ge, we, 1e-5)
     # scalar camera broadcast
     assert torch.equal(e2p(x.to(DEV), 90, 30.0, 10.0, (8, 8), mode="nearest").cpu(),
                        G.e2p(x, 90, 30.0, 10.0, (8, 8), mode="nearest"))

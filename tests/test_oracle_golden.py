@@ -40,6 +40,26 @@ def test_grids_bit_exact():
         assert np.array_equal(mask, g["p2e_mask_16"][i])
 
 
+def test_p2e_and_cfg4_fixtures_bit_exact():
+    """tests/golden/grids_r2.npz (tools/make_golden_grids.py, from the reference's p2e / e2p): the oracle reproduces
+    mask, float32 maps (SHA-256) and nearest indices for all 20 cameras x 4 rotation offsets."""
+    import hashlib
+    g = golden("grids_r2.npz")
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+    for rot in (0, 90, 180, 270):
+        for name, (vh, vw, H, W) in {"64": (64, 64, 64, 128), "8": (8, 8, 8, 16)}.items():
+            key = "%s_rot%d" % (name, rot)
+            maps = [G.p2e_grid(vh, vw, 90, (g["theta"][i] + rot) % 360, g["phi"][i], H, W) for i in range(20)]
+            u, v = (np.stack([m[k] for m in maps]).astype(np.float32) for k in (0, 1))
+            assert np.array_equal(np.packbits(np.stack([m[2] for m in maps])), g["p2e_mask_" + key])
+            assert np.array_equal(sha(u), g["p2e_u_sha_" + key]) and np.array_equal(sha(v), g["p2e_v_sha_" + key])
+            idx = np.stack([G.nearest_indices(m[0], m[1], vh, vw) for m in maps])
+            assert np.array_equal(idx, g["p2e_idx_" + key].astype(np.int64))
+        for i in range(0, 20, 7):                                # cfg 4 e2p indices (a sample of cameras: CPU time)
+            mx, my = G.e2p_grid(128, 256, 90, (g["theta"][i] + rot) % 360, g["phi"][i], 64, 64)
+            assert np.array_equal(G.nearest_indices(mx, my, 128, 256), g["e2p_idx_cfg4_rot%d" % rot][i].astype(np.int64))
+
+
 def test_init_noise_gather():
     g, gn = golden("grids.npz"), golden("init_noise.npz")
     gen = torch.Generator().manual_seed(0)
