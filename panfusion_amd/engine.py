@@ -49,18 +49,42 @@ def _w16(t, dev, dtype):
     return t.detach().to(device=dev, dtype=torch.float32).to(dtype).contiguous()
 
 
-def _lin_weight(lin):
-    """Effective weight of a (LoRA-compatible) linear: W + up @ down
-    (PanoGenerator.py:132-151, rank-4 LoRA with scale 1 folded for inference)."""
+def _lora_delta(lora):
+    """up @ down of a diffusers LoRALinearLayer (scale network_alpha / rank when an alpha is set)."""
+    down, up = lora.down.weight.detach().float(), lora.up.weight.detach().float()
+    delta = up @ down
+    alpha = getattr(lora, "network_alpha", None)
+    if alpha is not None:
+        delta = delta * (float(alpha) / down.shape[0])
+    return delta
+
+
+def _lin_weight(lin, processor_lora=None):
+    """Effective weight of a (LoRA-compatible) linear: W + up @ down (PanoGenerator.py:132-151, rank-4 LoRA
+    with scale 1 folded for inference).  The LoRA matrices live in ONE of two places:
+      * ``lin.lora_layer.{down,up}`` -- where diffusers 0.24 keeps them after the first Attention.forward
+        migrated them out of the processor (and where its own saved checkpoints have them);
+      * ``attn.processor.to_{q,k,v,out}_lora.{down,up}`` (``processor_lora``) -- where
+        ``unet.set_attn_processor(LoRAAttnProcessor(...))`` puts them and where a reference checkpoint
+        loads them (convert_state_dict, PanoGenerator.py:101-111).  This engine never calls the modules'
+        forward, so the migration never happens: both places are read here."""
     w = lin.weight.detach().float()
-    lora = getattr(lin, "lora_layer", None)
+    own = getattr(lin, "lora_layer", None)
+    if own is not None and processor_lora is not None:
+        raise ValueError("LoRA weights found both in <linear>.lora_layer and in the attention processor")
+    lora = own if own is not None else processor_lora
     if lora is not None:
-        delta = lora.up.weight.detach().float() @ lora.down.weight.detach().float()
-        alpha = getattr(lora, "network_alpha", None)
-        if alpha is not None:
-            delta = delta * (alpha / lora.down.weight.shape[0])
-        w = w + delta
+        w = w + _lora_delta(lora)
     return w
+
+
+def _processor_lora(attn, name):
+    """attn.processor.to_{q,k,v,out}_lora of an un-migrated diffusers LoRAAttnProcessor, or None."""
+    proc = getattr(attn, "processor", None)
+    lora = getattr(proc, name, None) if proc is not None else None
+    if lora is not None and not (hasattr(lora, "down") and hasattr(lora, "up")):
+        raise TypeError("%s.%s has no down / up matrices" % (type(proc).__name__, name))
+    return lora
 
 
 def _conv3_weight(conv, dev, dtype):
@@ -136,14 +160,17 @@ def pack_resnet(res, dev, dtype, mixed=False):
 def pack_attention(attn, dev, dtype, self_attn):
     a = NS()
     a.heads = attn.heads
-    wq, wk, wv = _lin_weight(attn.to_q), _lin_weight(attn.to_k), _lin_weight(attn.to_v)
+    wq = _lin_weight(attn.to_q, _processor_lora(attn, "to_q_lora"))
+    wk = _lin_weight(attn.to_k, _processor_lora(attn, "to_k_lora"))
+    wv = _lin_weight(attn.to_v, _processor_lora(attn, "to_v_lora"))
     a.dim = wq.shape[0]
     if self_attn:
         a.wqk = _w16(torch.cat([wq, wk], 0), dev, dtype)
     else:
         a.wq, a.wk = _w16(wq, dev, dtype), _w16(wk, dev, dtype)
     a.wv = _w16(wv, dev, dtype)
-    a.wo, a.bo = _w16(_lin_weight(attn.to_out[0]), dev, dtype), _bias(attn.to_out[0], dev)
+    a.wo = _w16(_lin_weight(attn.to_out[0], _processor_lora(attn, "to_out_lora")), dev, dtype)
+    a.bo = _bias(attn.to_out[0], dev)
     return a
 
 
@@ -497,14 +524,34 @@ class EPATables:
     """Geometry that depends only on (cameras, sizes): bias tables, tile flags, PE tables.
     Built once per key on the device and kept (immutable keyed caches)."""
 
+    MAX_ENTRIES = 16        # LRU bound: a rotation step that does not divide 360 would otherwise grow ~0.35 GB per step
+    PINNING = 0             # > 0 while a hipGraph is being warmed up / captured: a captured graph reads its tables by
+                            # address, so the sets fetched then are pinned and never evicted
+
+    class pinned:
+        def __enter__(self):
+            EPATables.PINNING += 1
+
+        def __exit__(self, *exc):
+            EPATables.PINNING -= 1
+            return False
+
     def __init__(self):
         self.cache = {}
+        self.pins = set()
 
     def get(self, fov, theta, phi, ph, pw, eh, ew, freq, device):
         key = (tuple(float(v) for v in fov), tuple(float(v) for v in theta),
                tuple(float(v) for v in phi), ph, pw, eh, ew, freq.numel(), freq.data_ptr())
-        hit = self.cache.get(key)
-        if hit is None:
+        if EPATables.PINNING:
+            self.pins.add(key)
+        hit = self.cache.pop(key, None)
+        if hit is not None:
+            self.cache[key] = hit               # most recently used last
+        else:
+            victims = [k for k in self.cache if k not in self.pins]
+            while len(self.cache) >= self.MAX_ENTRIES and victims:
+                self.cache.pop(victims.pop(0))
             bias_e, bias_p, flags_e, flags_p = ops.epa_tables(fov, theta, phi, ph, pw, eh, ew, device)
             _, _, lonlat = ops.e2p_grid(fov, theta, phi, eh, ew, ph, pw, device, want_lonlat=True)
             pe_p = ops.spherical_pe(lonlat.view(-1, 2), freq)              # [m*P, C]

@@ -38,6 +38,9 @@ class MultiViewBaseModel(nn.Module):
         # to fill 256 CUs; side by side with the view branch they fill each other's tails)
         self.two_streams = os.environ.get("PF_STREAMS", "2") != "1"
         self._side = None
+        # packed 16-bit weights go stale when a checkpoint is loaded -- also through a parent module (the
+        # reference's LightningModule), where an overridden load_state_dict would never run
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.repack())
 
         if self.unet is not None:      # EPA block widths, reference MVGenModel.py:19-32
             self.cp_blocks_encoder = nn.ModuleList(
@@ -66,11 +69,6 @@ class MultiViewBaseModel(nn.Module):
             for blk in [*self.cp_blocks_encoder, self.cp_blocks_mid, *self.cp_blocks_decoder]:
                 blk.compute_dtype, blk.precision = self.compute_dtype, self.precision
                 blk.repack()
-
-    def load_state_dict(self, *a, **k):
-        out = super().load_state_dict(*a, **k)
-        self.repack()
-        return out
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()

@@ -9,10 +9,29 @@ from ... import engine, ops
 from ..modules.transformer import BasicTransformerBlock, SphericalPE
 
 
+_HOST_CAMS = {}        # (data_ptr, version, numel, device) of a device tensor -> its host values
+
+
+def _host_values(v):
+    """Angles are read as host scalars (the reference does `.item()` per camera).  A device tensor costs a
+    synchronising copy: done once per (storage, version), not once per forward (the reference's cameras are
+    GPU tensors that do not change inside a sampling loop)."""
+    if not isinstance(v, torch.Tensor):
+        return list(v)
+    if not v.is_cuda:
+        return v.detach().tolist()
+    key = (v.data_ptr(), v._version, v.numel(), str(v.device), v.dtype)
+    hit = _HOST_CAMS.get(key)
+    if hit is None:
+        if len(_HOST_CAMS) > 256:
+            _HOST_CAMS.clear()
+        hit = _HOST_CAMS[key] = v.detach().cpu().tolist()
+    return hit
+
+
 def camera_groups(cameras, b):
     """cameras: dict of flattened (b*m,) values -> per-batch-element host tuples."""
-    host = lambda v: v.detach().cpu().tolist() if isinstance(v, torch.Tensor) else list(v)
-    fov, theta, phi = host(cameras["FoV"]), host(cameras["theta"]), host(cameras["phi"])
+    fov, theta, phi = _host_values(cameras["FoV"]), _host_values(cameras["theta"]), _host_values(cameras["phi"])
     m = len(fov) // b
     return m, [(tuple(fov[i * m:(i + 1) * m]), tuple(theta[i * m:(i + 1) * m]), tuple(phi[i * m:(i + 1) * m]))
                for i in range(b)]
@@ -27,6 +46,9 @@ class WarpAttn(nn.Module):
         self.compute_dtype = compute_dtype
         self._packed = None
         self._tables = engine.EPATables()
+        # checkpoints loaded through a PARENT module never reach a load_state_dict override of this class
+        # (nn.Module recurses via _load_from_state_dict): the post hook fires either way
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.repack())
 
     def packed(self, device):
         key = (device, self.compute_dtype, self.precision)
@@ -37,11 +59,6 @@ class WarpAttn(nn.Module):
 
     def repack(self):
         self._packed = None
-
-    def load_state_dict(self, *a, **k):
-        out = super().load_state_dict(*a, **k)
-        self.repack()                      # packed 16-bit copies are stale now
-        return out
 
     def tables_for(self, groups, ph, pw, eh, ew, device):
         e = self.packed(device)

@@ -137,13 +137,34 @@ class UNetParams(_Holder):
         self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=1e-5)
         self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)
 
-    def add_lora(self, rank=4):
-        # attention projections only (q, k, v, out), PanoGenerator.py:132-151
+    def attention_modules(self):
         for blk in [*self.down_blocks, self.mid_block, *self.up_blocks]:
             for t in getattr(blk, "attentions", []) or []:
-                for a in (t.transformer_blocks[0].attn1, t.transformer_blocks[0].attn2):
-                    for lin in (a.to_q, a.to_k, a.to_v, a.to_out[0]):
-                        lin.set_lora(rank)
+                yield t.transformer_blocks[0].attn1
+                yield t.transformer_blocks[0].attn2
+
+    def add_lora(self, rank=4, layout="lora_layer"):
+        """Rank-`rank` LoRA on the attention projections (q, k, v, out), PanoGenerator.py:132-151.
+        layout "lora_layer": ``<linear>.lora_layer.{down,up}`` (diffusers' post-migration / saved layout);
+        layout "processor":  ``<attn>.processor.to_{q,k,v,out}_lora.{down,up}`` -- what
+        ``unet.set_attn_processor(LoRAAttnProcessor(...))`` creates and what the keys of a reference
+        checkpoint address after ``convert_state_dict`` (PanoGenerator.py:101-111)."""
+        for a in self.attention_modules():
+            if layout == "lora_layer":
+                for lin in (a.to_q, a.to_k, a.to_v, a.to_out[0]):
+                    lin.set_lora(rank)
+            elif layout == "processor":
+                proc = _Holder()
+                for name, lin in (("to_q_lora", a.to_q), ("to_k_lora", a.to_k), ("to_v_lora", a.to_v),
+                                  ("to_out_lora", a.to_out[0])):
+                    lora = _Holder()
+                    lora.down = nn.Linear(lin.in_features, rank, bias=False)
+                    lora.up = nn.Linear(rank, lin.out_features, bias=False)
+                    nn.init.zeros_(lora.up.weight)          # diffusers LoRALinearLayer: up starts at zero
+                    setattr(proc, name, lora)
+                a.processor = proc
+            else:
+                raise ValueError("layout must be 'lora_layer' or 'processor'")
 
 
 class ControlNetParams(_Holder):

@@ -109,15 +109,23 @@ class DenoiseLoop:
         return self.model(pair(self.lat), pair(self.pano), self.tstep, self.prompt, self.pano_prompt, cams2,
                           None, self._layout_for(cams))
 
+    MAX_GRAPHS = 8        # distinct rotation offsets kept as graphs (4 at rot_diff = 90); beyond that: eager launches
+
     def _denoise_graphed(self, cams):
         key = tuple(float(v) for v in cams["theta"].reshape(-1))
         g = self.graphs.get(key)
+        if g is None and len(self.graphs) >= self.MAX_GRAPHS:
+            # a rotation step that does not divide 360 never revisits an offset: capturing (and keeping) a graph
+            # plus its table set per step would re-capture every step and grow without bound
+            return self._denoise(cams)
         if g is None:
-            self._denoise(cams)                      # warm-up: builds tables, sets kernel attributes
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self._denoise(cams)
+            from .engine import EPATables
+            with EPATables.pinned():                 # the graph reads its geometry tables by address
+                self._denoise(cams)                  # warm-up: builds tables, sets kernel attributes
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self._denoise(cams)
             g = (graph, out)
             self.graphs[key] = g
         g[0].replay()

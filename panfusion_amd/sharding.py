@@ -224,10 +224,12 @@ class SegmentedGraph:
         return _Ctx()
 
     def eager(self, fn):
-        """Called while recording: close the current graph segment, run `fn` eagerly (it is re-run at
-        every replay), open the next segment."""
+        """Called while recording: close the current graph segment, note `fn` as the eager call that runs
+        between the two segments at every replay, open the next segment.  `fn` is NOT run while recording:
+        nothing is -- the captured kernels around it only get recorded, so its inputs hold no data yet --
+        and a recording pass without collectives cannot fall out of step with its peers if the capture
+        fails on one rank (the fallback decision is taken collectively afterwards)."""
         self._end()
-        fn()
         self.items.append(("call", fn))
         self._begin()
 
@@ -311,8 +313,8 @@ class ShardedDenoiseLoop(DenoiseLoop):
     def __init__(self, model, shard, *a, **k):
         super().__init__(model, *a, **k)
         self.shard = shard
-        self.layout = "cfg2 x viewgroups%d %s" % (shard.G, "views " + "/".join(map(str, shard.counts)) +
-                                                  (" (group 0 owns the panorama)" if shard.pano_g is not None else ""))
+        self.layout_desc = "cfg2 x viewgroups%d %s" % (shard.G, "views " + "/".join(map(str, shard.counts)) +
+                                                       (" (group 0 owns the panorama)" if shard.pano_g is not None else ""))
         model.shard = shard
 
     def _local(self, cams):
@@ -320,8 +322,10 @@ class ShardedDenoiseLoop(DenoiseLoop):
         v0, v1 = s.views
         c = s.cfg
         ts = self.tstep[:1, v0:v1] if v1 > v0 else self.tstep[:1, :1]     # a panorama-only owner still needs t
+        lay = self._layout_for(cams)                 # panorama ControlNet condition (CFG pair): this rank's sample,
+        lay = lay[c:c + 1] if (lay is not None and s.has_pano) else None   # on the ranks that run the panorama branch
         return self.model(self.lat[:, v0:v1].contiguous(), self.pano, ts,
-                          self.prompt[c:c + 1, v0:v1], self.pano_prompt[c:c + 1], cams)
+                          self.prompt[c:c + 1, v0:v1], self.pano_prompt[c:c + 1], cams, None, lay)
 
     def _gather(self, out):
         return gather_eps(out[0], out[1], self.shard, pano_shape=(1,) + tuple(self.pano.shape[1:]))
@@ -335,17 +339,25 @@ class ShardedDenoiseLoop(DenoiseLoop):
         key = tuple(float(v) for v in cams["theta"].reshape(-1))
         g = self.graphs.get(key)
         if g is None:
+            from .engine import EPATables
             self._local(cams)                        # warm-up: tables, kernel attributes, communicator
             torch.cuda.synchronize()
-            seg = SegmentedGraph()
+            seg, out, ok = SegmentedGraph(), None, 1
             try:
-                with seg.record():
+                with EPATables.pinned(), seg.record():   # no collective runs in here (SegmentedGraph.eager)
                     out = self._local(cams)
-            except RuntimeError as e:                # capture refused (driver / communicator state): the same
-                import sys                           # kernels are launched eagerly instead -- slower host side, same results
-                print("panfusion_amd.sharding: hipGraph capture failed (%s); launching eagerly" % e, file=sys.stderr)
+            except RuntimeError as e:                # capture refused (driver / communicator state)
+                import sys
+                print("panfusion_amd.sharding: hipGraph capture failed on rank %d (%s)" % (self.shard.rank, e), file=sys.stderr)
                 torch.cuda.synchronize()
+                ok = 0
+            # the fallback is decided by ALL ranks together: if the capture failed anywhere, everybody drops
+            # its graphs and launches eagerly from here on (same kernels, same collective sequence on every rank)
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.pano.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
                 self.use_graphs = False
+                self.graphs.clear()
                 return self._denoise(cams)
             g = (seg, out)
             self.graphs[key] = g
@@ -353,9 +365,10 @@ class ShardedDenoiseLoop(DenoiseLoop):
         return self._gather(g[1])
 
 
-def build_sharded(build_model, build_inputs, dev, dtype, cfg, m, lat_hw, pano_hw, cams_deg, steps, use_graphs):
+def build_sharded(build_model, build_inputs, dev, dtype, cfg, m, lat_hw, pano_hw, cams_deg, steps, use_graphs,
+                  precision=None):
     shard = make_shard(m)
-    model = build_model(dev, dtype, cfg)
+    model = build_model(dev, dtype, cfg, precision=precision)
     inputs = build_inputs(dev, m, lat_hw, pano_hw, cfg["cross_attention_dim"], cams_deg)
     loop = ShardedDenoiseLoop(model, shard, *inputs, steps=steps, use_graphs=use_graphs)
     return model, loop

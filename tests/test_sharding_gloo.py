@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_loop(sharded, steps=2, split=None, layout=None):
+def _run_loop(sharded, steps=2, split=None, layout=None, precision="fast"):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import fake_ops
@@ -33,7 +33,7 @@ def _run_loop(sharded, steps=2, split=None, layout=None):
     from panfusion_amd.pipeline import DenoiseLoop
     g = golden("mvgen_tiny.npz")
     t = lambda k: torch.from_numpy(g[k])
-    model = hip_model(build_tiny_oracle())
+    model = hip_model(build_tiny_oracle(), precision=precision)
     cam1 = {k: v[None] for k, v in cam4().items()}
     args = (t("latents")[:1], t("pano_latent")[:1], t("prompt_embd"), t("pano_prompt_embd"), cam1)
     if sharded:
@@ -43,12 +43,12 @@ def _run_loop(sharded, steps=2, split=None, layout=None):
     return loop.run()
 
 
-def _worker(rank, world, port, out, split=None, layout=None):
+def _worker(rank, world, port, out, split=None, layout=None, precision="fast"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        lat, pano = _run_loop(True, split=split, layout=layout)
+        lat, pano = _run_loop(True, split=split, layout=layout, precision=precision)
         torch.save((lat, pano), os.path.join(out, "r%d.pt" % rank))
     finally:
         dist.destroy_process_group()
@@ -86,16 +86,18 @@ def test_plan_layout():
     assert sum(s.counts) == 20 and s.counts[0] == 0 and max(s.counts[1:]) - min(s.counts[1:]) <= 1
 
 
-@pytest.mark.parametrize("world,split,layout", [(2, None, None), (4, None, "even"), (4, None, None), (6, (2, 1, 1), None),
-                                                (6, (0, 2, 2), None), (6, None, None), (8, None, None)])
-def test_sharded_loop_equals_single_process(world, split, layout):
+@pytest.mark.parametrize("world,split,layout,precision", [
+    (2, None, None, "fast"), (4, None, "even", "fast"), (4, None, None, "fast"), (6, (2, 1, 1), None, "fast"),
+    (6, (0, 2, 2), None, "fast"), (6, None, None, "fast"), (8, None, None, "fast"),
+    (4, None, "even", "mixed"), (6, (0, 2, 2), None, "mixed")])       # fp32 streams + split-precision GEMMs, sharded
+def test_sharded_loop_equals_single_process(world, split, layout, precision):
     """(4, auto) = (0, 4), (6, auto) = (0, 2, 2), (8, auto) = (0, 2, 1, 1) and (6, (2, 1, 1)): the panorama-rank layout -- group 0 of a CFG half owns the panorama branch and
     fewer views, the other ranks run the view branch only and receive the panorama tokens by broadcast (unequal,
     padded gathers).  (4, "even"): views split evenly, panorama branch replicated.  (6, (0, 2, 2)): a panorama-only
     owner -- no view branch on ranks 0 / 3, they contribute empty blocks to the gathers."""
-    want = _run_loop(False)
+    want = _run_loop(False, precision=precision)
     with tempfile.TemporaryDirectory() as out:
-        mp.spawn(_worker, args=(world, _free_port(), out, split, layout), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), out, split, layout, precision), nprocs=world, join=True)
         res = [torch.load(os.path.join(out, "r%d.pt" % r)) for r in range(world)]
     for lat, pano in res:                       # every rank holds the full, identical latents
         rel = lambda a, b: float((a - b).norm() / b.norm())       # fp32 round-off of differently batched convs
