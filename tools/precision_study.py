@@ -50,17 +50,25 @@ class Policy:
         self.cur = None             # tag of the GEMM being executed (for live weight rounding)
         self.count = None
         self.exact = set()          # tags computed exactly (split-precision / fp32 layers)
+        self.exact_levels = {}      # tag -> set of UNet levels (0 = full resolution .. 3) where it is exact; absent: all
+        self.level = 0
 
     @property
     def active(self):
         return self.window is None or self.block in self.window
 
     def r(self, cls, x, tag=None):
-        if cls in self.rounded and self.active and (self.tags is None or tag in self.tags) and tag not in self.exact:
+        if cls in self.rounded and self.active and (self.tags is None or tag in self.tags) and not self.is_exact(tag):
             if self.count is not None:
                 self.count[(cls, tag)] = self.count.get((cls, tag), 0) + 1
             return x.to(self.dt).float()
         return x
+
+    def is_exact(self, tag):
+        if tag not in self.exact:
+            return False
+        lv = self.exact_levels.get(tag)
+        return lv is None or self.level in lv
 
     def mark(self, name, *tensors):
         if self.trace is not None:
@@ -203,7 +211,14 @@ def emulate(policy):
         def f(self, *a, **k):
             policy.block += 1
             policy.names[policy.block] = "%s.%s" % ("pano" if getattr(self, "pano", a and len(a) > 4 and a[4]) else "pers", name.strip("_"))
+            if name == "__init__":
+                self._level = 0
+            policy.level = self._level - (1 if name == "upsample" else 0)     # an upsampling conv works at the finer level
             out = orig[name](self, *a, **k)
+            if name == "downsample":
+                self._level += 1
+            elif name == "upsample":
+                self._level -= 1
             if name == "__init__":
                 self.h = policy.r("stream", self.h, "conv_in")
                 self.skips = [self.h]
@@ -221,6 +236,7 @@ def emulate(policy):
     def head_counted(self):
         policy.block += 1
         policy.names[policy.block] = "%s.head" % ("pano" if self.pano else "pers")
+        policy.level = 0
         return head(self)
 
     for n in ("resnet", "attention", "downsample", "upsample", "__init__"):
@@ -383,7 +399,12 @@ def main():
     for name in args.schemes.split(","):
         base, _, ex = name.partition("+")
         pol = Policy(args.fmt, SCHEMES[base])
-        pol.exact = set().union(*[EXACT[e] for e in ex.split("+") if e])
+        for e in [e for e in ex.split("+") if e]:
+            grp, _, lv = e.partition("@")
+            pol.exact |= EXACT[grp]
+            if lv:
+                for tag in EXACT[grp]:
+                    pol.exact_levels[tag] = set(int(c) for c in lv)
         pol.trace = [] if args.trace else None
         es, ep = run(pol)
         print("%-12s %s  views %.3e  pano %.3e" % (name, args.fmt, es, ep), flush=True)
