@@ -151,6 +151,17 @@ pf_status pf_nhwc_to_nchw(const void* x, int src_dtype, int n, int C, int h, int
  * dtype_a, b of type dtype_b (any of PF_BF16 / PF_F16 / PF_F32). */
 pf_status pf_add(const void* a, int dtype_a, const void* b, int dtype_b, long n, void* y, void* stream);
 
+/* Row softmax of fp32 scores: probs[r][j] = exp(scale (s[r][j] - max_j)) / sum_j, 16-bit out.  The VAE decoder's
+ * mid-block attention has ONE head of width 512 (diffusers Attention in AutoencoderKL, reached from
+ * PanoGenerator.py:213-220 decode_latent): its scores and the P.V product run on pf_conv_gemm (batched), this
+ * kernel sits between them.  scores [rows][scores_ld] fp32, probs [rows][probs_ld] (out_dtype 16-bit). */
+pf_status pf_softmax_rows(const float* scores, long rows, int n, long scores_ld, float scale, int out_dtype,
+                          void* probs, long probs_ld, void* stream);
+
+/* models/modules/utils.py:9-15 tensor_to_image: x fp32 NCHW in [-1, 1] -> y uint8 NHWC,
+ * round((x / 2 + 0.5).clamp(0, 1) * 255) (half to even, like torch.round). */
+pf_status pf_tensor_to_image(const float* x, int n, int C, int h, int w, uint8_t* y, void* stream);
+
 /* Fused classifier-free-guidance merge + DDIM update (+ optional width roll of the result):
  * eps = eps_uncond + g*(eps_cond - eps_uncond)                (PanoGenerator.py:253-262)
  * x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t); x' = sqrt(a_prev) x0 + sqrt(1-a_prev) eps  (DDIM eta=0)

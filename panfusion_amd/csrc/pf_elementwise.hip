@@ -411,6 +411,85 @@ __global__ void k_cfg_ddim(const float* __restrict__ x, const float* __restrict_
     out[r * W + wo] = xn;
 }
 
+// ---- row softmax (VAE mid-block attention: one head of width 512, scores through the GEMM kernel) -------
+// p[r][j] = exp(scale * (s[r][j] - max_j s[r][j])) / sum, fp32 scores -> 16-bit probabilities.  One block
+// per row; rows of up to 256 * PT columns live in registers between the three sweeps, longer rows are
+// re-read from memory.
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, w) : v + w;
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                                   // red[] may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+template <typename T, int PT>
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ s, long s_ld, int n, float scale,
+                                                      unsigned short* __restrict__ p, long p_ld) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const float* src = s + row * s_ld;
+    unsigned short* dst = p + row * p_ld;
+    const int t = threadIdx.x;
+    const bool cached = n <= 256 * PT;
+    float v[PT];
+    float m = -INFINITY;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int j = t + 256 * i;
+            v[i] = j < n ? src[j] : -INFINITY;
+            m = fmaxf(m, v[i]);
+        }
+    } else {
+        for (int j = t; j < n; j += 256) m = fmaxf(m, src[j]);
+    }
+    m = block_reduce(m, true, red);
+    const float c = scale * 1.44269504088896340736f;   // exp(scale * (x - m)) = exp2(c * x - c * m)
+    float sum = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            v[i] = exp2f(c * (v[i] - m));              // exp2f(-inf) = 0 for the padding lanes
+            sum += v[i];
+        }
+    } else {
+        for (int j = t; j < n; j += 256) sum += exp2f(c * (src[j] - m));
+    }
+    sum = block_reduce(sum, false, red);
+    const float inv = 1.0f / sum;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int j = t + 256 * i;
+            if (j < n) dst[j] = from_f32<T>(v[i] * inv);
+        }
+    } else {
+        for (int j = t; j < n; j += 256) dst[j] = from_f32<T>(exp2f(c * (src[j] - m)) * inv);
+    }
+}
+
+// models/modules/utils.py:9-15 tensor_to_image: fp32 NCHW image in [-1, 1] -> uint8 NHWC, (x / 2 + 0.5).clamp(0, 1) * 255
+// rounded half-to-even like torch.round.
+__global__ void k_tensor_to_image(const float* __restrict__ x, int n, int C, long hw, uint8_t* __restrict__ y) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    const long total = static_cast<long>(n) * C * hw;
+    if (i >= total) return;
+    const int c = i % C;
+    const long p = (i / C) % hw, b = i / (C * hw);
+    float v = x[(b * C + c) * hw + p] / 2.0f + 0.5f;
+    v = fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f;
+    y[i] = static_cast<uint8_t>(nearbyintf(v));
+}
+
 // ---- boundary convolutions ---------------------------------------------------------------------
 // conv_in: x fp32 NCHW [n][cin][h][w] -> y NHWC 16-bit; weights fp32 [3][3][cin][cout].
 template <typename T, bool OUT_F32>
@@ -745,6 +824,27 @@ extern "C" pf_status pf_cfg_ddim_step(const float* x, const float* eu, const flo
     hipLaunchKernelGGL(k_cfg_ddim, dim3(cdiv(rows * W, 256)), dim3(256), 0, as_stream(stream), x, eu, ec, g, sa,
                        sb, sap, sbp, rows, W, roll, out);
     PF_CHECK_LAUNCH("pf_cfg_ddim_step");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_softmax_rows(const float* scores, long rows, int n, long scores_ld, float scale, int out_dtype,
+                                     void* probs, long probs_ld, void* stream) {
+    PF_REQUIRE(scores && probs && rows > 0 && n > 0, "pf_softmax_rows: bad arguments");
+    PF_REQUIRE(scores_ld >= n && probs_ld >= n, "pf_softmax_rows: leading dimensions must cover n=%d", n);
+    PF_REQUIRE(rows < (1L << 31), "pf_softmax_rows: too many rows");
+    PF_DISPATCH_16(out_dtype, "pf_softmax_rows",
+        hipLaunchKernelGGL((k_softmax_rows<T, 40>), dim3(static_cast<unsigned>(rows)), dim3(256), 0, as_stream(stream),
+                           scores, scores_ld, n, scale, static_cast<unsigned short*>(probs), probs_ld));
+    PF_CHECK_LAUNCH("pf_softmax_rows");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_tensor_to_image(const float* x, int n, int C, int h, int w, uint8_t* y, void* stream) {
+    PF_REQUIRE(x && y && n > 0 && C > 0 && h > 0 && w > 0, "pf_tensor_to_image: bad arguments");
+    const long total = static_cast<long>(n) * C * h * w;
+    hipLaunchKernelGGL(k_tensor_to_image, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), x, n, C,
+                       static_cast<long>(h) * w, y);
+    PF_CHECK_LAUNCH("pf_tensor_to_image");
     return PF_OK;
 }
 

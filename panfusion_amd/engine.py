@@ -153,8 +153,19 @@ def pack_resnet(res, dev, dtype, mixed=False):
             r.ws3 = _split_weight(sc.weight.detach().float().reshape(r.cout, r.cin), 1, dev, dtype)
     else:
         r.ws = r.bs = None
-    r.temb = res.time_emb_proj      # consumed by pack_unet (concatenated projection)
+    r.temb = getattr(res, "time_emb_proj", None)      # consumed by pack_unet (concatenated projection); None: VAE resnets
     return r
+
+
+def pack_resnet_plain(res, dev, dtype, mixed=False):
+    """A resnet without time embedding (the VAE decoder's, vae.py)."""
+    r = pack_resnet(res, dev, dtype, mixed)
+    del r.temb
+    return r
+
+
+def run_resnet_plain(r, x):
+    return run_resnet(r, x, None, None)
 
 
 def pack_attention(attn, dev, dtype, self_attn):
@@ -374,7 +385,7 @@ def run_resnet(r, x, skip, temb_all, groups_eps=None):
     hw = h * w
     sc, sh = ops.groupnorm_scale_shift(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, r.norm1.b)
     y = ops.scale_shift_act(x, skip, n, hw, sc, sh, 1, out_dtype=r.dtype)
-    rowvec = temb_all[:, r.temb_off:]
+    rowvec = temb_all[:, r.temb_off:] if temb_all is not None else None
     h1 = ops.conv_gemm(y, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec)
     h1 = h1.view(n, hw, r.cout)
     sc, sh = ops.groupnorm_scale_shift(h1, None, n, hw, r.norm2.groups, r.norm2.eps, r.norm2.g, r.norm2.b)

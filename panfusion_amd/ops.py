@@ -258,6 +258,26 @@ def nhwc_to_nchw(x, dtype, out=None):
     return out
 
 
+def softmax_rows(scores, scale, out_dtype, out=None):
+    """scores fp32 [..., rows, n] (contiguous rows) -> probabilities [..., rows, n] in out_dtype (16-bit)."""
+    n = scores.shape[-1]
+    rows = scores.numel() // n
+    if out is None:
+        out = torch.empty(scores.shape, device=scores.device, dtype=out_dtype)
+    check(_lib.lib().pf_softmax_rows(_p(scores), rows, n, _ld(scores), float(scale), dt(out), _p(out), _ld(out), _stream()),
+          "pf_softmax_rows")
+    return out
+
+
+def tensor_to_image(x):
+    """fp32 NCHW image in [-1, 1] -> uint8 NHWC (models/modules/utils.py:9-15)."""
+    x = x.float().contiguous()
+    n, Cc, h, w = x.shape
+    out = torch.empty(n, h, w, Cc, device=x.device, dtype=torch.uint8)
+    check(_lib.lib().pf_tensor_to_image(_p(x), n, Cc, h, w, _p(out), _stream()), "pf_tensor_to_image")
+    return out
+
+
 def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
     """x / eps fp32 [..., W]; coef = (sqrt a_t, sqrt(1-a_t), sqrt a_prev, sqrt(1-a_prev))."""
     W = x.shape[-1]
@@ -287,6 +307,8 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     h_out = (hl + 2 * pad - ksize) // stride + 1
     w_out = (wl + 2 * pad - ksize) // stride + 1
     M = n_img * h_out * w_out
+    if out is not None:
+        out_dtype = out.dtype
     out_dtype = out_dtype or (residual.dtype if residual is not None else a0.dtype)
     n_store = n_out // 2 if geglu else n_out
     if out is None:

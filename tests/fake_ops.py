@@ -170,6 +170,14 @@ def nhwc_to_nchw(x, dtype, out=None):
     return x.permute(0, 3, 1, 2).to(dtype).contiguous()
 
 
+def softmax_rows(scores, scale, out_dtype, out=None):
+    return torch.softmax(scores.float() * scale, -1).to(out_dtype)
+
+
+def tensor_to_image(x):
+    return ((x.float() / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
 def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
     sa, sb, sap, sbp = coef
     eps = eps_uncond + guidance * (eps_cond - eps_uncond)
@@ -182,8 +190,21 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, c1=None,
-              a0_ld=None, a1_ld=None, algo_k=None, **kw):
-    assert batch == 1
+              a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, **kw):
+    if batch > 1:          # independent problems (attention scores / P.V of the VAE): plain linears only
+        assert ksize == 1 and a1 is None and bias is None and residual is None and rowvec is None and not geglu
+        K = c0 or a0.shape[-1]
+        A = a0.float().reshape(-1)[:a_bstride * (batch - 1) + w_in * K] if a_bstride else None
+        outs = []
+        for b in range(batch):
+            Ab = a0.float().reshape(-1)[b * a_bstride:b * a_bstride + w_in * K].reshape(w_in, K) if a_bstride else a0.float().reshape(w_in, K)
+            Wb = w.float().reshape(-1)[b * w_bstride:b * w_bstride + n_out * K].reshape(n_out, K)
+            outs.append(Ab @ Wb.t())
+        y = torch.stack(outs).to(out_dtype or a0.dtype)
+        if out is not None:
+            out.copy_(y.reshape(out.shape))
+            return out
+        return y
     # [pixel][ld] rows of which the first c channels are taken (the split-precision GEMM passes the [hi | lo]
     # pair as source 0 and its hi half again as source 1: same storage, c1 = ld / 2)
     x = a0.float().reshape(-1, a0_ld or a0.shape[-1])[:, :(c0 or a0.shape[-1])]

@@ -8,7 +8,7 @@ import fake_ops
 from conftest import build_tiny_oracle, cam4, golden, rel_l2
 from oracle import mvgen as MV
 
-MODS = ["panfusion_amd.engine", "panfusion_amd.pipeline", "panfusion_amd.models.pano.modules",
+MODS = ["panfusion_amd.engine", "panfusion_amd.pipeline", "panfusion_amd.vae", "panfusion_amd.models.pano.modules",
         "panfusion_amd.models.pano.utils", "panfusion_amd.utils.pano",
         "panfusion_amd.external.Perspective_and_Equirectangular.e2p",
         "panfusion_amd.external.Perspective_and_Equirectangular.p2e"]
@@ -211,3 +211,35 @@ def test_reference_api_wrappers(fake_backend):
     assert torch.equal(pc, wc) and torch.equal(ec, wec)
     z = torch.randn(2, 2, 3, 4, 8)
     assert torch.equal(unpad_pano(pad_pano(z, 2), 2), z) and torch.equal(pad_pano(z, 2), G.pad_pano(z, 2))
+
+
+@pytest.mark.parametrize("precision,dtype,tol", [("fast", torch.float32, 2e-5), ("mixed", torch.float32, 2e-5),
+                                                 ("mixed", torch.float16, 2e-3)])
+def test_vae_decode_host_logic(fake_backend, precision, dtype, tol):
+    """SURVEY.md §8f row 1 (PanFusion.py:166-172, PanoGenerator.py:213-238): weight packing and layer sequencing of
+    the VAE decoder (post_quant_conv as a centre tap, value bias folded behind the output projection, attention as
+    two batched GEMMs + row softmax, nearest-x2 upsampling convs, padded-panorama decode + crop, tensor_to_image)
+    on the CPU test double against the oracle restatement of diffusers' AutoencoderKL decoder."""
+    from oracle import sd2_unet as U
+    from oracle import vae as OV
+    from panfusion_amd import vae as PV
+    from panfusion_amd.models.vae_params import VAEDecoderParams
+    cfg = OV.tiny_vae_config(width=64, groups=8)
+    ov = OV.AutoencoderKLDecoder(**cfg)
+    U.init_synthetic(ov, 51)
+    params = VAEDecoderParams(**cfg)
+    missing = params.load_state_dict(ov.state_dict(), strict=True)       # identical key sets (diffusers names)
+    dec = PV.VAEDecoder(params, compute_dtype=dtype, precision=precision)
+    g = torch.Generator().manual_seed(5)
+    lat, pano = torch.randn(1, 2, 4, 8, 8, generator=g), torch.randn(1, 1, 4, 8, 16, generator=g)
+    with torch.no_grad():
+        want = OV.decode_latent(lat, ov)
+        wi, wp = OV.decode_views_and_pano(lat, pano, ov, latent_pad=4)
+    got = PV.decode_latent(lat, dec)
+    assert got.shape == (1, 2, 3, 64, 64) and rel_l2(got, want) < tol, rel_l2(got, want)
+    gi, gp = PV.decode_views_and_pano(lat, pano, dec, latent_pad=4)
+    assert gi.dtype == torch.uint8 and gi.shape == (1, 2, 64, 64, 3) and gp.shape == (1, 1, 64, 128, 3)
+    want_u8 = lambda x: OV.tensor_to_image(x)
+    # uint8 images: identical except where fp32 round-off straddles a rounding boundary
+    assert float((gi.int() - want_u8(wi).int()).abs().float().mean()) < (0.01 if dtype == torch.float32 else 0.5)
+    assert int((gp.int() - want_u8(wp).int()).abs().max()) <= (1 if dtype == torch.float32 else 8)

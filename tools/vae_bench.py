@@ -1,0 +1,47 @@
+"""Time of the VAE decode that follows the sampling loop (PanFusion.py:166-172): 20 view latents 64x64 -> 512^2 images
+and the 64x(128+16) padded panorama latent -> 512x1152 -> crop, SD-2 VAE widths, synthetic weights.
+
+    python tools/vae_bench.py [--dtype fp16|bf16] [--precision mixed|fast] [--reps 3]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--precision", default=None)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--views", type=int, default=20)
+    args = ap.parse_args()
+    from panfusion_amd import vae as PV
+    from panfusion_amd.models.sd2_unet_params import fill_synthetic
+    from panfusion_amd.models.vae_params import SD2_VAE, VAEDecoderParams
+    dev = torch.device("cuda")
+    with torch.device(dev):
+        params = VAEDecoderParams(**SD2_VAE)
+    fill_synthetic(params, 9)
+    dec = PV.VAEDecoder(params, compute_dtype={"fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype], precision=args.precision)
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, args.views, 4, 64, 64, generator=g).to(dev)
+    pano = torch.randn(1, 1, 4, 64, 128, generator=g).to(dev)
+    flop = (args.views + 144 / 64) * 1.24e12                 # ~1.24 TFLOP per 512^2 image (convs 1.20 + attention 0.04)
+    PV.decode_views_and_pano(lat, pano, dec)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        images, pano_img = PV.decode_views_and_pano(lat, pano, dec)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.reps
+    print("VAE decode of %d views + padded panorama, %s %s: %.1f ms  (~%.0f TF/s algorithmic)  peak memory %.1f GB"
+          % (args.views, args.dtype, dec.precision, dt * 1e3, flop / dt / 1e12, torch.cuda.max_memory_allocated() / 2 ** 30))
+
+
+if __name__ == "__main__":
+    main()
