@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 typedef enum { PF_OK = 0, PF_ERR_ARG = 1, PF_ERR_LAUNCH = 2, PF_ERR_UNSUPPORTED = 3 } pf_status;
-typedef enum { PF_BF16 = 0, PF_F16 = 1, PF_F32 = 2 } pf_dtype;
+typedef enum { PF_BF16 = 0, PF_F16 = 1, PF_F32 = 2, PF_U8 = 3 } pf_dtype;
 
 int pf_version(void);
 const char* pf_last_error_string(void);
@@ -54,6 +54,18 @@ pf_status pf_e2p_grid(const double* host_fov, const double* host_theta, const do
 pf_status pf_p2e_grid(const double* host_fov, const double* host_theta, const double* host_phi,
                       int ncam, int ph, int pw, int h, int w,
                       float* map_u, float* map_v, uint8_t* mask, void* stream);
+
+/* Dataset-side view cropping, external/py360convert/e2p.py:6-43 (called from utils/pano.py:160-161
+ * Equirectangular.to_perspective, dataset/PanoDataset.py:133-140): `ncam` perspective crops (oh, ow) of ONE
+ * equirectangular image img [H][W][C] (PF_U8 or PF_F32, channels last like the numpy array) -> out
+ * [ncam][oh][ow][C], same dtype.  Per camera (host arrays, DEGREES): horizontal / vertical field of view,
+ * yaw u, pitch v, in-plane rotation (may be NULL = 0).  order 0 = nearest, 1 = bilinear; sampling is
+ * scipy.ndimage.map_coordinates(mode='wrap') on the pole-padded image (utils.py:120-133), restated bit for bit
+ * (double accumulation; PF_U8 rounds half up and clamps like scipy's integer outputs). */
+pf_status pf_py360_e2p(const void* img, int dtype, int H, int W, int C, const double* host_hfov,
+                       const double* host_vfov, const double* host_u, const double* host_v,
+                       const double* host_in_rot, int ncam, int oh, int ow, int order, void* out,
+                       void* stream);
 
 /* Integer gather indices of kornia.remap(mode='nearest', align_corners=True) -> F.grid_sample
  * (e2p.py:76): idx[i] = iy*src_w+ix or -1 when the sample falls outside.  n entries. */

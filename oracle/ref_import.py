@@ -130,6 +130,8 @@ def load():
         pad_pano=pano_utils.pad_pano, unpad_pano=pano_utils.unpad_pano,
         icosahedron_sample_camera=pano_utils.icosahedron_sample_camera,
         horizon_sample_camera=pano_utils.horizon_sample_camera,
+        random_sample_camera=pano_utils.random_sample_camera,
+        py360_e2p=importlib.import_module("external.py360convert.e2p").e2p,
         get_masks=pm_utils.get_masks, get_coords=pm_utils.get_coords,
         WarpAttn=pm_modules.WarpAttn, MultiViewBaseModel=mvgen.MultiViewBaseModel,
         BasicTransformerBlock=tfm.BasicTransformerBlock, SphericalPE=tfm.SphericalPE,

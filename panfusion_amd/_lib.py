@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PF_HIP_LIB") or os.path.join(_HERE, "libpanfusion_hip.so")   # PF_HIP_LIB: A/B another build
 
 PF_OK = 0
-PF_BF16, PF_F16, PF_F32 = 0, 1, 2
+PF_BF16, PF_F16, PF_F32, PF_U8 = 0, 1, 2, 3
 
 c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 c_dp = C.POINTER(C.c_double)
@@ -54,6 +54,8 @@ SIGNATURES = {
                             c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_p2e_grid": (c_int, [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_int, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_py360_e2p": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_int, c_int,
+                             c_void_p, c_void_p]),
     "pf_nearest_indices": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
     "pf_remap": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                          c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -526,6 +526,149 @@ extern "C" pf_status pf_spherical_pe(const float* coords, long n, const float* f
     return PF_OK;
 }
 
+// ---- py360convert.e2p (dataset-side view cropping) ------------------------------------------------------
+// external/py360convert/e2p.py:6-43 + utils.py:67-133,231-243: rays (x, -y, 1) with x / y float32 linspaces over
+// +-tan(fov/2), rotated by Rx(v) Ry(u) Ri(in_rot) (row vector times matrix, double), lon = atan2(x, z),
+// lat = atan2(y, sqrt(x^2 + z^2)), pixel = ((lon / 2pi + 0.5) W - 0.5, (-lat / pi + 0.5) H - 0.5), sampled by
+// scipy.ndimage.map_coordinates(order 0 / 1, mode='wrap') on the image extended by two rows (last and first row
+// rolled by W/2: the poles).  scipy's legacy 'wrap' has period len - 1 and computes in double; integer outputs
+// are rounded half up and clamped -- restated literally (checked bit for bit against scipy in oracle/py360.py).
+struct P360Cam { double Rx[9], Ry[9], Ri[9], x_max, y_max; };
+constexpr int P360_BATCH = 16;
+struct P360Batch { P360Cam c[P360_BATCH]; };
+
+__device__ __forceinline__ double scipy_wrap_coord(double in, long len) {
+    if (len <= 1) return 0.0;
+    const double sz = static_cast<double>(len - 1);
+    if (in < 0) in += sz * static_cast<double>(static_cast<long>(-in / sz) + 1);
+    else if (in > sz) in -= sz * static_cast<double>(static_cast<long>(in / sz));
+    return in;
+}
+__device__ __forceinline__ long scipy_wrap_index(long idx, long len) {
+    const long s2 = len - 1;
+    if (s2 <= 0) return 0;
+    if (idx < 0) idx += s2 * (-idx / s2 + 1);
+    else if (idx >= len) idx -= s2 * (idx / s2);
+    return idx;
+}
+
+template <typename E> __device__ __forceinline__ E p360_store(double t);
+template <> __device__ __forceinline__ float p360_store<float>(double t) { return static_cast<float>(t); }
+template <> __device__ __forceinline__ uint8_t p360_store<uint8_t>(double t) {   // scipy CASE_INTERP_OUT_UINT
+    t = t > 0 ? t + 0.5 : 0.0;
+    t = t > 255.0 ? 255.0 : t;
+    return static_cast<uint8_t>(t);
+}
+
+template <typename E>
+__global__ void k_py360_e2p(const P360Batch cams, int ncam, const E* __restrict__ img, int H, int W, int C,
+                            int oh, int ow, int order, E* __restrict__ out) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= static_cast<long>(ncam) * oh * ow) return;
+    const int xo = i % ow, yo = (i / ow) % oh, cam = i / (static_cast<long>(ow) * oh);
+    const P360Cam& cp = cams.c[cam];
+    // np.linspace(-m, m, num, dtype=float32): float64 arithmetic, cast to float32
+    const double vx = static_cast<double>(static_cast<float>(linspace_at(-cp.x_max, cp.x_max, ow, xo)));
+    const double vy = -static_cast<double>(static_cast<float>(linspace_at(-cp.y_max, cp.y_max, oh, yo)));
+    double v[3] = {vx, vy, 1.0}, t[3];
+    const double* Rs[3] = {cp.Rx, cp.Ry, cp.Ri};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double* R = Rs[r];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = v[0] * R[k] + v[1] * R[3 + k] + v[2] * R[6 + k];
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2];
+    }
+    const double lon = atan2(v[0], v[2]);
+    const double lat = atan2(v[1], sqrt(v[0] * v[0] + v[2] * v[2]));
+    const double cx = (lon / (2 * kPi) + 0.5) * W - 0.5;
+    const double cy = (-lat / kPi + 0.5) * H - 0.5;
+    const long HP = H + 2;                                  // rows H, H+1: last / first row rolled by W/2
+    const double y = scipy_wrap_coord(cy, HP), x = scipy_wrap_coord(cx, W);
+    auto pixel = [&](long iy, long ix, int c) -> double {
+        iy = scipy_wrap_index(iy, HP);
+        ix = scipy_wrap_index(ix, W);
+        if (iy >= H) {                                      // np.roll(row, W // 2): padded[j] = row[(j - W/2) mod W]
+            long src = (ix - W / 2) % W;
+            if (src < 0) src += W;
+            ix = src;
+            iy = iy == H ? H - 1 : 0;
+        }
+        return static_cast<double>(img[(iy * W + ix) * C + c]);
+    };
+    E* dst = out + i * C;
+    if (order == 0) {
+        const long iy = static_cast<long>(floor(y + 0.5)), ix = static_cast<long>(floor(x + 0.5));
+        for (int c = 0; c < C; ++c) dst[c] = p360_store<E>(pixel(iy, ix, c));
+    } else {
+        const double fy0 = floor(y), fx0 = floor(x);
+        const long y0 = static_cast<long>(fy0), x0 = static_cast<long>(fx0);
+        const double wy1 = y - fy0, wx1 = x - fx0, wy0 = 1.0 - wy1, wx0 = 1.0 - wx1;
+        for (int c = 0; c < C; ++c) {
+            double acc = 0.0;
+            acc = acc + pixel(y0, x0, c) * wy0 * wx0;
+            acc = acc + pixel(y0, x0 + 1, c) * wy0 * wx1;
+            acc = acc + pixel(y0 + 1, x0, c) * wy1 * wx0;
+            acc = acc + pixel(y0 + 1, x0 + 1, c) * wy1 * wx1;
+            dst[c] = p360_store<E>(acc);
+        }
+    }
+}
+
+// utils.py:231-243 rotation_matrix(rad, ax), same operation order, double
+static void p360_rotation(double rad, const double ax_in[3], double R[9]) {
+    double n = sqrt(ax_in[0] * ax_in[0] + ax_in[1] * ax_in[1] + ax_in[2] * ax_in[2]);
+    double ax[3] = {ax_in[0] / n, ax_in[1] / n, ax_in[2] / n};
+    const double c = cos(rad), s = sin(rad);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = ((i == j) ? c : 0.0) + (ax[i] * ax[j]) * (1.0 - c);
+    const double a[3] = {ax[0] * s, ax[1] * s, ax[2] * s};
+    const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+    for (int i = 0; i < 9; ++i) R[i] = R[i] + K[i];
+}
+
+extern "C" pf_status pf_py360_e2p(const void* img, int dtype, int H, int W, int C, const double* host_hfov,
+                                  const double* host_vfov, const double* host_u, const double* host_v,
+                                  const double* host_in_rot, int ncam, int oh, int ow, int order, void* out,
+                                  void* stream) {
+    PF_REQUIRE(img && out && host_hfov && host_vfov && host_u && host_v && ncam > 0, "pf_py360_e2p: null pointer");
+    PF_REQUIRE(H > 1 && W > 1 && C > 0 && oh > 0 && ow > 0, "pf_py360_e2p: bad sizes");
+    PF_REQUIRE(order == 0 || order == 1, "pf_py360_e2p: order must be 0 (nearest) or 1 (bilinear)");
+    PF_REQUIRE(dtype == PF_F32 || dtype == PF_U8, "pf_py360_e2p: dtype must be PF_F32 or PF_U8");
+    hipStream_t st = as_stream(stream);
+    const long per = static_cast<long>(oh) * ow;
+    for (int c0 = 0; c0 < ncam; c0 += P360_BATCH) {
+        const int n = ncam - c0 < P360_BATCH ? ncam - c0 : P360_BATCH;
+        P360Batch b;
+        for (int i = 0; i < n; ++i) {
+            // e2p.py:16-32: degrees -> radians exactly as the reference spells it (x * np.pi / 180)
+            const double hf = host_hfov[c0 + i] * kPi / 180, vf = host_vfov[c0 + i] * kPi / 180;
+            const double u = -host_u[c0 + i] * kPi / 180, v = host_v[c0 + i] * kPi / 180;
+            const double rot = (host_in_rot ? host_in_rot[c0 + i] : 0.0) * kPi / 180;
+            P360Cam& cp = b.c[i];
+            cp.x_max = tan(hf / 2);
+            cp.y_max = tan(vf / 2);
+            const double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0};
+            p360_rotation(v, ex, cp.Rx);
+            p360_rotation(u, ey, cp.Ry);
+            double z1[3], z2[3];                             // np.array([0, 0, 1.0]).dot(Rx).dot(Ry)
+            for (int k = 0; k < 3; ++k) z1[k] = 0.0 * cp.Rx[k] + 0.0 * cp.Rx[3 + k] + 1.0 * cp.Rx[6 + k];
+            for (int k = 0; k < 3; ++k) z2[k] = z1[0] * cp.Ry[k] + z1[1] * cp.Ry[3 + k] + z1[2] * cp.Ry[6 + k];
+            p360_rotation(rot, z2, cp.Ri);
+        }
+        for (int i = n; i < P360_BATCH; ++i) b.c[i] = b.c[0];
+        const dim3 grid(cdiv(n * per, 256)), block(256);
+        if (dtype == PF_F32)
+            hipLaunchKernelGGL(k_py360_e2p<float>, grid, block, 0, st, b, n, static_cast<const float*>(img), H, W, C, oh, ow,
+                               order, static_cast<float*>(out) + c0 * per * C);
+        else
+            hipLaunchKernelGGL(k_py360_e2p<uint8_t>, grid, block, 0, st, b, n, static_cast<const uint8_t*>(img), H, W, C, oh,
+                               ow, order, static_cast<uint8_t*>(out) + c0 * per * C);
+    }
+    PF_CHECK_LAUNCH("pf_py360_e2p");
+    return PF_OK;
+}
+
 static size_t round256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
 extern "C" size_t pf_epa_tables_workspace_size(int ncam, int ph, int pw, int eh, int ew) {

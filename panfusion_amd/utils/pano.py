@@ -7,6 +7,14 @@ import torch
 from .. import ops
 
 
+def random_sample_camera(n):
+    """utils/pano.py:15-25: n uniformly random viewing directions -- normalised Gaussian triples drawn from numpy's
+    global RNG (same draws as the reference under the same np.random.seed), phi = asin(z), theta = atan2(x, y)."""
+    xyz = np.random.normal(size=(n, 3))
+    xyz = xyz / (np.linalg.norm(xyz, axis=-1, keepdims=True) + 1e-9)
+    return np.arctan2(xyz[:, 0], xyz[:, 1]), np.arcsin(xyz[:, 2].clip(-1, 1))
+
+
 def horizon_sample_camera(n):
     """utils/pano.py:28-31."""
     theta = np.linspace(0, 2 * np.pi, n, endpoint=False)
@@ -41,3 +49,30 @@ def unpad_pano(pano_pad, padding):
     if padding <= 0:
         return pano_pad
     return pano_pad[..., padding:-padding]
+
+
+class Equirectangular:
+    """The dataset's panorama holder (utils/pano.py:142-171), numpy image in ``.equirectangular``; the view crops
+    (``to_perspective``, and the batched ``to_perspectives`` the dataset loop wants) run on the HIP kernel behind
+    ``external.py360convert.e2p``."""
+
+    def __init__(self, equirectangular):
+        self.equirectangular = equirectangular
+
+    def to_perspective(self, fov, yaw, pitch, hw, mode="bilinear"):
+        from ..external.py360convert import e2p
+        return e2p(self.equirectangular, fov, yaw, pitch, hw, mode=mode)
+
+    def to_perspectives(self, fov, yaws, pitches, hw, mode="bilinear"):
+        """All crops of dataset/PanoDataset.py:136-139 in one launch: [m, h, w, C]."""
+        from ..external.py360convert import e2p_views
+        return e2p_views(self.equirectangular, fov, yaws, pitches, hw, mode=mode)
+
+    def rotate(self, degree):
+        if degree % 360 == 0:
+            return
+        self.equirectangular = np.roll(self.equirectangular, int(degree / 360 * self.equirectangular.shape[1]), axis=1)
+
+    def flip(self, flip=True):
+        if flip:
+            self.equirectangular = np.flip(self.equirectangular, 1)

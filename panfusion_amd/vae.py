@@ -65,6 +65,7 @@ def pack_vae_decoder(vae, dev, dtype, mixed):
             c = blk.upsamplers[0].conv
             b.up = NS(w=engine._conv3_weight(c, dev, dtype), b=engine._bias(c, dev), c=c.weight.shape[0])
         v.up.append(b)
+    v.c_level1 = d.up_blocks[-2].resnets[0].conv1.weight.shape[0] if len(d.up_blocks) > 1 else v.c_top
     v.norm_out = engine._norm(d.conv_norm_out, dev)
     co = d.conv_out
     v.c_img = co.weight.shape[0]
@@ -119,13 +120,18 @@ class VAEDecoder:
     @torch.no_grad()
     def decode(self, z, chunk=None):
         """``vae.decode(z).sample``: z (n, 4, h, w) on the GPU -> image (n, 3, 8h, 8w) fp32.  chunk: images per pass
-        (the 512^2-resolution activations of the last level are 20 x 512 x 512 x 128 x 4 B = 2.7 GB per tensor in the
-        mixed scheme; all 20 views fit the 288 GB comfortably, a chunk bounds it on smaller allocations)."""
+        (default: as many as keep every GEMM operand under the kernel's 2 GiB addressing limit -- 7 of the 512^2
+        views at a time, the padded panorama alone)."""
         v = self.packed(z.device)
         z = z.float().contiguous()
         n = z.shape[0]
-        if chunk is not None and n > chunk:
-            return torch.cat([self.decode(z[i:i + chunk]) for i in range(0, n, chunk)])
+        if chunk is None:
+            # pf_conv_gemm addresses an operand with 32-bit byte offsets (< 2 GiB): the largest one is the split pair
+            # [hi | lo] of the second-finest level's width at full resolution (8h x 8w x 2 C1 16-bit values per image)
+            per_image = 64 * z.shape[2] * z.shape[3] * 4 * v.c_level1
+            chunk = max(1, ((1 << 31) - 1) // per_image)
+        if n > chunk:
+            return torch.cat([self.decode(z[i:i + chunk], chunk) for i in range(0, n, chunk)])
         dt = v.dtype
         # post_quant_conv (1x1 as the centre tap of the 3x3 boundary kernel), then conv_in on its NCHW view
         pq = ops.conv_in(z, v.pq_w, v.pq_b, 8, torch.float32)              # NHWC [n, h, w, 8] fp32

@@ -554,3 +554,39 @@ def test_attention_online_softmax_rescale_branch():
     vt = v.transpose(1, 2).contiguous()
     out = ops().attention(q, k, vt, B, H, D, nq, nk, q_ld=D, k_ld=D, vt_ld=nk, q_bs=nq * D, k_bs=nk * D, vt_bs=D * nk, scale=1.0)
     check("attention rescale", out, attn_ref(qf, kf, vf, H, 1.0), 2.5 * TOL[dtype])
+
+
+# ------------------------------------------------------------------------------------ dataset-side cropping
+def test_py360_e2p_bit_exact_vs_reference_fixture():
+    """external/py360convert e2p (dataset/PanoDataset.py:133-140) on the GPU, against the
+    fixture the reference's own module wrote (scipy map_coordinates): identical bytes for uint8 RGB and float32,
+    bilinear and nearest, poles / seam / asymmetric field of view; single-crop and batched entry points."""
+    from panfusion_amd.external.py360convert import e2p, e2p_views
+    g = golden("py360_e2p.npz")
+    us, vs = g["cams"][:, 0], g["cams"][:, 1]
+    for mode in ("bilinear", "nearest"):
+        for key in ("rgb", "gray"):
+            got = e2p_views(g[key], (90, 90), us, vs, (24, 24), mode=mode)
+            want = g[key + "_" + mode]
+            assert got.dtype == want.dtype and got.shape == want.shape
+            assert np.array_equal(got, want), "%s %s: %d of %d values differ" % (key, mode, (got != want).sum(), want.size)
+    assert np.array_equal(e2p_views(g["rgb"], (60, 45), us, vs, (18, 24)), g["rgb_fov60x45"])
+    assert np.array_equal(e2p(g["rgb"], (90, 90), us[1], vs[1], (24, 24)), g["rgb_bilinear"][1])
+    # tensor in, tensor out (no host round trip)
+    t = e2p_views(torch.from_numpy(g["gray"]).to(DEV), (90, 90), us, vs, (24, 24))
+    assert t.is_cuda and np.array_equal(t.cpu().numpy(), g["gray_bilinear"])
+
+
+def test_py360_e2p_dataset_size_vs_oracle():
+    """The dataset's real shape: 20 icosahedron crops of 512^2 from a 1024x2048 RGB panorama, against the numpy
+    oracle (oracle/py360.py, pinned to the reference) on a few of the cameras."""
+    from oracle import py360
+    from panfusion_amd.external.py360convert import e2p_views
+    rng = np.random.default_rng(5)
+    pano = (rng.random((1024, 2048, 3)) * 255).astype(np.uint8)
+    thd, phd = ico()
+    got = e2p_views(pano, (90, 90), thd, phd, (512, 512))
+    assert got.shape == (20, 512, 512, 3) and got.dtype == np.uint8
+    for i in (0, 7, 19):
+        want = py360.e2p(pano, (90, 90), thd[i], phd[i], (512, 512))
+        assert np.array_equal(got[i], want), "camera %d: %d values differ" % (i, (got[i] != want).sum())

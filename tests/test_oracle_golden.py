@@ -146,3 +146,15 @@ def test_unet_driven_equals_plain_forward():
         _, a = MV.DualBranchDenoiser(None, unet, pano_pad=False)(None, x, torch.tensor([500, 20]), None, txt, None)
         b = unet(x[:, 0], torch.tensor([500, 20]), txt[:, 0])
     assert rel_l2(a[:, 0], b) < 1e-5
+
+
+def test_py360_e2p_fixture():
+    """tests/golden/py360_e2p.npz (tools/make_golden_py360.py: the reference's external/py360convert on scipy)."""
+    from oracle import py360
+    g = golden("py360_e2p.npz")
+    for mode in ("bilinear", "nearest"):
+        for key in ("rgb", "gray"):
+            got = np.stack([py360.e2p(g[key], (90, 90), u, v, (24, 24), mode=mode) for u, v in g["cams"]])
+            assert np.array_equal(got, g[key + "_" + mode]), (key, mode)
+    got = np.stack([py360.e2p(g["rgb"], (60, 45), u, v, (18, 24)) for u, v in g["cams"]])
+    assert np.array_equal(got, g["rgb_fov60x45"])

@@ -25,6 +25,16 @@ def ico_deg(ref):
     return np.degrees(th), np.degrees(ph)
 
 
+def test_random_sample_camera_same_draws(ref):
+    """utils/pano.py:15-25 against the product's sampler under the same numpy seed."""
+    from panfusion_amd.utils.pano import random_sample_camera
+    np.random.seed(123)
+    want = ref.random_sample_camera(20)
+    np.random.seed(123)
+    got = random_sample_camera(20)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
 def test_cameras(ref):
     a, b = ref.icosahedron_sample_camera(), G.icosahedron_cameras()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
@@ -114,3 +124,25 @@ def test_denoiser_matches(ref):
     c90 = dict(c0, theta=(c0["theta"] + 90) % 360)
     m0, m90 = G.get_masks(8, 8, 8, 16, c0)[0], G.get_masks(8, 8, 8, 16, c90)[0]
     assert not torch.equal(torch.roll(m0, 4, dims=2), m90)
+
+
+def test_py360_e2p_bit_exact(ref):
+    """oracle/py360.py (numpy restatement incl. scipy's map_coordinates 'wrap' semantics) against the reference's own
+    external/py360convert running on scipy: random cameras, odd sizes, uint8 / float32 / 2-D, both modes, an
+    in-plane rotation, asymmetric field of view."""
+    from oracle import py360
+    ref_e2p = ref.py360_e2p
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        H = int(rng.integers(9, 40))
+        W = 2 * H + int(rng.integers(0, 3))
+        img = (rng.random((H, W, 3)) * 255).astype(np.uint8) if trial % 3 == 0 else \
+            rng.standard_normal((H, W, 2)).astype(np.float32) if trial % 3 == 1 else rng.standard_normal((H, W)).astype(np.float32)
+        u, v = float(rng.uniform(-180, 180)), float(rng.uniform(-90, 90))
+        fov = (float(rng.uniform(40, 120)), float(rng.uniform(40, 120)))
+        hw = (int(rng.integers(5, 30)), int(rng.integers(5, 30)))
+        rot = float(rng.uniform(-30, 30)) if trial % 4 == 0 else 0
+        for mode in ("bilinear", "nearest"):
+            want = ref_e2p(img, fov, u, v, hw, in_rot_deg=rot, mode=mode)
+            got = py360.e2p(img, fov, u, v, hw, in_rot_deg=rot, mode=mode)
+            assert got.dtype == want.dtype and np.array_equal(got, want), (trial, mode)
