@@ -564,12 +564,24 @@ def test_py360_e2p_bit_exact_vs_reference_fixture():
     from panfusion_amd.external.py360convert import e2p, e2p_views
     g = golden("py360_e2p.npz")
     us, vs = g["cams"][:, 0], g["cams"][:, 1]
+    from oracle import py360
+    # nearest mode rounds the sampling position: a position within 1e-9 of a half-integer is a tie that the last
+    # ulp of the BLAS matrix product decides in the reference (the pole-facing camera (90, 90) of the fixture has
+    # one: x == z up to 1 ulp -> coor_x = 7.4999999999999964); such pixels are excluded, everything else is exact
+    def no_tie(u, v):
+        cx, cy = py360.coordinates(32, 64, (90, 90), u, v, (24, 24))
+        cx, cy = py360._wrap_coord(cx, 64), py360._wrap_coord(cy, 34)
+        frac = lambda c: np.abs((c + 0.5) - np.round(c + 0.5))
+        return (frac(cx) > 1e-9) & (frac(cy) > 1e-9)
+    keep = np.stack([no_tie(u, v) for u, v in zip(us, vs)])
+    assert keep.mean() > 0.999
     for mode in ("bilinear", "nearest"):
         for key in ("rgb", "gray"):
             got = e2p_views(g[key], (90, 90), us, vs, (24, 24), mode=mode)
             want = g[key + "_" + mode]
             assert got.dtype == want.dtype and got.shape == want.shape
-            assert np.array_equal(got, want), "%s %s: %d of %d values differ" % (key, mode, (got != want).sum(), want.size)
+            ok = (got == want) if mode == "bilinear" else ((got == want) | ~(keep[..., None] if got.ndim == 4 else keep))
+            assert ok.all(), "%s %s: %d of %d values differ" % (key, mode, (~ok).sum(), want.size)
     assert np.array_equal(e2p_views(g["rgb"], (60, 45), us, vs, (18, 24)), g["rgb_fov60x45"])
     assert np.array_equal(e2p(g["rgb"], (90, 90), us[1], vs[1], (24, 24)), g["rgb_bilinear"][1])
     # tensor in, tensor out (no host round trip)
