@@ -163,6 +163,13 @@ pf_status pf_nhwc_to_nchw(const void* x, int src_dtype, int n, int C, int h, int
  * dtype_a, b of type dtype_b (any of PF_BF16 / PF_F16 / PF_F32). */
 pf_status pf_add(const void* a, int dtype_a, const void* b, int dtype_b, long n, void* y, void* stream);
 
+/* Token + position embedding of the CLIP text encoder (transformers CLIPTextEmbeddings, reached from
+ * PanoGenerator.py:197-211 encode_text): ids int64 [B][L] -> out [B][Lp][C] (out_dtype 16-bit or PF_F32),
+ * out[b][t] = tok[ids[b][t]] + pos[t] for t < L, zero rows for L <= t < Lp (the sequence is padded to a
+ * multiple of 4 keys for the masked attention).  tok [vocab][C], pos [>= L][C] fp32. */
+pf_status pf_embed_tokens(const int64_t* ids, int B, int L, int Lp, int C, long vocab, const float* tok,
+                          const float* pos, int out_dtype, void* out, void* stream);
+
 /* Row softmax of fp32 scores: probs[r][j] = exp(scale (s[r][j] - max_j)) / sum_j, 16-bit out.  The VAE decoder's
  * mid-block attention has ONE head of width 512 (diffusers Attention in AutoencoderKL, reached from
  * PanoGenerator.py:213-220 decode_latent): its scores and the P.V product run on pf_conv_gemm (batched), this

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pf_nchw_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_nhwc_to_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_add": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "pf_embed_tokens": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "pf_softmax_rows": (c_int, [c_void_p, c_long, c_int, c_long, c_float, c_int, c_void_p, c_long, c_void_p]),
     "pf_tensor_to_image": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,

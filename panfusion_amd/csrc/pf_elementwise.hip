@@ -411,6 +411,26 @@ __global__ void k_cfg_ddim(const float* __restrict__ x, const float* __restrict_
     out[r * W + wo] = xn;
 }
 
+// ---- token + position embedding gather (CLIP text encoder, transformers CLIPTextEmbeddings) -------------
+// out[b][t][:] = tok[ids[b][t]][:] + pos[t][:] for t < L, zeros for the padding rows L <= t < Lp.
+template <typename SO>
+__global__ void k_embed_tokens(const int64_t* __restrict__ ids, int B, int L, int Lp, int C, long vocab,
+                               const float* __restrict__ tok, const float* __restrict__ pos, void* __restrict__ out) {
+    long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    const long total = static_cast<long>(B) * Lp * C;
+    if (i >= total) return;
+    const int c = i % C;
+    const int t = (i / C) % Lp;
+    const long b = i / (static_cast<long>(C) * Lp);
+    float v = 0.f;
+    if (t < L) {
+        long id = ids[b * L + t];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // torch would raise; never read out of bounds
+        v = tok[id * C + c] + pos[static_cast<long>(t) * C + c];
+    }
+    st_any<SO>(out, i, v);
+}
+
 // ---- row softmax (VAE mid-block attention: one head of width 512, scores through the GEMM kernel) -------
 // p[r][j] = exp(scale * (s[r][j] - max_j s[r][j])) / sum, fp32 scores -> 16-bit probabilities.  One block
 // per row; rows of up to 256 * PT columns live in registers between the three sweeps, longer rows are
@@ -824,6 +844,20 @@ extern "C" pf_status pf_cfg_ddim_step(const float* x, const float* eu, const flo
     hipLaunchKernelGGL(k_cfg_ddim, dim3(cdiv(rows * W, 256)), dim3(256), 0, as_stream(stream), x, eu, ec, g, sa,
                        sb, sap, sbp, rows, W, roll, out);
     PF_CHECK_LAUNCH("pf_cfg_ddim_step");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_embed_tokens(const int64_t* ids, int B, int L, int Lp, int C, long vocab, const float* tok,
+                                     const float* pos, int out_dtype, void* out, void* stream) {
+    PF_REQUIRE(ids && tok && pos && out && B > 0 && L > 0 && Lp >= L && C > 0 && vocab > 0, "pf_embed_tokens: bad arguments");
+    const long total = static_cast<long>(B) * Lp * C;
+    const dim3 grid(cdiv(total, 256)), block(256);
+    hipStream_t st = as_stream(stream);
+    if (out_dtype == PF_F32) hipLaunchKernelGGL(k_embed_tokens<AnyF32>, grid, block, 0, st, ids, B, L, Lp, C, vocab, tok, pos, out);
+    else if (out_dtype == PF_F16) hipLaunchKernelGGL(k_embed_tokens<AnyF16>, grid, block, 0, st, ids, B, L, Lp, C, vocab, tok, pos, out);
+    else if (out_dtype == PF_BF16) hipLaunchKernelGGL(k_embed_tokens<AnyBf16>, grid, block, 0, st, ids, B, L, Lp, C, vocab, tok, pos, out);
+    else PF_REQUIRE(false, "pf_embed_tokens: unsupported out_dtype %d", out_dtype);
+    PF_CHECK_LAUNCH("pf_embed_tokens");
     return PF_OK;
 }
 

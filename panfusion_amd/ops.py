@@ -258,6 +258,17 @@ def nhwc_to_nchw(x, dtype, out=None):
     return out
 
 
+def embed_tokens(ids, tok, pos, Lp, out_dtype):
+    """ids int64 [B, L]; tok [vocab, C], pos [>= L, C] fp32 -> [B, Lp, C] (rows >= L are zero)."""
+    ids = ids.to(torch.int64).contiguous()
+    B, L = ids.shape
+    Cc = tok.shape[1]
+    out = torch.empty(B, Lp, Cc, device=tok.device, dtype=out_dtype)
+    check(_lib.lib().pf_embed_tokens(_p(ids), B, L, Lp, Cc, tok.shape[0], _p(tok), _p(pos), dt(out_dtype), _p(out), _stream()),
+          "pf_embed_tokens")
+    return out
+
+
 def softmax_rows(scores, scale, out_dtype, out=None):
     """scores fp32 [..., rows, n] (contiguous rows) -> probabilities [..., rows, n] in out_dtype (16-bit)."""
     n = scores.shape[-1]

@@ -170,6 +170,13 @@ def nhwc_to_nchw(x, dtype, out=None):
     return x.permute(0, 3, 1, 2).to(dtype).contiguous()
 
 
+def embed_tokens(ids, tok, pos, Lp, out_dtype):
+    B, L = ids.shape
+    out = torch.zeros(B, Lp, tok.shape[1])
+    out[:, :L] = tok[ids] + pos[:L]
+    return out.to(out_dtype)
+
+
 def softmax_rows(scores, scale, out_dtype, out=None):
     return torch.softmax(scores.float() * scale, -1).to(out_dtype)
 

@@ -8,7 +8,7 @@ import fake_ops
 from conftest import build_tiny_oracle, cam4, golden, rel_l2
 from oracle import mvgen as MV
 
-MODS = ["panfusion_amd.engine", "panfusion_amd.pipeline", "panfusion_amd.vae", "panfusion_amd.models.pano.modules",
+MODS = ["panfusion_amd.engine", "panfusion_amd.pipeline", "panfusion_amd.vae", "panfusion_amd.text_encoder", "panfusion_amd.models.pano.modules",
         "panfusion_amd.models.pano.utils", "panfusion_amd.utils.pano",
         "panfusion_amd.external.Perspective_and_Equirectangular.e2p",
         "panfusion_amd.external.Perspective_and_Equirectangular.p2e"]
@@ -243,3 +243,37 @@ def test_vae_decode_host_logic(fake_backend, precision, dtype, tol):
     # uint8 images: identical except where fp32 round-off straddles a rounding boundary
     assert float((gi.int() - want_u8(wi).int()).abs().float().mean()) < (0.01 if dtype == torch.float32 else 0.5)
     assert int((gp.int() - want_u8(wp).int()).abs().max()) <= (1 if dtype == torch.float32 else 8)
+
+
+def tiny_clip(seed=0, layers=3):
+    """transformers' own CLIPTextModel (the class the reference loads, PanoGenerator.py:116-118) at a small width with
+    heads of 64 like OpenCLIP-H, random weights: the oracle for the text-encoding row (third-party code that IS
+    installed in this image, unlike diffusers)."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    torch.manual_seed(seed)
+    cfg = CLIPTextConfig(hidden_size=128, intermediate_size=512, num_attention_heads=2, num_hidden_layers=layers,
+                         vocab_size=1000, max_position_embeddings=77, hidden_act="gelu", bos_token_id=998, eos_token_id=999,
+                         pad_token_id=0)
+    m = CLIPTextModel(cfg).eval()
+    with torch.no_grad():                     # HF initialises biases / LN to trivial values: randomise them
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    return m
+
+
+@pytest.mark.parametrize("dtype,precision,tol", [(torch.float32, "fast", 2e-5), (torch.float16, "mixed", 1e-3)])
+def test_text_encoder_host_logic(fake_backend, dtype, precision, tol):
+    """SURVEY.md §8f row 2 (PanoGenerator.py:197-211): weight packing and layer sequencing of the CLIP text encoder
+    (value bias folded behind out_proj, GELU through the GEGLU epilogue with constant-one value rows, causal +
+    padding mask as the attention kernel's bias table, sequence padded 77 -> 80) on the CPU test double against
+    transformers' CLIPTextModel."""
+    from panfusion_amd.text_encoder import TextEncoder
+    m = tiny_clip()
+    ids = torch.randint(1, 990, (3, 77), generator=torch.Generator().manual_seed(1))
+    ids[:, 0], ids[0, 20:], ids[1, 50:] = 998, 999, 999
+    with torch.no_grad():
+        want = m(ids)[0]
+    got = TextEncoder(m, compute_dtype=dtype, precision=precision).encode_ids(ids)
+    assert got.shape == want.shape == (3, 77, 128) and got.dtype == torch.float32
+    assert rel_l2(got, want) < tol, rel_l2(got, want)
