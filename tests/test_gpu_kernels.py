@@ -574,7 +574,7 @@ def test_py360_e2p_bit_exact_vs_reference_fixture():
         frac = lambda c: np.abs((c + 0.5) - np.round(c + 0.5))
         return (frac(cx) > 1e-9) & (frac(cy) > 1e-9)
     keep = np.stack([no_tie(u, v) for u, v in zip(us, vs)])
-    assert keep.mean() > 0.999
+    assert keep.mean() > 0.9                      # (axis-aligned cameras put whole columns exactly on half-integers)
     for mode in ("bilinear", "nearest"):
         for key in ("rgb", "gray"):
             got = e2p_views(g[key], (90, 90), us, vs, (24, 24), mode=mode)
@@ -582,6 +582,7 @@ def test_py360_e2p_bit_exact_vs_reference_fixture():
             assert got.dtype == want.dtype and got.shape == want.shape
             ok = (got == want) if mode == "bilinear" else ((got == want) | ~(keep[..., None] if got.ndim == 4 else keep))
             assert ok.all(), "%s %s: %d of %d values differ" % (key, mode, (~ok).sum(), want.size)
+            assert (got != want).sum() <= 4 * (want.shape[-1] if want.ndim == 4 else 1)    # ... and ties are a handful of pixels
     assert np.array_equal(e2p_views(g["rgb"], (60, 45), us, vs, (18, 24)), g["rgb_fov60x45"])
     assert np.array_equal(e2p(g["rgb"], (90, 90), us[1], vs[1], (24, 24)), g["rgb_bilinear"][1])
     # tensor in, tensor out (no host round trip)
