@@ -1015,7 +1015,10 @@ static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
     const long rounds = cdiv(tiles256, 256);
     static const int fill_pct = tuning("PF_GEMM8_FILL", 60);
     const bool filled = tiles256 * 100 >= rounds * 256 * fill_pct;
-    if (big_min_tiles > 0 && tiles256 >= big_min_tiles && filled) {
+    // short-K layers (K < PF_GEMM8_MIN_K) go to the 4-wave kernel: two co-resident blocks per CU overlap one block's
+    // epilogue with the other's K loop, which a single persistent 8-wave block cannot do
+    static const int big_min_k = tuning("PF_GEMM8_MIN_K", 0);
+    if (big_min_tiles > 0 && tiles256 >= big_min_tiles && filled && K >= big_min_k) {
         GemmPlan g;
         g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64; g.m_split = 0;
         return g;
@@ -1024,7 +1027,7 @@ static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
     // become a second launch whose K range is split so that it fills the chip once more.  320 tiles then
     // cost 1.25 rounds instead of 2.
     static const int tail_on = tuning("PF_GEMM_TAIL_SPLIT", 1);
-    if (big_min_tiles > 0 && tail_on && allow_split && batch == 1 && N % 4 == 0 && tiles256 > 256 && K / 64 >= tuning("PF_GEMM_TAIL_MINKB", 40)) {
+    if (big_min_tiles > 0 && tail_on && allow_split && batch == 1 && N % 4 == 0 && tiles256 > 256 && K >= big_min_k && K / 64 >= tuning("PF_GEMM_TAIL_MINKB", 40)) {
         const long ntl = cdiv(N, 32 * nrep), mt = cdiv(M, 256);
         const long rows1 = (tiles256 / 256) * 256 / ntl;            // tile rows of the unsplit launch
         const long tiles2 = (mt - rows1) * ntl;

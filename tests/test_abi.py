@@ -126,6 +126,8 @@ def test_attention_and_norm_reject_bad_arguments():
     assert lib.pf_attention(C.byref(a), None) == 1 and b"vt_ld" in lib.pf_last_error_string()
     a.vt_ld, a.bias = 64, 0x50000                                  # bias without flags
     assert lib.pf_attention(C.byref(a), None) == 1 and b"bias and flags" in lib.pf_last_error_string()
+    a.flags, a.flags_ld, a.bias_ld, a.nk = 0x60000, 4, 64, 62        # bias rows are read as float4: nk must be a multiple of 4
+    assert lib.pf_attention(C.byref(a), None) == 1 and b"nk % 4" in lib.pf_last_error_string()
     assert lib.pf_layernorm(0x10000, None, 0, _lib.PF_F16, 4, 4100, 0x20000, 0x30000, 1e-5, _lib.PF_F16, 0x40000, None) == 1
     assert lib.pf_layernorm(0x10000, None, 0, _lib.PF_F16, 4, 64, 0x20000, 0x30000, 1e-5, _lib.PF_BF16, 0x40000, None) == 1   # 16-bit in != out
     # scale without shift; fp32 output cannot be a split pair

@@ -127,7 +127,7 @@ def test_three_ddim_steps_golden(oracle_model, graphs):
     l3, p3 = loop.run()
     el, ep = rel_l2(l3.cpu(), torch.from_numpy(gd["latents"])), rel_l2(p3.cpu(), torch.from_numpy(gd["pano_latent"]))
     print("3 DDIM steps rel-L2 (graphs=%s): %.3e %.3e" % (graphs, el, ep))
-    assert el <= 2e-2 and ep <= 2e-2, (el, ep)
+    assert el <= 5e-3 and ep <= 5e-3, (el, ep)       # measured 1.3e-3 / 1.6e-3 (fp16 mixed, three accumulated steps)
 
 
 def test_graph_replay_equals_eager(oracle_model):

@@ -31,6 +31,7 @@ def fake_dist(world, rank):
 
     dist.all_gather_into_tensor = all_gather_into_tensor
     dist.broadcast = lambda t, src=0, group=None: None
+    dist.all_reduce = lambda t, op=None, group=None: None
     dist.barrier = lambda *a, **k: None
 
 
@@ -40,6 +41,8 @@ def main():
     ap.add_argument("--ranks", default="0")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--precision", default=None, choices=["mixed", "fast"])
     args = ap.parse_args()
     import bench
     from panfusion_amd import sharding
@@ -52,8 +55,9 @@ def main():
     cfg = dict(SD2_BASE)
     for rank in [int(r) for r in args.ranks.split(",")]:
         fake_dist(args.world, rank)
-        model, loop = sharding.build_sharded(bench.build_model, bench.build_inputs, dev, torch.bfloat16, cfg, 20, (64, 64), (64, 128),
-                                             cams_deg, args.steps + args.warmup + 1, True)
+        dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
+        model, loop = sharding.build_sharded(bench.build_model, bench.build_inputs, dev, dtype, cfg, 20, (64, 64), (64, 128),
+                                             cams_deg, args.steps + args.warmup + 1, True, precision=args.precision)
         loop.prepare()
         for _ in range(args.warmup):
             loop.step()
@@ -63,7 +67,7 @@ def main():
             loop.step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / args.steps
-        print("world %d rank %d  %-60s %7.2f ms/step  (graphs %s)" % (args.world, rank, loop.layout, ms, loop.use_graphs), flush=True)
+        print("world %d rank %d  %-60s %7.2f ms/step  (graphs %s)" % (args.world, rank, "%s %s %s" % (loop.layout_desc, args.dtype, model.precision), ms, loop.use_graphs), flush=True)
         del model, loop
         torch.cuda.empty_cache()
 
