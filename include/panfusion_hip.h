@@ -224,13 +224,16 @@ typedef struct {
     int dtype;           /* PF_BF16 or PF_F16: A, W, residual                               */
     int batch;           /* >= 1: independent problems, strides below (elements)            */
     long a_bstride, w_bstride, out_bstride, res_bstride;
-    int epilogue;        /* PF_EPILOGUE_NONE, or PF_EPILOGUE_GEGLU: W rows interleaved (value_j, gate_j);
-                          * out [M][n_out/2] = value * gelu(gate) (transformer.py:8-21, erf GELU)    */
+    int epilogue;        /* PF_EPILOGUE_NONE; PF_EPILOGUE_GEGLU: W rows interleaved (value_j, gate_j),
+                          * out [M][n_out/2] = value * gelu(gate) (transformer.py:8-21, erf GELU);
+                          * PF_EPILOGUE_SPLIT: out is the 16-bit pair [M][hi(n_out) | lo(n_out)] of the fp32
+                          * result (hi = round16(v), lo = round16(v - hi)), out_ld >= 2 n_out: the A operand
+                          * of a following split-precision GEMM without a separate split pass            */
     void* workspace;     /* split-K scratch (may be NULL: no split) of pf_conv_gemm_workspace_size   */
     size_t workspace_bytes;
 } pf_conv_desc;
 
-enum { PF_EPILOGUE_NONE = 0, PF_EPILOGUE_GEGLU = 1 };
+enum { PF_EPILOGUE_NONE = 0, PF_EPILOGUE_GEGLU = 1, PF_EPILOGUE_SPLIT = 2 };
 
 /* Bytes of fp32 scratch that let pf_conv_gemm split the K range of a problem whose output grid alone
  * cannot fill the 256 CUs (the 8x8 / 16x16 levels and the whole panorama branch); 0 = not wanted.

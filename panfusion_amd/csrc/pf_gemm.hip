@@ -40,6 +40,7 @@ struct GemmParams {
     const float* bias; const float* rowvec; int rowvec_ld;
     const void* residual; int res_ld; int res_f32;   // residual: 16-bit T, or fp32 (the fp32 residual stream)
     void* out; int out_ld; int out_f32; int geglu;
+    int split_out;               // 16-bit pair output [M][hi(N) | lo(N)] (PF_EPILOGUE_SPLIT): the A operand of a split-precision GEMM
     long a_bs, w_bs, out_bs, res_bs;
     int mtiles, ntiles;
     int splits, kb_per_split;      // split-K: blockIdx.y walks K-blocks [y*kb_per_split, ...)
@@ -130,6 +131,16 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
             w2[e] = from_f32<T>(v[2 * e] * (0.5f * g * (1.0f + erf_as(g * 0.70710678118654752440f))));
         }
         *reinterpret_cast<u16x2*>(o) = w2;
+    } else if (p.split_out) {
+        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
+        u16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = from_f32<T>(v[e]);
+            lo[e] = from_f32<T>(v[e] - to_f32<T>(hi[e]));
+        }
+        *reinterpret_cast<u16x4*>(o) = hi;
+        *reinterpret_cast<u16x4*>(o + p.N) = lo;
     } else if (p.out_f32) {
         float* o = static_cast<float*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
         *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
@@ -283,7 +294,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x
 // (16 bytes), the four column groups of a fragment make a 64-byte row segment, so no LDS staging is
 // needed.  Straight-line like epilogue_fast: rows / quads beyond the edge are clamped for the loads and
 // only the store is predicated; the residual of a group of two fragment rows is requested one group ahead.
-template <typename T, int MREP, int NREP, bool RES>
+template <typename T, int MREP, int NREP, bool RES, bool PAIR = false>
 __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4 (&acc)[MREP][NREP],
                                              int m0, int n0, int row_base, int col_base, int lane) {
     constexpr int G = 1, NG = MREP / G;                           // (two fp32 row groups in flight would spill)
@@ -305,6 +316,7 @@ __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4
     }
     const float* resp = RES ? static_cast<const float*>(p.residual) + bz * p.res_bs : nullptr;
     float* outp = static_cast<float*>(p.out) + bz * p.out_bs;
+    unsigned short* outp16 = static_cast<unsigned short*>(p.out) + bz * p.out_bs;    // PAIR: [M][hi(N) | lo(N)] 16-bit
     float4 res[2][G][NREP];
     auto request = [&](int g, int bf) {
         if (!RES) return;
@@ -332,7 +344,20 @@ __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4
                     const float4 r = res[g & 1][ii][j];
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
-                if (m < p.M && nok[j]) *reinterpret_cast<float4*>(op + ncl[j]) = v;
+                if (PAIR) {
+                    if (m < p.M && nok[j]) {
+                        unsigned short* o16 = outp16 + static_cast<long>(m) * p.out_ld + ncl[j];
+                        const float f[4] = {v.x, v.y, v.z, v.w};
+                        u16x4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hi[e] = from_f32<T>(f[e]);
+                            lo[e] = from_f32<T>(f[e] - to_f32<T>(hi[e]));
+                        }
+                        *reinterpret_cast<u16x4*>(o16) = hi;
+                        *reinterpret_cast<u16x4*>(o16 + p.N) = lo;
+                    }
+                } else if (m < p.M && nok[j]) *reinterpret_cast<float4*>(op + ncl[j]) = v;
             }
         }
     }
@@ -354,11 +379,15 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, long bz, f32x
     after_ring();
     stamp(p, 5);
     const int n_store = p.geglu ? p.N >> 1 : p.N;
+    if (p.split_out && !p.rowvec && (p.N & 3) == 0 && (p.out_ld & 3) == 0 && p.N >= 4) {
+        if (!p.residual) { epilogue_f32<T, MREP, NREP, false, true>(p, bz, acc, m0, n0, row_base, col_base, lane); return; }
+        if (p.res_f32 && (p.res_ld & 3) == 0) { epilogue_f32<T, MREP, NREP, true, true>(p, bz, acc, m0, n0, row_base, col_base, lane); return; }
+    }
     if (p.out_f32 && !p.geglu && !p.rowvec && (p.N & 3) == 0 && (p.out_ld & 3) == 0 && p.N >= 4) {
         if (!p.residual) { epilogue_f32<T, MREP, NREP, false>(p, bz, acc, m0, n0, row_base, col_base, lane); return; }
         if (p.res_f32 && (p.res_ld & 3) == 0) { epilogue_f32<T, MREP, NREP, true>(p, bz, acc, m0, n0, row_base, col_base, lane); return; }
     }
-    const bool staged = !p.out_f32 && !p.res_f32 && (p.out_ld & 7) == 0 && (n_store & 7) == 0 && (p.N & 3) == 0;
+    const bool staged = !p.out_f32 && !p.res_f32 && !p.split_out && (p.out_ld & 7) == 0 && (n_store & 7) == 0 && (p.N & 3) == 0;
     if (staged && !(p.rowvec && p.residual) && !(p.geglu && (p.rowvec || p.residual))) {
         if (p.geglu) epilogue_fast<T, MREP, NREP, NT, BM, BN, HALVES, 3>(p, bz, acc, smem16, m0, n0, row_base, col_base, lane, t);
         else if (p.rowvec && p.rows_per_img < BM) goto generic;
@@ -1117,7 +1146,11 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
                (!d->bias || aligned16(d->bias)) && (!d->rowvec || aligned16(d->rowvec)) &&
                (!d->residual || aligned16(d->residual)), "pf_conv_gemm: pointers must be 16-byte aligned");
     PF_REQUIRE(d->batch >= 1, "pf_conv_gemm: batch must be >= 1");
-    PF_REQUIRE(d->epilogue == PF_EPILOGUE_NONE || d->epilogue == PF_EPILOGUE_GEGLU, "pf_conv_gemm: unknown epilogue %d", d->epilogue);
+    PF_REQUIRE(d->epilogue == PF_EPILOGUE_NONE || d->epilogue == PF_EPILOGUE_GEGLU || d->epilogue == PF_EPILOGUE_SPLIT,
+               "pf_conv_gemm: unknown epilogue %d", d->epilogue);
+    if (d->epilogue == PF_EPILOGUE_SPLIT)
+        PF_REQUIRE(d->n_out % 4 == 0 && d->out_dtype == d->dtype && d->out_ld >= 2 * d->n_out && !d->rowvec,
+                   "pf_conv_gemm: SPLIT epilogue needs n_out %% 4 == 0, a 16-bit output with out_ld >= 2 n_out, no row vector");
     if (d->epilogue == PF_EPILOGUE_GEGLU)
         PF_REQUIRE(d->n_out % 4 == 0 && d->out_dtype == d->dtype && !d->residual && d->out_ld >= d->n_out / 2 && d->out_ld % 2 == 0,
                    "pf_conv_gemm: GEGLU epilogue needs n_out %% 4 == 0, 16-bit output, no residual, out_ld >= n_out/2");
@@ -1140,6 +1173,7 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     p.res_f32 = d->residual != nullptr && d->res_dtype == PF_F32;
     p.out = d->out; p.out_ld = d->out_ld; p.out_f32 = d->out_dtype == PF_F32;
     p.geglu = d->epilogue == PF_EPILOGUE_GEGLU;
+    p.split_out = d->epilogue == PF_EPILOGUE_SPLIT;
     p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;
     p.mtiles = p.ntiles = 0;
     p.prof = nullptr;

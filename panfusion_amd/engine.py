@@ -449,11 +449,13 @@ def run_transformer(t, x, text, kv=None):
     tok = _attend(t.attn2, ln, text.reshape(n * L, -1), n, hw, L, dh, self_attn=False, residual=tok, kv=kv)
     ln = ops.layernorm(tok, t.ln3.g, t.ln3.b, t.ln3.eps, out_dtype=t.dtype)
     g = ops.linear(ln, t.w_ff1, bias=t.b_ff1, geglu=True)
-    tok = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok)
     if t.w_out3 is not None:
-        out = exact_gemm(split_operand(tok, dtype=t.dtype), t.w_out3, Cc, w_in=n * hw, bias=t.b_out,
-                         residual=x.view(n * hw, Cc))
+        # the token stream's last value feeds proj_out only: FF2's epilogue emits it directly as the [hi | lo]
+        # pair of the split-precision proj_out (no fp32 round trip, no separate split pass)
+        pair = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok, split_out=True)
+        out = exact_gemm(pair, t.w_out3, Cc, w_in=n * hw, bias=t.b_out, residual=x.view(n * hw, Cc))
     else:
+        tok = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok)
         out = ops.linear(tok, t.w_out, bias=t.b_out, residual=x.view(n * hw, Cc))
     return out.view(n, h, w, Cc)
 

@@ -305,11 +305,12 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,
               a_bstride=0, w_bstride=0, out_bstride=0, res_bstride=0, a0_ld=None, a1_ld=None, c0=None, c1=None,
-              out_ld=None, res_ld=None, geglu=False, algo_k=None):
+              out_ld=None, res_ld=None, geglu=False, algo_k=None, split_out=False):
     """out[m, n] = sum_k A[m, k] W[n, k] (+bias +rowvec[img] +residual).  a0/a1 NHWC, the last
     dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out).  The output takes the
     residual's dtype unless out_dtype says otherwise (fp32 residual stream in, fp32 out).
-    algo_k: K of the layer for the FLOP count when the launched K carries split-precision passes."""
+    algo_k: K of the layer for the FLOP count when the launched K carries split-precision passes.
+    split_out: the result leaves as the 16-bit pair [M, hi(n_out) | lo(n_out)] (operand of engine.exact_gemm)."""
     c0 = c0 if c0 is not None else a0.shape[-1]
     c1 = (c1 if c1 is not None else a1.shape[-1]) if a1 is not None else 0
     if w_in is None:
@@ -320,8 +321,10 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     M = n_img * h_out * w_out
     if out is not None:
         out_dtype = out.dtype
+    if split_out:
+        out_dtype = a0.dtype
     out_dtype = out_dtype or (residual.dtype if residual is not None else a0.dtype)
-    n_store = n_out // 2 if geglu else n_out
+    n_store = n_out // 2 if geglu else (2 * n_out if split_out else n_out)
     if out is None:
         out = torch.empty((batch, M, n_store) if batch > 1 else (M, n_store), device=a0.device, dtype=out_dtype)
     d = ConvDesc()
@@ -340,7 +343,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     d.out_dtype, d.dtype = dt(out_dtype), dt(a0)
     d.batch = batch
     d.a_bstride, d.w_bstride, d.out_bstride, d.res_bstride = a_bstride, w_bstride, out_bstride, res_bstride
-    d.epilogue = 1 if geglu else 0
+    d.epilogue = 1 if geglu else (2 if split_out else 0)
     nbytes = _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
     ws = torch.empty(nbytes, device=a0.device, dtype=torch.uint8) if nbytes else None   # split-K slabs
     d.workspace, d.workspace_bytes = _p(ws), nbytes
@@ -364,12 +367,12 @@ def gemm_workspace_bytes(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, k
     return _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
 
 
-def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False):
+def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False, split_out=False):
     """x [rows, K] 16-bit, w [N, K] 16-bit.  geglu: w / bias rows interleaved (value_j, gate_j),
     returns [rows, N/2] = value * gelu(gate)."""
     rows, K = x.shape
     return conv_gemm(x, w, w.shape[0], w_in=rows, bias=bias, residual=residual, out=out, out_dtype=out_dtype,
-                     geglu=geglu)
+                     geglu=geglu, split_out=split_out)
 
 
 def interleave_geglu(w, b=None):

@@ -197,7 +197,7 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, c1=None,
-              a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, **kw):
+              a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, split_out=False, **kw):
     if batch > 1:          # independent problems (attention scores / P.V of the VAE): plain linears only
         assert ksize == 1 and a1 is None and bias is None and residual is None and rowvec is None and not geglu
         K = c0 or a0.shape[-1]
@@ -233,7 +233,11 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
         y = y + residual.float().reshape(-1, residual.shape[-1])[:, :n_out]
     if geglu:                                     # rows interleaved (value_j, gate_j)
         y = y[:, 0::2] * F.gelu(y[:, 1::2])
-    y = y.to(out_dtype or (residual.dtype if residual is not None else a0.dtype))
+    if split_out:
+        hi = y.to(a0.dtype)
+        y = torch.cat([hi, (y - hi.float()).to(a0.dtype)], -1)
+    else:
+        y = y.to(out_dtype or (residual.dtype if residual is not None else a0.dtype))
     if out is not None:
         if out.shape[-1] != y.shape[-1] and out.numel() != y.numel():   # wider row stride: pad columns untouched
             out.view(-1, out.shape[-1])[:, :y.shape[-1]] = y
@@ -243,9 +247,9 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     return y
 
 
-def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False):
+def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False, split_out=False):
     return conv_gemm(x, w, w.shape[0], w_in=x.shape[0], bias=bias, residual=residual, out=out, out_dtype=out_dtype,
-                     geglu=geglu)
+                     geglu=geglu, split_out=split_out)
 
 
 def interleave_geglu(w, b=None):

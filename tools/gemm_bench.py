@@ -39,18 +39,22 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--phases", action="store_true", help="per-block phase stamps (pf_debug_gemm_profile)")
     ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--stream32", action="store_true", help="fp32 residual in / fp32 out where the shape has a residual (mixed scheme)")
     args = ap.parse_args()
     dev = "cuda"
+    T16 = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
     for name in args.shapes.split(","):
         n, h, w, cin, cout, ks, ex = SHAPES[name]
         g = torch.Generator(device=dev).manual_seed(1)
-        x = torch.randn(n, h, w, cin, device=dev, generator=g).to(torch.bfloat16)
-        wt = (torch.randn(cout, ks * ks * cin, device=dev, generator=g) / (ks * ks * cin) ** 0.5).to(torch.bfloat16)
+        x = torch.randn(n, h, w, cin, device=dev, generator=g).to(T16)
+        wt = (torch.randn(cout, ks * ks * cin, device=dev, generator=g) / (ks * ks * cin) ** 0.5).to(T16)
         b = torch.randn(cout, device=dev, generator=g)
         M = n * h * w
         n_store = cout // 2 if ex.get("geglu") else cout
-        res = torch.randn(M, n_store, device=dev, generator=g).to(torch.bfloat16) if ex.get("res") else None
-        out = torch.empty(M, n_store, device=dev, dtype=torch.bfloat16)
+        TS = torch.float32 if (args.stream32 and ex.get("res")) else T16
+        res = torch.randn(M, n_store, device=dev, generator=g).to(TS) if ex.get("res") else None
+        out = torch.empty(M, n_store, device=dev, dtype=TS)
         kw = dict(n_img=n, h_in=h, w_in=w, ksize=ks, pad=ks // 2, bias=b, residual=res, out=out, geglu=bool(ex.get("geglu")))
         for _ in range(3):
             ops.conv_gemm(x, wt, cout, **kw)
