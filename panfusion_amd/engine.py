@@ -449,11 +449,14 @@ def run_transformer(t, x, text, kv=None):
     tok = _attend(t.attn2, ln, text.reshape(n * L, -1), n, hw, L, dh, self_attn=False, residual=tok, kv=kv)
     ln = ops.layernorm(tok, t.ln3.g, t.ln3.b, t.ln3.eps, out_dtype=t.dtype)
     g = ops.linear(ln, t.w_ff1, bias=t.b_ff1, geglu=True)
-    if t.w_out3 is not None:
+    if t.w_out3 is not None and os.environ.get("PF_FF2_PAIR", "1") != "0":
         # the token stream's last value feeds proj_out only: FF2's epilogue emits it directly as the [hi | lo]
         # pair of the split-precision proj_out (no fp32 round trip, no separate split pass)
         pair = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok, split_out=True)
         out = exact_gemm(pair, t.w_out3, Cc, w_in=n * hw, bias=t.b_out, residual=x.view(n * hw, Cc))
+    elif t.w_out3 is not None:           # A/B switch PF_FF2_PAIR=0: fp32 token stream + a separate split pass
+        tok = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok)
+        out = exact_gemm(split_operand(tok, dtype=t.dtype), t.w_out3, Cc, w_in=n * hw, bias=t.b_out, residual=x.view(n * hw, Cc))
     else:
         tok = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok)
         out = ops.linear(tok, t.w_out, bias=t.b_out, residual=x.view(n * hw, Cc))

@@ -113,6 +113,24 @@ def test_gemm_fp32_residual_and_output(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", D16)
+@pytest.mark.parametrize("M,N,K", [(40 * 1024, 640, 2560), (4096, 320, 1280), (1000, 320, 5120), (333, 132, 64)])
+def test_gemm_split_pair_epilogue(dtype, M, N, K):
+    """PF_EPILOGUE_SPLIT: bias (+ fp32 residual) -> the 16-bit pair [hi | lo] of the fp32 result (FF2 feeding the
+    split-precision proj_out); hi is the 16-bit rounding of the fp32 epilogue output, lo the rounded remainder."""
+    o = ops()
+    x = rnd(M, K, seed=40).to(dtype)
+    w = (rnd(N, K, seed=41) / K ** 0.5).to(dtype)
+    b, res = rnd(N, seed=42), rnd(M, N, seed=43)
+    for r in (res, None):
+        want = o.linear(x, w, bias=b, residual=r, out_dtype=torch.float32)
+        pair = o.linear(x, w, bias=b, residual=r, split_out=True)
+        assert pair.dtype == dtype and pair.shape == (M, 2 * N)
+        hi, lo = pair[:, :N], pair[:, N:]
+        assert torch.equal(hi, want.to(dtype))
+        assert torch.equal(lo, (want - hi.float()).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", D16)
 def test_split_precision_gemm_reproduces_fp32(dtype):
     """exact_gemm: [A_hi | A_lo] x [W_hi | W_hi | W_lo] in one launch == the fp32 product to ~2^-2p."""
     from panfusion_amd import engine
