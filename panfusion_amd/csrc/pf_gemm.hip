@@ -1044,18 +1044,17 @@ static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
     const long rounds = cdiv(tiles256, 256);
     static const int fill_pct = tuning("PF_GEMM8_FILL", 60);
     const bool filled = tiles256 * 100 >= rounds * 256 * fill_pct;
-    // short-K layers (K < PF_GEMM8_MIN_K) go to the 4-wave kernel: two co-resident blocks per CU overlap one block's
-    // epilogue with the other's K loop, which a single persistent 8-wave block cannot do
-    static const int big_min_k = tuning("PF_GEMM8_MIN_K", 0);
-    if (big_min_tiles > 0 && tiles256 >= big_min_tiles && filled && K >= big_min_k) {
-        GemmPlan g;
-        g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64; g.m_split = 0;
-        return g;
-    }
+    // a badly filled last round of a LONG-K layer (320 tiles of a 16x16-level 3x3 conv = 1.25 rounds) is better spent on a
+    // split-K tail launch than on a second full round: the tail split below goes first when the fill is under
+    // PF_GEMM8_TAIL_FIRST % (same-box A/B on the mixed scheme: 69.7 -> 68.7 ms per step)
+    static const int tail_first_pct = tuning("PF_GEMM8_TAIL_FIRST", 80);
+    static const int big_min_k = tuning("PF_GEMM8_MIN_K", 0);      // A/B: least K for the 8-wave kernel (measured neutral)
     // Tail split: whole rounds of 256 tiles run unsplit; the tile rows left over (a badly filled last round)
     // become a second launch whose K range is split so that it fills the chip once more.  320 tiles then
     // cost 1.25 rounds instead of 2.
     static const int tail_on = tuning("PF_GEMM_TAIL_SPLIT", 1);
+    GemmPlan tail;
+    bool tail_ok = false;
     if (big_min_tiles > 0 && tail_on && allow_split && batch == 1 && N % 4 == 0 && tiles256 > 256 && K >= big_min_k && K / 64 >= tuning("PF_GEMM_TAIL_MINKB", 40)) {
         const long ntl = cdiv(N, 32 * nrep), mt = cdiv(M, 256);
         const long rows1 = (tiles256 / 256) * 256 / ntl;            // tile rows of the unsplit launch
@@ -1063,14 +1062,20 @@ static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
         long sp = tiles2 > 0 ? (256 + tiles2 / 2) / tiles2 : 1;
         if (sp > (K / 64) / 8) sp = (K / 64) / 8;
         if (rows1 > 0 && tiles2 > 0 && sp >= 2 && rows1 * ntl * 100 >= (tiles256 / 256) * 256 * 90) {
-            GemmPlan g;
-            g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64;
-            g.m_split = static_cast<int>(rows1 * 256);
-            g.tail_kb = static_cast<int>(cdiv(K / 64, sp));
-            g.tail_splits = static_cast<int>(cdiv(K / 64, g.tail_kb));
-            return g;
+            tail.big = true; tail.mrep = 8; tail.nrep = nrep; tail.splits = 1; tail.kb_per_split = K / 64;
+            tail.m_split = static_cast<int>(rows1 * 256);
+            tail.tail_kb = static_cast<int>(cdiv(K / 64, sp));
+            tail.tail_splits = static_cast<int>(cdiv(K / 64, tail.tail_kb));
+            tail_ok = true;
         }
     }
+    if (tail_ok && tiles256 * 100 < rounds * 256 * tail_first_pct) return tail;
+    if (big_min_tiles > 0 && tiles256 >= big_min_tiles && filled && K >= big_min_k) {
+        GemmPlan g;
+        g.big = true; g.mrep = 8; g.nrep = nrep; g.splits = 1; g.kb_per_split = K / 64; g.m_split = 0;
+        return g;
+    }
+    if (tail_ok) return tail;
     // long-K layers with few output tiles (the 8x8 level, the panorama's inner levels): 256-row tiles
     // re-read the weight panel 2-4x less often than the 64-row tiles of the small kernel; split K so
     // that one round of blocks covers the chip
