@@ -288,17 +288,21 @@ def main():
     dom = max(fam, key=lambda k: fam[k][1]) if fam else None
     roofline = None
     traffic = None                                    # PMC-derived bytes per launch of the dominant kernel (profiles/)
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
-            traffic = json.load(fh)
-    except (OSError, ValueError):
-        pass
+    traffic_file = None
+    for name in ("r2_traffic.json", "r1_traffic.json"):           # newest committed PMC summary (r2: fp16 mixed; r1: bf16 all-16-bit)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                traffic, traffic_file = json.load(fh), name
+            break
+        except (OSError, ValueError):
+            pass
     if dom:
         fl, sec, n = fam[dom]
         roofline = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS,
                     "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_DENSE_TFLOPS,
                     "traffic": traffic["bytes_per_launch"] if traffic and dom in traffic.get("kernel", "") else None,
-                    "traffic_note": "bytes per launch from rocprofv3 PMC passes committed in profiles/r1_traffic.json (not re-measured in this run)",
+                    "traffic_note": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, L2<->fabric incl. Infinity-Cache hits: an upper bound on HBM bytes) from the "
+                                    "rocprofv3 PMC passes committed in profiles/%s (not re-measured in this run)" % traffic_file,
                     "launches_per_step": n, "avg_launch_us": sec / n * 1e6, "algorithmic_flop_per_launch": fl / n,
                     "share_of_step_time": sec / (elapsed / args.steps),
                     "other": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]}

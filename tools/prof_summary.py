@@ -48,7 +48,7 @@ def pmc(path, out):
 
 
 def traffic(fetch_txt, write_txt, out, family="k_conv_gemm"):
-    """profiles/r1_traffic.json (read by bench.py for roofline.traffic) from the two PMC summaries."""
+    """profiles/r<N>_traffic.json (read by bench.py for roofline.traffic) from the two PMC summaries."""
     import json
     tot, n = {}, {}
     for path in (fetch_txt, write_txt):
