@@ -9,7 +9,7 @@ from ... import engine, ops
 from ..modules.transformer import BasicTransformerBlock, SphericalPE
 
 
-_HOST_CAMS = {}        # (data_ptr, version, numel, device) of a device tensor -> its host values
+_HOST_CAMS = {}        # storage identity + version of a device tensor -> (the tensor, its host values)
 
 
 def _host_values(v):
@@ -20,13 +20,15 @@ def _host_values(v):
         return list(v)
     if not v.is_cuda:
         return v.detach().tolist()
-    key = (v.data_ptr(), v._version, v.numel(), str(v.device), v.dtype)
+    key = (v.data_ptr(), v._version, tuple(v.shape), tuple(v.stride()), str(v.device), v.dtype)
     hit = _HOST_CAMS.get(key)
     if hit is None:
         if len(_HOST_CAMS) > 256:
             _HOST_CAMS.clear()
-        hit = _HOST_CAMS[key] = v.detach().cpu().tolist()
-    return hit
+        # the entry holds the tensor: its storage cannot be freed and handed to another tensor (same address, version 0,
+        # other angles) while the key is alive
+        hit = _HOST_CAMS[key] = (v, v.detach().cpu().tolist())
+    return hit[1]
 
 
 def camera_groups(cameras, b):

@@ -126,10 +126,18 @@ class DenoiseLoop:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     out = self._denoise(cams)
-            g = (graph, out)
+            g = (graph, out, self._graph_keepalive())
             self.graphs[key] = g
         g[0].replay()
         return g[1]
+
+    def _graph_keepalive(self):
+        """Tensors a captured graph reads by address but that live in bounded caches of the model (16-bit prompt
+        casts, text K / V^T per UNet): referenced from the graph entry so that an eviction cannot free them under it."""
+        keep = [list(getattr(self.model, "_prompt_cache", {}).values())]
+        for packed in getattr(self.model, "_packed", {}).values():
+            keep.append(list(getattr(packed, "text_kv_cache", {}).values()))
+        return keep
 
     def prepare(self):
         """Untimed set-up: build the geometry tables (and capture one hipGraph) for every rotation

@@ -359,7 +359,7 @@ class ShardedDenoiseLoop(DenoiseLoop):
                 self.use_graphs = False
                 self.graphs.clear()
                 return self._denoise(cams)
-            g = (seg, out)
+            g = (seg, out, self._graph_keepalive())
             self.graphs[key] = g
         g[0].replay()
         return self._gather(g[1])
