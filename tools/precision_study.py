@@ -50,6 +50,7 @@ class Policy:
         self.cur = None             # tag of the GEMM being executed (for live weight rounding)
         self.count = None
         self.exact = set()          # tags computed exactly (split-precision / fp32 layers)
+        self.exact_cls = None       # None: operands AND weights of an exact tag are exact; {"op"} / {"w"}: only that side (2-pass)
         self.exact_levels = {}      # tag -> set of UNet levels (0 = full resolution .. 3) where it is exact; absent: all
         self.level = 0
 
@@ -58,14 +59,16 @@ class Policy:
         return self.window is None or self.block in self.window
 
     def r(self, cls, x, tag=None):
-        if cls in self.rounded and self.active and (self.tags is None or tag in self.tags) and not self.is_exact(tag):
+        if cls in self.rounded and self.active and (self.tags is None or tag in self.tags) and not self.is_exact(tag, cls):
             if self.count is not None:
                 self.count[(cls, tag)] = self.count.get((cls, tag), 0) + 1
             return x.to(self.dt).float()
         return x
 
-    def is_exact(self, tag):
+    def is_exact(self, tag, cls=None):
         if tag not in self.exact:
+            return False
+        if self.exact_cls is not None and cls is not None and cls not in self.exact_cls and cls in ("op", "w"):
             return False
         lv = self.exact_levels.get(tag)
         return lv is None or self.level in lv
@@ -398,7 +401,11 @@ def main():
         return
     for name in args.schemes.split(","):
         base, _, ex = name.partition("+")
+        side = None
+        if base.endswith(":op") or base.endswith(":w"):
+            base, side = base.rsplit(":", 1)
         pol = Policy(args.fmt, SCHEMES[base])
+        pol.exact_cls = {side} if side else None
         for e in [e for e in ex.split("+") if e]:
             grp, _, lv = e.partition("@")
             pol.exact |= EXACT[grp]
