@@ -141,3 +141,49 @@ def test_full_size_step_is_deterministic_and_graph_replay_equals_eager():
             assert all(torch.isfinite(x).all() for x in a)
         outs.append([x.clone() for x in loop.run()])
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+# ---- size-independent properties at the BASELINE.json configs[1] sizes (no oracle can run these shapes in seconds) ----
+def test_conv_scaling_by_powers_of_two_is_exact_full_size():
+    """Scaling the input of the implicit-GEMM conv by 2^k scales every product and partial sum by 2^k exactly, so the
+    fp32-accumulated, once-rounded output scales bit for bit (64^2 level: 40 images, 320 -> 320, K = 2880); the same for the
+    split-precision 1x1 GEMM of the mixed scheme on an fp32 stream tensor, and additivity holds to one rounding."""
+    from panfusion_amd import engine
+    o = ops()
+    n, h, w, cin, cout = 40, 64, 64, 320, 320
+    x = rnd(n, h, w, cin, seed=21).half()
+    wt = (rnd(cout, 9 * cin, seed=22) / (9 * cin) ** 0.5).half()
+    run = lambda t: o.conv_gemm(t, wt, cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1)
+    y = run(x)
+    assert torch.equal(run(x * 4.0), y * 4.0) and torch.equal(run(x * 0.125), y * 0.125)
+    x2 = rnd(n, h, w, cin, seed=23).half()
+    s = run(x + x2).float()                       # x + x2 is rounded to fp16 first: compare against the same operand
+    want = run(x).float() + run(x2).float()
+    assert rel(s, want) <= 8e-4
+    xs = rnd(n * h * w, cin, seed=24)             # fp32 stream tensor -> [hi | lo] pair -> 3-pass GEMM, fp32 out
+    w3 = engine._split_weight(rnd(cout, cin, seed=25) / cin ** 0.5, 1, DEV, torch.float16)
+    ex = lambda t: engine.exact_gemm(engine.split_operand(t, dtype=torch.float16), w3, cout, w_in=n * h * w, out_dtype=torch.float32)
+    assert torch.equal(ex(xs * 8.0), ex(xs) * 8.0)
+
+
+def test_attention_shift_and_permutation_invariance_full_size():
+    """softmax is invariant to a constant added to a whole score row (here: to every entry of the EPA bias table, all tiles
+    flagged) and attention is invariant to a permutation of the keys applied to K rows, V^T columns and bias columns alike:
+    checked on the panorama-query EPA direction at the benchmark geometry (2048 queries x 20480 keys x 20 heads of 32)."""
+    o = ops()
+    B, H, D, E, mP = 1, 20, 32, 2048, 20480
+    Cc = H * D
+    q = rnd(B * E, Cc, seed=31).half()
+    k = rnd(B * mP, Cc, seed=32).half()
+    vt = rnd(B, Cc, mP, seed=33).half()
+    bias = (rnd(E, mP, seed=34) * 0.5).contiguous()
+    flags = torch.ones(E // 32, mP // 32, dtype=torch.uint8, device=DEV)
+    run = lambda kk, vv, bb: o.attention(q, kk, vv, B, H, D, E, mP, q_ld=Cc, k_ld=Cc, vt_ld=mP, q_bs=E * Cc, k_bs=mP * Cc,
+                                         vt_bs=Cc * mP, bias=bb, flags=flags)
+    base = run(k, vt, bias)
+    shifted = run(k, vt, bias + 3.0)
+    assert rel(shifted, base) <= 1.5e-3           # two independent fp16 roundings of P and O
+    perm = torch.randperm(mP, generator=torch.Generator(device=DEV).manual_seed(35), device=DEV)
+    permuted = run(k.view(B, mP, Cc)[:, perm].reshape(B * mP, Cc).contiguous(), vt[:, :, perm].contiguous(), bias[:, perm].contiguous())
+    assert rel(permuted, base) <= 1.5e-3
+    assert torch.isfinite(base).all()
