@@ -146,8 +146,8 @@ def test_full_size_step_is_deterministic_and_graph_replay_equals_eager():
 # ---- size-independent properties at the BASELINE.json configs[1] sizes (no oracle can run these shapes in seconds) ----
 def test_conv_scaling_by_powers_of_two_is_exact_full_size():
     """Scaling the input of the implicit-GEMM conv by 2^k scales every product and partial sum by 2^k exactly, so the
-    fp32-accumulated, once-rounded output scales bit for bit (64^2 level: 40 images, 320 -> 320, K = 2880); the same for the
-    split-precision 1x1 GEMM of the mixed scheme on an fp32 stream tensor, and additivity holds to one rounding."""
+    fp32-accumulated output scales bit for bit (64^2 level: 40 images, 320 -> 320, K = 2880); the split-precision 1x1
+    GEMM of the mixed scheme on an fp32 stream tensor scales to 1e-6, and additivity holds to one rounding."""
     from panfusion_amd import engine
     o = ops()
     n, h, w, cin, cout = 40, 64, 64, 320, 320
@@ -164,7 +164,9 @@ def test_conv_scaling_by_powers_of_two_is_exact_full_size():
     xs = keep_normal(rnd(n * h * w, cin, seed=24))             # fp32 stream tensor -> [hi | lo] pair -> 3-pass GEMM, fp32 out
     w3 = engine._split_weight(rnd(cout, cin, seed=25) / cin ** 0.5, 1, DEV, torch.float16)
     ex = lambda t: engine.exact_gemm(engine.split_operand(t, dtype=torch.float16), w3, cout, w_in=n * h * w, out_dtype=torch.float32)
-    assert torch.equal(ex(xs * 8.0), ex(xs) * 8.0)      # (hi and lo both scale exactly: lo stays clear of the subnormal range)
+    # (not bit for bit: the lo halves of small activations, ~2^-12 |x|, sit in fp16's subnormal range, where a scaling
+    # changes their rounding -- an absolute error of <= 2^-25 per element)
+    assert rel(ex(xs * 8.0), ex(xs) * 8.0) <= 1e-6
 
 
 def test_attention_shift_and_permutation_invariance_full_size():
