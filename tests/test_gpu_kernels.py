@@ -603,3 +603,33 @@ def test_py360_e2p_dataset_size_vs_oracle():
     for i in (0, 7, 19):
         want = py360.e2p(pano, (90, 90), thd[i], phd[i], (512, 512))
         assert np.array_equal(got[i], want), "camera %d: %d values differ" % (i, (got[i] != want).sum())
+
+
+def test_py360_e2p_random_cases_vs_oracle():
+    """Random cameras / fields of view / in-plane rotations / odd image sizes, uint8 and float32, both modes, against the
+    numpy oracle (pinned to the reference module); nearest-mode ties (positions within 1e-9 of a half-integer) excluded."""
+    from oracle import py360
+    from panfusion_amd.external.py360convert import e2p
+    rng = np.random.default_rng(21)
+    for trial in range(10):
+        H = int(rng.integers(9, 60))
+        W = 2 * H + int(rng.integers(0, 3))
+        img = (rng.random((H, W, 3)) * 255).astype(np.uint8) if trial % 2 == 0 else rng.standard_normal((H, W, 2)).astype(np.float32)
+        u, v = float(rng.uniform(-180, 180)), float(rng.uniform(-89, 89))
+        fov = (float(rng.uniform(40, 120)), float(rng.uniform(40, 120)))
+        hw = (int(rng.integers(5, 40)), int(rng.integers(5, 40)))
+        rot = float(rng.uniform(-30, 30)) if trial % 3 == 0 else 0.0
+        for mode in ("bilinear", "nearest"):
+            want = py360.e2p(img, fov, u, v, hw, in_rot_deg=rot, mode=mode)
+            got = e2p(img, fov, u, v, hw, in_rot_deg=rot, mode=mode)
+            assert got.dtype == want.dtype and got.shape == want.shape
+            if mode == "nearest":
+                cx, cy = py360.coordinates(H, W, fov, u, v, hw, rot)
+                cx, cy = py360._wrap_coord(cx, W), py360._wrap_coord(cy, H + 2)
+                frac = lambda c: np.abs((c + 0.5) - np.round(c + 0.5))
+                keep = ((frac(cx) > 1e-9) & (frac(cy) > 1e-9))[..., None]
+                assert ((got == want) | ~keep).all(), (trial, mode)
+            elif img.dtype == np.uint8:
+                assert np.array_equal(got, want), (trial, mode, int((got != want).sum()))
+            else:       # float32 bilinear: weights differ by the device's atan2 / sqrt ulps -> a few float32 ulp of the result
+                assert np.allclose(got, want, rtol=0, atol=2e-6), (trial, mode, float(np.abs(got - want).max()))
