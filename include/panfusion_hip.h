@@ -277,9 +277,76 @@ typedef struct {
     float scale;
     const float* bias; long bias_ld;
     const uint8_t* flags; int flags_ld;
+    float* lse;      /* optional fp32 [B][H][nq]: log2 of the softmax denominator in the exp2 domain,
+                      * lse = log2(sum_j exp2(log2e * (scale * q.k_j + bias_j))) -- what pf_attention_bwd reads */
 } pf_attn_desc;
 
 pf_status pf_attention(const pf_attn_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training: backward of the EPA block (reference models/pano/modules.py:15-59 under autograd;
+ * models/modules/transformer.py:77-161 -- the reference recomputes the block in backward,
+ * CheckpointFunction, and so does the caller of these entry points).
+ * ------------------------------------------------------------------------------------------ */
+
+/* delta[b][h][i] = sum_d dout[b][i][h*D+d] * out[b][i][h*D+d]   (fp32 [B][H][nq]; rows of width ld, batch stride bs). */
+pf_status pf_attention_delta(const void* out, const void* dout, int dtype, int B, int H, int D, long nq,
+                             int ld, long bs, float* delta, void* stream);
+
+/* Backward of pf_attention given lse (forward) and delta:
+ *   P = exp2(log2e * (scale * q.k + bias) - lse),  dV = P^T dO,  dS = P o (dO V^T - delta),
+ *   dQ = scale * dS K,  dK = scale * dS^T Q.
+ * All of q, k, v, dout are ROW-major ([B][n][ld], head h at column h*D); kt, qt, dot are the transposes of k, q, dout
+ * ([B][H*D][*_ld], tokens contiguous) -- the A operands of the products whose reduction runs over tokens.
+ * dq [B][nq][dq_ld], dk / dv [B][nk][dk_ld / dv_ld] in `dtype`.  nq and nk must be multiples of 32 (EPA token counts
+ * are multiples of 64).  Two launches: queries-stationary (dq) and keys-stationary (dk, dv); no atomics, results do
+ * not depend on scheduling. */
+typedef struct {
+    const void* q; const void* k; const void* v; const void* dout;
+    const void* qt; const void* kt; const void* dot;
+    void* dq; void* dk; void* dv;
+    int dtype;
+    int B, H, D;
+    int nq, nk;
+    int q_ld, k_ld, v_ld, do_ld;          /* row-major operands */
+    int qt_ld, kt_ld, dot_ld;             /* transposed operands */
+    int dq_ld, dk_ld, dv_ld;
+    long q_bs, k_bs, v_bs, do_bs, qt_bs, kt_bs, dot_bs, dq_bs, dk_bs, dv_bs;
+    float scale;
+    const float* bias; long bias_ld;      /* as pf_attention: [nq][bias_ld] */
+    const uint8_t* flags; int flags_ld;
+    const float* lse; const float* delta; /* fp32 [B][H][nq] */
+} pf_attn_bwd_desc;
+
+pf_status pf_attention_bwd(const pf_attn_bwd_desc* desc, void* stream);
+
+/* LayerNorm backward (rows of width C <= 2048, C % 8 == 0).  x (+ pe, as pf_layernorm) is the forward input, dy fp32
+ * [rows][C] the gradient of the normalised output, dres (optional fp32 [rows][C]) a gradient that by-passes the norm:
+ *   dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.
+ * partials: fp32 [2][n_part][C] -- per-block sums of dy * xhat (gamma) and dy (beta) over the block's rows, reduced in
+ * a fixed order by pf_colsum afterwards; n_part = pf_layernorm_bwd_parts(rows). */
+int pf_layernorm_bwd_parts(long rows);
+pf_status pf_layernorm_bwd(const void* x, const float* pe, long pe_rows, int dtype, long rows, int C,
+                           const float* gamma, float eps, const float* dy, const float* dres, float* dx,
+                           float* partials, void* stream);
+
+/* GEGLU backward: u [rows][2*inner] = [a | gate] (forward input of pf_geglu), dg [rows][inner] ->
+ * du [rows][2*inner] = [dg * gelu(gate) | dg * a * gelu'(gate)]. */
+pf_status pf_geglu_bwd(const void* u, const void* dg, int dtype, long rows, int inner, void* du, void* stream);
+
+/* Column sums: x [rows][N] (16-bit or PF_F32, row stride ld) -> out fp32 [N], fixed summation order.
+ * workspace: fp32 scratch of pf_colsum_workspace_size(rows, N) bytes. */
+size_t pf_colsum_workspace_size(long rows, int N);
+pf_status pf_colsum(const void* x, int dtype, long rows, int N, long ld, float* out, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* Gradient normalisation for 16-bit backward operands.  state: 4 floats on the device.
+ *   pf_amax_f32: state[0] = max(state[0], max |x|) (reset = 1 clears it first);
+ *   pf_pow2_scale: state[1] = 2^-e with amax * 2^-e in [1, 2) (1 when amax is 0 or not finite), state[2] = 2^e;
+ *   pf_scale_f32: y = x * state[index]; y fp32 (may alias x) or 16-bit. */
+pf_status pf_amax_f32(const float* x, long n, float* state, int reset, void* stream);
+pf_status pf_pow2_scale(float* state, void* stream);
+pf_status pf_scale_f32(const float* x, long n, const float* state, int index, int out_dtype, void* y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,25 @@ class AttnDesc(C.Structure):
         ("q_bs", c_long), ("k_bs", c_long), ("vt_bs", c_long), ("o_bs", c_long),
         ("scale", c_float),
         ("bias", c_void_p), ("bias_ld", c_long), ("flags", c_void_p), ("flags_ld", c_int),
+        ("lse", c_void_p),
+    ]
+
+
+class AttnBwdDesc(C.Structure):
+    """pf_attn_bwd_desc"""
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("dout", c_void_p),
+        ("qt", c_void_p), ("kt", c_void_p), ("dot", c_void_p),
+        ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
+        ("dtype", c_int), ("B", c_int), ("H", c_int), ("D", c_int), ("nq", c_int), ("nk", c_int),
+        ("q_ld", c_int), ("k_ld", c_int), ("v_ld", c_int), ("do_ld", c_int),
+        ("qt_ld", c_int), ("kt_ld", c_int), ("dot_ld", c_int),
+        ("dq_ld", c_int), ("dk_ld", c_int), ("dv_ld", c_int),
+        ("q_bs", c_long), ("k_bs", c_long), ("v_bs", c_long), ("do_bs", c_long), ("qt_bs", c_long), ("kt_bs", c_long),
+        ("dot_bs", c_long), ("dq_bs", c_long), ("dk_bs", c_long), ("dv_bs", c_long),
+        ("scale", c_float),
+        ("bias", c_void_p), ("bias_ld", c_long), ("flags", c_void_p), ("flags_ld", c_int),
+        ("lse", c_void_p), ("delta", c_void_p),
     ]
 
 
@@ -94,6 +113,17 @@ SIGNATURES = {
     "pf_conv_out": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                             c_void_p, c_void_p]),
     "pf_attention": (c_int, [C.POINTER(AttnDesc), c_void_p]),
+    "pf_attention_delta": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_void_p, c_void_p]),
+    "pf_attention_bwd": (c_int, [C.POINTER(AttnBwdDesc), c_void_p]),
+    "pf_layernorm_bwd_parts": (c_int, [c_long]),
+    "pf_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_int, c_void_p, c_float, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
+    "pf_geglu_bwd": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_void_p]),
+    "pf_colsum_workspace_size": (c_size_t, [c_long, c_int]),
+    "pf_colsum": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pf_amax_f32": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p]),
+    "pf_pow2_scale": (c_int, [c_void_p, c_void_p]),
+    "pf_scale_f32": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 
 

@@ -31,20 +31,7 @@ struct AttnParams {
     long q_bs, k_bs, vt_bs, o_bs;
     float scale_log2e;
     const float* bias; long bias_ld; const uint8_t* flags; int flags_ld;
-};
-
-template <typename T> struct Mfma32;
-template <> struct Mfma32<Bf16> {
-    typedef __attribute__((ext_vector_type(8))) __bf16 frag;
-    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct Mfma32<F16> {
-    typedef __attribute__((ext_vector_type(8))) _Float16 frag;
-    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
+    float* lse;
 };
 
 template <typename T, int D>
@@ -190,6 +177,7 @@ __global__ __launch_bounds__(256) void k_attention(const AttnParams p) {
                 for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(o[d][4 * g + e] * inv);
                 *reinterpret_cast<u16x4*>(op + d * 32 + 8 * g + 4 * hi) = w;
             }
+        if (p.lse && hi == 0) p.lse[(b * p.H + h) * p.nq + q0 + ql] = m_run + __log2f(l_run);
     }
 }
 
@@ -495,6 +483,8 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
                 for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(o[d][4 * g + e] * inv);
                 *reinterpret_cast<u16x4*>(op + d * 32 + 8 * g + 4 * hi) = w;
             }
+        // (m_run is a reference point in raw-score units, not necessarily the maximum: deferred rescale)
+        if (p.lse && hi == 0) p.lse[(b * p.H + h) * p.nq + q0 + ql] = m_run * c2 + __log2f(l_run);
     }
 }
 
@@ -538,6 +528,7 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     p.q_bs = d->q_bs; p.k_bs = d->k_bs; p.vt_bs = d->vt_bs; p.o_bs = d->o_bs;
     p.scale_log2e = d->scale * 1.44269504088896340736f;
     p.bias = d->bias; p.bias_ld = d->bias_ld; p.flags = d->flags; p.flags_ld = d->flags_ld;
+    p.lse = d->lse;
     dim3 grid(cdiv(d->nq, 128), d->H, d->B), block(256);
     hipStream_t st = as_stream(stream);
     const bool lds = use_lds_attention() && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0;

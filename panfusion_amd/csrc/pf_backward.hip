@@ -1,0 +1,606 @@
+// Training kernels for gfx950 (CDNA4): backward of the EPA block -- the trainable part of the denoiser next to the
+// rank-4 LoRA (reference models/pano/modules.py:15-59 under autograd, models/modules/transformer.py:40-161; the
+// reference wraps the block in its CheckpointFunction, transformer.py:77-127: the forward is recomputed in backward,
+// which is what the host side of these entry points does as well).
+//
+//   attention backward   two MFMA kernels that recompute P from the forward's log-sum-exp:
+//                          k_attn_bwd_dq   a wavefront owns 32 queries and walks the keys   -> dQ
+//                          k_attn_bwd_dkv  a wavefront owns 32 keys and walks the queries   -> dK, dV
+//                        both use the transposed-product layout of the forward kernel (pf_attention.hip): the owner
+//                        index is the MFMA column = the lane, so per-owner scalars (lse, delta) are lane scalars in the
+//                        first kernel and the probabilities feed the second product straight from the registers.
+//   LayerNorm backward   one row per wavefront, per-block partial sums for gamma / beta (reduced by k_colsum)
+//   GEGLU backward, column sums (bias gradients), gradient normalisation (amax -> power-of-two scale).
+#include "pf_common.h"
+#include <algorithm>
+#include <type_traits>
+
+namespace pf {
+
+__device__ __forceinline__ float wave_sum_b(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- attention backward ------------------------------------------------------------------------------------------
+struct AttnBwdParams {
+    const unsigned short *q, *k, *v, *dout, *qt, *kt, *dot;
+    unsigned short *dq, *dk, *dv;
+    int H, nq, nk;
+    int q_ld, k_ld, v_ld, do_ld, qt_ld, kt_ld, dot_ld, dq_ld, dk_ld, dv_ld;
+    long q_bs, k_bs, v_bs, do_bs, qt_bs, kt_bs, dot_bs, dq_bs, dk_bs, dv_bs;
+    float scale, scale_log2e;
+    const float* bias; long bias_ld; const uint8_t* flags; int flags_ld;
+    const float *lse, *delta;
+};
+
+constexpr float LOG2E = 1.44269504088896340736f;
+
+// A-operand fragment of a TRANSPOSED tensor ([rows = head dim][tokens contiguous]) for a product whose reduction runs
+// over 32 tokens starting at t0: the k-slot order (lo = t0 + 16 s2 + 4 hi + 0..3, up = the same + 8) is the permutation
+// in which the score registers of a lane enumerate the tokens (forward kernel, O^T += V^T P^T).
+__device__ __forceinline__ u16x8 load_t_frag(const unsigned short* row, int t0, int s2, int hi) {
+    const unsigned short* pp = row + t0 + 16 * s2 + 4 * hi;
+    const u16x4 lo = *reinterpret_cast<const u16x4*>(pp);
+    const u16x4 up = *reinterpret_cast<const u16x4*>(pp + 8);
+    return u16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnBwdParams p) {
+    constexpr int KS = D / 16, DB = D / 32;
+    typedef typename Mfma32<T>::frag frag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 31, hi = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= p.nq) return;
+    const int h = blockIdx.y;
+    const long b = blockIdx.z;
+    const unsigned short* qp = p.q + b * p.q_bs + static_cast<long>(q0 + ql) * p.q_ld + h * D;
+    const unsigned short* dop = p.dout + b * p.do_bs + static_cast<long>(q0 + ql) * p.do_ld + h * D;
+    const unsigned short* kp = p.k + b * p.k_bs + h * D;
+    const unsigned short* vp = p.v + b * p.v_bs + h * D;
+    const unsigned short* ktp = p.kt + b * p.kt_bs + static_cast<long>(h) * D * p.kt_ld;
+
+    frag qf[KS], dof[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        qf[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(qp + 16 * s + 8 * hi));
+        dof[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(dop + 16 * s + 8 * hi));
+    }
+    const long stat = (b * p.H + h) * p.nq + q0 + ql;
+    const float lse = p.lse[stat], delta = p.delta[stat];
+    const float c2 = p.scale_log2e;
+
+    f32x16 acc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+    const uint8_t* flag_row = p.flags ? p.flags + static_cast<long>(q0 >> 5) * p.flags_ld : nullptr;
+    const float* bias_row = p.bias ? p.bias + static_cast<long>(q0 + ql) * p.bias_ld : nullptr;
+    const int nkt = p.nk / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 32;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u16x8 kf = *reinterpret_cast<const u16x8*>(kp + static_cast<long>(k0 + ql) * p.k_ld + 16 * ks + 8 * hi);
+            const u16x8 vf = *reinterpret_cast<const u16x8*>(vp + static_cast<long>(k0 + ql) * p.v_ld + 16 * ks + 8 * hi);
+            s = Mfma32<T>::run(__builtin_bit_cast(frag, kf), qf[ks], s);          // S^T  [key][query]
+            dp = Mfma32<T>::run(__builtin_bit_cast(frag, vf), dof[ks], dp);       // dP^T [key][query]
+        }
+        float sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = s[r] * c2;
+        if (flag_row && flag_row[kt]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias_row + k0 + 8 * g + 4 * hi);
+                sv[4 * g + 0] += bv.x * LOG2E;
+                sv[4 * g + 1] += bv.y * LOG2E;
+                sv[4 * g + 2] += bv.z * LOG2E;
+                sv[4 * g + 3] += bv.w * LOG2E;
+            }
+        }
+        u16x8 pb[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pr = exp2f(sv[r] - lse);
+            pb[r >> 3][r & 7] = from_f32<T>(pr * (dp[r] - delta));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const u16x8 a = load_t_frag(ktp + static_cast<long>(d * 32 + ql) * p.kt_ld, k0, s2, hi);
+                acc[d] = Mfma32<T>::run(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, pb[s2]), acc[d]);   // dQ^T += K^T dS^T
+            }
+    }
+    unsigned short* op = p.dq + b * p.dq_bs + static_cast<long>(q0 + ql) * p.dq_ld + h * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u16x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(acc[d][4 * g + e] * p.scale);
+            *reinterpret_cast<u16x4*>(op + d * 32 + 8 * g + 4 * hi) = w;
+        }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnBwdParams p) {
+    constexpr int KS = D / 16, DB = D / 32;
+    typedef typename Mfma32<T>::frag frag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kl = lane & 31, hi = lane >> 5;
+    const int k0 = (blockIdx.x * 4 + wave) * 32;
+    if (k0 >= p.nk) return;
+    const int h = blockIdx.y;
+    const long b = blockIdx.z;
+    const unsigned short* kp = p.k + b * p.k_bs + static_cast<long>(k0 + kl) * p.k_ld + h * D;
+    const unsigned short* vp = p.v + b * p.v_bs + static_cast<long>(k0 + kl) * p.v_ld + h * D;
+    const unsigned short* qp = p.q + b * p.q_bs + h * D;
+    const unsigned short* dop = p.dout + b * p.do_bs + h * D;
+    const unsigned short* qtp = p.qt + b * p.qt_bs + static_cast<long>(h) * D * p.qt_ld;
+    const unsigned short* dotp = p.dot + b * p.dot_bs + static_cast<long>(h) * D * p.dot_ld;
+
+    frag kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        kf[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(kp + 16 * s + 8 * hi));
+        vf[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(vp + 16 * s + 8 * hi));
+    }
+    const float c2 = p.scale_log2e;
+    const float* lsep = p.lse + (b * p.H + h) * p.nq;
+    const float* delp = p.delta + (b * p.H + h) * p.nq;
+
+    f32x16 acc_k[DB], acc_v[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_k[d][r] = 0.f; acc_v[d][r] = 0.f; }
+
+    const int kt = k0 >> 5;
+    const int nqt = p.nq / 32;
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int q0 = qt * 32;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u16x8 qf = *reinterpret_cast<const u16x8*>(qp + static_cast<long>(q0 + kl) * p.q_ld + 16 * ks + 8 * hi);
+            const u16x8 df = *reinterpret_cast<const u16x8*>(dop + static_cast<long>(q0 + kl) * p.do_ld + 16 * ks + 8 * hi);
+            s = Mfma32<T>::run(__builtin_bit_cast(frag, qf), kf[ks], s);           // S  [query][key]
+            dp = Mfma32<T>::run(__builtin_bit_cast(frag, df), vf[ks], dp);         // dP [query][key]
+        }
+        // register r <-> query q0 + (r & 3) + 8 (r >> 2) + 4 hi; the lane's column is key k0 + kl
+        float sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = s[r] * c2;
+        if (p.flags && p.flags[static_cast<long>(qt) * p.flags_ld + kt]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                sv[r] += p.bias[static_cast<long>(qi) * p.bias_ld + k0 + kl] * LOG2E;
+            }
+        }
+        u16x8 pp[2], pd[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 l4 = *reinterpret_cast<const float4*>(lsep + q0 + 8 * g + 4 * hi);
+            const float4 d4 = *reinterpret_cast<const float4*>(delp + q0 + 8 * g + 4 * hi);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const float pr = exp2f(sv[r] - lv[e]);
+                pp[r >> 3][r & 7] = from_f32<T>(pr);
+                pd[r >> 3][r & 7] = from_f32<T>(pr * (dp[r] - dv[e]));
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const u16x8 a_do = load_t_frag(dotp + static_cast<long>(d * 32 + kl) * p.dot_ld, q0, s2, hi);
+                const u16x8 a_q = load_t_frag(qtp + static_cast<long>(d * 32 + kl) * p.qt_ld, q0, s2, hi);
+                acc_v[d] = Mfma32<T>::run(__builtin_bit_cast(frag, a_do), __builtin_bit_cast(frag, pp[s2]), acc_v[d]);   // dV^T += dO^T P
+                acc_k[d] = Mfma32<T>::run(__builtin_bit_cast(frag, a_q), __builtin_bit_cast(frag, pd[s2]), acc_k[d]);    // dK^T += Q^T dS
+            }
+    }
+    unsigned short* okp = p.dk + b * p.dk_bs + static_cast<long>(k0 + kl) * p.dk_ld + h * D;
+    unsigned short* ovp = p.dv + b * p.dv_bs + static_cast<long>(k0 + kl) * p.dv_ld + h * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u16x4 wk, wv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wk[e] = from_f32<T>(acc_k[d][4 * g + e] * p.scale);
+                wv[e] = from_f32<T>(acc_v[d][4 * g + e]);
+            }
+            *reinterpret_cast<u16x4*>(okp + d * 32 + 8 * g + 4 * hi) = wk;
+            *reinterpret_cast<u16x4*>(ovp + d * 32 + 8 * g + 4 * hi) = wv;
+        }
+}
+
+template <typename T>
+__global__ void k_attn_delta(const unsigned short* __restrict__ o, const unsigned short* __restrict__ d_o, int B, int H,
+                             int D, long nq, int ld, long bs, float* __restrict__ delta) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;       // (b, q, h), h fastest
+    if (i >= static_cast<long>(B) * nq * H) return;
+    const int h = i % H;
+    const long q = (i / H) % nq, b = i / (H * nq);
+    const long off = b * bs + q * ld + h * D;
+    float acc = 0.f;
+    for (int c = 0; c < D; c += 8) {
+        float a[8], g[8];
+        unpack8<T>(*reinterpret_cast<const u16x8*>(o + off + c), a);
+        unpack8<T>(*reinterpret_cast<const u16x8*>(d_o + off + c), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += a[j] * g[j];
+    }
+    delta[(b * H + h) * nq + q] = acc;
+}
+
+// ---- LayerNorm backward -------------------------------------------------------------------------------------------
+constexpr int LN_BWD_MAX_PARTS = 512;
+
+template <typename TI> __device__ __forceinline__ void load8_any(const void* base, long idx, float (&f)[8]) {
+    unpack8<TI>(*reinterpret_cast<const u16x8*>(static_cast<const unsigned short*>(base) + idx), f);
+}
+template <> __device__ __forceinline__ void load8_any<float>(const void* base, long idx, float (&f)[8]) {
+    const float* xp = static_cast<const float*>(base) + idx;
+    const float4 a = reinterpret_cast<const float4*>(xp)[0], c = reinterpret_cast<const float4*>(xp)[1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const void* __restrict__ xv, const float* __restrict__ pe, long pe_rows,
+                                                       long rows, int C, const float* __restrict__ gamma, float eps,
+                                                       const float* __restrict__ dy, const float* __restrict__ dres,
+                                                       float* __restrict__ dx, float* __restrict__ partials, int n_part) {
+    constexpr int KMAX = 4;                            // octets per lane (C <= 2048)
+    __shared__ float flat[4 * 2048];                   // the four waves' column sums, one quantity at a time
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int OCT = C / 8;
+    float sg[KMAX][8], sb[KMAX][8];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sg[k][j] = 0.f; sb[k][j] = 0.f; }
+
+    for (long row = blockIdx.x * 4L + wave; row < rows; row += 4L * gridDim.x) {
+        float v[KMAX][8], g[KMAX][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int oct = lane + 64 * k;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[k][j] = 0.f; g[k][j] = 0.f; }
+            if (oct < OCT) {
+                load8_any<TI>(xv, row * C + oct * 8, v[k]);
+                if (pe) {
+                    const float4* pp = reinterpret_cast<const float4*>(pe + (row % pe_rows) * C + oct * 8);
+                    const float4 a = pp[0], c = pp[1];
+                    v[k][0] += a.x; v[k][1] += a.y; v[k][2] += a.z; v[k][3] += a.w; v[k][4] += c.x; v[k][5] += c.y; v[k][6] += c.z; v[k][7] += c.w;
+                }
+                const float4* gp = reinterpret_cast<const float4*>(dy + row * C + oct * 8);
+                const float4 a = gp[0], c = gp[1];
+                g[k][0] = a.x; g[k][1] = a.y; g[k][2] = a.z; g[k][3] = a.w; g[k][4] = c.x; g[k][5] = c.y; g[k][6] = c.z; g[k][7] = c.w;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[k][j];
+            }
+        }
+        const float mean = wave_sum_b(s) / static_cast<float>(C);
+        float qv = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (lane + 64 * k < OCT) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; qv += d * d; }
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum_b(qv) / static_cast<float>(C) + eps);
+        // xhat in v, g = dy * gamma; row sums of g and g * xhat
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int oct = lane + 64 * k;
+            if (oct < OCT) {
+                const float4* gp = reinterpret_cast<const float4*>(gamma + oct * 8);
+                const float4 a = gp[0], c = gp[1];
+                const float gm[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (v[k][j] - mean) * rstd;
+                    v[k][j] = xh;
+                    sg[k][j] += g[k][j] * xh;
+                    sb[k][j] += g[k][j];
+                    g[k][j] *= gm[j];
+                    s1 += g[k][j];
+                    s2 += g[k][j] * xh;
+                }
+            }
+        }
+        const float m1 = wave_sum_b(s1) / static_cast<float>(C), m2 = wave_sum_b(s2) / static_cast<float>(C);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int oct = lane + 64 * k;
+            if (oct < OCT) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = rstd * (g[k][j] - m1 - v[k][j] * m2);
+                if (dres) {
+                    const float4* rp = reinterpret_cast<const float4*>(dres + row * C + oct * 8);
+                    const float4 a = rp[0], c = rp[1];
+                    o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; o[4] += c.x; o[5] += c.y; o[6] += c.z; o[7] += c.w;
+                }
+                float4* op = reinterpret_cast<float4*>(dx + row * C + oct * 8);
+                op[0] = float4{o[0], o[1], o[2], o[3]};
+                op[1] = float4{o[4], o[5], o[6], o[7]};
+            }
+        }
+    }
+    // the four waves of the block: fixed-order sum through LDS, one partial row per block
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int oct = lane + 64 * k;
+            if (oct < OCT) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) flat[wave * C + oct * 8 + j] = which == 0 ? sg[k][j] : sb[k][j];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256)
+            partials[(static_cast<long>(which) * n_part + blockIdx.x) * C + c] = ((flat[c] + flat[C + c]) + flat[2 * C + c]) + flat[3 * C + c];
+    }
+}
+
+// ---- GEGLU backward -----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_geglu_bwd(const unsigned short* __restrict__ u, const unsigned short* __restrict__ dg, long total_oct,
+                            int inner, unsigned short* __restrict__ du) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= total_oct) return;
+    const int OCT = inner / 8;
+    const long row = i / OCT;
+    const int c = (i % OCT) * 8;
+    float a[8], g[8], d[8], da[8], dgate[8];
+    unpack8<T>(*reinterpret_cast<const u16x8*>(u + row * 2 * inner + c), a);
+    unpack8<T>(*reinterpret_cast<const u16x8*>(u + row * 2 * inner + inner + c), g);
+    unpack8<T>(*reinterpret_cast<const u16x8*>(dg + row * inner + c), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float cdf = 0.5f * (1.0f + erff(g[j] * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * __expf(-0.5f * g[j] * g[j]);
+        da[j] = d[j] * g[j] * cdf;
+        dgate[j] = d[j] * a[j] * (cdf + g[j] * pdf);
+    }
+    *reinterpret_cast<u16x8*>(du + row * 2 * inner + c) = pack8<T>(da);
+    *reinterpret_cast<u16x8*>(du + row * 2 * inner + inner + c) = pack8<T>(dgate);
+}
+
+// ---- column sums --------------------------------------------------------------------------------------------------
+constexpr int COLSUM_SLABS = 64;
+
+template <typename S>
+__global__ __launch_bounds__(256) void k_colsum_partial(const void* __restrict__ x, long rows, int N, long ld, int slabs,
+                                                        float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+    const long per = (rows + slabs - 1) / slabs, r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    float acc = 0.f;
+    if (col < N)
+        for (long r = r0 + ty; r < r1; r += 4) acc += ld_any<S>(x, r * ld + col);
+    red[ty][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (ty == 0 && col < N)
+        part[static_cast<long>(blockIdx.y) * N + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ void k_colsum_final(const float* __restrict__ part, int slabs, int N, float* __restrict__ out) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= N) return;
+    float acc = 0.f;
+    for (int s = 0; s < slabs; ++s) acc += part[static_cast<long>(s) * N + col];
+    out[col] = acc;
+}
+
+// ---- gradient normalisation ---------------------------------------------------------------------------------------
+__global__ void k_amax(const float* __restrict__ x, long n, unsigned* __restrict__ state) {
+    float m = 0.f;
+    for (long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * blockDim.x) {
+        const float a = fabsf(x[i]);
+        m = (a > m || a != a) ? a : m;                 // NaN propagates into the maximum (-> scale 1 downstream)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(m, o);
+        m = (w > m || w != w) ? w : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(state, __float_as_uint(m));     // |x| >= 0: the bit pattern orders like the value (NaN > inf)
+}
+
+__global__ void k_pow2_scale(float* state) {
+    const float amax = state[0];
+    float inv = 1.f, fwd = 1.f;
+    if (amax > 0.f && amax < INFINITY) {               // (false for NaN)
+        const int e = static_cast<int>(floorf(log2f(amax)));
+        const int ec = max(-120, min(120, e));
+        inv = exp2f(static_cast<float>(-ec));
+        fwd = exp2f(static_cast<float>(ec));
+    }
+    state[1] = inv;
+    state[2] = fwd;
+}
+
+template <typename SO>
+__global__ void k_scale_f32(const float* __restrict__ x, long n, const float* __restrict__ scale, void* __restrict__ y) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    st_any<SO>(y, i, x[i] * scale[0]);
+}
+
+}  // namespace pf
+
+using namespace pf;
+
+extern "C" pf_status pf_attention_delta(const void* out, const void* dout, int dtype, int B, int H, int D, long nq,
+                                        int ld, long bs, float* delta, void* stream) {
+    PF_REQUIRE(out && dout && delta && B > 0 && H > 0 && nq > 0, "pf_attention_delta: bad arguments");
+    PF_REQUIRE(D % 8 == 0 && ld % 8 == 0 && bs % 8 == 0 && aligned16(out) && aligned16(dout), "pf_attention_delta: D, ld, bs must be multiples of 8, pointers 16-byte aligned");
+    const long total = static_cast<long>(B) * nq * H;
+    PF_DISPATCH_16(dtype, "pf_attention_delta",
+        hipLaunchKernelGGL(k_attn_delta<T>, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                           static_cast<const unsigned short*>(out), static_cast<const unsigned short*>(dout), B, H, D, nq, ld, bs, delta));
+    PF_CHECK_LAUNCH("pf_attention_delta");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_attention_bwd(const pf_attn_bwd_desc* d, void* stream) {
+    PF_REQUIRE(d, "pf_attention_bwd: null descriptor");
+    PF_REQUIRE(d->q && d->k && d->v && d->dout && d->qt && d->kt && d->dot && d->dq && d->dk && d->dv && d->lse && d->delta,
+               "pf_attention_bwd: null pointer");
+    PF_REQUIRE(d->D == 32 || d->D == 64, "pf_attention_bwd: head dim %d unsupported (32 or 64)", d->D);
+    PF_REQUIRE(d->B > 0 && d->H > 0 && d->nq > 0 && d->nk > 0 && d->nq % 32 == 0 && d->nk % 32 == 0,
+               "pf_attention_bwd: nq=%d and nk=%d must be positive multiples of 32", d->nq, d->nk);
+    PF_REQUIRE(d->q_ld % 8 == 0 && d->k_ld % 8 == 0 && d->v_ld % 8 == 0 && d->do_ld % 8 == 0, "pf_attention_bwd: row-major leading dimensions must be multiples of 8");
+    PF_REQUIRE(d->qt_ld % 4 == 0 && d->kt_ld % 4 == 0 && d->dot_ld % 4 == 0 && d->qt_ld >= d->nq && d->dot_ld >= d->nq && d->kt_ld >= d->nk,
+               "pf_attention_bwd: transposed leading dimensions must be multiples of 4 and cover the token count");
+    PF_REQUIRE(d->dq_ld % 4 == 0 && d->dk_ld % 4 == 0 && d->dv_ld % 4 == 0, "pf_attention_bwd: output leading dimensions must be multiples of 4");
+    PF_REQUIRE(d->q_bs % 8 == 0 && d->k_bs % 8 == 0 && d->v_bs % 8 == 0 && d->do_bs % 8 == 0 && d->qt_bs % 4 == 0 && d->kt_bs % 4 == 0 &&
+               d->dot_bs % 4 == 0 && d->dq_bs % 4 == 0 && d->dk_bs % 4 == 0 && d->dv_bs % 4 == 0, "pf_attention_bwd: batch strides misaligned");
+    PF_REQUIRE(aligned16(d->q) && aligned16(d->k) && aligned16(d->v) && aligned16(d->dout) && aligned16(d->qt) && aligned16(d->kt) &&
+               aligned16(d->dot) && aligned16(d->dq) && aligned16(d->dk) && aligned16(d->dv) && aligned16(d->lse) && aligned16(d->delta),
+               "pf_attention_bwd: pointers must be 16-byte aligned");
+    PF_REQUIRE((d->bias == nullptr) == (d->flags == nullptr), "pf_attention_bwd: bias and flags come together");
+    if (d->bias) {
+        PF_REQUIRE(d->bias_ld % 4 == 0 && d->bias_ld >= d->nk && aligned16(d->bias), "pf_attention_bwd: bias needs an aligned ld >= nk");
+        PF_REQUIRE(d->flags_ld >= d->nk / 32, "pf_attention_bwd: flags_ld too small");
+    }
+    AttnBwdParams p;
+    auto u16 = [](const void* v) { return static_cast<const unsigned short*>(v); };
+    p.q = u16(d->q); p.k = u16(d->k); p.v = u16(d->v); p.dout = u16(d->dout); p.qt = u16(d->qt); p.kt = u16(d->kt); p.dot = u16(d->dot);
+    p.dq = static_cast<unsigned short*>(d->dq); p.dk = static_cast<unsigned short*>(d->dk); p.dv = static_cast<unsigned short*>(d->dv);
+    p.H = d->H; p.nq = d->nq; p.nk = d->nk;
+    p.q_ld = d->q_ld; p.k_ld = d->k_ld; p.v_ld = d->v_ld; p.do_ld = d->do_ld; p.qt_ld = d->qt_ld; p.kt_ld = d->kt_ld; p.dot_ld = d->dot_ld;
+    p.dq_ld = d->dq_ld; p.dk_ld = d->dk_ld; p.dv_ld = d->dv_ld;
+    p.q_bs = d->q_bs; p.k_bs = d->k_bs; p.v_bs = d->v_bs; p.do_bs = d->do_bs; p.qt_bs = d->qt_bs; p.kt_bs = d->kt_bs; p.dot_bs = d->dot_bs;
+    p.dq_bs = d->dq_bs; p.dk_bs = d->dk_bs; p.dv_bs = d->dv_bs;
+    p.scale = d->scale; p.scale_log2e = d->scale * LOG2E;
+    p.bias = d->bias; p.bias_ld = d->bias_ld; p.flags = d->flags; p.flags_ld = d->flags_ld;
+    p.lse = d->lse; p.delta = d->delta;
+    hipStream_t st = as_stream(stream);
+    const dim3 block(256), gq(cdiv(d->nq, 128), d->H, d->B), gk(cdiv(d->nk, 128), d->H, d->B);
+    PF_DISPATCH_16(d->dtype, "pf_attention_bwd",
+        if (d->D == 64) {
+            hipLaunchKernelGGL((k_attn_bwd_dq<T, 64>), gq, block, 0, st, p);
+            hipLaunchKernelGGL((k_attn_bwd_dkv<T, 64>), gk, block, 0, st, p);
+        } else {
+            hipLaunchKernelGGL((k_attn_bwd_dq<T, 32>), gq, block, 0, st, p);
+            hipLaunchKernelGGL((k_attn_bwd_dkv<T, 32>), gk, block, 0, st, p);
+        });
+    PF_CHECK_LAUNCH("pf_attention_bwd");
+    return PF_OK;
+}
+
+extern "C" int pf_layernorm_bwd_parts(long rows) {
+    return static_cast<int>(std::max(1L, std::min<long>(LN_BWD_MAX_PARTS, cdiv(rows, 4))));
+}
+
+extern "C" pf_status pf_layernorm_bwd(const void* x, const float* pe, long pe_rows, int dtype, long rows, int C,
+                                      const float* gamma, float eps, const float* dy, const float* dres, float* dx,
+                                      float* partials, void* stream) {
+    PF_REQUIRE(x && gamma && dy && dx && partials && rows > 0, "pf_layernorm_bwd: bad arguments");
+    PF_REQUIRE(C > 0 && C % 8 == 0 && C <= 2048, "pf_layernorm_bwd: C=%d must be a multiple of 8, at most 2048", C);
+    PF_REQUIRE(!pe || pe_rows > 0, "pf_layernorm_bwd: pe_rows must be positive");
+    PF_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && (!pe || aligned16(pe)) && (!dres || aligned16(dres)),
+               "pf_layernorm_bwd: pointers must be 16-byte aligned");
+    const int parts = pf_layernorm_bwd_parts(rows);
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(parts), block(256);
+    if (dtype == PF_F32) hipLaunchKernelGGL(k_layernorm_bwd<float>, grid, block, 0, st, x, pe, pe_rows, rows, C, gamma, eps, dy, dres, dx, partials, parts);
+    else if (dtype == PF_F16) hipLaunchKernelGGL(k_layernorm_bwd<F16>, grid, block, 0, st, x, pe, pe_rows, rows, C, gamma, eps, dy, dres, dx, partials, parts);
+    else if (dtype == PF_BF16) hipLaunchKernelGGL(k_layernorm_bwd<Bf16>, grid, block, 0, st, x, pe, pe_rows, rows, C, gamma, eps, dy, dres, dx, partials, parts);
+    else PF_REQUIRE(false, "pf_layernorm_bwd: unsupported dtype %d", dtype);
+    PF_CHECK_LAUNCH("pf_layernorm_bwd");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_geglu_bwd(const void* u, const void* dg, int dtype, long rows, int inner, void* du, void* stream) {
+    PF_REQUIRE(u && dg && du && rows > 0 && inner > 0 && inner % 8 == 0, "pf_geglu_bwd: bad arguments");
+    PF_REQUIRE(aligned16(u) && aligned16(dg) && aligned16(du), "pf_geglu_bwd: pointers must be 16-byte aligned");
+    const long total = rows * (inner / 8);
+    PF_DISPATCH_16(dtype, "pf_geglu_bwd",
+        hipLaunchKernelGGL(k_geglu_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), static_cast<const unsigned short*>(u),
+                           static_cast<const unsigned short*>(dg), total, inner, static_cast<unsigned short*>(du)));
+    PF_CHECK_LAUNCH("pf_geglu_bwd");
+    return PF_OK;
+}
+
+static int colsum_slabs(long rows) { return static_cast<int>(std::max(1L, std::min<long>(COLSUM_SLABS, cdiv(rows, 64)))); }
+
+extern "C" size_t pf_colsum_workspace_size(long rows, int N) {
+    if (rows <= 0 || N <= 0) return 0;
+    return static_cast<size_t>(colsum_slabs(rows)) * N * sizeof(float);
+}
+
+extern "C" pf_status pf_colsum(const void* x, int dtype, long rows, int N, long ld, float* out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    PF_REQUIRE(x && out && workspace && rows > 0 && N > 0 && ld >= N, "pf_colsum: bad arguments");
+    PF_REQUIRE(workspace_bytes >= pf_colsum_workspace_size(rows, N), "pf_colsum: workspace too small (%zu < %zu bytes)", workspace_bytes,
+               pf_colsum_workspace_size(rows, N));
+    const int slabs = colsum_slabs(rows);
+    const dim3 grid(cdiv(N, 64), slabs), block(256);
+    hipStream_t st = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    if (dtype == PF_F32) hipLaunchKernelGGL(k_colsum_partial<AnyF32>, grid, block, 0, st, x, rows, N, ld, slabs, part);
+    else if (dtype == PF_F16) hipLaunchKernelGGL(k_colsum_partial<AnyF16>, grid, block, 0, st, x, rows, N, ld, slabs, part);
+    else if (dtype == PF_BF16) hipLaunchKernelGGL(k_colsum_partial<AnyBf16>, grid, block, 0, st, x, rows, N, ld, slabs, part);
+    else PF_REQUIRE(false, "pf_colsum: unsupported dtype %d", dtype);
+    hipLaunchKernelGGL(k_colsum_final, dim3(cdiv(N, 256)), dim3(256), 0, st, part, slabs, N, out);
+    PF_CHECK_LAUNCH("pf_colsum");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_amax_f32(const float* x, long n, float* state, int reset, void* stream) {
+    PF_REQUIRE(x && state && n > 0, "pf_amax_f32: bad arguments");
+    hipStream_t st = as_stream(stream);
+    if (reset && hipMemsetAsync(state, 0, sizeof(float), st) != hipSuccess) {
+        pf::set_error("pf_amax_f32: clearing the state failed");
+        return PF_ERR_LAUNCH;
+    }
+    const long blocks = std::min<long>(1024, cdiv(n, 256));
+    hipLaunchKernelGGL(k_amax, dim3(blocks), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(state));
+    PF_CHECK_LAUNCH("pf_amax_f32");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_pow2_scale(float* state, void* stream) {
+    PF_REQUIRE(state, "pf_pow2_scale: null state");
+    hipLaunchKernelGGL(k_pow2_scale, dim3(1), dim3(1), 0, as_stream(stream), state);
+    PF_CHECK_LAUNCH("pf_pow2_scale");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_scale_f32(const float* x, long n, const float* state, int index, int out_dtype, void* y, void* stream) {
+    PF_REQUIRE(x && state && y && n > 0 && index >= 0 && index < 4, "pf_scale_f32: bad arguments");
+    const dim3 grid(cdiv(n, 256)), block(256);
+    hipStream_t st = as_stream(stream);
+    if (out_dtype == PF_F32) hipLaunchKernelGGL(k_scale_f32<AnyF32>, grid, block, 0, st, x, n, state + index, y);
+    else if (out_dtype == PF_F16) hipLaunchKernelGGL(k_scale_f32<AnyF16>, grid, block, 0, st, x, n, state + index, y);
+    else if (out_dtype == PF_BF16) hipLaunchKernelGGL(k_scale_f32<AnyBf16>, grid, block, 0, st, x, n, state + index, y);
+    else PF_REQUIRE(false, "pf_scale_f32: unsupported dtype %d", out_dtype);
+    PF_CHECK_LAUNCH("pf_scale_f32");
+    return PF_OK;
+}

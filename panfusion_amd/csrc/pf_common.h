@@ -78,6 +78,33 @@ template <typename T> __device__ __forceinline__ u16x8 pack8(const float (&f)[8]
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
+// Element access by storage tag (fp32 / bf16 / fp16) for the kernels that take any of the three.
+template <typename S> __device__ __forceinline__ float ld_any(const void* p, long i);
+struct AnyF32 {}; struct AnyBf16 {}; struct AnyF16 {};
+template <> __device__ __forceinline__ float ld_any<AnyF32>(const void* p, long i) { return static_cast<const float*>(p)[i]; }
+template <> __device__ __forceinline__ float ld_any<AnyBf16>(const void* p, long i) { return to_f32<Bf16>(static_cast<const unsigned short*>(p)[i]); }
+template <> __device__ __forceinline__ float ld_any<AnyF16>(const void* p, long i) { return to_f32<F16>(static_cast<const unsigned short*>(p)[i]); }
+template <typename S> __device__ __forceinline__ void st_any(void* p, long i, float v);
+template <> __device__ __forceinline__ void st_any<AnyF32>(void* p, long i, float v) { static_cast<float*>(p)[i] = v; }
+template <> __device__ __forceinline__ void st_any<AnyBf16>(void* p, long i, float v) { static_cast<unsigned short*>(p)[i] = from_f32<Bf16>(v); }
+template <> __device__ __forceinline__ void st_any<AnyF16>(void* p, long i, float v) { static_cast<unsigned short*>(p)[i] = from_f32<F16>(v); }
+
+// v_mfma_f32_32x32x16 on 16-bit operands (attention forward / backward).  A[row][k]: lane l supplies row l & 31,
+// k = 8 (l >> 5) .. +7; B[k][col]: col l & 31, same k; C[row][col]: lane l holds col l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+template <typename T> struct Mfma32;
+template <> struct Mfma32<Bf16> {
+    typedef __attribute__((ext_vector_type(8))) __bf16 frag;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma32<F16> {
+    typedef __attribute__((ext_vector_type(8))) _Float16 frag;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
 // Dispatch a 16-bit dtype id to a tag type.
 #define PF_DISPATCH_16(dtype, name, ...)                                         \
     do {                                                                         \

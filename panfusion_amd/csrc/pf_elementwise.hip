@@ -359,15 +359,6 @@ __global__ void k_pad_rows(const E* __restrict__ x, long rows, int w, int wo, in
 }
 
 // ---- layout converters ------------------------------------------------------------------------
-template <typename S> __device__ __forceinline__ float ld_any(const void* p, long i);
-struct AnyF32 {}; struct AnyBf16 {}; struct AnyF16 {};
-template <> __device__ __forceinline__ float ld_any<AnyF32>(const void* p, long i) { return static_cast<const float*>(p)[i]; }
-template <> __device__ __forceinline__ float ld_any<AnyBf16>(const void* p, long i) { return to_f32<Bf16>(static_cast<const unsigned short*>(p)[i]); }
-template <> __device__ __forceinline__ float ld_any<AnyF16>(const void* p, long i) { return to_f32<F16>(static_cast<const unsigned short*>(p)[i]); }
-template <typename S> __device__ __forceinline__ void st_any(void* p, long i, float v);
-template <> __device__ __forceinline__ void st_any<AnyF32>(void* p, long i, float v) { static_cast<float*>(p)[i] = v; }
-template <> __device__ __forceinline__ void st_any<AnyBf16>(void* p, long i, float v) { static_cast<unsigned short*>(p)[i] = from_f32<Bf16>(v); }
-template <> __device__ __forceinline__ void st_any<AnyF16>(void* p, long i, float v) { static_cast<unsigned short*>(p)[i] = from_f32<F16>(v); }
 
 // y = a + b element-wise; a / y of type SA, b of type SB (fp32 stream + 16-bit ControlNet residual, ...)
 template <typename SA, typename SB>

@@ -53,7 +53,8 @@ class WarpAttn(nn.Module):
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.repack())
 
     def packed(self, device):
-        key = (device, self.compute_dtype, self.precision)
+        # (the parameters' version counters: an optimizer step between two training forwards re-packs)
+        key = (device, self.compute_dtype, self.precision, tuple(t._version for t in self.transformer.parameters()))
         if self._packed is None or self._packed.key != key:
             self._packed = engine.pack_epa(self, device, self.compute_dtype, self.precision == "mixed")
             self._packed.key = key
@@ -82,7 +83,7 @@ class WarpAttn(nn.Module):
         return engine.run_epa(e, tabs, xp, xe, m, shard=shard, equi_hw=(eh, ew), side=side, pers_hw=(ph, pw))
 
     @torch.no_grad()
-    def forward(self, pers_x, equi_x, cameras):
+    def forward_inference(self, pers_x, equi_x, cameras):
         b = equi_x.shape[0]
         m, groups = camera_groups(cameras, b)
         dt = engine.stream_dtype(self.compute_dtype, self.precision)
@@ -91,3 +92,49 @@ class WarpAttn(nn.Module):
         op, oe = self.forward_nhwc(xp, xe, groups, m)
         return (ops.nhwc_to_nchw(op, torch.float32).to(pers_x.dtype),
                 ops.nhwc_to_nchw(oe, torch.float32).to(equi_x.dtype))
+
+    def forward(self, pers_x, equi_x, cameras):
+        """Same call as the reference (modules.py:15).  Under autograd (training, PanFusion.py:64-98) the block is
+        differentiable in its two inputs and its own parameters: forward on the inference kernels, backward on the
+        HIP backward kernels with the block recomputed (the reference's CheckpointFunction, transformer.py:77-127)."""
+        from ... import training
+        params = training.train_params(self)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (pers_x, equi_x, *params)):
+            return training.WarpAttnFunction.apply(self, cameras, pers_x, equi_x, *params)
+        return self.forward_inference(pers_x, equi_x, cameras)
+
+    @torch.no_grad()
+    def backward_block(self, pers_x, equi_x, cameras, d_pers, d_equi):
+        """Gradients of forward() for output gradients d_pers / d_equi (NCHW, None = zero):
+        (d pers_x, d equi_x, [parameter gradients in training.train_params order])."""
+        from ... import training
+        b = equi_x.shape[0]
+        m, groups = camera_groups(cameras, b)
+        dev = pers_x.device
+        bm, Cc, ph, pw = pers_x.shape
+        _, _, eh, ew = equi_x.shape
+        tabs = self.tables_for(groups, ph, pw, eh, ew, dev)
+        sdt = engine.stream_dtype(self.compute_dtype, self.precision)
+        tok = lambda x, d: ops.nchw_to_nhwc(x.float(), d).view(-1, Cc)
+        zeros = lambda like: torch.zeros(like.shape, device=dev, dtype=torch.float32)
+        d_pers = zeros(pers_x) if d_pers is None else d_pers
+        d_equi = zeros(equi_x) if d_equi is None else d_equi
+        e = self.packed_train(dev)
+        rec = training.epa_recompute(e, tabs, tok(equi_x, sdt), tok(pers_x, sdt), b, m)
+        dx_e, dx_p, grads = training.epa_backward(e, tabs, rec, tok(d_equi, torch.float32), tok(d_pers, torch.float32), b, m)
+        dx_p = ops.nhwc_to_nchw(dx_p.view(bm, ph, pw, Cc), torch.float32).to(pers_x.dtype)
+        dx_e = ops.nhwc_to_nchw(dx_e.view(b, eh, ew, Cc), torch.float32).to(equi_x.dtype)
+        params = training.train_params(self)
+        return dx_p, dx_e, [g.view(p_.shape).to(p_.dtype) for g, p_ in zip(grads, params)]
+
+    def packed_train(self, device):
+        """16-bit weight copies for the backward GEMMs, rebuilt when a parameter changed (optimizer steps bump
+        the tensors' version counters)."""
+        from ... import training
+        key = (device, self.compute_dtype, tuple((t.data_ptr(), t._version) for t in training.train_params(self)))
+        hit = getattr(self, "_packed_train", None)
+        if hit is None or hit.key != key:
+            hit = training.pack_epa_train(self, device, self.compute_dtype)
+            hit.key = key
+            self._packed_train = hit
+        return hit

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import PF_BF16, PF_F16, PF_F32, AttnDesc, ConvDesc, check
+from ._lib import PF_BF16, PF_F16, PF_F32, AttnBwdDesc, AttnDesc, ConvDesc, check
 
 _DT = {torch.bfloat16: PF_BF16, torch.float16: PF_F16, torch.float32: PF_F32}
 
@@ -420,7 +420,8 @@ def conv_out(x, wgt, bias, cout, wrap=False, out=None):
 
 # ---------------------------------------------------------------------------- attention
 def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, k_bs, vt_bs, o_bs=None,
-              scale=None, bias=None, flags=None, out=None):
+              scale=None, bias=None, flags=None, out=None, lse=None):
+    """lse: optional fp32 [B, H, nq] output (log2-domain log-sum-exp of the rows) for attention_bwd."""
     o_ld = o_ld or H * D
     o_bs = o_bs if o_bs is not None else nq * o_ld
     if out is None:
@@ -433,7 +434,102 @@ def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, 
     d.scale = scale if scale is not None else D ** -0.5
     d.bias, d.bias_ld = _p(bias), (_ld(bias) if bias is not None else 0)
     d.flags, d.flags_ld = _p(flags), (_ld(flags) if flags is not None else 0)
+    d.lse = _p(lse)
     _traced("k_attention", 4.0 * B * H * nq * nk * D,
             lambda: check(_lib.lib().pf_attention(C.byref(d), _stream()), "pf_attention"),
             "B%d H%d D%d nq%d nk%d bias%d" % (B, H, D, nq, nk, bias is not None))
+    return out
+
+
+# ---------------------------------------------------------------------------- training (EPA block backward)
+def transpose_tokens(x, out=None):
+    """x [B, T, C] (contiguous, 16-bit or fp32) -> [B, C, T]: the token-contiguous operand layout of the products whose
+    reduction runs over tokens (attention backward, weight gradients)."""
+    B, T, Cc = x.shape
+    if out is None:
+        out = torch.empty(B, Cc, T, device=x.device, dtype=x.dtype)
+    check(_lib.lib().pf_nhwc_to_nchw(_p(x), dt(x), B, Cc, 1, T, dt(out), _p(out), _stream()), "pf_nhwc_to_nchw")
+    return out
+
+
+def attention_delta(out, dout, B, H, D, nq):
+    """rowsum(dout * out) per head: out / dout [B, nq, H*D] contiguous 16-bit -> fp32 [B, H, nq]."""
+    delta = torch.empty(B, H, nq, device=out.device, dtype=torch.float32)
+    check(_lib.lib().pf_attention_delta(_p(out), _p(dout), dt(out), B, H, D, nq, H * D, nq * H * D, _p(delta), _stream()),
+          "pf_attention_delta")
+    return delta
+
+
+def attention_bwd(q, k, v, dout, qt, kt, dot, lse, delta, dq, dk, dv, B, H, D, nq, nk, *, q_ld, k_ld, v_ld, do_ld,
+                  dq_ld, dk_ld, dv_ld, q_bs, k_bs, v_bs, do_bs, dq_bs, dk_bs, dv_bs, scale=None, bias=None, flags=None):
+    """Backward of attention(): row-major q / k / v / dout (column views allowed: leading dimension + batch stride),
+    transposed qt / kt / dot [B, H*D, tokens] (contiguous), lse / delta fp32 [B, H, nq]; writes dq, dk, dv."""
+    d = AttnBwdDesc()
+    d.q, d.k, d.v, d.dout = _p(q), _p(k), _p(v), _p(dout)
+    d.qt, d.kt, d.dot = _p(qt), _p(kt), _p(dot)
+    d.dq, d.dk, d.dv = _p(dq), _p(dk), _p(dv)
+    d.dtype, d.B, d.H, d.D, d.nq, d.nk = dt(q), B, H, D, nq, nk
+    d.q_ld, d.k_ld, d.v_ld, d.do_ld = q_ld, k_ld, v_ld, do_ld
+    d.qt_ld, d.kt_ld, d.dot_ld = qt.shape[-1], kt.shape[-1], dot.shape[-1]
+    d.dq_ld, d.dk_ld, d.dv_ld = dq_ld, dk_ld, dv_ld
+    d.q_bs, d.k_bs, d.v_bs, d.do_bs = q_bs, k_bs, v_bs, do_bs
+    d.qt_bs, d.kt_bs, d.dot_bs = qt.shape[-2] * qt.shape[-1], kt.shape[-2] * kt.shape[-1], dot.shape[-2] * dot.shape[-1]
+    d.dq_bs, d.dk_bs, d.dv_bs = dq_bs, dk_bs, dv_bs
+    d.scale = scale if scale is not None else D ** -0.5
+    d.bias, d.bias_ld = _p(bias), (_ld(bias) if bias is not None else 0)
+    d.flags, d.flags_ld = _p(flags), (_ld(flags) if flags is not None else 0)
+    d.lse, d.delta = _p(lse), _p(delta)
+    _traced("k_attention_bwd", 10.0 * B * H * nq * nk * D,
+            lambda: check(_lib.lib().pf_attention_bwd(C.byref(d), _stream()), "pf_attention_bwd"),
+            "B%d H%d D%d nq%d nk%d bias%d" % (B, H, D, nq, nk, bias is not None))
+
+
+def colsum(x, out=None):
+    """x [rows, N] (16-bit or fp32, rows may be strided) -> fp32 [N] column sums in a fixed order."""
+    rows, N = x.shape
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+    nbytes = _lib.lib().pf_colsum_workspace_size(rows, N)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    check(_lib.lib().pf_colsum(_p(x), dt(x), rows, N, _ld(x), _p(out), _p(ws), nbytes, _stream()), "pf_colsum")
+    return out
+
+
+def layernorm_bwd(x, gamma, dy, eps=1e-5, pe=None, dres=None, dx=None):
+    """Backward of layernorm(x + pe): x [rows, C] (16-bit or fp32), dy fp32 [rows, C] (gradient of the normalised,
+    affine output), dres optional fp32 gradient added to dx.  Returns (dx fp32, dgamma fp32 [C], dbeta fp32 [C])."""
+    rows, Cc = x.shape
+    if dx is None:
+        dx = torch.empty(rows, Cc, device=x.device, dtype=torch.float32)
+    parts = _lib.lib().pf_layernorm_bwd_parts(rows)
+    partials = torch.empty(2, parts, Cc, device=x.device, dtype=torch.float32)
+    check(_lib.lib().pf_layernorm_bwd(_p(x), _p(pe), 0 if pe is None else pe.shape[0], dt(x), rows, Cc, _p(gamma), eps,
+                                      _p(dy), _p(dres), _p(dx), _p(partials), _stream()), "pf_layernorm_bwd")
+    return dx, colsum(partials[0]), colsum(partials[1])
+
+
+def geglu_bwd(u, dg, out=None):
+    """u [rows, 2*inner] = [a | gate] (input of geglu), dg [rows, inner] -> du [rows, 2*inner]."""
+    rows, two_inner = u.shape
+    if out is None:
+        out = torch.empty_like(u)
+    check(_lib.lib().pf_geglu_bwd(_p(u), _p(dg), dt(u), rows, two_inner // 2, _p(out), _stream()), "pf_geglu_bwd")
+    return out
+
+
+def grad_scale_state(tensors):
+    """Device-side power-of-two normalisation of a set of fp32 gradients (no host synchronisation): returns the
+    4-float state tensor; state[1] = 2^-e with max|g| * 2^-e in [1, 2), state[2] = 2^e."""
+    state = torch.empty(4, device=tensors[0].device, dtype=torch.float32)
+    for i, t in enumerate(tensors):
+        check(_lib.lib().pf_amax_f32(_p(t), t.numel(), _p(state), int(i == 0), _stream()), "pf_amax_f32")
+    check(_lib.lib().pf_pow2_scale(_p(state), _stream()), "pf_pow2_scale")
+    return state
+
+
+def scale_by_state(x, state, index, out_dtype=torch.float32, out=None):
+    """y = x * state[index] (x fp32 contiguous); out may alias x when fp32."""
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    check(_lib.lib().pf_scale_f32(_p(x), x.numel(), _p(state), index, dt(out), _p(out), _stream()), "pf_scale_f32")
     return out

@@ -290,7 +290,7 @@ def conv_out(x, wgt, bias, cout, wrap=False, out=None):
 
 
 def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, k_bs, vt_bs, o_bs=None,
-              scale=None, bias=None, flags=None, out=None):
+              scale=None, bias=None, flags=None, out=None, lse=None):
     C = H * D
     qh = q.float().reshape(-1, q.shape[-1])[:B * nq, :C].reshape(B, nq, H, D).transpose(1, 2)
     kh = k.float().reshape(-1, k.shape[-1])[:B * nk, :C].reshape(B, nk, H, D).transpose(1, 2)
@@ -300,8 +300,82 @@ def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, 
         tiles = flags.bool().repeat_interleave(32, 0).repeat_interleave(32, 1)[:nq, :nk]
         assert not bool((bias[:nq, :nk].ne(0) & ~tiles).any()), "non-zero bias outside flagged tiles"
         s = s + bias[:nq, :nk]
+    if lse is not None:                               # log2-domain log-sum-exp of the rows
+        lse.copy_((torch.logsumexp(s, -1) * 1.4426950408889634).reshape(lse.shape))
     o = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, nq, C).to(q.dtype)
     if out is not None:
         out.copy_(o.reshape(out.shape))
         return out
     return o
+
+
+# ---------------------------------------------------------------------------- training (EPA block backward)
+def transpose_tokens(x, out=None):
+    return x.transpose(1, 2).contiguous()
+
+
+def attention_delta(out, dout, B, H, D, nq):
+    return (out.float() * dout.float()).reshape(B, nq, H, D).sum(-1).transpose(1, 2).contiguous()
+
+
+def attention_bwd(q, k, v, dout, qt, kt, dot, lse, delta, dq, dk, dv, B, H, D, nq, nk, *, scale=None, bias=None, flags=None,
+                  **strides):
+    heads = lambda t, n: t.float().reshape(B, n, H, D).transpose(1, 2)
+    qh, kh, vh, doh = heads(q, nq), heads(k, nk), heads(v, nk), heads(dout, nq)
+    # the transposed operands must be the transposes of the row-major ones (the kernel reads both)
+    for t, r, n in ((qt, q, nq), (kt, k, nk), (dot, dout, nq)):
+        assert torch.equal(t.reshape(B, H * D, n).transpose(1, 2), r.reshape(B, n, H * D))
+    scale = scale if scale is not None else D ** -0.5
+    s = qh @ kh.transpose(-1, -2) * scale
+    if bias is not None:
+        s = s + bias[:nq, :nk]
+    p = torch.exp2(s * 1.4426950408889634 - lse.reshape(B, H, nq, 1))
+    dvh = p.transpose(-1, -2) @ doh
+    ds = p * (doh @ vh.transpose(-1, -2) - delta.reshape(B, H, nq, 1))
+    back = lambda t, n: t.transpose(1, 2).reshape(B, n, H * D)
+    dq.copy_(back(ds @ kh * scale, nq).to(dq.dtype))
+    dk.copy_(back(ds.transpose(-1, -2) @ qh * scale, nk).to(dk.dtype))
+    dv.copy_(back(dvh, nk).to(dv.dtype))
+
+
+def colsum(x, out=None):
+    return x.float().sum(0)
+
+
+def layernorm_bwd(x, gamma, dy, eps=1e-5, pe=None, dres=None, dx=None):
+    v = x.float()
+    if pe is not None:
+        v = v + pe.repeat(x.shape[0] // pe.shape[0], 1)
+    mean = v.mean(-1, keepdim=True)
+    rstd = (v.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+    xh = (v - mean) * rstd
+    g = dy * gamma
+    r = rstd * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
+    if dres is not None:
+        r = r + dres
+    if dx is not None:
+        dx.copy_(r)
+        r = dx
+    return r, (dy * xh).sum(0), dy.sum(0)
+
+
+def geglu_bwd(u, dg, out=None):
+    a, g = u.float().chunk(2, -1)
+    cdf = 0.5 * (1 + torch.erf(g * 2 ** -0.5))
+    pdf = torch.exp(-0.5 * g * g) * 0.3989422804014327
+    d = dg.float()
+    return torch.cat([d * g * cdf, d * a * (cdf + g * pdf)], -1).to(u.dtype)
+
+
+def grad_scale_state(tensors):
+    amax = max(float(t.abs().max()) for t in tensors)
+    e = int(np.floor(np.log2(amax))) if np.isfinite(amax) and amax > 0 else 0
+    return torch.tensor([amax, 2.0 ** -e, 2.0 ** e, 0.0], dtype=torch.float32)
+
+
+def scale_by_state(x, state, index, out_dtype=torch.float32, out=None):
+    y = (x * state[index]).to(out.dtype if out is not None else out_dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y

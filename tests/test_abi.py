@@ -40,7 +40,7 @@ def test_struct_layouts_match_header(tmp_path):
     """The ctypes mirrors of pf_conv_desc / pf_attn_desc are pinned to the C header: a probe compiled by gcc
     against include/panfusion_hip.h prints sizeof and offsetof of every field; they must equal ctypes'."""
     import subprocess
-    structs = {"pf_conv_desc": _lib.ConvDesc, "pf_attn_desc": _lib.AttnDesc}
+    structs = {"pf_conv_desc": _lib.ConvDesc, "pf_attn_desc": _lib.AttnDesc, "pf_attn_bwd_desc": _lib.AttnBwdDesc}
     lines = []
     for cname, cls in structs.items():
         lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -137,6 +137,40 @@ def test_attention_and_norm_reject_bad_arguments():
     assert lib.pf_groupnorm_stats(0x10000, 60, None, 0, _lib.PF_F16, 1, 16, 32, 1e-5, 0x20000, 0x30000, 0x40000, 0x50000,
                                   0x60000, 1 << 20, None) == 1
     assert lib.pf_geglu(0x10000, _lib.PF_F16, 4, 12, 0x20000, None) == 1
+
+
+def test_backward_entry_points_reject_bad_arguments():
+    lib = _lib.lib()
+    d = _lib.AttnBwdDesc()
+    for i, f in enumerate(("q", "k", "v", "dout", "qt", "kt", "dot", "dq", "dk", "dv", "lse", "delta")):
+        setattr(d, f, 0x10000 * (i + 1))
+    d.dtype, d.B, d.H, d.D, d.nq, d.nk = _lib.PF_F16, 1, 2, 32, 64, 96
+    d.q_ld = d.k_ld = d.v_ld = d.do_ld = d.dq_ld = d.dk_ld = d.dv_ld = 64
+    d.qt_ld = d.dot_ld = 64
+    d.kt_ld = 96
+    d.scale = 32 ** -0.5
+    d.nq = 48                                                       # token counts: multiples of 32
+    assert lib.pf_attention_bwd(C.byref(d), None) == 1 and b"multiples of 32" in lib.pf_last_error_string()
+    d.nq, d.kt_ld = 64, 64                                          # K^T must cover nk tokens
+    assert lib.pf_attention_bwd(C.byref(d), None) == 1 and b"cover the token count" in lib.pf_last_error_string()
+    d.kt_ld, d.D = 96, 48
+    assert lib.pf_attention_bwd(C.byref(d), None) == 1 and b"head dim" in lib.pf_last_error_string()
+    d.D, d.bias = 32, 0x70000                                       # bias without flags
+    assert lib.pf_attention_bwd(C.byref(d), None) == 1 and b"bias and flags" in lib.pf_last_error_string()
+    d.bias, d.lse = None, None
+    assert lib.pf_attention_bwd(C.byref(d), None) == 1 and b"null pointer" in lib.pf_last_error_string()
+    assert lib.pf_attention_delta(0x10000, 0x20000, _lib.PF_F16, 1, 2, 32, 64, 60, 64 * 60, 0x30000, None) == 1
+    assert lib.pf_layernorm_bwd(0x10000, None, 0, _lib.PF_F32, 8, 4100, 0x20000, 1e-5, 0x30000, None, 0x40000, 0x50000, None) == 1
+    assert lib.pf_layernorm_bwd(0x10000, None, 0, _lib.PF_U8, 8, 64, 0x20000, 1e-5, 0x30000, None, 0x40000, 0x50000, None) == 1
+    assert lib.pf_layernorm_bwd_parts(10) == 3 and lib.pf_layernorm_bwd_parts(10 ** 7) == 512
+    assert lib.pf_geglu_bwd(0x10000, 0x20000, _lib.PF_F16, 4, 12, 0x30000, None) == 1
+    need = lib.pf_colsum_workspace_size(100000, 320)
+    assert need == 64 * 320 * 4
+    assert lib.pf_colsum(0x10000, _lib.PF_F16, 100000, 320, 320, 0x20000, 0x30000, need - 4, None) == 1
+    assert b"workspace too small" in lib.pf_last_error_string()
+    assert lib.pf_colsum(0x10000, _lib.PF_F16, 100000, 320, 300, 0x20000, 0x30000, need, None) == 1     # ld < N
+    assert lib.pf_scale_f32(0x10000, 16, 0x20000, 4, _lib.PF_F32, 0x30000, None) == 1                  # state index
+    assert lib.pf_pow2_scale(None, None) == 1
 
 
 def test_pf_hip_lib_selects_another_build(tmp_path):

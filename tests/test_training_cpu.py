@@ -1,0 +1,98 @@
+"""Host logic of the EPA training path (panfusion_amd/training.py: recompute + backward sequencing, which gradient lands
+in which slot, the power-of-two gradient normalisation, the autograd wiring of WarpAttn.forward) on the CPU with
+tests/fake_ops.py standing in for the HIP front end, against torch autograd through the oracle's EPA block (reference
+models/pano/modules.py:15-59 + models/modules/transformer.py:40-161).  fp32 throughout: agreement at round-off."""
+import importlib
+
+import pytest
+import torch
+
+import fake_ops
+from conftest import cam4, rel_l2
+from oracle import mvgen as MV
+
+MODS = ["panfusion_amd.engine", "panfusion_amd.training", "panfusion_amd.models.pano.modules"]
+
+
+@pytest.fixture
+def fake_backend(monkeypatch):
+    for name in MODS:
+        monkeypatch.setattr(importlib.import_module(name), "ops", fake_ops)
+
+
+def make_blocks(dim, seed=0):
+    from panfusion_amd.models.pano import WarpAttn
+    torch.manual_seed(seed)
+    ref = MV.EPABlock(dim)
+    with torch.no_grad():                      # zero-initialised output layers would make most gradients vanish
+        for p in ref.parameters():
+            p.copy_(torch.randn_like(p) * (0.3 if p.dim() == 1 else p.shape[-1] ** -0.5))
+        ref.transformer.norm1.weight.add_(1.0)
+        ref.transformer.norm2.weight.add_(1.0)
+    hip = WarpAttn(dim, compute_dtype=torch.float32, precision="fast")
+    hip.load_state_dict(ref.state_dict())
+    return ref, hip
+
+
+def run_case(ref, hip, b, dim, ph, eh, grad_scale=1.0, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    m = 4
+    cams = {k: torch.cat([v] * b) for k, v in cam4().items()}
+    xp = torch.randn(b * m, dim, ph, ph, generator=g)
+    xe = torch.randn(b, dim, eh, 2 * eh, generator=g)
+    wp, we = torch.randn(xp.shape, generator=g) * grad_scale, torch.randn(xe.shape, generator=g) * grad_scale
+    out = {}
+    for name, mod in (("ref", ref), ("hip", hip)):
+        a, c = xp.clone().requires_grad_(True), xe.clone().requires_grad_(True)
+        for p in mod.parameters():
+            p.grad = None
+        op, oe = mod(a, c, cams)
+        ((op * wp).sum() + (oe * we).sum()).backward()
+        out[name] = dict(op=op.detach(), oe=oe.detach(), dxp=a.grad, dxe=c.grad,
+                         **{k: p.grad for k, p in mod.named_parameters()})
+    return out
+
+
+def test_epa_backward_matches_autograd(fake_backend):
+    ref, hip = make_blocks(64)
+    out = run_case(ref, hip, 1, 64, 8, 8)
+    assert set(out["ref"]) == set(out["hip"]) and len(out["ref"]) == 4 + 13
+    for k, want in out["ref"].items():
+        assert want is not None and out["hip"][k] is not None, k
+        assert rel_l2(out["hip"][k], want) < 2e-5, (k, rel_l2(out["hip"][k], want))
+
+
+def test_epa_backward_batch_of_two_and_tiny_gradients(fake_backend):
+    """b = 2 (one attention launch over both samples: same cameras) and upstream gradients of 1e-7 (what an MSE over a
+    latent batch hands down): the device-side normalisation keeps the 16-bit operands in range and is undone exactly."""
+    ref, hip = make_blocks(64, seed=3)
+    out = run_case(ref, hip, 2, 64, 8, 8, grad_scale=1e-7)
+    for k, want in out["ref"].items():
+        assert rel_l2(out["hip"][k], want) < 2e-5, (k, rel_l2(out["hip"][k], want))
+    assert float(out["hip"]["dxp"].abs().max()) < 1e-4            # (the gradients really are tiny)
+
+
+def test_optimizer_step_repacks_forward_and_backward_weights(fake_backend):
+    ref, hip = make_blocks(64, seed=5)
+    opt_r, opt_h = torch.optim.SGD(ref.parameters(), lr=0.05), torch.optim.SGD(hip.parameters(), lr=0.05)
+    first = run_case(ref, hip, 1, 64, 8, 8)
+    opt_r.step()
+    opt_h.step()
+    second = run_case(ref, hip, 1, 64, 8, 8)
+    assert rel_l2(second["ref"]["op"], first["ref"]["op"]) > 1e-3       # the step changed the block
+    for k, want in second["ref"].items():
+        assert rel_l2(second["hip"][k], want) < 5e-5, (k, rel_l2(second["hip"][k], want))
+
+
+def test_inference_path_unchanged_without_grad(fake_backend):
+    ref, hip = make_blocks(64, seed=7)
+    cams = cam4()
+    xp, xe = torch.randn(4, 64, 8, 8), torch.randn(1, 64, 8, 16)
+    with torch.no_grad():
+        op, oe = hip(xp, xe, cams)
+        rp, re_ = ref(xp, xe, cams)
+    assert not op.requires_grad and rel_l2(op, rp) < 2e-5 and rel_l2(oe, re_) < 2e-5
+    for p in hip.parameters():
+        p.requires_grad_(False)
+    op, oe = hip(xp, xe, cams)                   # nothing requires grad: no autograd node either
+    assert op.grad_fn is None
