@@ -1,0 +1,178 @@
+"""Backward kernels of the EPA block on the GPU: each kernel against torch autograd of the same op in fp32, then the
+whole block (WarpAttn.forward under autograd) against autograd through the oracle's EPA block (reference
+models/pano/modules.py:15-59, models/modules/transformer.py:40-161) on the CPU.  Needs an MI355X: `-m gpu`.
+
+Tolerances: the forward bar of north_star (1e-3 rel-L2) is kept for the block's input gradients and parameter
+gradients in the fp16 mixed configuration; single kernels with 16-bit operands are held to a few roundings of their
+operand type."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import cam4, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+D16 = [torch.float16, torch.bfloat16]
+TOL = {torch.bfloat16: 8e-3, torch.float16: 1.2e-3}
+LOG2E = 1.4426950408889634
+
+
+def ops():
+    from panfusion_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def sparse_bias(nq, nk, seed):
+    """EPA-like bias: non-zero in a few 32x32 tiles only, with the tile flags."""
+    g = torch.Generator().manual_seed(seed)
+    flags = (torch.rand(nq // 32, nk // 32, generator=g) < 0.2).to(torch.uint8)
+    bias = torch.rand(nq, nk, generator=g) * flags.bool().repeat_interleave(32, 0).repeat_interleave(32, 1)
+    return bias.to(DEV).contiguous(), flags.to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("dtype", D16)
+@pytest.mark.parametrize("D,H,nq,nk,biased", [(32, 3, 128, 320, True), (32, 2, 96, 64, False), (64, 2, 160, 96, False),
+                                              (32, 10, 512, 1280, True)])
+def test_attention_lse_and_backward(dtype, D, H, nq, nk, biased):
+    o = ops()
+    B, Cc = 2, H * D
+    qkv_q = rnd(B, nq, 3 * Cc, seed=1).to(dtype)          # q taken from columns [0, C) of a (q | k | v) row
+    qkv_k = rnd(B, nk, 3 * Cc, seed=2).to(dtype)          # k, v from columns [C, 3C)
+    dout = rnd(B, nq, Cc, seed=3).to(dtype)
+    bias, flags = sparse_bias(nq, nk, 4) if biased else (None, None)
+    ld = 3 * Cc
+    q, k, v = qkv_q[:, :, :Cc], qkv_k[:, :, Cc:2 * Cc], qkv_k[:, :, 2 * Cc:]
+    qt_all, kt_all = o.transpose_tokens(qkv_q), o.transpose_tokens(qkv_k)
+    assert torch.equal(qt_all, qkv_q.transpose(1, 2))
+    lse = torch.empty(B, H, nq, device=DEV, dtype=torch.float32)
+    out = o.attention(q, k, kt_all[:, 2 * Cc:], B, H, D, nq, nk, q_ld=ld, k_ld=ld, vt_ld=nk, q_bs=nq * ld, k_bs=nk * ld,
+                      vt_bs=ld * nk, bias=bias, flags=flags, lse=lse)
+    # fp32 reference with autograd on the same 16-bit inputs
+    heads = lambda t, n: t.float().reshape(B, n, H, D).transpose(1, 2)
+    qr, kr, vr = (t.clone().float().requires_grad_(True) for t in (q, k, v))
+    s = heads(qr, nq) @ heads(kr, nk).transpose(-1, -2) * D ** -0.5
+    if biased:
+        s = s + bias
+    want = (s.softmax(-1) @ heads(vr, nk)).transpose(1, 2).reshape(B, nq, Cc)
+    want.backward(dout.float())
+    assert rel_l2(out.cpu(), want.detach().cpu()) < TOL[dtype]
+    assert float((lse - torch.logsumexp(s.detach(), -1) * LOG2E).abs().max()) < 2e-4
+
+    delta = o.attention_delta(out, dout, B, H, D, nq)
+    assert rel_l2(delta.cpu(), (out.float() * dout.float()).reshape(B, nq, H, D).sum(-1).transpose(1, 2).cpu()) < 1e-5
+    dqkv_q, dqkv_k = torch.zeros_like(qkv_q), torch.zeros_like(qkv_k)
+    o.attention_bwd(q, k, v, dout, qt_all[:, :Cc], kt_all[:, Cc:2 * Cc], o.transpose_tokens(dout), lse, delta,
+                    dqkv_q[:, :, :Cc], dqkv_k[:, :, Cc:2 * Cc], dqkv_k[:, :, 2 * Cc:], B, H, D, nq, nk,
+                    q_ld=ld, k_ld=ld, v_ld=ld, do_ld=Cc, dq_ld=ld, dk_ld=ld, dv_ld=ld,
+                    q_bs=nq * ld, k_bs=nk * ld, v_bs=nk * ld, do_bs=nq * Cc, dq_bs=nq * ld, dk_bs=nk * ld, dv_bs=nk * ld,
+                    bias=bias, flags=flags)
+    got = dict(dq=dqkv_q[:, :, :Cc], dk=dqkv_k[:, :, Cc:2 * Cc], dv=dqkv_k[:, :, 2 * Cc:])
+    for name, ref in (("dq", qr.grad), ("dk", kr.grad), ("dv", vr.grad)):
+        err = rel_l2(got[name].float().cpu(), ref.cpu())
+        assert err < 2.5 * TOL[dtype], (name, err)
+    # the slots the call does not own stay untouched
+    assert not dqkv_q[:, :, Cc:].any() and not dqkv_k[:, :, :Cc].any()
+
+
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,Cc", [(300, 320), (4099, 640), (64, 1280), (2000, 2048)])
+def test_layernorm_backward(xdtype, rows, Cc):
+    o = ops()
+    x = (rnd(rows, Cc, seed=1, scale=2.0) + 0.3).to(xdtype)
+    pe = rnd(100, Cc, seed=2) if rows % 100 == 0 else None
+    gamma, beta = rnd(Cc, seed=3) * 0.2 + 1, rnd(Cc, seed=4) * 0.1
+    dy, dres = rnd(rows, Cc, seed=5), rnd(rows, Cc, seed=6)
+    xr = x.float().clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    v = xr + (pe.repeat(rows // 100, 1) if pe is not None else 0)
+    F.layer_norm(v, (Cc,), gr, br, 1e-5).backward(dy)
+    dx, dg, db = o.layernorm_bwd(x, gamma, dy, 1e-5, pe=pe, dres=dres)
+    assert rel_l2(dx.cpu(), (xr.grad + dres).cpu()) < 5e-6
+    assert rel_l2(dg.cpu(), gr.grad.cpu()) < 5e-6 and rel_l2(db.cpu(), br.grad.cpu()) < 5e-6
+    dx2, _, _ = o.layernorm_bwd(x, gamma, dy, 1e-5, pe=pe)
+    assert rel_l2(dx2.cpu(), xr.grad.cpu()) < 5e-6
+    assert torch.equal(o.layernorm_bwd(x, gamma, dy, 1e-5, pe=pe, dres=dres)[1], dg)       # fixed summation order
+
+
+@pytest.mark.parametrize("dtype", D16)
+def test_geglu_backward_and_colsum(dtype):
+    o = ops()
+    rows, inner = 777, 1280
+    u, dg = rnd(rows, 2 * inner, seed=1, scale=1.5).to(dtype), rnd(rows, inner, seed=2).to(dtype)
+    ur = u.float().clone().requires_grad_(True)
+    a, g = ur.chunk(2, -1)
+    (a * F.gelu(g)).backward(dg.float())
+    du = o.geglu_bwd(u, dg)
+    assert du.dtype == dtype and rel_l2(du.float().cpu(), ur.grad.cpu()) < {torch.float16: 4e-4, torch.bfloat16: 3e-3}[dtype]
+    for x in (u, u.float(), u[:, 8:328]):                      # 16-bit, fp32, a column view (row stride > N)
+        s = o.colsum(x)
+        assert s.dtype == torch.float32 and rel_l2(s.cpu(), x.double().sum(0).float().cpu()) < 2e-6
+        assert torch.equal(s, o.colsum(x))
+    big = rnd(70001, 72, seed=3)
+    assert rel_l2(o.colsum(big).cpu(), big.double().sum(0).float().cpu()) < 2e-6
+
+
+def test_gradient_normalisation_state():
+    o = ops()
+    a, b = rnd(1000, seed=1) * 3e-6, rnd(5000, seed=2) * 1e-6
+    st = o.grad_scale_state([a, b]).cpu()
+    amax = max(float(a.abs().max()), float(b.abs().max()))
+    assert float(st[0]) == amax and float(st[1]) * float(st[2]) == 1.0
+    assert 1.0 <= amax * float(st[1]) < 2.0 and float(torch.tensor(float(st[1])).log2()) % 1 == 0
+    state = o.grad_scale_state([a, b])
+    y = o.scale_by_state(a, state, 1)
+    assert torch.equal(y, a * state[1])
+    h = o.scale_by_state(a, state, 1, out_dtype=torch.float16)
+    assert h.dtype == torch.float16 and torch.equal(h, (a * state[1]).half())
+    o.scale_by_state(y, state, 2, out=y)
+    assert torch.equal(y, a)                                       # power of two: exact round trip
+    z = torch.zeros(64, device=DEV)
+    assert o.grad_scale_state([z]).cpu().tolist()[1:3] == [1.0, 1.0]
+    z[3] = float("nan")
+    assert o.grad_scale_state([z]).cpu().tolist()[1:3] == [1.0, 1.0]
+
+
+def _blocks(dim, dtype, precision, seed=0):
+    from oracle import mvgen as MV
+    from panfusion_amd.models.pano import WarpAttn
+    torch.manual_seed(seed)
+    ref = MV.EPABlock(dim)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn_like(p) * (0.3 if p.dim() == 1 else p.shape[-1] ** -0.5))
+        ref.transformer.norm1.weight.add_(1.0)
+        ref.transformer.norm2.weight.add_(1.0)
+    hip = WarpAttn(dim, compute_dtype=dtype, precision=precision).to(DEV)
+    hip.load_state_dict(ref.state_dict())
+    return ref, hip
+
+
+@pytest.mark.parametrize("dtype,precision,tol", [(torch.float16, "mixed", 1e-3), (torch.bfloat16, "fast", 1.5e-2)])
+@pytest.mark.parametrize("b,dim,ph,eh,gscale", [(1, 320, 16, 16, 1e-6), (2, 128, 8, 16, 1.0)])
+def test_warpattn_training_step_vs_oracle_autograd(dtype, precision, tol, b, dim, ph, eh, gscale):
+    """Forward + backward of the block through WarpAttn.forward (autograd.Function) on the GPU against torch autograd of
+    the oracle block on the CPU: outputs, input gradients and all 13 parameter gradients."""
+    ref, hip = _blocks(dim, dtype, precision)
+    g = torch.Generator().manual_seed(11)
+    m = 4
+    cams = {k: torch.cat([v] * b) for k, v in cam4().items()}
+    xp, xe = torch.randn(b * m, dim, ph, ph, generator=g), torch.randn(b, dim, eh, 2 * eh, generator=g)
+    wp, we = torch.randn(xp.shape, generator=g) * gscale, torch.randn(xe.shape, generator=g) * gscale
+    res = {}
+    for name, mod, dev in (("ref", ref, "cpu"), ("hip", hip, DEV)):
+        a, c = xp.to(dev).requires_grad_(True), xe.to(dev).requires_grad_(True)
+        op, oe = mod(a, c, cams)
+        ((op * wp.to(dev)).sum() + (oe * we.to(dev)).sum()).backward()
+        res[name] = dict(op=op.detach(), oe=oe.detach(), dxp=a.grad, dxe=c.grad, **{k: p.grad for k, p in mod.named_parameters()})
+    worst = {}
+    for k, want in res["ref"].items():
+        worst[k] = rel_l2(res["hip"][k].float().cpu(), want)
+    print("\n" + "  ".join("%s %.2e" % (k.replace("transformer.", ""), v) for k, v in worst.items()))
+    assert max(worst.values()) < tol, worst
