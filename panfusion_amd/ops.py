@@ -463,17 +463,19 @@ def attention_delta(out, dout, B, H, D, nq):
 def attention_bwd(q, k, v, dout, qt, kt, dot, lse, delta, dq, dk, dv, B, H, D, nq, nk, *, q_ld, k_ld, v_ld, do_ld,
                   dq_ld, dk_ld, dv_ld, q_bs, k_bs, v_bs, do_bs, dq_bs, dk_bs, dv_bs, scale=None, bias=None, flags=None):
     """Backward of attention(): row-major q / k / v / dout (column views allowed: leading dimension + batch stride),
-    transposed qt / kt / dot [B, H*D, tokens] (contiguous), lse / delta fp32 [B, H, nq]; writes dq, dk, dv."""
+    transposed qt / kt / dot [B, H*D, tokens] (tokens contiguous; row slices of a wider transpose allowed),
+    lse / delta fp32 [B, H, nq]; writes dq, dk, dv."""
+    assert qt.dim() == 3 and kt.dim() == 3 and dot.dim() == 3 and qt.stride(-1) == kt.stride(-1) == dot.stride(-1) == 1
     d = AttnBwdDesc()
     d.q, d.k, d.v, d.dout = _p(q), _p(k), _p(v), _p(dout)
     d.qt, d.kt, d.dot = _p(qt), _p(kt), _p(dot)
     d.dq, d.dk, d.dv = _p(dq), _p(dk), _p(dv)
     d.dtype, d.B, d.H, d.D, d.nq, d.nk = dt(q), B, H, D, nq, nk
     d.q_ld, d.k_ld, d.v_ld, d.do_ld = q_ld, k_ld, v_ld, do_ld
-    d.qt_ld, d.kt_ld, d.dot_ld = qt.shape[-1], kt.shape[-1], dot.shape[-1]
+    d.qt_ld, d.kt_ld, d.dot_ld = qt.stride(-2), kt.stride(-2), dot.stride(-2)      # (row slices of a wider transpose)
     d.dq_ld, d.dk_ld, d.dv_ld = dq_ld, dk_ld, dv_ld
     d.q_bs, d.k_bs, d.v_bs, d.do_bs = q_bs, k_bs, v_bs, do_bs
-    d.qt_bs, d.kt_bs, d.dot_bs = qt.shape[-2] * qt.shape[-1], kt.shape[-2] * kt.shape[-1], dot.shape[-2] * dot.shape[-1]
+    d.qt_bs, d.kt_bs, d.dot_bs = qt.stride(0), kt.stride(0), dot.stride(0)
     d.dq_bs, d.dk_bs, d.dv_bs = dq_bs, dk_bs, dv_bs
     d.scale = scale if scale is not None else D ** -0.5
     d.bias, d.bias_ld = _p(bias), (_ld(bias) if bias is not None else 0)
