@@ -167,7 +167,7 @@ def test_warpattn_training_step_vs_oracle_autograd(dtype, precision, tol, b, dim
     wp, we = torch.randn(xp.shape, generator=g) * gscale, torch.randn(xe.shape, generator=g) * gscale
     res = {}
     for name, mod, dev in (("ref", ref, "cpu"), ("hip", hip, DEV)):
-        a, c = xp.to(dev).requires_grad_(True), xe.to(dev).requires_grad_(True)
+        a, c = xp.clone().to(dev).requires_grad_(True), xe.clone().to(dev).requires_grad_(True)
         op, oe = mod(a, c, cams)
         ((op * wp.to(dev)).sum() + (oe * we.to(dev)).sum()).backward()
         res[name] = dict(op=op.detach(), oe=oe.detach(), dxp=a.grad, dxe=c.grad, **{k: p.grad for k, p in mod.named_parameters()})
