@@ -163,6 +163,13 @@ def test_warpattn_training_step_vs_oracle_autograd(dtype, precision, tol, b, dim
     g = torch.Generator().manual_seed(11)
     m = 4
     cams = {k: torch.cat([v] * b) for k, v in cam4().items()}
+    if dim == 320:
+        # C = 320 has 80 PE frequencies up to 2^79 (SphericalPE, transformer.py:166-172): a coordinate that is 0 on one
+        # side and 5e-17 on the other (axis-aligned cameras: cos(90 deg) residues, decided by the BLAS summation order
+        # of the host library) flips its sin / cos completely.  Generic angles, as the icosahedron cameras of the real
+        # configurations have, keep the comparison about the kernels.
+        cams["theta"] = cams["theta"] + 7.3
+        cams["phi"] = cams["phi"] + 3.1
     xp, xe = torch.randn(b * m, dim, ph, ph, generator=g), torch.randn(b, dim, eh, 2 * eh, generator=g)
     wp, we = torch.randn(xp.shape, generator=g) * gscale, torch.randn(xe.shape, generator=g) * gscale
     res = {}
