@@ -96,3 +96,53 @@ def test_inference_path_unchanged_without_grad(fake_backend):
         p.requires_grad_(False)
     op, oe = hip(xp, xe, cams)                   # nothing requires grad: no autograd node either
     assert op.grad_fn is None
+
+
+# ------------------------------------------------------------------------------------ data-parallel training (gloo)
+def _ddp_worker(rank, world, port, out):
+    import os
+    import sys
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    for name in MODS:
+        importlib.import_module(name).ops = fake_ops
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, hip = make_blocks(64, seed=9)
+        ddp = torch.nn.parallel.DistributedDataParallel(hip)
+        g = torch.Generator().manual_seed(100 + rank)                      # every rank its own sample
+        xp, xe = torch.randn(4, 64, 8, 8, generator=g), torch.randn(1, 64, 8, 16, generator=g)
+        op, oe = ddp(xp, xe, cam4())
+        (op.square().mean() + oe.square().mean()).backward()
+        torch.save({k: p.grad for k, p in hip.named_parameters()}, os.path.join(out, "r%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_all_reduces_the_block_gradients(tmp_path):
+    """The reference trains with DDP (main.py:68, one sample per GPU): the block's parameter gradients come out of an
+    autograd.Function, so DDP's reducer hooks see them like any other -- two gloo ranks with different samples end with
+    the mean of the two single-process gradients (the RCCL all-reduce of the GPU run is the same code path)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(tmp_path / ("r%d.pt" % r)) for r in range(2)]
+    singles = []
+    for rank in range(2):                                # autograd through the oracle block, one process
+        ref, _ = make_blocks(64, seed=9)
+        g = torch.Generator().manual_seed(100 + rank)
+        xp, xe = torch.randn(4, 64, 8, 8, generator=g), torch.randn(1, 64, 8, 16, generator=g)
+        op, oe = ref(xp, xe, cam4())
+        (op.square().mean() + oe.square().mean()).backward()
+        singles.append({k: p.grad for k, p in ref.named_parameters()})
+    for k in singles[0]:
+        want = (singles[0][k] + singles[1][k]) / 2
+        assert torch.equal(got[0][k], got[1][k])
+        assert rel_l2(got[0][k], want) < 2e-5, (k, rel_l2(got[0][k], want))
