@@ -298,8 +298,8 @@ pf_status pf_attention_delta(const void* out, const void* dout, int dtype, int B
  *   dQ = scale * dS K,  dK = scale * dS^T Q.
  * All of q, k, v, dout are ROW-major ([B][n][ld], head h at column h*D); kt, qt, dot are the transposes of k, q, dout
  * ([B][H*D][*_ld], tokens contiguous) -- the A operands of the products whose reduction runs over tokens.
- * dq [B][nq][dq_ld], dk / dv [B][nk][dk_ld / dv_ld] in `dtype`.  nq and nk must be multiples of 32 (EPA token counts
- * are multiples of 64).  Two launches: queries-stationary (dq) and keys-stationary (dk, dv); no atomics, results do
+ * dq [B][nq][dq_ld], dk / dv [B][nk][dk_ld / dv_ld] in `dtype`.  Token counts that are not multiples of 32 take a
+ * guarded instantiation (the 4x4 level of a 256^2 view has 16 tokens); with a bias nk % 4 == 0.  Two launches: queries-stationary (dq) and keys-stationary (dk, dv); no atomics, results do
  * not depend on scheduling. */
 typedef struct {
     const void* q; const void* k; const void* v; const void* dout;
@@ -329,6 +329,27 @@ int pf_layernorm_bwd_parts(long rows);
 pf_status pf_layernorm_bwd(const void* x, const float* pe, long pe_rows, int dtype, long rows, int C,
                            const float* gamma, float eps, const float* dy, const float* dres, float* dx,
                            float* partials, void* stream);
+
+/* GroupNorm (+ SiLU) backward for the forward y = act(x * scale + shift) of pf_groupnorm_stats + pf_scale_shift_act:
+ * x = channel concat of x0 [n][hw][c0] and x1 [n][hw][c1] (16-bit or PF_F32), scale / shift fp32 [n][c0+c1] as the forward
+ * produced them, dy fp32 [n][hw][c0+c1], dres optional fp32 gradient of the same shape added to the result;
+ * dx0 [n][hw][c0], dx1 [n][hw][c1] fp32.  gamma / beta take no gradient here (frozen UNet).  act: 0 none, 1 SiLU. */
+size_t pf_groupnorm_bwd_workspace_size(int n_img, int hw, int groups);
+pf_status pf_groupnorm_bwd(const void* x0, int c0, const void* x1, int c1, int dtype, int n_img, int hw, int groups,
+                           float eps, const float* gamma, const float* scale, const float* shift, int act,
+                           const float* dy, const float* dres, float* dx0, float* dx1, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* Data movement of the backward pass (NHWC):
+ *   pf_zero_insert2   y [n][2h][2w][C] = x at the even positions, zero elsewhere (16-bit): the data gradient of a
+ *                     stride-2 convolution is the stride-1 convolution of this with the flipped kernel;
+ *   pf_sum2x2         y [n][h][w][C] = sums of the 2x2 blocks of x [n][2h][2w][C] (fp32): nearest x2 up-sampling backward;
+ *   pf_pad_width_bwd  dy [n][h][w+2pad][C] -> dx [n][h][w][C]: the margins fold back onto the columns they copy (fp32);
+ *   pf_crop_width_bwd dy [n][h][w-2crop][C] -> dx [n][h][w][C] with zero margins (fp32). */
+pf_status pf_zero_insert2(const void* x, int dtype, int n, int h, int w, int C, void* y, void* stream);
+pf_status pf_sum2x2(const float* x, int n, int h, int w, int C, float* y, void* stream);
+pf_status pf_pad_width_bwd(const float* dy, int n, int h, int w, int C, int pad, float* dx, void* stream);
+pf_status pf_crop_width_bwd(const float* dy, int n, int h, int w, int C, int crop, float* dx, void* stream);
 
 /* GEGLU backward: u [rows][2*inner] = [a | gate] (forward input of pf_geglu), dg [rows][inner] ->
  * du [rows][2*inner] = [dg * gelu(gate) | dg * a * gelu'(gate)]. */

@@ -47,7 +47,18 @@ __device__ __forceinline__ u16x8 load_t_frag(const unsigned short* row, int t0, 
     return u16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
 }
 
-template <typename T, int D>
+// the same with the tokens >= n_tok read as zero and nothing read past the row (ragged token counts)
+__device__ __forceinline__ u16x8 load_t_frag_guard(const unsigned short* row, int t0, int s2, int hi, int n_tok) {
+    u16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = t0 + 16 * s2 + 4 * hi + (j & 3) + 8 * (j >> 2);
+        v[j] = t < n_tok ? row[t] : static_cast<unsigned short>(0);
+    }
+    return v;
+}
+
+template <typename T, int D, bool TAIL>
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnBwdParams p) {
     constexpr int KS = D / 16, DB = D / 32;
     typedef typename Mfma32<T>::frag frag;
@@ -57,8 +68,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnBwdParams p) {
     if (q0 >= p.nq) return;
     const int h = blockIdx.y;
     const long b = blockIdx.z;
-    const unsigned short* qp = p.q + b * p.q_bs + static_cast<long>(q0 + ql) * p.q_ld + h * D;
-    const unsigned short* dop = p.dout + b * p.do_bs + static_cast<long>(q0 + ql) * p.do_ld + h * D;
+    const int qrow = TAIL ? min(q0 + ql, p.nq - 1) : q0 + ql;
+    const unsigned short* qp = p.q + b * p.q_bs + static_cast<long>(qrow) * p.q_ld + h * D;
+    const unsigned short* dop = p.dout + b * p.do_bs + static_cast<long>(qrow) * p.do_ld + h * D;
     const unsigned short* kp = p.k + b * p.k_bs + h * D;
     const unsigned short* vp = p.v + b * p.v_bs + h * D;
     const unsigned short* ktp = p.kt + b * p.kt_bs + static_cast<long>(h) * D * p.kt_ld;
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnBwdParams p) {
         qf[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(qp + 16 * s + 8 * hi));
         dof[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(dop + 16 * s + 8 * hi));
     }
-    const long stat = (b * p.H + h) * p.nq + q0 + ql;
+    const long stat = (b * p.H + h) * p.nq + qrow;
     const float lse = p.lse[stat], delta = p.delta[stat];
     const float c2 = p.scale_log2e;
 
@@ -80,17 +92,18 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnBwdParams p) {
         for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
     const uint8_t* flag_row = p.flags ? p.flags + static_cast<long>(q0 >> 5) * p.flags_ld : nullptr;
-    const float* bias_row = p.bias ? p.bias + static_cast<long>(q0 + ql) * p.bias_ld : nullptr;
-    const int nkt = p.nk / 32;
+    const float* bias_row = p.bias ? p.bias + static_cast<long>(qrow) * p.bias_ld : nullptr;
+    const int nkt = (p.nk + 31) / 32;
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 32;
+        const int krow = TAIL ? min(k0 + ql, p.nk - 1) : k0 + ql;
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const u16x8 kf = *reinterpret_cast<const u16x8*>(kp + static_cast<long>(k0 + ql) * p.k_ld + 16 * ks + 8 * hi);
-            const u16x8 vf = *reinterpret_cast<const u16x8*>(vp + static_cast<long>(k0 + ql) * p.v_ld + 16 * ks + 8 * hi);
+            const u16x8 kf = *reinterpret_cast<const u16x8*>(kp + static_cast<long>(krow) * p.k_ld + 16 * ks + 8 * hi);
+            const u16x8 vf = *reinterpret_cast<const u16x8*>(vp + static_cast<long>(krow) * p.v_ld + 16 * ks + 8 * hi);
             s = Mfma32<T>::run(__builtin_bit_cast(frag, kf), qf[ks], s);          // S^T  [key][query]
             dp = Mfma32<T>::run(__builtin_bit_cast(frag, vf), dof[ks], dp);       // dP^T [key][query]
         }
@@ -100,6 +113,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnBwdParams p) {
         if (flag_row && flag_row[kt]) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                if (TAIL && k0 + 8 * g + 4 * hi + 3 >= p.nk) continue;      // (nk % 4 == 0 with a bias: whole quads)
                 const float4 bv = *reinterpret_cast<const float4*>(bias_row + k0 + 8 * g + 4 * hi);
                 sv[4 * g + 0] += bv.x * LOG2E;
                 sv[4 * g + 1] += bv.y * LOG2E;
@@ -110,17 +124,20 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnBwdParams p) {
         u16x8 pb[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pr = exp2f(sv[r] - lse);
+            float pr = exp2f(sv[r] - lse);
+            if (TAIL && k0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.nk) pr = 0.f;
             pb[r >> 3][r & 7] = from_f32<T>(pr * (dp[r] - delta));
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
-                const u16x8 a = load_t_frag(ktp + static_cast<long>(d * 32 + ql) * p.kt_ld, k0, s2, hi);
+                const unsigned short* trow = ktp + static_cast<long>(d * 32 + ql) * p.kt_ld;
+                const u16x8 a = TAIL ? load_t_frag_guard(trow, k0, s2, hi, p.nk) : load_t_frag(trow, k0, s2, hi);
                 acc[d] = Mfma32<T>::run(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, pb[s2]), acc[d]);   // dQ^T += K^T dS^T
             }
     }
+    if (TAIL && q0 + ql >= p.nq) return;
     unsigned short* op = p.dq + b * p.dq_bs + static_cast<long>(q0 + ql) * p.dq_ld + h * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnBwdParams p) {
         }
 }
 
-template <typename T, int D>
+template <typename T, int D, bool TAIL>
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnBwdParams p) {
     constexpr int KS = D / 16, DB = D / 32;
     typedef typename Mfma32<T>::frag frag;
@@ -143,8 +160,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnBwdParams p) {
     if (k0 >= p.nk) return;
     const int h = blockIdx.y;
     const long b = blockIdx.z;
-    const unsigned short* kp = p.k + b * p.k_bs + static_cast<long>(k0 + kl) * p.k_ld + h * D;
-    const unsigned short* vp = p.v + b * p.v_bs + static_cast<long>(k0 + kl) * p.v_ld + h * D;
+    const int krow = TAIL ? min(k0 + kl, p.nk - 1) : k0 + kl;
+    const unsigned short* kp = p.k + b * p.k_bs + static_cast<long>(krow) * p.k_ld + h * D;
+    const unsigned short* vp = p.v + b * p.v_bs + static_cast<long>(krow) * p.v_ld + h * D;
     const unsigned short* qp = p.q + b * p.q_bs + h * D;
     const unsigned short* dop = p.dout + b * p.do_bs + h * D;
     const unsigned short* qtp = p.qt + b * p.qt_bs + static_cast<long>(h) * D * p.qt_ld;
@@ -167,16 +185,17 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnBwdParams p) {
         for (int r = 0; r < 16; ++r) { acc_k[d][r] = 0.f; acc_v[d][r] = 0.f; }
 
     const int kt = k0 >> 5;
-    const int nqt = p.nq / 32;
+    const int nqt = (p.nq + 31) / 32;
     for (int qt = 0; qt < nqt; ++qt) {
         const int q0 = qt * 32;
+        const int qrow = TAIL ? min(q0 + kl, p.nq - 1) : q0 + kl;
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const u16x8 qf = *reinterpret_cast<const u16x8*>(qp + static_cast<long>(q0 + kl) * p.q_ld + 16 * ks + 8 * hi);
-            const u16x8 df = *reinterpret_cast<const u16x8*>(dop + static_cast<long>(q0 + kl) * p.do_ld + 16 * ks + 8 * hi);
+            const u16x8 qf = *reinterpret_cast<const u16x8*>(qp + static_cast<long>(qrow) * p.q_ld + 16 * ks + 8 * hi);
+            const u16x8 df = *reinterpret_cast<const u16x8*>(dop + static_cast<long>(qrow) * p.do_ld + 16 * ks + 8 * hi);
             s = Mfma32<T>::run(__builtin_bit_cast(frag, qf), kf[ks], s);           // S  [query][key]
             dp = Mfma32<T>::run(__builtin_bit_cast(frag, df), vf[ks], dp);         // dP [query][key]
         }
@@ -188,19 +207,31 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnBwdParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                sv[r] += p.bias[static_cast<long>(qi) * p.bias_ld + k0 + kl] * LOG2E;
+                if (!TAIL || (qi < p.nq && k0 + kl < p.nk)) sv[r] += p.bias[static_cast<long>(qi) * p.bias_ld + k0 + kl] * LOG2E;
             }
         }
         u16x8 pp[2], pd[2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 l4 = *reinterpret_cast<const float4*>(lsep + q0 + 8 * g + 4 * hi);
-            const float4 d4 = *reinterpret_cast<const float4*>(delp + q0 + 8 * g + 4 * hi);
-            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+            float lv[4], dv[4];
+            if (TAIL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qi = min(q0 + 8 * g + 4 * hi + e, p.nq - 1);
+                    lv[e] = lsep[qi];
+                    dv[e] = delp[qi];
+                }
+            } else {
+                const float4 l4 = *reinterpret_cast<const float4*>(lsep + q0 + 8 * g + 4 * hi);
+                const float4 d4 = *reinterpret_cast<const float4*>(delp + q0 + 8 * g + 4 * hi);
+                lv[0] = l4.x; lv[1] = l4.y; lv[2] = l4.z; lv[3] = l4.w;
+                dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * g + e;
-                const float pr = exp2f(sv[r] - lv[e]);
+                float pr = exp2f(sv[r] - lv[e]);
+                if (TAIL && q0 + 8 * g + 4 * hi + e >= p.nq) pr = 0.f;
                 pp[r >> 3][r & 7] = from_f32<T>(pr);
                 pd[r >> 3][r & 7] = from_f32<T>(pr * (dp[r] - dv[e]));
             }
@@ -209,12 +240,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnBwdParams p) {
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
-                const u16x8 a_do = load_t_frag(dotp + static_cast<long>(d * 32 + kl) * p.dot_ld, q0, s2, hi);
-                const u16x8 a_q = load_t_frag(qtp + static_cast<long>(d * 32 + kl) * p.qt_ld, q0, s2, hi);
+                const unsigned short* rdo = dotp + static_cast<long>(d * 32 + kl) * p.dot_ld;
+                const unsigned short* rq = qtp + static_cast<long>(d * 32 + kl) * p.qt_ld;
+                const u16x8 a_do = TAIL ? load_t_frag_guard(rdo, q0, s2, hi, p.nq) : load_t_frag(rdo, q0, s2, hi);
+                const u16x8 a_q = TAIL ? load_t_frag_guard(rq, q0, s2, hi, p.nq) : load_t_frag(rq, q0, s2, hi);
                 acc_v[d] = Mfma32<T>::run(__builtin_bit_cast(frag, a_do), __builtin_bit_cast(frag, pp[s2]), acc_v[d]);   // dV^T += dO^T P
                 acc_k[d] = Mfma32<T>::run(__builtin_bit_cast(frag, a_q), __builtin_bit_cast(frag, pd[s2]), acc_k[d]);    // dK^T += Q^T dS
             }
     }
+    if (TAIL && k0 + kl >= p.nk) return;
     unsigned short* okp = p.dk + b * p.dk_bs + static_cast<long>(k0 + kl) * p.dk_ld + h * D;
     unsigned short* ovp = p.dv + b * p.dv_bs + static_cast<long>(k0 + kl) * p.dv_ld + h * D;
 #pragma unroll
@@ -366,6 +400,189 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const void* __restrict__ 
     }
 }
 
+// ---- GroupNorm (+ SiLU) backward ----------------------------------------------------------------------------------
+// y = act(x * scale + shift) with scale = gamma * rstd, shift = beta - mean * scale per (image, channel) as the forward
+// left them (pf_groupnorm_stats); x = channel concat of two sources.  Given dy:
+//   dz = dy * act'(z),  g = dz * gamma,  dx = rstd * (g - mean_grp(g) - xhat * mean_grp(g * xhat))   (+ dres)
+// Three launches: per-(image, pixel chunk) partial sums of (x, x^2, g, g x) per group; one block per image folds them
+// into (mean, rstd, mean g, mean g xhat); the apply pass.  gamma / beta take no gradient (the UNet is frozen: only the
+// LoRA matrices and the EPA blocks train, PanoGenerator.py:141-160).
+__device__ __forceinline__ float act_grad(float z, int act) {
+    if (!act) return 1.0f;
+    const float sg = 1.0f / (1.0f + __expf(-z));
+    return sg * (1.0f + z * (1.0f - sg));
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void k_gn_bwd_partial(const void* __restrict__ x0, int c0, const void* __restrict__ x1, int c1,
+                                                        int hw, int groups, int pix_per_chunk, const float* __restrict__ gamma,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                        const float* __restrict__ dy, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [4][pix_par][C]
+    const int C = c0 + c1, OCT = C / 8, cpg = C / groups;
+    const int OCTB = OCT < 256 ? OCT : 256;
+    const int pix_par = 256 / OCTB;
+    const int img = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * pix_per_chunk, p1 = min(p0 + pix_per_chunk, hw);
+    const int t = threadIdx.x, slot = t / OCTB, olane = t % OCTB;
+    for (int ob = 0; ob < OCT; ob += OCTB) {
+        const int oct = ob + olane;
+        if (slot < pix_par && oct < OCT) {
+            const int c = oct * 8;
+            float a[4][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[q][j] = 0.f;
+            float sc[8], sh[8], gm[8];
+            load8_any<float>(scale, static_cast<long>(img) * C + c, sc);
+            load8_any<float>(shift, static_cast<long>(img) * C + c, sh);
+            load8_any<float>(gamma, c, gm);
+            for (int pp = p0 + slot; pp < p1; pp += pix_par) {
+                const long pix = static_cast<long>(img) * hw + pp;
+                float v[8], d[8];
+                if (c < c0) load8_any<TI>(x0, pix * c0 + c, v); else load8_any<TI>(x1, pix * c1 + (c - c0), v);
+                load8_any<float>(dy, pix * C + c, d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g = d[j] * act_grad(v[j] * sc[j] + sh[j], act) * gm[j];
+                    a[0][j] += v[j];
+                    a[1][j] += v[j] * v[j];
+                    a[2][j] += g;
+                    a[3][j] += g * v[j];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sm[(q * pix_par + slot) * C + c + j] = a[q][j];
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < groups * 4; i += 256) {
+        const int g = i >> 2, q = i & 3;
+        float s = 0.f;
+        for (int sl = 0; sl < pix_par; ++sl)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) s += sm[(q * pix_par + sl) * C + c];
+        partial[((static_cast<long>(img) * gridDim.x + chunk) * groups + g) * 4 + q] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gn_bwd_finalize(const float* __restrict__ partial, int nchunks, int groups, int C, int hw,
+                                                         float eps, float* __restrict__ stats) {
+    const int img = blockIdx.x;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < nchunks; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + ((static_cast<long>(img) * nchunks + k) * groups + g) * 4);
+            a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+        }
+        const double cnt = static_cast<double>(hw) * (C / groups);
+        const double mean = a[0] / cnt;
+        double var = a[1] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + static_cast<double>(eps));
+        float* o = stats + (static_cast<long>(img) * groups + g) * 4;
+        o[0] = static_cast<float>(mean);
+        o[1] = static_cast<float>(rstd);
+        o[2] = static_cast<float>(a[2] / cnt);                               // mean g
+        o[3] = static_cast<float>(rstd * (a[3] - mean * a[2]) / cnt);        // mean g * xhat
+    }
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(const void* __restrict__ x0, int c0, const void* __restrict__ x1, int c1, int hw,
+                                                      int groups, const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int act, const float* __restrict__ dy,
+                                                      const float* __restrict__ dres, const float* __restrict__ stats,
+                                                      float* __restrict__ dx0, float* __restrict__ dx1) {
+    const unsigned C = c0 + c1, OCT = C / 8, per_img = static_cast<unsigned>(hw) * OCT, cpg = C / groups;
+    const unsigned img = blockIdx.y;
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= per_img) return;
+    const unsigned p = j / OCT, c = (j - p * OCT) * 8;
+    const long pix = static_cast<long>(img) * hw + p;
+    float v[8], d[8], sc[8], sh[8], gm[8], o[8];
+    if (c < static_cast<unsigned>(c0)) load8_any<TI>(x0, pix * c0 + c, v); else load8_any<TI>(x1, pix * c1 + (c - c0), v);
+    load8_any<float>(dy, pix * C + c, d);
+    load8_any<float>(scale, static_cast<long>(img) * C + c, sc);
+    load8_any<float>(shift, static_cast<long>(img) * C + c, sh);
+    load8_any<float>(gamma, c, gm);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float* st = stats + (static_cast<long>(img) * groups + (c + e) / cpg) * 4;      // (groups of >= 1 channel)
+        const float g = d[e] * act_grad(v[e] * sc[e] + sh[e], act) * gm[e];
+        const float xh = (v[e] - st[0]) * st[1];
+        o[e] = st[1] * (g - st[2] - xh * st[3]);
+    }
+    if (dres) {
+        float r[8];
+        load8_any<float>(dres, pix * C + c, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r[e];
+    }
+    float* dst = (c < static_cast<unsigned>(c0)) ? dx0 + pix * c0 + c : dx1 + pix * c1 + (c - c0);
+    reinterpret_cast<float4*>(dst)[0] = float4{o[0], o[1], o[2], o[3]};
+    reinterpret_cast<float4*>(dst)[1] = float4{o[4], o[5], o[6], o[7]};
+}
+
+// ---- data movement of the backward pass ---------------------------------------------------------------------------
+// zero insertion (data gradient of a stride-2 convolution = stride-1 convolution of the zero-stuffed gradient with the
+// flipped kernel): y[n][2i][2j] = x[n][i][j], zero elsewhere; 16-bit octets.
+__global__ void k_zero_insert2(const u16x8* __restrict__ x, int n, int h, int w, int OCT, u16x8* __restrict__ y) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    const long total = static_cast<long>(n) * 4 * h * w * OCT;
+    if (i >= total) return;
+    const int o = i % OCT;
+    const long pix = i / OCT;
+    const int xx = pix % (2 * w), yy = (pix / (2 * w)) % (2 * h);
+    const long img = pix / (4L * h * w);
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!(xx & 1) && !(yy & 1)) v = x[((img * h + (yy >> 1)) * w + (xx >> 1)) * OCT + o];
+    y[i] = v;
+}
+
+// nearest x2 up-sampling backward: y[n][i][j] = sum of the 2x2 block of x [n][2h][2w][C], fp32 quads.
+__global__ void k_sum2x2(const float4* __restrict__ x, int n, int h, int w, int Q, float4* __restrict__ y) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    const long total = static_cast<long>(n) * h * w * Q;
+    if (i >= total) return;
+    const int q = i % Q;
+    const long pix = i / Q;
+    const int xx = pix % w, yy = (pix / w) % h;
+    const long img = pix / (static_cast<long>(h) * w);
+    const float4* b = x + ((img * 2 * h + 2 * yy) * 2 * w + 2 * xx) * Q + q;
+    const float4 a0 = b[0], a1 = b[Q], a2 = b[2L * w * Q], a3 = b[2L * w * Q + Q];
+    y[i] = float4{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w)};
+}
+
+// backward of the circular width pad (utils/pano.py:74-99): dx[.., j] = dy[.., j + pad] + the wrapped copies
+// (left margin column i is a copy of column w - pad + i, right margin column w + pad + i a copy of column i);
+// backward of the crop: dy placed at column offset `crop`, zero margins.  fp32 quads of the channel axis.
+__global__ void k_pad_width_bwd(const float4* __restrict__ dy, long rows, int w, int pad, int Q, float4* __restrict__ dx) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= rows * w * Q) return;
+    const int q = i % Q;
+    const int j = (i / Q) % w;
+    const long r = i / (static_cast<long>(Q) * w);
+    const float4* row = dy + r * (w + 2 * pad) * Q + q;
+    float4 a = row[static_cast<long>(j + pad) * Q];
+    if (j >= w - pad) { const float4 b = row[static_cast<long>(j - (w - pad)) * Q]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    if (j < pad) { const float4 b = row[static_cast<long>(w + pad + j) * Q]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    dx[i] = a;
+}
+
+__global__ void k_crop_width_bwd(const float4* __restrict__ dy, long rows, int w, int crop, int Q, float4* __restrict__ dx) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= rows * w * Q) return;
+    const int q = i % Q;
+    const int j = (i / Q) % w;
+    const long r = i / (static_cast<long>(Q) * w);
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    if (j >= crop && j < w - crop) a = dy[(r * (w - 2 * crop) + (j - crop)) * Q + q];
+    dx[i] = a;
+}
+
 // ---- GEGLU backward -----------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void k_geglu_bwd(const unsigned short* __restrict__ u, const unsigned short* __restrict__ dg, long total_oct,
@@ -472,8 +689,7 @@ extern "C" pf_status pf_attention_bwd(const pf_attn_bwd_desc* d, void* stream) {
     PF_REQUIRE(d->q && d->k && d->v && d->dout && d->qt && d->kt && d->dot && d->dq && d->dk && d->dv && d->lse && d->delta,
                "pf_attention_bwd: null pointer");
     PF_REQUIRE(d->D == 32 || d->D == 64, "pf_attention_bwd: head dim %d unsupported (32 or 64)", d->D);
-    PF_REQUIRE(d->B > 0 && d->H > 0 && d->nq > 0 && d->nk > 0 && d->nq % 32 == 0 && d->nk % 32 == 0,
-               "pf_attention_bwd: nq=%d and nk=%d must be positive multiples of 32", d->nq, d->nk);
+    PF_REQUIRE(d->B > 0 && d->H > 0 && d->nq > 0 && d->nk > 0, "pf_attention_bwd: bad sizes");
     PF_REQUIRE(d->q_ld % 8 == 0 && d->k_ld % 8 == 0 && d->v_ld % 8 == 0 && d->do_ld % 8 == 0, "pf_attention_bwd: row-major leading dimensions must be multiples of 8");
     PF_REQUIRE(d->qt_ld % 4 == 0 && d->kt_ld % 4 == 0 && d->dot_ld % 4 == 0 && d->qt_ld >= d->nq && d->dot_ld >= d->nq && d->kt_ld >= d->nk,
                "pf_attention_bwd: transposed leading dimensions must be multiples of 4 and cover the token count");
@@ -485,8 +701,8 @@ extern "C" pf_status pf_attention_bwd(const pf_attn_bwd_desc* d, void* stream) {
                "pf_attention_bwd: pointers must be 16-byte aligned");
     PF_REQUIRE((d->bias == nullptr) == (d->flags == nullptr), "pf_attention_bwd: bias and flags come together");
     if (d->bias) {
-        PF_REQUIRE(d->bias_ld % 4 == 0 && d->bias_ld >= d->nk && aligned16(d->bias), "pf_attention_bwd: bias needs an aligned ld >= nk");
-        PF_REQUIRE(d->flags_ld >= d->nk / 32, "pf_attention_bwd: flags_ld too small");
+        PF_REQUIRE(d->nk % 4 == 0 && d->bias_ld % 4 == 0 && d->bias_ld >= d->nk && aligned16(d->bias), "pf_attention_bwd: bias needs nk %% 4 == 0 and an aligned ld >= nk");
+        PF_REQUIRE(d->flags_ld >= (d->nk + 31) / 32, "pf_attention_bwd: flags_ld too small");
     }
     AttnBwdParams p;
     auto u16 = [](const void* v) { return static_cast<const unsigned short*>(v); };
@@ -502,13 +718,14 @@ extern "C" pf_status pf_attention_bwd(const pf_attn_bwd_desc* d, void* stream) {
     p.lse = d->lse; p.delta = d->delta;
     hipStream_t st = as_stream(stream);
     const dim3 block(256), gq(cdiv(d->nq, 128), d->H, d->B), gk(cdiv(d->nk, 128), d->H, d->B);
+    const bool tail = d->nq % 32 != 0 || d->nk % 32 != 0;        // ragged token counts: guarded loads, masked tails
     PF_DISPATCH_16(d->dtype, "pf_attention_bwd",
         if (d->D == 64) {
-            hipLaunchKernelGGL((k_attn_bwd_dq<T, 64>), gq, block, 0, st, p);
-            hipLaunchKernelGGL((k_attn_bwd_dkv<T, 64>), gk, block, 0, st, p);
+            if (tail) { hipLaunchKernelGGL((k_attn_bwd_dq<T, 64, true>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv<T, 64, true>), gk, block, 0, st, p); }
+            else { hipLaunchKernelGGL((k_attn_bwd_dq<T, 64, false>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv<T, 64, false>), gk, block, 0, st, p); }
         } else {
-            hipLaunchKernelGGL((k_attn_bwd_dq<T, 32>), gq, block, 0, st, p);
-            hipLaunchKernelGGL((k_attn_bwd_dkv<T, 32>), gk, block, 0, st, p);
+            if (tail) { hipLaunchKernelGGL((k_attn_bwd_dq<T, 32, true>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv<T, 32, true>), gk, block, 0, st, p); }
+            else { hipLaunchKernelGGL((k_attn_bwd_dq<T, 32, false>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv<T, 32, false>), gk, block, 0, st, p); }
         });
     PF_CHECK_LAUNCH("pf_attention_bwd");
     return PF_OK;
@@ -602,5 +819,99 @@ extern "C" pf_status pf_scale_f32(const float* x, long n, const float* state, in
     else if (out_dtype == PF_BF16) hipLaunchKernelGGL(k_scale_f32<AnyBf16>, grid, block, 0, st, x, n, state + index, y);
     else PF_REQUIRE(false, "pf_scale_f32: unsupported dtype %d", out_dtype);
     PF_CHECK_LAUNCH("pf_scale_f32");
+    return PF_OK;
+}
+
+static int gn_bwd_chunks(int hw, int* pix_per_chunk) {
+    int ppc = 64;
+    while (ppc > 8 && cdiv(hw, ppc) < 16) ppc >>= 1;
+    *pix_per_chunk = ppc;
+    return static_cast<int>(cdiv(hw, ppc));
+}
+
+extern "C" size_t pf_groupnorm_bwd_workspace_size(int n_img, int hw, int groups) {
+    if (n_img <= 0 || hw <= 0 || groups <= 0) return 0;
+    int ppc;
+    const int chunks = gn_bwd_chunks(hw, &ppc);
+    return (static_cast<size_t>(n_img) * chunks * groups * 4 + static_cast<size_t>(n_img) * groups * 4) * sizeof(float);
+}
+
+extern "C" pf_status pf_groupnorm_bwd(const void* x0, int c0, const void* x1, int c1, int dtype, int n_img, int hw, int groups,
+                                      float eps, const float* gamma, const float* scale, const float* shift, int act,
+                                      const float* dy, const float* dres, float* dx0, float* dx1, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    PF_REQUIRE(x0 && gamma && scale && shift && dy && dx0 && workspace && n_img > 0 && hw > 0, "pf_groupnorm_bwd: bad arguments");
+    if (!x1) c1 = 0;
+    PF_REQUIRE(c1 == 0 || dx1, "pf_groupnorm_bwd: two sources need two gradient outputs");
+    const int C = c0 + c1;
+    PF_REQUIRE(c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0 && groups > 0 && C % groups == 0, "pf_groupnorm_bwd: channels (%d,%d) must be multiples of 8 and divide into %d groups", c0, c1, groups);
+    PF_REQUIRE(n_img <= 65535, "pf_groupnorm_bwd: at most 65535 images per call");
+    PF_REQUIRE(act == 0 || act == 1, "pf_groupnorm_bwd: act must be 0 (none) or 1 (SiLU)");
+    PF_REQUIRE(workspace_bytes >= pf_groupnorm_bwd_workspace_size(n_img, hw, groups), "pf_groupnorm_bwd: workspace too small");
+    PF_REQUIRE(aligned16(x0) && (!x1 || aligned16(x1)) && aligned16(dy) && aligned16(dx0) && (!dx1 || aligned16(dx1)) && aligned16(gamma) &&
+               aligned16(scale) && aligned16(shift) && (!dres || aligned16(dres)) && aligned16(workspace), "pf_groupnorm_bwd: pointers must be 16-byte aligned");
+    int ppc;
+    const int chunks = gn_bwd_chunks(hw, &ppc);
+    float* partial = static_cast<float*>(workspace);
+    float* stats = partial + static_cast<size_t>(n_img) * chunks * groups * 4;
+    const int OCT = C / 8, OCTB = OCT < 256 ? OCT : 256, pix_par = 256 / OCTB;
+    const size_t smem = static_cast<size_t>(4) * pix_par * C * sizeof(float);
+    PF_REQUIRE(smem <= 64 * 1024, "pf_groupnorm_bwd: %d channels exceed the 64 KiB staging buffer", C);
+    hipStream_t st = as_stream(stream);
+    const dim3 g1(chunks, n_img), g3(cdiv(static_cast<long>(hw) * OCT, 256), n_img), block(256);
+#define PF_GNB(TI) do {                                                                                                     \
+        hipLaunchKernelGGL(k_gn_bwd_partial<TI>, g1, block, smem, st, x0, c0, x1, c1, hw, groups, ppc, gamma, scale, shift, act, dy, partial); \
+        hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(n_img), block, 0, st, partial, chunks, groups, C, hw, eps, stats);             \
+        hipLaunchKernelGGL(k_gn_bwd_apply<TI>, g3, block, 0, st, x0, c0, x1, c1, hw, groups, gamma, scale, shift, act, dy, dres, stats, dx0, dx1); \
+    } while (0)
+    if (dtype == PF_F32) PF_GNB(float);
+    else if (dtype == PF_F16) PF_GNB(F16);
+    else if (dtype == PF_BF16) PF_GNB(Bf16);
+    else PF_REQUIRE(false, "pf_groupnorm_bwd: unsupported dtype %d", dtype);
+#undef PF_GNB
+    PF_CHECK_LAUNCH("pf_groupnorm_bwd");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_zero_insert2(const void* x, int dtype, int n, int h, int w, int C, void* y, void* stream) {
+    PF_REQUIRE(x && y && x != y && n > 0 && h > 0 && w > 0 && C > 0 && C % 8 == 0, "pf_zero_insert2: bad arguments");
+    PF_REQUIRE(dtype == PF_F16 || dtype == PF_BF16, "pf_zero_insert2: 16-bit tensors only");
+    PF_REQUIRE(aligned16(x) && aligned16(y), "pf_zero_insert2: pointers must be 16-byte aligned");
+    const long total = static_cast<long>(n) * 4 * h * w * (C / 8);
+    hipLaunchKernelGGL(k_zero_insert2, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), static_cast<const u16x8*>(x), n, h, w, C / 8,
+                       static_cast<u16x8*>(y));
+    PF_CHECK_LAUNCH("pf_zero_insert2");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_sum2x2(const float* x, int n, int h, int w, int C, float* y, void* stream) {
+    PF_REQUIRE(x && y && x != y && n > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "pf_sum2x2: bad arguments");
+    PF_REQUIRE(aligned16(x) && aligned16(y), "pf_sum2x2: pointers must be 16-byte aligned");
+    const long total = static_cast<long>(n) * h * w * (C / 4);
+    hipLaunchKernelGGL(k_sum2x2, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(x), n, h, w, C / 4,
+                       reinterpret_cast<float4*>(y));
+    PF_CHECK_LAUNCH("pf_sum2x2");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_pad_width_bwd(const float* dy, int n, int h, int w, int C, int pad, float* dx, void* stream) {
+    PF_REQUIRE(dy && dx && dy != dx && n > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "pf_pad_width_bwd: bad arguments");
+    PF_REQUIRE(pad >= 0 && pad <= w, "pf_pad_width_bwd: pad must be in [0, w]");
+    PF_REQUIRE(aligned16(dy) && aligned16(dx), "pf_pad_width_bwd: pointers must be 16-byte aligned");
+    const long rows = static_cast<long>(n) * h, total = rows * w * (C / 4);
+    hipLaunchKernelGGL(k_pad_width_bwd, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(dy), rows, w, pad,
+                       C / 4, reinterpret_cast<float4*>(dx));
+    PF_CHECK_LAUNCH("pf_pad_width_bwd");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_crop_width_bwd(const float* dy, int n, int h, int w, int C, int crop, float* dx, void* stream) {
+    PF_REQUIRE(dy && dx && dy != dx && n > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "pf_crop_width_bwd: bad arguments");
+    PF_REQUIRE(crop >= 0 && 2 * crop < w, "pf_crop_width_bwd: crop too large");
+    PF_REQUIRE(aligned16(dy) && aligned16(dx), "pf_crop_width_bwd: pointers must be 16-byte aligned");
+    const long rows = static_cast<long>(n) * h, total = rows * w * (C / 4);
+    hipLaunchKernelGGL(k_crop_width_bwd, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(dy), rows, w, crop,
+                       C / 4, reinterpret_cast<float4*>(dx));
+    PF_CHECK_LAUNCH("pf_crop_width_bwd");
     return PF_OK;
 }

@@ -154,6 +154,7 @@ def pack_resnet(res, dev, dtype, mixed=False):
     else:
         r.ws = r.bs = None
     r.temb = getattr(res, "time_emb_proj", None)      # consumed by pack_unet (concatenated projection); None: VAE resnets
+    r.src = res                                       # (train_engine builds the backward operands from the module)
     return r
 
 
@@ -187,6 +188,7 @@ def pack_attention(attn, dev, dtype, self_attn):
 
 def pack_transformer(tf, dev, dtype, mixed=False):
     t = NS()
+    t.src = tf
     t.dtype, t.stream = dtype, (torch.float32 if mixed else dtype)
     t.w_in3 = t.w_out3 = None
     if mixed:
@@ -217,6 +219,7 @@ def pack_unet(unet, dev, dtype, mixed=False):
     co = getattr(unet, "conv_out", None)       # a ControlNet has the encoder half only
     if co is not None:
         u.cout = co.weight.shape[0]
+        u.src_conv_out = co
         u.w_conv_out = _f32(co.weight.detach().permute(0, 2, 3, 1), dev)      # [cout,3,3,cin]
         u.b_conv_out = _bias(co, dev)
         u.norm_out = _norm(unet.conv_norm_out, dev)
@@ -239,7 +242,7 @@ def pack_unet(unet, dev, dtype, mixed=False):
             b.attns = [pack_transformer(a, dev, dtype, mixed) for a in blk.attentions]
         if blk.downsamplers is not None:
             c = blk.downsamplers[0].conv
-            b.down = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0], w3=None)
+            b.down = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0], w3=None, src=c)
             if mixed:
                 b.down.w3 = _split_weight(c.weight.detach().float().permute(0, 2, 3, 1).reshape(c.weight.shape[0], -1),
                                           9, dev, dtype)
@@ -254,7 +257,7 @@ def pack_unet(unet, dev, dtype, mixed=False):
             b.attns = [pack_transformer(a, dev, dtype, mixed) for a in blk.attentions]
         if blk.upsamplers is not None:
             c = blk.upsamplers[0].conv
-            b.up = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0])
+            b.up = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0], src=c)
         u.up.append(b)
 
     # one GEMM for every resnet's Linear(silu(temb)) (diffusers ResnetBlock2D.time_emb_proj)

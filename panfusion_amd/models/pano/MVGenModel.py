@@ -21,11 +21,15 @@ from .modules import WarpAttn, camera_groups
 
 class MultiViewBaseModel(nn.Module):
     def __init__(self, unet, pano_unet, pers_cn=None, pano_cn=None, pano_pad=True,
-                 compute_dtype=torch.float16, precision=None):
+                 compute_dtype=torch.float16, precision=None, differentiable=False):
         """compute_dtype: the 16-bit MFMA operand type; precision: "mixed" (fp32 residual streams +
         split-precision stream-path GEMMs: the scheme that meets the 1e-3 parity bar, default for fp16)
-        or "fast" (everything 16-bit); None -> engine.default_precision (PF_PRECISION overrides)."""
+        or "fast" (everything 16-bit); None -> engine.default_precision (PF_PRECISION overrides).
+        differentiable: with autograd enabled, forward() returns outputs that back-propagate into the EPA blocks and
+        the LoRA matrices of both UNets (the reference's training_step, PanFusion.py:64-98) -- same forward kernels,
+        backward in train_engine.py.  Under torch.no_grad() (validation, predict) nothing changes."""
         super().__init__()
+        self.differentiable = differentiable
         self.precision = precision or engine.default_precision(compute_dtype)
         self.unet = unet
         self.pano_unet = pano_unet
@@ -84,9 +88,56 @@ class MultiViewBaseModel(nn.Module):
         return hit[0]
 
     # ------------------------------------------------------------------ forward
-    @torch.no_grad()
+    def trainable_tensors(self):
+        """EPA parameters and the LoRA matrices of both UNets: what the reference optimises (PanoGenerator.py:129-160,
+        MVGenModel.py:34-36), in the order DenoiserFunction returns their gradients."""
+        from ... import train_engine
+        out, seen = [], set()
+
+        def add(t):
+            if id(t) not in seen:
+                seen.add(id(t))
+                out.append(t)
+        if self.unet is not None:
+            for blk in [*self.cp_blocks_encoder, self.cp_blocks_mid, *self.cp_blocks_decoder]:
+                for t in blk.transformer.parameters():
+                    add(t)
+        for unet in (self.unet, self.pano_unet):
+            if unet is None:
+                continue
+            for mod in unet.modules():
+                if all(hasattr(mod, a) for a in ("to_q", "to_k", "to_v", "to_out")):
+                    for name, lin in (("to_q", mod.to_q), ("to_k", mod.to_k), ("to_v", mod.to_v), ("to_out", mod.to_out[0])):
+                        ref = train_engine.lora_of(mod, lin, name + "_lora")
+                        if ref is not None:
+                            add(ref.down)
+                            add(ref.up)
+        return out
+
     def forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras,
                 pers_layout_cond=None, pano_layout_cond=None):
+        """Reference signature (MVGenModel.py:38-39).  Inference unless the model was built ``differentiable`` and
+        autograd is recording."""
+        args = (latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras, pers_layout_cond, pano_layout_cond)
+        if self.differentiable and torch.is_grad_enabled():
+            from ... import train_engine
+            params = [t for t in self.trainable_tensors() if t.requires_grad]
+            if params:
+                return train_engine.DenoiserFunction.apply(self, args, *params)
+        return self._forward(*args)
+
+    def refold_lora(self):
+        """Re-pack the UNets when a LoRA matrix changed since the last pack (optimizer steps bump the version counters):
+        the forward kernels read W + up @ down folded into one 16-bit weight."""
+        key = tuple(t._version for t in self.trainable_tensors())
+        if getattr(self, "_lora_key", key) != key:
+            self._packed.clear()
+        self._lora_key = key
+
+    @torch.no_grad()
+    def _forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras,
+                 pers_layout_cond=None, pano_layout_cond=None, tape=None):
+        """tape: a list that receives (layer, inputs) records for train_engine.backward (training forward)."""
         if self.pers_cn is None:
             pers_layout_cond = None                 # reference MVGenModel.py:62-65
         if self.pano_cn is None:
@@ -97,6 +148,13 @@ class MultiViewBaseModel(nn.Module):
         branches = []
         cn_res = {}                                 # id(branch) -> (12 skip residuals, mid residual)
         shard = getattr(self, "shard", None)      # set by sharding.ShardedDenoiseLoop: latents hold only
+        if tape is not None:
+            if shard is not None or pers_layout_cond is not None or pano_layout_cond is not None:
+                raise NotImplementedError("the training path covers the un-sharded denoiser without ControlNet conditions")
+            from ... import train_engine
+            make_branch = lambda *a, **k: train_engine.TrainBranch(tape, *a, **k)
+        else:
+            make_branch = engine.Branch
         if two:                                   # this rank's views, cameras all m of them
             b, m = latents.shape[:2]
             flat_cams = {k: v.reshape(-1) for k, v in cameras.items()}
@@ -109,8 +167,8 @@ class MultiViewBaseModel(nn.Module):
         pano_only = two and shard is not None and m == 0
         pers = None
         if two and not pano_only:
-            pers = engine.Branch(self.packed("unet", dev), latents.flatten(0, 1), timestep.reshape(-1),
-                                 self._prompt16(prompt_embd), pano=False, pad=False)
+            pers = make_branch(self.packed("unet", dev), latents.flatten(0, 1), timestep.reshape(-1),
+                               self._prompt16(prompt_embd), pano=False, pad=False)
             branches.append(pers)
             if pers_layout_cond is not None:        # reference :66-74 (ControlNet on the view branch)
                 cn_res[id(pers)] = engine.run_controlnet(
@@ -123,7 +181,7 @@ class MultiViewBaseModel(nn.Module):
         view_only = two and shard is not None and not shard.has_pano
         main = torch.cuda.current_stream(dev) if pano_latent.is_cuda else None
         side = None
-        if two and self.two_streams and main is not None and not view_only and not pano_only:
+        if two and self.two_streams and main is not None and not view_only and not pano_only and tape is None:
             if self._side is None:
                 self._side = torch.cuda.Stream(dev)
             side = self._side
@@ -153,8 +211,8 @@ class MultiViewBaseModel(nn.Module):
         pano = None
         if not view_only:
             with on_pano():
-                pano = engine.Branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
-                                     self._prompt16(pano_prompt_embd), pano=True, pad=self.pano_pad)
+                pano = make_branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
+                                   self._prompt16(pano_prompt_embd), pano=True, pad=self.pano_pad)
                 pano.precompute_text_kv()
                 if pano_layout_cond is not None:    # reference :75-83: plain convolutions on the un-padded latent
                     cn_res[id(pano)] = engine.run_controlnet(
@@ -183,6 +241,8 @@ class MultiViewBaseModel(nn.Module):
                 return
             join()
             keep.append(pano.h)
+            if tape is not None:
+                tape.append(("fuse", pers, pano, block, pers.h, pano.h, groups, m_total))
             epa_side = side if os.environ.get("PF_EPA_STREAMS", "2") != "1" else None
             pers.h, pano.h = block.forward_nhwc(pers.h, pano.h, groups, m_total, shard=shard, side=epa_side)
             keep.append(pano.h)
@@ -248,4 +308,6 @@ class MultiViewBaseModel(nn.Module):
             sample = latents.new_zeros(b, 0, *latents.shape[2:]).to(out_dtype)
         else:
             sample = pers.head().to(out_dtype).unflatten(0, (b, m)) if two else None
+        if tape is not None:
+            return sample, pano_sample, pers, pano
         return sample, pano_sample

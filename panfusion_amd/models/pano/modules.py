@@ -127,6 +127,21 @@ class WarpAttn(nn.Module):
         params = training.train_params(self)
         return dx_p, dx_e, [g.view(p_.shape).to(p_.dtype) for g, p_ in zip(grads, params)]
 
+    @torch.no_grad()
+    def backward_nhwc(self, xp, xe, groups, m, d_p, d_e):
+        """The same on the denoiser's internal layout: xp [b*m, ph, pw, C], xe [b, eh, ew, C] (the inputs of forward_nhwc),
+        d_p / d_e fp32 NHWC gradients of its two outputs -> (dxp, dxe fp32 NHWC, parameter gradients)."""
+        from ... import training
+        dev = xp.device
+        bm, ph, pw, Cc = xp.shape
+        b, eh, ew, _ = xe.shape
+        tabs = self.tables_for(groups, ph, pw, eh, ew, dev)
+        e = self.packed_train(dev)
+        rec = training.epa_recompute(e, tabs, xe.reshape(-1, Cc), xp.reshape(-1, Cc), b, m)
+        dx_e, dx_p, grads = training.epa_backward(e, tabs, rec, d_e.reshape(-1, Cc).float(), d_p.reshape(-1, Cc).float(), b, m)
+        params = training.train_params(self)
+        return dx_p.view(bm, ph, pw, Cc), dx_e.view(b, eh, ew, Cc), [g.view(p_.shape) for g, p_ in zip(grads, params)]
+
     def packed_train(self, device):
         """16-bit weight copies for the backward GEMMs, rebuilt when a parameter changed (optimizer steps bump
         the tensors' version counters)."""

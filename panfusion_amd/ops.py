@@ -535,3 +535,49 @@ def scale_by_state(x, state, index, out_dtype=torch.float32, out=None):
         out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     check(_lib.lib().pf_scale_f32(_p(x), x.numel(), _p(state), index, dt(out), _p(out), _stream()), "pf_scale_f32")
     return out
+
+
+def groupnorm_bwd(x0, x1, n_img, hw, groups, eps, gamma, scale, shift, act, dy, dres=None):
+    """Backward of scale_shift_act(groupnorm_scale_shift(..)): x0 [n, hw, c0] (+ x1 [n, hw, c1]), dy fp32 [n, hw, c0 + c1]
+    -> (dx0, dx1) fp32 (dx1 None without a second source).  dres: fp32 gradient of the concat added to the result."""
+    c0 = x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    dx0 = torch.empty(n_img, hw, c0, device=x0.device, dtype=torch.float32)
+    dx1 = torch.empty(n_img, hw, c1, device=x0.device, dtype=torch.float32) if c1 else None
+    nbytes = _lib.lib().pf_groupnorm_bwd_workspace_size(n_img, hw, groups)
+    ws = torch.empty(nbytes, device=x0.device, dtype=torch.uint8)
+    check(_lib.lib().pf_groupnorm_bwd(_p(x0), c0, _p(x1), c1, dt(x0), n_img, hw, groups, eps, _p(gamma), _p(scale), _p(shift),
+                                      int(act), _p(dy), _p(dres), _p(dx0), _p(dx1), _p(ws), nbytes, _stream()), "pf_groupnorm_bwd")
+    return dx0, dx1
+
+
+def zero_insert2(x):
+    """x NHWC 16-bit [n, h, w, C] -> [n, 2h, 2w, C] with x at the even positions (stride-2 conv data gradient)."""
+    n, h, w, Cc = x.shape
+    out = torch.empty(n, 2 * h, 2 * w, Cc, device=x.device, dtype=x.dtype)
+    check(_lib.lib().pf_zero_insert2(_p(x), dt(x), n, h, w, Cc, _p(out), _stream()), "pf_zero_insert2")
+    return out
+
+
+def sum2x2(x):
+    """x fp32 NHWC [n, 2h, 2w, C] -> [n, h, w, C] block sums (nearest x2 up-sampling backward)."""
+    n, h2, w2, Cc = x.shape
+    out = torch.empty(n, h2 // 2, w2 // 2, Cc, device=x.device, dtype=torch.float32)
+    check(_lib.lib().pf_sum2x2(_p(x), n, h2 // 2, w2 // 2, Cc, _p(out), _stream()), "pf_sum2x2")
+    return out
+
+
+def pad_width_bwd(dy, pad):
+    """Gradient of pad_width: dy fp32 [n, h, w + 2 pad, C] -> [n, h, w, C]."""
+    n, h, wp, Cc = dy.shape
+    out = torch.empty(n, h, wp - 2 * pad, Cc, device=dy.device, dtype=torch.float32)
+    check(_lib.lib().pf_pad_width_bwd(_p(dy), n, h, wp - 2 * pad, Cc, pad, _p(out), _stream()), "pf_pad_width_bwd")
+    return out
+
+
+def crop_width_bwd(dy, crop):
+    """Gradient of crop_width: dy fp32 [n, h, w - 2 crop, C] -> [n, h, w, C] (zero margins)."""
+    n, h, wc, Cc = dy.shape
+    out = torch.empty(n, h, wc + 2 * crop, Cc, device=dy.device, dtype=torch.float32)
+    check(_lib.lib().pf_crop_width_bwd(_p(dy), n, h, wc + 2 * crop, Cc, crop, _p(out), _stream()), "pf_crop_width_bwd")
+    return out

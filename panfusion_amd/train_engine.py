@@ -1,0 +1,540 @@
+"""Backward of the dual-branch denoiser: the training step of the reference through the same boundary
+(``PanFusion.training_step``, PanFusion.py:64-98: one ``mv_base_model`` call, MSE on both outputs; trainable are the EPA
+blocks and the rank-4 LoRA matrices on the attention projections of both UNets, PanoGenerator.py:129-160 -- the UNet
+weights themselves are frozen).
+
+The forward of a training step IS the inference forward (engine.Branch, same kernels, same precision scheme): a
+``TrainBranch`` only notes, per layer, which packed layer ran on which input tensors.  The backward walks that tape in
+reverse; every entry recomputes the activations its layer needs from the saved inputs (16-bit MFMA operands, fp32
+residual stream) and applies the layer's backward:
+
+  resnet        GN+SiLU backward (pf_groupnorm_bwd), 3x3 data gradients = the forward GEMM kernel on flipped,
+                transposed weights, 1x1 shortcut on the transposed weight, the two-source concat splits into (dx, dskip)
+  transformer   GN / proj_in / [LN - self-attention - LN - text cross-attention - LN - GEGLU FF] / proj_out, attention
+                backward from the recomputed log-sum-exp, LoRA gradients as four thin GEMMs per projection
+  down / up     stride-2 conv: zero-stuffed gradient through the stride-1 kernel; nearest x2 + conv: 2x2 sums after it
+  panorama      circular pad / crop around every conv-bearing module (MVGenModel.py:110-115): fold / zero-margin kernels
+  head          conv_out's data gradient = the boundary conv kernel (conv_in) on rearranged weights, then GN+SiLU backward
+  EPA fusion    training.epa_recompute / epa_backward
+
+Every entry normalises its incoming gradient by a power of two on the device (max |d| in [1, 2)) before it becomes a
+16-bit operand and scales its results back (training.py: an MSE over 1e5 latent elements hands down 1e-5).
+"""
+import torch
+
+from . import engine, ops, training
+
+NS = engine.NS
+F32 = torch.float32
+
+
+# ---------------------------------------------------------------------------------------------- weights of the backward GEMMs
+def flip_conv3_weight(w, dtype):
+    """torch conv weight [cout, cin, 3, 3] -> data-gradient operand [cin, 9 * cout]: Wd[ci][ky][kx][co] = W[co][ci][2-ky][2-kx]."""
+    w = w.detach().float()
+    return w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dtype).contiguous()
+
+
+def conv_out_dgrad_weight(w):
+    """conv_out weight [cout, C, 3, 3] -> the boundary conv kernel's layout [3, 3, cin = cout, C] for its data gradient."""
+    return w.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()
+
+
+def _t16(w, dev, dtype):
+    """W [N, K] -> W^T [K, N] as a GEMM weight operand (the data gradient dx = dy W is a GEMM with weight W^T)."""
+    return w.detach().to(device=dev, dtype=F32).t().to(dtype).contiguous()
+
+
+def _w16(w, dev, dtype):
+    return w.detach().to(device=dev, dtype=F32).to(dtype).contiguous()
+
+
+def conv3_dgrad(dy, wflip, cin, mode, dtype):
+    """dy fp32 NHWC [n, ho, wo, cout] -> dx fp32 NHWC.  mode "s1": 3x3 pad 1; "s2": stride 2 (dx [n, 2ho, 2wo, cin]);
+    "up": nearest x2 before the conv (dx [n, ho/2, wo/2, cin])."""
+    n, ho, wo, cout = dy.shape
+    d16 = engine.to16(dy, dtype)
+    if mode == "s2":
+        d16 = ops.zero_insert2(d16)
+        ho, wo = 2 * ho, 2 * wo
+    dx = ops.conv_gemm(d16, wflip, cin, n_img=n, h_in=ho, w_in=wo, ksize=3, pad=1, out_dtype=F32).view(n, ho, wo, cin)
+    return ops.sum2x2(dx) if mode == "up" else dx
+
+
+def conv_out_dgrad(d_eps, wgt, cin, wrap):
+    """d_eps fp32 NCHW [n, cout, h, w] -> fp32 NHWC [n, h, w, cin] (circular in width for the panorama)."""
+    zero = torch.zeros(cin, device=d_eps.device, dtype=F32)
+    return ops.conv_in(d_eps.float(), wgt, zero, cin, F32, wrap=wrap)
+
+
+def _normalise(d):
+    state = ops.grad_scale_state([d])
+    return ops.scale_by_state(d, state, 1), state
+
+
+def _unscale(t, state):
+    return ops.scale_by_state(t, state, 2, out=t)
+
+
+# ---------------------------------------------------------------------------------------------- LoRA
+class LoRARef:
+    """One rank-r LoRA pair of a projection: W' = W + s * up @ down (engine._lin_weight folds it for the forward)."""
+
+    def __init__(self, lora):
+        self.down, self.up = lora.down.weight, lora.up.weight               # [r, K], [N, r]
+        alpha = getattr(lora, "network_alpha", None)
+        self.scale = 1.0 if alpha is None else float(alpha) / self.down.shape[0]
+
+    def operands(self, dev, dtype):
+        r = self.down.shape[0]
+        pad = (r + 63) // 64 * 64
+        d = torch.zeros(pad, self.down.shape[1], device=dev, dtype=dtype)
+        d[:r] = self.down.detach().to(device=dev, dtype=F32).to(dtype)
+        u = torch.zeros(pad, self.up.shape[0], device=dev, dtype=dtype)
+        u[:r] = self.up.detach().to(device=dev, dtype=F32).t().to(dtype)
+        return d, u                                                          # down padded [64, K], up^T padded [64, N]
+
+
+def lora_of(attn, lin, name):
+    lora = getattr(lin, "lora_layer", None) or engine._processor_lora(attn, name)
+    return None if lora is None else LoRARef(lora)
+
+
+def _pad_tokens(x16, xt16):
+    """Token counts of the reduction GEMMs must be multiples of 64 (pf_conv_gemm's channel rule): zero rows / columns."""
+    T = x16.shape[0]
+    Tp = (T + 63) // 64 * 64
+    if Tp == T:
+        return x16, xt16
+    xp = torch.zeros(Tp, x16.shape[1], device=x16.device, dtype=x16.dtype)
+    xp[:T].copy_(x16)
+    xtp = ops.transpose_tokens(xp.view(1, Tp, -1)).view(-1, Tp)
+    return xp, xtp
+
+
+def lora_grads(ref, x16, xt16, dy16, dyt16, sink):
+    """Gradients of one LoRA pair from the projection's input x [T, K] and output gradient dy [T, N] (16-bit, with their
+    token-contiguous transposes): d_up = s dy^T (x down^T), d_down = s (dy up)^T x -- four thin GEMMs with the rank padded
+    to 64, the reductions over tokens on token-contiguous operands."""
+    if ref is None:
+        return
+    dev, dtype = x16.device, x16.dtype
+    x16, xt16 = _pad_tokens(x16, xt16)
+    dy16, dyt16 = _pad_tokens(dy16, dyt16)
+    T = x16.shape[0]
+    down, upt = ref.operands(dev, dtype)
+    r = ref.down.shape[0]
+    pt = ops.conv_gemm(down, x16, T, w_in=down.shape[0])                     # (x down^T)^T   [64, T]
+    qt = ops.conv_gemm(upt, dy16, T, w_in=upt.shape[0])                      # (dy up)^T      [64, T]
+    d_up = ops.conv_gemm(dyt16, pt, pt.shape[0], w_in=dyt16.shape[0], out_dtype=F32)       # [N, 64]
+    d_down = ops.conv_gemm(qt, xt16, xt16.shape[0], w_in=qt.shape[0], out_dtype=F32)       # [64, K]
+    sink(ref.up, d_up[:, :r], ref.scale)
+    sink(ref.down, d_down[:r], ref.scale)
+
+
+# ---------------------------------------------------------------------------------------------- per-layer training packs
+def resnet_train(r, dev):
+    """Backward operands of a packed resnet (frozen weights: built once, kept on the pack)."""
+    tw = getattr(r, "train", None)
+    if tw is None:
+        src = r.src
+        tw = NS(w1=flip_conv3_weight(src.conv1.weight.to(dev), r.dtype), w2=flip_conv3_weight(src.conv2.weight.to(dev), r.dtype), ws=None)
+        sc = getattr(src, "conv_shortcut", None)
+        if sc is not None:
+            tw.ws = _t16(sc.weight.reshape(r.cout, r.cin), dev, r.dtype)            # [cin, cout]
+        r.train = tw
+    return tw
+
+
+def _attn_train(a, attn, dev, dtype, self_attn, key):
+    """Forward + backward operands of one attention with the CURRENT LoRA matrices folded in."""
+    w = lambda lin, name: engine._lin_weight(lin, engine._processor_lora(attn, name)).to(dev)
+    wq, wk, wv, wo = w(attn.to_q, "to_q_lora"), w(attn.to_k, "to_k_lora"), w(attn.to_v, "to_v_lora"), w(attn.to_out[0], "to_out_lora")
+    t = NS(key=key, heads=a.heads, dim=wq.shape[0])
+    if self_attn:
+        wqkv = torch.cat([wq, wk, wv], 0)
+        t.wqkv, t.wqkv_t = _w16(wqkv, dev, dtype), _t16(wqkv, dev, dtype)
+    else:
+        wkv = torch.cat([wk, wv], 0)
+        t.wq, t.wq_t = _w16(wq, dev, dtype), _t16(wq, dev, dtype)
+        t.wkv = _w16(wkv, dev, dtype)
+    t.wv = _w16(wv, dev, dtype)
+    t.wo, t.wo_t, t.bo = _w16(wo, dev, dtype), _t16(wo, dev, dtype), a.bo
+    t.lora = {n: lora_of(attn, lin, n + "_lora") for n, lin in (("to_q", attn.to_q), ("to_k", attn.to_k), ("to_v", attn.to_v), ("to_out", attn.to_out[0]))}
+    return t
+
+
+def transformer_train(t, dev):
+    """Backward operands of a packed transformer: the frozen parts once, the LoRA-carrying attentions whenever a LoRA
+    matrix changed (optimizer steps bump the parameters' version counters)."""
+    src = t.src
+    blk = src.transformer_blocks[0]
+    tw = getattr(t, "train", None)
+    if tw is None:
+        tw = NS(attn_key=None)
+        tw.w_in, tw.w_in_t = _w16(src.proj_in.weight.reshape(src.proj_in.weight.shape[0], -1), dev, t.dtype), \
+            _t16(src.proj_in.weight.reshape(src.proj_in.weight.shape[0], -1), dev, t.dtype)
+        tw.w_out_t = _t16(src.proj_out.weight.reshape(src.proj_out.weight.shape[0], -1), dev, t.dtype)
+        ff1, ff2 = blk.ff.net[0].proj, blk.ff.net[2]
+        tw.w1, tw.w1_t, tw.b1 = _w16(ff1.weight, dev, t.dtype), _t16(ff1.weight, dev, t.dtype), engine._bias(ff1, dev)
+        tw.w2, tw.w2_t = _w16(ff2.weight, dev, t.dtype), _t16(ff2.weight, dev, t.dtype)
+        t.train = tw
+    loras = [p for a in (blk.attn1, blk.attn2) for n, lin in (("to_q", a.to_q), ("to_k", a.to_k), ("to_v", a.to_v), ("to_out", a.to_out[0]))
+             for ref in [lora_of(a, lin, n + "_lora")] if ref is not None for p in (ref.down, ref.up)]
+    key = tuple((p.data_ptr(), p._version) for p in loras)
+    if tw.attn_key != key:
+        tw.attn1 = _attn_train(t.attn1, blk.attn1, dev, t.dtype, True, key)
+        tw.attn2 = _attn_train(t.attn2, blk.attn2, dev, t.dtype, False, key)
+        tw.attn_key = key
+    return tw
+
+
+TEXT_PAD = 128        # text keys per sample in the recomputed cross-attention: 77 tokens + masked zero rows (token counts of
+                      # the LoRA reductions must be multiples of 64, pf_attention_bwd wants whole key quads under a bias)
+_TEXT_BIAS = {}
+
+
+def text_bias(nq, L, dev):
+    """Bias table [nq, TEXT_PAD] that masks the padded text keys (-1e30 on columns >= L) + its 32x32 tile flags."""
+    key = (nq, L, str(dev))
+    hit = _TEXT_BIAS.get(key)
+    if hit is None:
+        if len(_TEXT_BIAS) > 16:
+            _TEXT_BIAS.clear()
+        bias = torch.zeros(nq, TEXT_PAD, device=dev, dtype=F32)
+        bias[:, L:] = -1e30
+        flags = torch.zeros((nq + 31) // 32, TEXT_PAD // 32, device=dev, dtype=torch.uint8)
+        flags[:, L // 32:] = 1
+        hit = _TEXT_BIAS[key] = (bias, flags)
+    return hit
+
+
+def pad_text(text, dtype):
+    """text [n, L, Dt] -> [n, TEXT_PAD, Dt] 16-bit with zero rows behind the L tokens."""
+    n, L, Dt = text.shape
+    out = torch.zeros(n, TEXT_PAD, Dt, device=text.device, dtype=dtype)
+    out[:, :L] = text.to(dtype)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- layer backward passes
+def resnet_backward(r, x, skip, rowvec, dout):
+    """x [n, h, w, cx] (+ skip [n, h, w, cs]) as the forward saw them, dout fp32 [n, h, w, cout] -> (dx, dskip) fp32."""
+    tw = resnet_train(r, x.device)
+    n, h, w, cx = x.shape
+    hw, M = h * w, n * h * w
+    cin = cx + (skip.shape[-1] if skip is not None else 0)
+    # recompute: GN1 -> SiLU -> conv1 (+ bias + temb) -> GN2 statistics
+    sc1, sh1 = ops.groupnorm_scale_shift(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, r.norm1.b)
+    y1 = ops.scale_shift_act(x, skip, n, hw, sc1, sh1, 1, out_dtype=r.dtype)
+    h1 = ops.conv_gemm(y1, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec, out_dtype=F32)
+    h1 = h1.view(n, hw, r.cout)
+    sc2, sh2 = ops.groupnorm_scale_shift(h1, None, n, hw, r.norm2.groups, r.norm2.eps, r.norm2.g, r.norm2.b)
+    # backward
+    d, state = _normalise(dout.reshape(n, h, w, r.cout))
+    dy2 = conv3_dgrad(d, tw.w2, r.cout, "s1", r.dtype)                                   # gradient of silu(gn2(h1))
+    dh1, _ = ops.groupnorm_bwd(h1, None, n, hw, r.norm2.groups, r.norm2.eps, r.norm2.g, sc2, sh2, 1, dy2.view(n, hw, r.cout))
+    dy1 = conv3_dgrad(dh1.view(n, h, w, r.cout), tw.w1, cin, "s1", r.dtype)              # gradient of silu(gn1(x | skip))
+    if tw.ws is not None:
+        dsc = ops.linear(engine.to16(d, r.dtype).view(M, r.cout), tw.ws, out_dtype=F32)  # shortcut: d Ws  [M, cin]
+    else:
+        assert skip is None and cin == r.cout
+        dsc = d
+    dx, dskip = ops.groupnorm_bwd(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, sc1, sh1, 1,
+                                  dy1.view(n, hw, cin), dres=dsc.view(n, hw, cin))
+    _unscale(dx, state)
+    if dskip is not None:
+        _unscale(dskip, state)
+        dskip = dskip.view(n, h, w, -1)
+    return dx.view(n, h, w, cx), dskip
+
+
+def _self_attention(tw, ln, n, hw, dh):
+    """Recompute of attn1 on the normalised tokens ln [n*hw, C]: (qkv, qkv^T, V^T for the forward kernel, output, lse)."""
+    Cc, H = tw.dim, tw.heads
+    qkv = ops.linear(ln, tw.wqkv)                                                        # [T, 3C]
+    qkv3 = qkv.view(n, hw, 3 * Cc)
+    qkvt = ops.transpose_tokens(qkv3)                                                    # [n, 3C, hw]
+    if hw % 32 == 0:
+        vt = qkvt[:, 2 * Cc:]
+        vt_ld, vt_bs = hw, 3 * Cc * hw
+    else:                                           # the forward kernel reads V^T rows padded to 32 keys (4x4 level)
+        vt = ops.linear_t(ln.view(n, hw, Cc), tw.wv)
+        vt_ld, vt_bs = vt.shape[-1], vt.shape[1] * vt.shape[2]
+    a = torch.empty(n, hw, Cc, device=ln.device, dtype=ln.dtype)
+    lse = torch.empty(n, H, hw, device=ln.device, dtype=F32)
+    ld = 3 * Cc
+    ops.attention(qkv3[:, :, :Cc], qkv3[:, :, Cc:2 * Cc], vt, n, H, dh, hw, hw, q_ld=ld, k_ld=ld, vt_ld=vt_ld,
+                  q_bs=hw * ld, k_bs=hw * ld, vt_bs=vt_bs, out=a, lse=lse)
+    return qkv3, qkvt, a, lse
+
+
+def transformer_backward(t, x, text, dout, sink):
+    """x [n, h, w, C] as the forward saw it, text [n, L, Dt], dout fp32 [n, h, w, C] -> dx fp32; LoRA gradients into sink."""
+    dev = x.device
+    tw = transformer_train(t, dev)
+    a1w, a2w = tw.attn1, tw.attn2
+    n, h, w, Cc = x.shape
+    hw, T = h * w, n * h * w
+    H = a1w.heads
+    dh = Cc // H
+    L = text.shape[1]
+    dt16 = t.dtype
+    # ---- recompute
+    sc, sh = ops.groupnorm_scale_shift(x, None, n, hw, t.norm.groups, t.norm.eps, t.norm.g, t.norm.b)
+    y = ops.scale_shift_act(x, None, n, hw, sc, sh, 0, out_dtype=dt16)
+    tok0 = ops.linear(y.view(T, Cc), tw.w_in, bias=t.b_in, out_dtype=F32)
+    ln1 = ops.layernorm(tok0, t.ln1.g, t.ln1.b, t.ln1.eps, out_dtype=dt16)
+    qkv3, qkvt, a1, lse1 = _self_attention(a1w, ln1, n, hw, dh)
+    tok1 = ops.linear(a1.view(T, Cc), a1w.wo, bias=a1w.bo, residual=tok0)
+    ln2 = ops.layernorm(tok1, t.ln2.g, t.ln2.b, t.ln2.eps, out_dtype=dt16)
+    q2 = ops.linear(ln2, a2w.wq).view(n, hw, Cc)
+    q2t = ops.transpose_tokens(q2)
+    textp = pad_text(text, dt16)                                                         # [n, 128, Dt]
+    kv2 = ops.linear(textp.view(n * TEXT_PAD, -1), a2w.wkv).view(n, TEXT_PAD, 2 * Cc)    # (k | v)
+    kv2t = ops.transpose_tokens(kv2)                                                     # [n, 2C, 128]
+    tbias, tflags = text_bias(hw, L, dev)
+    a2 = torch.empty(n, hw, Cc, device=dev, dtype=dt16)
+    lse2 = torch.empty(n, H, hw, device=dev, dtype=F32)
+    ops.attention(q2, kv2[:, :, :Cc], kv2t[:, Cc:], n, H, dh, hw, TEXT_PAD, q_ld=Cc, k_ld=2 * Cc, vt_ld=TEXT_PAD,
+                  q_bs=hw * Cc, k_bs=TEXT_PAD * 2 * Cc, vt_bs=2 * Cc * TEXT_PAD, bias=tbias, flags=tflags, out=a2, lse=lse2)
+    tok2 = ops.linear(a2.view(T, Cc), a2w.wo, bias=a2w.bo, residual=tok1)
+    ln3 = ops.layernorm(tok2, t.ln3.g, t.ln3.b, t.ln3.eps, out_dtype=dt16)
+    u = ops.linear(ln3, tw.w1, bias=tw.b1)                                               # [T, 8C] = (value | gate)
+
+    # ---- backward
+    d, state = _normalise(dout.reshape(T, Cc))
+    scaled = lambda p_, g_, s_: sink(p_, _unscale(g_.contiguous(), state), s_)
+    dtok3 = ops.linear(engine.to16(d, dt16), tw.w_out_t, out_dtype=F32)                  # proj_out (its residual: d -> dx below)
+    # feed-forward
+    dg = ops.linear(engine.to16(dtok3, dt16), tw.w2_t)
+    du = ops.geglu_bwd(u, dg)
+    dln3 = ops.linear(du, tw.w1_t, out_dtype=F32)
+    dtok2, _, _ = ops.layernorm_bwd(tok2, t.ln3.g, dln3, t.ln3.eps, dres=dtok3)
+    # text cross-attention
+    d16 = engine.to16(dtok2, dt16)
+    da2 = ops.linear(d16, a2w.wo_t).view(n, hw, Cc)
+    lora_grads(a2w.lora["to_out"], a2.view(T, Cc), ops.transpose_tokens(a2.view(1, T, Cc)).view(Cc, T), d16,
+               ops.transpose_tokens(d16.view(1, T, Cc)).view(Cc, T), scaled)
+    delta2 = ops.attention_delta(a2, da2, n, H, dh, hw)
+    dq2 = torch.empty(n, hw, Cc, device=dev, dtype=dt16)
+    dkv2 = torch.empty(n, TEXT_PAD, 2 * Cc, device=dev, dtype=dt16)
+    ops.attention_bwd(q2, kv2[:, :, :Cc], kv2[:, :, Cc:], da2, q2t, kv2t[:, :Cc], ops.transpose_tokens(da2), lse2, delta2,
+                      dq2, dkv2[:, :, :Cc], dkv2[:, :, Cc:], n, H, dh, hw, TEXT_PAD,
+                      q_ld=Cc, k_ld=2 * Cc, v_ld=2 * Cc, do_ld=Cc, dq_ld=Cc, dk_ld=2 * Cc, dv_ld=2 * Cc,
+                      q_bs=hw * Cc, k_bs=TEXT_PAD * 2 * Cc, v_bs=TEXT_PAD * 2 * Cc, do_bs=hw * Cc, dq_bs=hw * Cc,
+                      dk_bs=TEXT_PAD * 2 * Cc, dv_bs=TEXT_PAD * 2 * Cc, bias=tbias, flags=tflags)
+    dln2 = ops.linear(dq2.view(T, Cc), a2w.wq_t, out_dtype=F32)
+    ln2t = ops.transpose_tokens(ln2.view(1, T, Cc)).view(Cc, T)
+    lora_grads(a2w.lora["to_q"], ln2, ln2t, dq2.view(T, Cc), ops.transpose_tokens(dq2.view(1, T, Cc)).view(Cc, T), scaled)
+    if a2w.lora["to_k"] is not None or a2w.lora["to_v"] is not None:
+        Tt = n * TEXT_PAD
+        tx = textp.view(Tt, -1)
+        txt = ops.transpose_tokens(textp.view(1, Tt, -1)).view(-1, Tt)
+        dkv2t = ops.transpose_tokens(dkv2.view(1, Tt, 2 * Cc)).view(2 * Cc, Tt)
+        # contiguous copies of the two column blocks (transposing the transpose's row blocks back: [C, Tt] -> [Tt, C])
+        dkc = ops.transpose_tokens(dkv2t[:Cc].reshape(1, Cc, Tt)).view(Tt, Cc)
+        dvc = ops.transpose_tokens(dkv2t[Cc:].reshape(1, Cc, Tt)).view(Tt, Cc)
+        lora_grads(a2w.lora["to_k"], tx, txt, dkc, dkv2t[:Cc], scaled)
+        lora_grads(a2w.lora["to_v"], tx, txt, dvc, dkv2t[Cc:], scaled)
+    dtok1, _, _ = ops.layernorm_bwd(tok1, t.ln2.g, dln2, t.ln2.eps, dres=dtok2)
+    # self-attention
+    d16 = engine.to16(dtok1, dt16)
+    da1 = ops.linear(d16, a1w.wo_t).view(n, hw, Cc)
+    lora_grads(a1w.lora["to_out"], a1.view(T, Cc), ops.transpose_tokens(a1.view(1, T, Cc)).view(Cc, T), d16,
+               ops.transpose_tokens(d16.view(1, T, Cc)).view(Cc, T), scaled)
+    delta1 = ops.attention_delta(a1, da1, n, H, dh, hw)
+    dqkv = torch.empty(n, hw, 3 * Cc, device=dev, dtype=dt16)
+    ld = 3 * Cc
+    ops.attention_bwd(qkv3[:, :, :Cc], qkv3[:, :, Cc:2 * Cc], qkv3[:, :, 2 * Cc:], da1, qkvt[:, :Cc], qkvt[:, Cc:2 * Cc],
+                      ops.transpose_tokens(da1), lse1, delta1, dqkv[:, :, :Cc], dqkv[:, :, Cc:2 * Cc], dqkv[:, :, 2 * Cc:],
+                      n, H, dh, hw, hw, q_ld=ld, k_ld=ld, v_ld=ld, do_ld=Cc, dq_ld=ld, dk_ld=ld, dv_ld=ld,
+                      q_bs=hw * ld, k_bs=hw * ld, v_bs=hw * ld, do_bs=hw * Cc, dq_bs=hw * ld, dk_bs=hw * ld, dv_bs=hw * ld)
+    dln1 = ops.linear(dqkv.view(T, 3 * Cc), a1w.wqkv_t, out_dtype=F32)
+    if any(a1w.lora[k] is not None for k in ("to_q", "to_k", "to_v")):
+        ln1t = ops.transpose_tokens(ln1.view(1, T, Cc)).view(Cc, T)
+        dqkvt = ops.transpose_tokens(dqkv.view(1, T, 3 * Cc)).view(3 * Cc, T)
+        for i, name in enumerate(("to_q", "to_k", "to_v")):
+            rows = dqkvt[i * Cc:(i + 1) * Cc]
+            cols = ops.transpose_tokens(rows.reshape(1, Cc, T)).view(T, Cc)              # contiguous column block of dqkv
+            lora_grads(a1w.lora[name], ln1, ln1t, cols, rows, scaled)
+    dtok0, _, _ = ops.layernorm_bwd(tok0, t.ln1.g, dln1, t.ln1.eps, dres=dtok1)
+    # proj_in and the GroupNorm in front of it; the block's own residual (out = proj_out(..) + x)
+    dy = ops.linear(engine.to16(dtok0, dt16), tw.w_in_t, out_dtype=F32)
+    dx, _ = ops.groupnorm_bwd(x, None, n, hw, t.norm.groups, t.norm.eps, t.norm.g, sc, sh, 0, dy.view(n, hw, Cc), dres=d.view(n, hw, Cc))
+    return _unscale(dx, state).view(n, h, w, Cc)
+
+
+def downsample_backward(d, dout, pano_pad, dev_dtype):
+    """dout fp32 [n, ho, wo, C] -> dx of the block input; panorama: pad 2 / conv s2 / crop 1 (MVGenModel.py:138-144)."""
+    tw = getattr(d, "train", None)
+    if tw is None:
+        tw = d.train = NS(w=flip_conv3_weight(d.src.weight, dev_dtype))
+    g, state = _normalise(dout)
+    if pano_pad:
+        g = ops.crop_width_bwd(g, 1)
+    dx = conv3_dgrad(g, tw.w.to(dout.device), d.src.weight.shape[1], "s2", dev_dtype)
+    if pano_pad:
+        dx = ops.pad_width_bwd(dx, 2)
+    return _unscale(dx, state)
+
+
+def upsample_backward(up, dout, pano_pad, dev_dtype):
+    """panorama: pad 1 / nearest x2 + conv / crop 2 (MVGenModel.py:272-277)."""
+    tw = getattr(up, "train", None)
+    if tw is None:
+        tw = up.train = NS(w=flip_conv3_weight(up.src.weight, dev_dtype))
+    g, state = _normalise(dout)
+    if pano_pad:
+        g = ops.crop_width_bwd(g, 2)
+    dx = conv3_dgrad(g, tw.w.to(dout.device), up.src.weight.shape[1], "up", dev_dtype)
+    if pano_pad:
+        dx = ops.pad_width_bwd(dx, 1)
+    return _unscale(dx, state)
+
+
+def head_backward(u, hin, d_eps, pano_pad):
+    """hin [n, h, w, C] the head's input, d_eps fp32 NCHW gradient of the predicted noise -> fp32 [n, h, w, C]."""
+    n, h, w, Cc = hin.shape
+    tw = getattr(u, "train_head", None)
+    if tw is None:
+        tw = u.train_head = NS(w=conv_out_dgrad_weight(u.src_conv_out.weight).to(hin.device))
+    g, state = _normalise(d_eps.float().contiguous())
+    sc, sh = ops.groupnorm_scale_shift(hin, None, n, h * w, u.norm_out.groups, u.norm_out.eps, u.norm_out.g, u.norm_out.b)
+    dy = conv_out_dgrad(g, tw.w, Cc, bool(pano_pad))
+    dx, _ = ops.groupnorm_bwd(hin, None, n, h * w, u.norm_out.groups, u.norm_out.eps, u.norm_out.g, sc, sh, 1, dy.view(n, h * w, Cc))
+    return _unscale(dx, state).view(n, h, w, Cc)
+
+
+# ---------------------------------------------------------------------------------------------- the tape
+class TrainBranch(engine.Branch):
+    """engine.Branch that notes which packed layer ran on which tensors (nothing else changes in the forward)."""
+
+    def __init__(self, tape, *args, **kw):
+        super().__init__(*args, **kw)
+        self.tape = tape
+
+    def resnet(self, r, skip=False):
+        x, s = self.h, (self.skips[-1] if skip else None)
+        super().resnet(r, skip)
+        self.tape.append(("resnet", self, r, x, s))
+
+    def attention(self, t):
+        x = self.h
+        super().attention(t)
+        self.tape.append(("attention", self, t, x))
+
+    def push(self):
+        super().push()
+        self.tape.append(("push", self))
+
+    def downsample(self, d):
+        super().downsample(d)
+        self.tape.append(("down", self, d))
+
+    def upsample(self, up):
+        super().upsample(up)
+        self.tape.append(("up", self, up))
+
+    def head(self):
+        x = self.h
+        out = super().head()
+        self.tape.append(("head", self, x))
+        return out
+
+
+class ParamGrads:
+    """Gradient sink: parameter tensor -> accumulated fp32 gradient (device tensors; torch adds are bookkeeping on tiny
+    LoRA / EPA matrices, the heavy reductions ran in the GEMM kernel)."""
+
+    def __init__(self):
+        self.grads = {}
+
+    def __call__(self, param, grad, scale=1.0):
+        g = grad.reshape(param.shape).to(F32)
+        if scale != 1.0:
+            g = g * scale
+        key = id(param)
+        if key in self.grads:
+            self.grads[key] = (param, ops.add(self.grads[key][1].contiguous(), g.contiguous()))
+        else:
+            self.grads[key] = (param, g)
+
+    def get(self, param):
+        hit = self.grads.get(id(param))
+        return None if hit is None else hit[1].to(param.dtype)
+
+
+def backward(tape, d_eps, sink):
+    """Walk the tape backwards.  d_eps: {branch: fp32 NCHW gradient of that branch's predicted noise}."""
+    dh, dskips = {}, {}
+    for entry in reversed(tape):
+        kind, br = entry[0], entry[1]
+        if kind == "fuse":
+            _, pers, pano, block, xp, xe, groups, m = entry
+            dp, de, grads = block.backward_nhwc(xp, xe, groups, m, dh[pers], dh[pano])
+            dh[pers], dh[pano] = dp, de
+            for p_, g_ in zip(training.train_params(block), grads):
+                sink(p_, g_)
+            continue
+        pad = br.pad
+        if kind == "head":
+            dh[br] = head_backward(br.u, entry[2], d_eps[br], pad)
+        elif kind == "up":
+            dh[br] = upsample_backward(entry[2], dh[br], pad, br.u.dtype)
+        elif kind == "down":
+            dh[br] = downsample_backward(entry[2], dh[br], pad, br.u.dtype)
+        elif kind == "push":
+            g = dskips[br].pop()
+            dh[br] = ops.add(dh[br], g) if dh.get(br) is not None else g
+        elif kind == "attention":
+            dh[br] = transformer_backward(entry[2], entry[3], br.text, dh[br], sink)
+        elif kind == "resnet":
+            _, _, r, x, s = entry
+            rowvec = br.temb[:, r.temb_off:]
+            d = dh[br]
+            if pad:                                   # pad 2 / resnet / crop 2 (MVGenModel.py:110-115)
+                d = ops.crop_width_bwd(d, 2)
+                x, s = ops.pad_width(x, 2), (ops.pad_width(s, 2) if s is not None else None)
+            dx, ds = resnet_backward(r, x, s, rowvec, d)
+            if pad:
+                dx, ds = ops.pad_width_bwd(dx, 2), (ops.pad_width_bwd(ds, 2) if ds is not None else None)
+            dh[br] = dx
+            if s is not None:
+                dskips.setdefault(br, []).append(ds)
+    return dh
+
+
+class DenoiserFunction(torch.autograd.Function):
+    """``MultiViewBaseModel.forward`` under autograd: the inference kernels forward (with a tape of layer inputs), the
+    tape walked backwards in ``backward``.  Gradients go to the EPA parameters and the LoRA matrices; the inputs
+    (latents, prompts) take none -- the reference's training step does not ask for them."""
+
+    @staticmethod
+    def forward(ctx, model, args, *params):
+        tape = []
+        model.refold_lora()
+        sample, pano_sample, pers, pano = model._forward(*args, tape=tape)
+        ctx.tape, ctx.pers, ctx.pano, ctx.params = tape, pers, pano, params
+        ctx.has_sample = sample is not None
+        ctx.sample_shape = None if sample is None else tuple(sample.shape)
+        if sample is None:
+            return pano_sample
+        return sample, pano_sample
+
+    @staticmethod
+    def backward(ctx, *douts):
+        d_sample, d_pano = (douts if ctx.has_sample else (None, douts[0]))
+        d_eps = {}
+        with torch.no_grad():
+            if ctx.pers is not None:
+                if d_sample is None:
+                    d_sample = torch.zeros(ctx.sample_shape, device=d_pano.device, dtype=F32)
+                d_eps[ctx.pers] = d_sample.flatten(0, 1).float().contiguous()
+            if d_pano is None:
+                d_pano = torch.zeros((ctx.sample_shape[0], 1) + tuple(ctx.pano.h.shape[0:0]), device=d_sample.device)
+            d_eps[ctx.pano] = d_pano.flatten(0, 1).float().contiguous()
+            sink = ParamGrads()
+            backward(ctx.tape, d_eps, sink)
+        ctx.tape = None
+        return (None, None, *[sink.get(p_) for p_ in ctx.params])

@@ -379,3 +379,44 @@ def scale_by_state(x, state, index, out_dtype=torch.float32, out=None):
         out.copy_(y)
         return out
     return y
+
+
+def groupnorm_bwd(x0, x1, n_img, hw, groups, eps, gamma, scale, shift, act, dy, dres=None):
+    x = _cat(x0.float().reshape(n_img, hw, -1), None if x1 is None else x1.float().reshape(n_img, hw, -1)).clone()
+    C = x.shape[-1]
+    mu = x.reshape(n_img, hw, groups, C // groups).mean((1, 3), keepdim=True).expand(-1, 1, -1, C // groups).reshape(n_img, C)
+    beta = (shift + mu * scale)[0]                   # shift = beta - mean * scale (pf_groupnorm_stats)
+    x.requires_grad_(True)
+    with torch.enable_grad():
+        z = F.group_norm(x.transpose(1, 2), groups, gamma, beta, eps).transpose(1, 2)
+        (F.silu(z) if act else z).backward(dy.reshape(z.shape))
+    g = x.grad
+    if dres is not None:
+        g = g + dres.reshape(g.shape)
+    c0 = x0.shape[-1]
+    return g[..., :c0].contiguous(), (g[..., c0:].contiguous() if x1 is not None else None)
+
+
+def zero_insert2(x):
+    n, h, w, C = x.shape
+    y = torch.zeros(n, 2 * h, 2 * w, C, dtype=x.dtype)
+    y[:, ::2, ::2] = x
+    return y
+
+
+def sum2x2(x):
+    n, h2, w2, C = x.shape
+    return x.reshape(n, h2 // 2, 2, w2 // 2, 2, C).sum((2, 4))
+
+
+def pad_width_bwd(dy, pad):
+    w = dy.shape[2] - 2 * pad
+    dx = dy[:, :, pad:pad + w].clone()
+    if pad:
+        dx[:, :, w - pad:] += dy[:, :, :pad]
+        dx[:, :, :pad] += dy[:, :, w + pad:]
+    return dx
+
+
+def crop_width_bwd(dy, crop):
+    return F.pad(dy, (0, 0, crop, crop))

@@ -31,14 +31,16 @@ def rnd(*shape, seed=0, scale=1.0):
 def sparse_bias(nq, nk, seed):
     """EPA-like bias: non-zero in a few 32x32 tiles only, with the tile flags."""
     g = torch.Generator().manual_seed(seed)
-    flags = (torch.rand(nq // 32, nk // 32, generator=g) < 0.2).to(torch.uint8)
-    bias = torch.rand(nq, nk, generator=g) * flags.bool().repeat_interleave(32, 0).repeat_interleave(32, 1)
+    flags = (torch.rand((nq + 31) // 32, (nk + 31) // 32, generator=g) < 0.2).to(torch.uint8)
+    bias = torch.rand(nq, nk, generator=g) * flags.bool().repeat_interleave(32, 0).repeat_interleave(32, 1)[:nq, :nk]
     return bias.to(DEV).contiguous(), flags.to(DEV).contiguous()
 
 
 @pytest.mark.parametrize("dtype", D16)
 @pytest.mark.parametrize("D,H,nq,nk,biased", [(32, 3, 128, 320, True), (32, 2, 96, 64, False), (64, 2, 160, 96, False),
-                                              (32, 10, 512, 1280, True)])
+                                              (32, 10, 512, 1280, True),
+                                              # ragged token counts (guarded instantiation): the 4x4 level of a 256^2 view, text keys
+                                              (64, 2, 16, 16, False), (64, 2, 100, 128, True), (32, 2, 40, 72, False)])
 def test_attention_lse_and_backward(dtype, D, H, nq, nk, biased):
     o = ops()
     B, Cc = 2, H * D
@@ -51,8 +53,14 @@ def test_attention_lse_and_backward(dtype, D, H, nq, nk, biased):
     qt_all, kt_all = o.transpose_tokens(qkv_q), o.transpose_tokens(qkv_k)
     assert torch.equal(qt_all, qkv_q.transpose(1, 2))
     lse = torch.empty(B, H, nq, device=DEV, dtype=torch.float32)
-    out = o.attention(q, k, kt_all[:, 2 * Cc:], B, H, D, nq, nk, q_ld=ld, k_ld=ld, vt_ld=nk, q_bs=nq * ld, k_bs=nk * ld,
-                      vt_bs=ld * nk, bias=bias, flags=flags, lse=lse)
+    vt, vt_ld, vt_bs = kt_all[:, 2 * Cc:], nk, ld * nk
+    if nk % 32:                                           # the forward kernel wants V^T rows padded to 32 keys
+        vt_ld = (nk + 31) // 32 * 32
+        vt = torch.zeros(B, Cc, vt_ld, device=DEV, dtype=dtype)
+        vt[:, :, :nk] = v.transpose(1, 2)
+        vt_bs = Cc * vt_ld
+    out = o.attention(q, k, vt, B, H, D, nq, nk, q_ld=ld, k_ld=ld, vt_ld=vt_ld, q_bs=nq * ld, k_bs=nk * ld,
+                      vt_bs=vt_bs, bias=bias, flags=flags, lse=lse)
     # fp32 reference with autograd on the same 16-bit inputs
     heads = lambda t, n: t.float().reshape(B, n, H, D).transpose(1, 2)
     qr, kr, vr = (t.clone().float().requires_grad_(True) for t in (q, k, v))
@@ -183,3 +191,82 @@ def test_warpattn_training_step_vs_oracle_autograd(dtype, precision, tol, b, dim
         worst[k] = rel_l2(res["hip"][k].float().cpu(), want)
     print("\n" + "  ".join("%s %.2e" % (k.replace("transformer.", ""), v) for k, v in worst.items()))
     assert max(worst.values()) < tol, worst
+
+
+# ------------------------------------------------------------------------------------ UNet-side backward kernels
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("n,hw,c0,c1,groups,act", [(3, 24 * 17, 64, 32, 32, 1), (2, 1024, 320, 0, 32, 1), (1, 64, 1280, 1280, 32, 0),
+                                                   (2, 300, 640, 320, 32, 1)])
+def test_groupnorm_backward(xdtype, n, hw, c0, c1, groups, act):
+    o = ops()
+    x0 = (rnd(n, hw, c0, seed=1, scale=2.0) + 0.5).to(xdtype)
+    x1 = rnd(n, hw, c1, seed=2).to(xdtype) if c1 else None
+    C = c0 + c1
+    gamma, beta = rnd(C, seed=3) * 0.2 + 1, rnd(C, seed=4) * 0.1
+    dy, dres = rnd(n, hw, C, seed=5), rnd(n, hw, C, seed=6)
+    sc, sh = o.groupnorm_scale_shift(x0, x1, n, hw, groups, 1e-5, gamma, beta)
+    xr = (torch.cat([x0, x1], -1) if c1 else x0).float().clone().requires_grad_(True)
+    z = F.group_norm(xr.transpose(1, 2), groups, gamma, beta, 1e-5).transpose(1, 2)
+    (F.silu(z) if act else z).backward(dy)
+    dx0, dx1 = o.groupnorm_bwd(x0, x1, n, hw, groups, 1e-5, gamma, sc, sh, act, dy, dres)
+    want = xr.grad + dres
+    assert rel_l2(dx0.cpu(), want[..., :c0].cpu()) < 2e-5, rel_l2(dx0.cpu(), want[..., :c0].cpu())
+    if c1:
+        assert rel_l2(dx1.cpu(), want[..., c0:].cpu()) < 2e-5
+    else:
+        assert dx1 is None
+    a0, _ = o.groupnorm_bwd(x0, x1, n, hw, groups, 1e-5, gamma, sc, sh, act, dy)
+    assert rel_l2(a0.cpu(), xr.grad[..., :c0].cpu()) < 2e-5
+
+
+def test_backward_data_movement_kernels():
+    o = ops()
+    x = rnd(2, 5, 6, 64, seed=1).half()
+    z = o.zero_insert2(x)
+    want = torch.zeros(2, 10, 12, 64, device=DEV, dtype=torch.float16)
+    want[:, ::2, ::2] = x
+    assert torch.equal(z, want)
+    g = rnd(2, 10, 12, 64, seed=2)
+    assert torch.allclose(o.sum2x2(g), g.reshape(2, 5, 2, 6, 2, 64).sum((2, 4)), atol=1e-6)
+    # pad / crop backward against autograd of the forward kernels' torch statements
+    for pad in (1, 2):
+        xr = rnd(2, 3, 8, 16, seed=3).requires_grad_(True)
+        yp = torch.cat([xr[:, :, -pad:], xr, xr[:, :, :pad]], 2)
+        assert torch.equal(o.pad_width(xr.detach(), pad), yp.detach())
+        dy = rnd(*yp.shape, seed=4)
+        yp.backward(dy)
+        assert torch.allclose(o.pad_width_bwd(dy, pad), xr.grad, atol=1e-6)
+        dyc = rnd(2, 3, 8 - 2 * pad, 16, seed=5)
+        assert torch.equal(o.crop_width_bwd(dyc, pad), F.pad(dyc, (0, 0, pad, pad)))
+
+
+@pytest.mark.parametrize("dtype", D16)
+def test_conv_data_gradients_through_the_forward_kernel(dtype):
+    """dgrad of the 3x3 / stride-2 / nearest-up convs = the forward GEMM kernel on flipped, transposed weights (+ zero insertion
+    / 2x2 sums), and of conv_out = the boundary conv kernel conv_in on rearranged weights: checked against autograd."""
+    from panfusion_amd import train_engine as TE
+    o = ops()
+    n, h, w, cin, cout = 2, 8, 12, 64, 128
+    wt = rnd(cout, cin, 3, 3, seed=1) * (9 * cin) ** -0.5
+    for mode in ("s1", "s2", "up"):
+        hin, win = (h, w) if mode != "up" else (h // 2, w // 2)
+        xr = rnd(n, cin, hin, win, seed=2).requires_grad_(True)
+        xi = F.interpolate(xr, scale_factor=2.0, mode="nearest") if mode == "up" else xr
+        y = F.conv2d(xi, wt, None, stride=2 if mode == "s2" else 1, padding=1)
+        dy = rnd(*y.shape, seed=3)
+        y.backward(dy)
+        dy_tok = dy.permute(0, 2, 3, 1).contiguous()
+        got = TE.conv3_dgrad(dy_tok, TE.flip_conv3_weight(wt, dtype), cin, mode, dtype)
+        err = rel_l2(got.permute(0, 3, 1, 2).cpu(), xr.grad.cpu())
+        assert got.shape == (n, hin, win, cin) and err < TOL[dtype], (mode, err)
+    # conv_out (C -> 4, pad 1, optional wrap)
+    wo, bo = rnd(4, 64, 3, 3, seed=4) * 0.05, rnd(4, seed=5)
+    for wrap in (False, True):
+        xr = rnd(n, 64, h, w, seed=6).requires_grad_(True)
+        xin = torch.cat([xr[..., -1:], xr, xr[..., :1]], -1) if wrap else xr
+        y = F.conv2d(xin, wo, bo, padding=1)
+        y = y[..., 1:-1] if wrap else y
+        dy = rnd(*y.shape, seed=7)
+        y.backward(dy)
+        got = TE.conv_out_dgrad(dy, TE.conv_out_dgrad_weight(wo), 64, wrap)
+        assert rel_l2(got.permute(0, 3, 1, 2).cpu(), xr.grad.cpu()) < 1e-5

@@ -146,3 +146,68 @@ def test_ddp_all_reduces_the_block_gradients(tmp_path):
         want = (singles[0][k] + singles[1][k]) / 2
         assert torch.equal(got[0][k], got[1][k])
         assert rel_l2(got[0][k], want) < 2e-5, (k, rel_l2(got[0][k], want))
+
+
+# ------------------------------------------------------------------------------------ the whole denoiser (host logic)
+DEN_MODS = MODS + ["panfusion_amd.train_engine"]
+
+
+@pytest.fixture
+def fake_denoiser_backend(monkeypatch):
+    for name in DEN_MODS:
+        monkeypatch.setattr(importlib.import_module(name), "ops", fake_ops)
+
+
+def _denoiser_case(seed=0):
+    from conftest import build_tiny_oracle, golden
+    g = golden("mvgen_tiny.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    oracle = build_tiny_oracle()
+    cams = {k: v[None] for k, v in cam4().items()}
+    args = (t("latents")[:1], t("pano_latent")[:1], torch.full((1, 4), 981), t("prompt_embd")[:1], t("pano_prompt_embd")[:1], cams)
+    gen = torch.Generator().manual_seed(seed)
+    w_s, w_p = torch.randn(args[0].shape, generator=gen), torch.randn(args[1].shape, generator=gen)
+    return oracle, args, w_s, w_p
+
+
+def test_denoiser_training_step_matches_autograd(fake_denoiser_backend):
+    """One training step of the dual-branch denoiser (forward on the engine, backward on train_engine's tape) against torch
+    autograd through the oracle denoiser (reference MultiViewBaseModel + EPA on the restated UNets with UNFUSED LoRA):
+    gradients of every EPA parameter and every LoRA matrix of both UNets.  fp32 test double: agreement at round-off."""
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    oracle, args, w_s, w_p = _denoiser_case()
+    s, ps = oracle(*args)
+    ((s * w_s).sum() + (ps * w_p).sum()).backward()
+    want = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None}
+    for p in oracle.parameters():
+        p.grad = None
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=torch.float32,
+                             precision="fast", differentiable=True)
+    hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    s2, ps2 = hip(*args)
+    assert s2.requires_grad and rel_l2(s2, s) < 2e-5 and rel_l2(ps2, ps) < 2e-5
+    ((s2 * w_s).sum() + (ps2 * w_p).sum()).backward()
+    got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    lora = [k for k in want if "lora" in k]
+    epa = [k for k in want if k.startswith("cp_blocks")]
+    assert len(lora) == 2 * 16 * 2 * 4 * 2 and len(epa) == 7 * 13        # 2 UNets x 16 blocks x 2 attentions x 4 projections x (down, up)
+    frozen = [k for k in got if k not in lora and k not in epa]
+    assert not frozen, frozen[:4]
+    worst = max((rel_l2(got[k], want[k]), k) for k in lora + epa)
+    print("worst gradient: %.2e at %s" % worst)
+    for k in lora + epa:
+        assert k in got, k
+        assert rel_l2(got[k], want[k]) < 1e-4, (k, rel_l2(got[k], want[k]))
+
+
+def test_denoiser_inference_is_untouched_by_the_training_switch(fake_denoiser_backend):
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    oracle, args, _, _ = _denoiser_case()
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=torch.float32,
+                             precision="fast", differentiable=True)
+    with torch.no_grad():
+        s, ps = hip(*args)
+    assert not s.requires_grad and s.grad_fn is None
+    hip.differentiable = False
+    s2, ps2 = hip(*args)
+    assert s2.grad_fn is None and torch.equal(s, s2) and torch.equal(ps, ps2)
