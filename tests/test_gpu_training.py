@@ -270,3 +270,44 @@ def test_conv_data_gradients_through_the_forward_kernel(dtype):
         y.backward(dy)
         got = TE.conv_out_dgrad(dy, TE.conv_out_dgrad_weight(wo), 64, wrap)
         assert rel_l2(got.permute(0, 3, 1, 2).cpu(), xr.grad.cpu()) < 1e-5
+
+
+def _tiny_denoiser(dtype, precision):
+    from conftest import build_tiny_oracle, golden
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    g = golden("mvgen_tiny.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    oracle = build_tiny_oracle()
+    cams = {k: v[None] for k, v in cam4().items()}
+    args = (t("latents")[:1], t("pano_latent")[:1], torch.full((1, 4), 981), t("prompt_embd")[:1], t("pano_prompt_embd")[:1], cams)
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=dtype, precision=precision,
+                             differentiable=True)
+    hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    return oracle, hip, args
+
+
+@pytest.mark.parametrize("dtype,precision,tol_out,tol_grad", [(torch.float16, "mixed", 1e-3, 1e-2), (torch.bfloat16, "fast", 2e-2, 1e-1)])
+def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, tol_grad):
+    """One training step of the dual-branch denoiser on the GPU (tiny widths, 4 views of 16^2, panorama 16x32, one sample) against
+    torch autograd through the oracle denoiser on the CPU: the two outputs, and the gradient of an MSE-like loss with
+    respect to every EPA tensor and every LoRA matrix (347 tensors).  Gradients are compared per tensor and as one vector."""
+    oracle, hip, args = _tiny_denoiser(dtype, precision)
+    gen = torch.Generator().manual_seed(5)
+    w_s, w_p = torch.randn(args[0].shape, generator=gen) * 1e-4, torch.randn(args[1].shape, generator=gen) * 1e-4
+    s, ps = oracle(*args)
+    ((s * w_s).sum() + (ps * w_p).sum()).backward()
+    want = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None}
+    for p in oracle.parameters():
+        p.grad = None
+    dev_args = tuple(a.to(DEV) if isinstance(a, torch.Tensor) else a for a in args)
+    s2, ps2 = hip(*dev_args)
+    eo = max(rel_l2(s2.detach().cpu(), s.detach()), rel_l2(ps2.detach().cpu(), ps.detach()))
+    ((s2 * w_s.to(DEV)).sum() + (ps2 * w_p.to(DEV)).sum()).backward()
+    got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    keys = [k for k in want if "lora" in k or k.startswith("cp_blocks")]
+    assert len(keys) == 256 + 91 and all(k in got for k in keys)
+    errs = sorted(((rel_l2(got[k].cpu().float(), want[k]), k) for k in keys), reverse=True)
+    allg = rel_l2(torch.cat([got[k].cpu().float().flatten() for k in keys]), torch.cat([want[k].flatten() for k in keys]))
+    print("\noutputs %.2e   all gradients as one vector %.2e   worst tensors: %s"
+          % (eo, allg, "  ".join("%.1e %s" % (e, k.replace("transformer_blocks.0.", "").replace(".lora_layer", "")) for e, k in errs[:4])))
+    assert eo < tol_out and allg < tol_grad and errs[0][0] < 4 * tol_grad, (eo, allg, errs[:4])
