@@ -64,6 +64,10 @@ def weight_grad(dy16, x16):
     token-contiguous (the reduction axis of the MFMA GEMM) by a transpose pass."""
     T, N = dy16.shape
     K = x16.shape[1]
+    if T % 64:                        # the GEMM's reduction length is a multiple of 64: zero rows change nothing
+        Tp = (T + 63) // 64 * 64
+        pad = lambda t: torch.cat([t, torch.zeros(Tp - T, t.shape[1], device=t.device, dtype=t.dtype)], 0)
+        dy16, x16, T = pad(dy16), pad(x16), Tp
     dyt = ops.transpose_tokens(dy16.view(1, T, N)).view(N, T)
     xt = ops.transpose_tokens(x16.view(1, T, K)).view(K, T)
     return ops.conv_gemm(dyt, xt, K, w_in=N, out_dtype=torch.float32)
