@@ -51,6 +51,7 @@ def pack_epa_train(block, dev, dtype):
     e.heads = e.dim // 32
     wqkv = torch.cat([w(a.to_q.weight), w(a.to_k.weight), w(a.to_v.weight)], 0)
     e.wqkv, e.wqkv_t = f16(wqkv), f16(wqkv.t())
+    e.wv = f16(w(a.to_v.weight))
     e.wo, e.wo_t, e.bo = f16(w(a.to_out.weight)), f16(w(a.to_out.weight).t()), w(a.to_out.bias).contiguous()
     e.w1, e.w1_t, e.b1 = f16(w(ff[0].proj.weight)), f16(w(ff[0].proj.weight).t()), w(ff[0].proj.bias).contiguous()
     e.w2, e.w2_t, e.b2 = f16(w(ff[2].weight)), f16(w(ff[2].weight).t()), w(ff[2].bias).contiguous()
@@ -102,15 +103,25 @@ def epa_recompute(e, tables, xe, xp, b, m):
     lse_e = torch.empty(b, H, E, device=x.device, dtype=torch.float32)
     lse_p = torch.empty(b, H, mP, device=x.device, dtype=torch.float32)
     ld = 3 * Cc
+
+    def values_t(qkvt_seg, ln_seg, n_tok):
+        """V^T [b, C, ld] for the forward kernel: a row slice of the (q | k | v) transpose, or -- token counts that are
+        not multiples of 32 (tiny test geometries) -- the transposed projection with rows padded to 32 keys."""
+        if n_tok % 32 == 0:
+            return qkvt_seg[:, 2 * Cc:], n_tok, ld * n_tok
+        vt = ops.linear_t(ln_seg.view(b, n_tok, Cc), e.wv)
+        return vt, vt.shape[-1], vt.shape[1] * vt.shape[2]
+    vt_p, vt_p_ld, vt_p_bs = values_t(qkvt_p, ln[Te:], mP)
+    vt_e, vt_e_ld, vt_e_bs = values_t(qkvt_e, ln[:Te], E)
     for i, n, t in _attention_calls(b, s.shared, tables):
         sl = slice(i, i + n)
         # panorama pixels query the views (modules.py:43-48) ...
-        ops.attention(qkv_e[sl, :, :Cc], qkv_p[sl, :, Cc:2 * Cc], qkvt_p[sl, 2 * Cc:], n, H, 32, E, mP,
-                      q_ld=ld, k_ld=ld, vt_ld=mP, q_bs=E * ld, k_bs=mP * ld, vt_bs=ld * mP,
+        ops.attention(qkv_e[sl, :, :Cc], qkv_p[sl, :, Cc:2 * Cc], vt_p[sl], n, H, 32, E, mP,
+                      q_ld=ld, k_ld=ld, vt_ld=vt_p_ld, q_bs=E * ld, k_bs=mP * ld, vt_bs=vt_p_bs,
                       bias=t.bias_e, flags=t.flags_e, out=a_e[sl], lse=lse_e[sl])
         # ... and the views query the panorama (modules.py:50-55)
-        ops.attention(qkv_p[sl, :, :Cc], qkv_e[sl, :, Cc:2 * Cc], qkvt_e[sl, 2 * Cc:], n, H, 32, mP, E,
-                      q_ld=ld, k_ld=ld, vt_ld=E, q_bs=mP * ld, k_bs=E * ld, vt_bs=ld * E,
+        ops.attention(qkv_p[sl, :, :Cc], qkv_e[sl, :, Cc:2 * Cc], vt_e[sl], n, H, 32, mP, E,
+                      q_ld=ld, k_ld=ld, vt_ld=vt_e_ld, q_bs=mP * ld, k_bs=E * ld, vt_bs=vt_e_bs,
                       bias=t.bias_p, flags=t.flags_p, out=a_p[sl], lse=lse_p[sl])
     y = ops.linear(a, e.wo, bias=e.bo, residual=x)                       # stream dtype of x
     z = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps, out_dtype=e.dtype)
