@@ -462,7 +462,7 @@ class ParamGrads:
 
     def get(self, param):
         hit = self.grads.get(id(param))
-        return None if hit is None else hit[1].to(param.dtype)
+        return None if hit is None else hit[1].to(device=param.device, dtype=param.dtype)      # (modules may live on the host)
 
 
 def backward(tape, d_eps, sink):
