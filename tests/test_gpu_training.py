@@ -290,7 +290,7 @@ def _tiny_denoiser(dtype, precision):
 def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, tol_grad):
     """One training step of the dual-branch denoiser on the GPU (tiny widths, 4 views of 16^2, panorama 16x32, one sample) against
     torch autograd through the oracle denoiser on the CPU: the two outputs, and the gradient of an MSE-like loss with
-    respect to every EPA tensor and every LoRA matrix (347 tensors).  Gradients are compared per tensor and as one vector."""
+    respect to every EPA tensor and every LoRA matrix (603 tensors).  Gradients are compared per tensor and as one vector."""
     oracle, hip, args = _tiny_denoiser(dtype, precision)
     gen = torch.Generator().manual_seed(5)
     w_s, w_p = torch.randn(args[0].shape, generator=gen) * 1e-4, torch.randn(args[1].shape, generator=gen) * 1e-4
@@ -305,7 +305,7 @@ def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, to
     ((s2 * w_s.to(DEV)).sum() + (ps2 * w_p.to(DEV)).sum()).backward()
     got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
     keys = [k for k in want if "lora" in k or k.startswith("cp_blocks")]
-    assert len(keys) == 256 + 91 and all(k in got for k in keys)
+    assert len(keys) == 512 + 91 and all(k in got for k in keys)
     errs = sorted(((rel_l2(got[k].cpu().float(), want[k]), k) for k in keys), reverse=True)
     allg = rel_l2(torch.cat([got[k].cpu().float().flatten() for k in keys]), torch.cat([want[k].flatten() for k in keys]))
     print("\noutputs %.2e   all gradients as one vector %.2e   worst tensors: %s"
