@@ -279,6 +279,7 @@ def _tiny_denoiser(dtype, precision):
     t = lambda k: torch.from_numpy(g[k])
     oracle = build_tiny_oracle()
     cams = {k: v[None] for k, v in cam4().items()}
+    cams["theta"], cams["phi"] = cams["theta"] + 7.3, cams["phi"] + 3.1     # generic angles (see the C = 320 note above: PE up to 2^63 here)
     args = (t("latents")[:1], t("pano_latent")[:1], torch.full((1, 4), 981), t("prompt_embd")[:1], t("pano_prompt_embd")[:1], cams)
     hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=dtype, precision=precision,
                              differentiable=True)
