@@ -287,7 +287,7 @@ def _tiny_denoiser(dtype, precision):
     return oracle, hip, args
 
 
-@pytest.mark.parametrize("dtype,precision,tol_out,tol_grad", [(torch.float16, "mixed", 1e-3, 1e-2), (torch.bfloat16, "fast", 2e-2, 1e-1)])
+@pytest.mark.parametrize("dtype,precision,tol_out,tol_grad", [(torch.float16, "mixed", 1e-3, 3e-3), (torch.bfloat16, "fast", 2e-2, 4e-2)])
 def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, tol_grad):
     """One training step of the dual-branch denoiser on the GPU (tiny widths, 4 views of 16^2, panorama 16x32, one sample) against
     torch autograd through the oracle denoiser on the CPU: the two outputs, and the gradient of an MSE-like loss with
