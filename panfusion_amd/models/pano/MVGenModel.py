@@ -126,12 +126,23 @@ class MultiViewBaseModel(nn.Module):
                 return train_engine.DenoiserFunction.apply(self, args, *params)
         return self._forward(*args)
 
+    @torch.no_grad()
     def refold_lora(self):
-        """Re-pack the UNets when a LoRA matrix changed since the last pack (optimizer steps bump the version counters):
-        the forward kernels read W + up @ down folded into one 16-bit weight."""
+        """Bring the packed attention projections up to date when a LoRA matrix changed since the last call (optimizer
+        steps bump the version counters): the forward kernels read W + up @ down folded into one 16-bit weight.  Only
+        the 4 x 32 projections per UNet are re-folded; the frozen weights (and the backward operands train_engine keeps
+        next to them) stay."""
         key = tuple(t._version for t in self.trainable_tensors())
         if getattr(self, "_lora_key", key) != key:
-            self._packed.clear()
+            for (which, *_), u in self._packed.items():
+                if which.endswith("_cn"):
+                    continue
+                for t in engine.all_transformers(u):
+                    blk = t.src.transformer_blocks[0]
+                    dev = t.w_in.device
+                    t.attn1 = engine.pack_attention(blk.attn1, dev, t.dtype, True)
+                    t.attn2 = engine.pack_attention(blk.attn2, dev, t.dtype, False)
+                u.__dict__.pop("text_kv_cache", None)          # K / V^T of the prompt depend on to_k / to_v
         self._lora_key = key
 
     @torch.no_grad()

@@ -211,3 +211,27 @@ def test_denoiser_inference_is_untouched_by_the_training_switch(fake_denoiser_ba
     hip.differentiable = False
     s2, ps2 = hip(*args)
     assert s2.grad_fn is None and torch.equal(s, s2) and torch.equal(ps, ps2)
+
+
+def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_backend):
+    """After an optimizer step on the LoRA matrices the next forward must see W + up' @ down' (re-folded attention
+    projections, text K / V cache dropped) -- and nothing else is re-packed."""
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    oracle, args, w_s, w_p = _denoiser_case()
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=torch.float32,
+                             precision="fast", differentiable=True)
+    hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    opt = torch.optim.SGD(hip.trainable_tensors(), lr=0.5)
+    s0, ps0 = hip(*args)
+    ((s0 * w_s).sum() + (ps0 * w_p).sum()).backward()
+    pack_before = hip.packed("unet", args[1].device)
+    res_before = pack_before.down[0].resnets[0].train
+    opt.step()                                            # oracle shares the UNet modules: it steps with it
+    for name in ("cp_blocks_encoder", "cp_blocks_mid", "cp_blocks_decoder"):
+        getattr(oracle, name).load_state_dict(getattr(hip, name).state_dict())
+    with torch.no_grad():
+        want_s, want_ps = oracle(*args)
+    s1, ps1 = hip(*args)
+    assert rel_l2(want_s, s0.detach()) > 1e-3                      # the step moved the outputs
+    assert rel_l2(s1.detach(), want_s) < 5e-5 and rel_l2(ps1.detach(), want_ps) < 5e-5
+    assert hip.packed("unet", args[1].device) is pack_before and pack_before.down[0].resnets[0].train is res_before
