@@ -351,6 +351,10 @@ pf_status pf_sum2x2(const float* x, int n, int h, int w, int C, float* y, void* 
 pf_status pf_pad_width_bwd(const float* dy, int n, int h, int w, int C, int pad, float* dx, void* stream);
 pf_status pf_crop_width_bwd(const float* dy, int n, int h, int w, int C, int crop, float* dx, void* stream);
 
+/* x [B][T][C] -> y [B][C][T] (16-bit): the token-contiguous operand layout of the products that reduce over tokens
+ * (attention backward, weight gradients).  C % 4 == 0. */
+pf_status pf_transpose_tokens(const void* x, int dtype, int B, long T, int C, void* y, void* stream);
+
 /* GEGLU backward: u [rows][2*inner] = [a | gate] (forward input of pf_geglu), dg [rows][inner] ->
  * du [rows][2*inner] = [dg * gelu(gate) | dg * a * gelu'(gate)]. */
 pf_status pf_geglu_bwd(const void* u, const void* dg, int dtype, long rows, int inner, void* du, void* stream);

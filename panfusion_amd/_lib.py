@@ -125,6 +125,7 @@ SIGNATURES = {
     "pf_sum2x2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_pad_width_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_crop_width_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_transpose_tokens": (c_int, [c_void_p, c_int, c_int, c_long, c_int, c_void_p, c_void_p]),
     "pf_geglu_bwd": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_void_p]),
     "pf_colsum_workspace_size": (c_size_t, [c_long, c_int]),
     "pf_colsum": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -583,6 +583,39 @@ __global__ void k_crop_width_bwd(const float4* __restrict__ dy, long rows, int w
     dx[i] = a;
 }
 
+// ---- token transpose ----------------------------------------------------------------------------------------------
+// x [B][T][C] -> y [B][C][T] for 16-bit elements: 64 x 64 tiles through LDS, 8-byte accesses on both sides
+// (the generic permute kernel moves single elements: one side of it is strided by the row length).
+__global__ __launch_bounds__(256) void k_transpose16(const unsigned short* __restrict__ x, long T, int C, unsigned short* __restrict__ y) {
+    __shared__ unsigned short tile[64][64 + 4];
+    const long b = blockIdx.z;
+    const long t0 = blockIdx.x * 64L;
+    const int c0 = blockIdx.y * 64;
+    const unsigned short* xb = x + b * T * C;
+    unsigned short* yb = y + b * T * C;
+    const int q = threadIdx.x & 15, r = threadIdx.x >> 4;          // 16 quads per 64-element row, 16 rows per pass
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long t = t0 + r + 16 * p;
+        const int c = c0 + 4 * q;
+        u16x4 v = {0, 0, 0, 0};
+        if (t < T && c + 3 < C) v = *reinterpret_cast<const u16x4*>(xb + t * C + c);
+        else if (t < T) { for (int e = 0; e < 4; ++e) if (c + e < C) v[e] = xb[t * C + c + e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[4 * q + e][r + 16 * p] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = c0 + r + 16 * p;
+        const long t = t0 + 4 * q;
+        if (c >= C) continue;
+        const unsigned short* src = &tile[r + 16 * p][4 * q];
+        if (t + 3 < T && (T & 3) == 0) *reinterpret_cast<u16x4*>(yb + static_cast<long>(c) * T + t) = u16x4{src[0], src[1], src[2], src[3]};
+        else { for (int e = 0; e < 4; ++e) if (t + e < T) yb[static_cast<long>(c) * T + t + e] = src[e]; }
+    }
+}
+
 // ---- GEGLU backward -----------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void k_geglu_bwd(const unsigned short* __restrict__ u, const unsigned short* __restrict__ dg, long total_oct,
@@ -634,18 +667,29 @@ __global__ void k_colsum_final(const float* __restrict__ part, int slabs, int N,
 }
 
 // ---- gradient normalisation ---------------------------------------------------------------------------------------
-__global__ void k_amax(const float* __restrict__ x, long n, unsigned* __restrict__ state) {
+__global__ __launch_bounds__(256) void k_amax(const float* __restrict__ x, long n, unsigned* __restrict__ state) {
+    __shared__ float red[4];
     float m = 0.f;
-    for (long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * blockDim.x) {
-        const float a = fabsf(x[i]);
-        m = (a > m || a != a) ? a : m;                 // NaN propagates into the maximum (-> scale 1 downstream)
+    const long n4 = n / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    auto take = [&](float a) { a = fabsf(a); m = (a > m || a != a) ? a : m; };      // NaN propagates into the maximum (-> scale 1 downstream)
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) {
+        const float4 v = x4[i];
+        take(v.x); take(v.y); take(v.z); take(v.w);
     }
+    if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) take(x[4 * n4 + threadIdx.x]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float w = __shfl_xor(m, o);
         m = (w > m || w != w) ? w : m;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(state, __float_as_uint(m));     // |x| >= 0: the bit pattern orders like the value (NaN > inf)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {                            // one atomic per block (4096 per launch serialised on one address before)
+#pragma unroll
+        for (int i = 1; i < 4; ++i) m = (red[i] > m || red[i] != red[i]) ? red[i] : m;
+        atomicMax(state, __float_as_uint(m));          // |x| >= 0: the bit pattern orders like the value (NaN > inf)
+    }
 }
 
 __global__ void k_pow2_scale(float* state) {
@@ -797,8 +841,9 @@ extern "C" pf_status pf_amax_f32(const float* x, long n, float* state, int reset
         pf::set_error("pf_amax_f32: clearing the state failed");
         return PF_ERR_LAUNCH;
     }
-    const long blocks = std::min<long>(1024, cdiv(n, 256));
-    hipLaunchKernelGGL(k_amax, dim3(blocks), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(state));
+    PF_REQUIRE(aligned16(x), "pf_amax_f32: x must be 16-byte aligned");
+    const long blocks = std::min<long>(512, cdiv(n, 1024));
+    hipLaunchKernelGGL(k_amax, dim3(std::max<long>(1, blocks)), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(state));
     PF_CHECK_LAUNCH("pf_amax_f32");
     return PF_OK;
 }
@@ -913,5 +958,16 @@ extern "C" pf_status pf_crop_width_bwd(const float* dy, int n, int h, int w, int
     hipLaunchKernelGGL(k_crop_width_bwd, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(dy), rows, w, crop,
                        C / 4, reinterpret_cast<float4*>(dx));
     PF_CHECK_LAUNCH("pf_crop_width_bwd");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_transpose_tokens(const void* x, int dtype, int B, long T, int C, void* y, void* stream) {
+    PF_REQUIRE(x && y && x != y && B > 0 && T > 0 && C > 0, "pf_transpose_tokens: bad arguments");
+    PF_REQUIRE(dtype == PF_F16 || dtype == PF_BF16, "pf_transpose_tokens: 16-bit tensors only");
+    PF_REQUIRE(C % 4 == 0 && aligned16(x) && aligned16(y), "pf_transpose_tokens: C must be a multiple of 4, pointers 16-byte aligned");
+    PF_REQUIRE(B <= 65535 && cdiv(C, 64) <= 65535, "pf_transpose_tokens: too many batches / channel tiles");
+    hipLaunchKernelGGL(k_transpose16, dim3(cdiv(T, 64), cdiv(C, 64), B), dim3(256), 0, as_stream(stream), static_cast<const unsigned short*>(x), T, C,
+                       static_cast<unsigned short*>(y));
+    PF_CHECK_LAUNCH("pf_transpose_tokens");
     return PF_OK;
 }

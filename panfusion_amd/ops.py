@@ -448,7 +448,10 @@ def transpose_tokens(x, out=None):
     B, T, Cc = x.shape
     if out is None:
         out = torch.empty(B, Cc, T, device=x.device, dtype=x.dtype)
-    check(_lib.lib().pf_nhwc_to_nchw(_p(x), dt(x), B, Cc, 1, T, dt(out), _p(out), _stream()), "pf_nhwc_to_nchw")
+    if x.dtype == torch.float32:
+        check(_lib.lib().pf_nhwc_to_nchw(_p(x), dt(x), B, Cc, 1, T, dt(out), _p(out), _stream()), "pf_nhwc_to_nchw")
+    else:
+        check(_lib.lib().pf_transpose_tokens(_p(x), dt(x), B, T, Cc, _p(out), _stream()), "pf_transpose_tokens")
     return out
 
 

@@ -312,3 +312,10 @@ def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, to
     print("\noutputs %.2e   all gradients as one vector %.2e   worst tensors: %s"
           % (eo, allg, "  ".join("%.1e %s" % (e, k.replace("transformer_blocks.0.", "").replace(".lora_layer", "")) for e, k in errs[:4])))
     assert eo < tol_out and allg < tol_grad and errs[0][0] < 4 * tol_grad, (eo, allg, errs[:4])
+
+
+@pytest.mark.parametrize("dtype", D16)
+@pytest.mark.parametrize("B,T,Cc", [(2, 128, 64), (3, 1000, 320), (1, 77, 1028), (1, 20480, 960), (2, 16, 192)])
+def test_transpose_tokens(dtype, B, T, Cc):
+    x = rnd(B, T, Cc, seed=1).to(dtype)
+    assert torch.equal(ops().transpose_tokens(x), x.transpose(1, 2).contiguous())
