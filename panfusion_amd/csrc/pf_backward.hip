@@ -13,6 +13,7 @@
 //   GEGLU backward, column sums (bias gradients), gradient normalisation (amax -> power-of-two scale).
 #include "pf_common.h"
 #include <algorithm>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace pf {
@@ -263,6 +264,334 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnBwdParams p) {
             }
             *reinterpret_cast<u16x4*>(okp + d * 32 + 8 * g + 4 * hi) = wk;
             *reinterpret_cast<u16x4*>(ovp + d * 32 + 8 * g + 4 * hi) = wv;
+        }
+}
+
+// ---- LDS-staged variants (token counts that are multiples of 32) ----------------------------------------------------
+// Same math and register layout; the tile every wavefront of the block walks past (32 tokens of the OTHER side: rows and
+// their transposes) is fetched once per block with coalesced 16-byte loads, staged through LDS and shared by the four
+// waves, double buffered with the next tile's global loads in flight during the MFMAs (one barrier per tile).  The direct
+// kernels issue fragment-shaped loads (32 cache lines per instruction) from every wave.
+//   row-major tiles [32][D] with rows padded to D + 8 elements (fragment reads: 16 bytes per lane, rows 144 / 80 bytes apart)
+//   transposed tiles [D][32] with rows padded to 36 elements (two 8-byte reads per lane, rows 72 bytes apart)
+template <int D> struct BwdTile {
+    static constexpr int RS = D + 8, TS = 32 + 4;
+    static constexpr int ROWMAJ = 32 * RS, TRANS = D * TS;
+    static constexpr int CH_R = 32 * (D / 8), CH_T = D * 4;      // 16-byte chunks per row-major / transposed tile
+};
+
+__device__ __forceinline__ u16x8 lds_t_frag(const unsigned short* row, int s2, int hi) {
+    const unsigned short* pp = row + 16 * s2 + 4 * hi;
+    const u16x4 lo = *reinterpret_cast<const u16x4*>(pp);
+    const u16x4 up = *reinterpret_cast<const u16x4*>(pp + 8);
+    return u16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(const AttnBwdParams p) {
+    constexpr int KS = D / 16, DB = D / 32;
+    typedef BwdTile<D> TL;
+    typedef typename Mfma32<T>::frag frag;
+    constexpr int BUF = 2 * TL::ROWMAJ + 2 * TL::TRANS;          // Q rows | dO rows | Q^T | dO^T
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int kl = lane & 31, hi = lane >> 5;
+    const int k0 = (blockIdx.x * 4 + wave) * 32;
+    const bool live = k0 < p.nk;                                   // (a block's trailing waves still help staging)
+    const int h = blockIdx.y;
+    const long b = blockIdx.z;
+    const int krow = live ? k0 + kl : p.nk - 1;
+    const unsigned short* kp = p.k + b * p.k_bs + static_cast<long>(krow) * p.k_ld + h * D;
+    const unsigned short* vp = p.v + b * p.v_bs + static_cast<long>(krow) * p.v_ld + h * D;
+    const unsigned short* qp = p.q + b * p.q_bs + h * D;
+    const unsigned short* dop = p.dout + b * p.do_bs + h * D;
+    const unsigned short* qtp = p.qt + b * p.qt_bs + static_cast<long>(h) * D * p.qt_ld;
+    const unsigned short* dotp = p.dot + b * p.dot_bs + static_cast<long>(h) * D * p.dot_ld;
+
+    frag kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        kf[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(kp + 16 * s + 8 * hi));
+        vf[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(vp + 16 * s + 8 * hi));
+    }
+    const float c2 = p.scale_log2e;
+    const float* lsep = p.lse + (b * p.H + h) * p.nq;
+    const float* delp = p.delta + (b * p.H + h) * p.nq;
+    f32x16 acc_k[DB], acc_v[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_k[d][r] = 0.f; acc_v[d][r] = 0.f; }
+
+    // staging ownership: row-major chunk c -> (row c / (D/8), 8 channels at (c % (D/8)) * 8); transposed chunk c -> (row c / 4, 8 tokens at (c % 4) * 8)
+    constexpr int NR = (TL::CH_R + 255) / 256, NT = (TL::CH_T + 255) / 256;
+    u16x8 rq[NR], rdo[NR], rqt[NT], rdot[NT];
+    auto stage_load = [&](int qt_) {
+        const int q0 = qt_ * 32;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int c = t + 256 * i;
+            if (c < TL::CH_R) {
+                const int row = c / (D / 8), ch = (c % (D / 8)) * 8;
+                rq[i] = *reinterpret_cast<const u16x8*>(qp + static_cast<long>(q0 + row) * p.q_ld + ch);
+                rdo[i] = *reinterpret_cast<const u16x8*>(dop + static_cast<long>(q0 + row) * p.do_ld + ch);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int c = t + 256 * i;
+            if (c < TL::CH_T) {
+                const int row = c >> 2, tk = (c & 3) * 8;
+                rqt[i] = *reinterpret_cast<const u16x8*>(qtp + static_cast<long>(row) * p.qt_ld + q0 + tk);
+                rdot[i] = *reinterpret_cast<const u16x8*>(dotp + static_cast<long>(row) * p.dot_ld + q0 + tk);
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+        unsigned short* Q = smem + buf * BUF;
+        unsigned short* DO = Q + TL::ROWMAJ;
+        unsigned short* QT = DO + TL::ROWMAJ;
+        unsigned short* DOT = QT + TL::TRANS;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int c = t + 256 * i;
+            if (c < TL::CH_R) {
+                const int off = (c / (D / 8)) * TL::RS + (c % (D / 8)) * 8;
+                *reinterpret_cast<u16x8*>(Q + off) = rq[i];
+                *reinterpret_cast<u16x8*>(DO + off) = rdo[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int c = t + 256 * i;
+            if (c < TL::CH_T) {
+                const int off = (c >> 2) * TL::TS + (c & 3) * 8;          // 8-byte aligned (72-byte rows)
+                const u16x8 a = rqt[i], d = rdot[i];
+                *reinterpret_cast<u16x4*>(QT + off) = u16x4{a[0], a[1], a[2], a[3]};
+                *reinterpret_cast<u16x4*>(QT + off + 4) = u16x4{a[4], a[5], a[6], a[7]};
+                *reinterpret_cast<u16x4*>(DOT + off) = u16x4{d[0], d[1], d[2], d[3]};
+                *reinterpret_cast<u16x4*>(DOT + off + 4) = u16x4{d[4], d[5], d[6], d[7]};
+            }
+        }
+    };
+
+    const int kt = k0 >> 5;
+    const int nqt = p.nq / 32;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int qt = 0; qt < nqt; ++qt) {
+        if (qt + 1 < nqt) stage_load(qt + 1);
+        if (live) {
+            const int q0 = qt * 32;
+            const unsigned short* Q = smem + (qt & 1) * BUF;
+            const unsigned short* DO = Q + TL::ROWMAJ;
+            const unsigned short* QT = DO + TL::ROWMAJ;
+            const unsigned short* DOT = QT + TL::TRANS;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u16x8 qf = *reinterpret_cast<const u16x8*>(Q + kl * TL::RS + 16 * ks + 8 * hi);
+                const u16x8 df = *reinterpret_cast<const u16x8*>(DO + kl * TL::RS + 16 * ks + 8 * hi);
+                s = Mfma32<T>::run(__builtin_bit_cast(frag, qf), kf[ks], s);
+                dp = Mfma32<T>::run(__builtin_bit_cast(frag, df), vf[ks], dp);
+            }
+            float sv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = s[r] * c2;
+            if (p.flags && p.flags[static_cast<long>(qt) * p.flags_ld + kt]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    sv[r] += p.bias[static_cast<long>(qi) * p.bias_ld + k0 + kl] * LOG2E;
+                }
+            }
+            u16x8 pp[2], pd[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 l4 = *reinterpret_cast<const float4*>(lsep + q0 + 8 * g + 4 * hi);
+                const float4 d4 = *reinterpret_cast<const float4*>(delp + q0 + 8 * g + 4 * hi);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float pr = exp2f(sv[r] - lv[e]);
+                    pp[r >> 3][r & 7] = from_f32<T>(pr);
+                    pd[r >> 3][r & 7] = from_f32<T>(pr * (dp[r] - dv[e]));
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const u16x8 a_do = lds_t_frag(DOT + (d * 32 + kl) * TL::TS, s2, hi);
+                    const u16x8 a_q = lds_t_frag(QT + (d * 32 + kl) * TL::TS, s2, hi);
+                    acc_v[d] = Mfma32<T>::run(__builtin_bit_cast(frag, a_do), __builtin_bit_cast(frag, pp[s2]), acc_v[d]);
+                    acc_k[d] = Mfma32<T>::run(__builtin_bit_cast(frag, a_q), __builtin_bit_cast(frag, pd[s2]), acc_k[d]);
+                }
+        }
+        if (qt + 1 < nqt) stage_store((qt + 1) & 1);      // that buffer was last read in step qt - 1: every wave passed the barrier since
+        __syncthreads();
+    }
+    if (!live) return;
+    unsigned short* okp = p.dk + b * p.dk_bs + static_cast<long>(k0 + kl) * p.dk_ld + h * D;
+    unsigned short* ovp = p.dv + b * p.dv_bs + static_cast<long>(k0 + kl) * p.dv_ld + h * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u16x4 wk, wv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wk[e] = from_f32<T>(acc_k[d][4 * g + e] * p.scale);
+                wv[e] = from_f32<T>(acc_v[d][4 * g + e]);
+            }
+            *reinterpret_cast<u16x4*>(okp + d * 32 + 8 * g + 4 * hi) = wk;
+            *reinterpret_cast<u16x4*>(ovp + d * 32 + 8 * g + 4 * hi) = wv;
+        }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq_lds(const AttnBwdParams p) {
+    constexpr int KS = D / 16, DB = D / 32;
+    typedef BwdTile<D> TL;
+    typedef typename Mfma32<T>::frag frag;
+    constexpr int BUF = 2 * TL::ROWMAJ + TL::TRANS;              // K rows | V rows | K^T
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ql = lane & 31, hi = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bool live = q0 < p.nq;
+    const int h = blockIdx.y;
+    const long b = blockIdx.z;
+    const int qrow = live ? q0 + ql : p.nq - 1;
+    const unsigned short* qp = p.q + b * p.q_bs + static_cast<long>(qrow) * p.q_ld + h * D;
+    const unsigned short* dop = p.dout + b * p.do_bs + static_cast<long>(qrow) * p.do_ld + h * D;
+    const unsigned short* kp = p.k + b * p.k_bs + h * D;
+    const unsigned short* vp = p.v + b * p.v_bs + h * D;
+    const unsigned short* ktp = p.kt + b * p.kt_bs + static_cast<long>(h) * D * p.kt_ld;
+
+    frag qf[KS], dof[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        qf[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(qp + 16 * s + 8 * hi));
+        dof[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(dop + 16 * s + 8 * hi));
+    }
+    const long stat = (b * p.H + h) * p.nq + qrow;
+    const float lse = p.lse[stat], delta = p.delta[stat];
+    const float c2 = p.scale_log2e;
+    f32x16 acc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+    constexpr int NR = (TL::CH_R + 255) / 256, NT = (TL::CH_T + 255) / 256;
+    u16x8 rk[NR], rv[NR], rkt[NT];
+    auto stage_load = [&](int kt_) {
+        const int k0 = kt_ * 32;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int c = t + 256 * i;
+            if (c < TL::CH_R) {
+                const int row = c / (D / 8), ch = (c % (D / 8)) * 8;
+                rk[i] = *reinterpret_cast<const u16x8*>(kp + static_cast<long>(k0 + row) * p.k_ld + ch);
+                rv[i] = *reinterpret_cast<const u16x8*>(vp + static_cast<long>(k0 + row) * p.v_ld + ch);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int c = t + 256 * i;
+            if (c < TL::CH_T) rkt[i] = *reinterpret_cast<const u16x8*>(ktp + static_cast<long>(c >> 2) * p.kt_ld + k0 + (c & 3) * 8);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        unsigned short* K = smem + buf * BUF;
+        unsigned short* V = K + TL::ROWMAJ;
+        unsigned short* KT = V + TL::ROWMAJ;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int c = t + 256 * i;
+            if (c < TL::CH_R) {
+                const int off = (c / (D / 8)) * TL::RS + (c % (D / 8)) * 8;
+                *reinterpret_cast<u16x8*>(K + off) = rk[i];
+                *reinterpret_cast<u16x8*>(V + off) = rv[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int c = t + 256 * i;
+            if (c < TL::CH_T) {
+                const int off = (c >> 2) * TL::TS + (c & 3) * 8;
+                const u16x8 a = rkt[i];
+                *reinterpret_cast<u16x4*>(KT + off) = u16x4{a[0], a[1], a[2], a[3]};
+                *reinterpret_cast<u16x4*>(KT + off + 4) = u16x4{a[4], a[5], a[6], a[7]};
+            }
+        }
+    };
+
+    const uint8_t* flag_row = p.flags ? p.flags + static_cast<long>(min(q0, p.nq - 32) >> 5) * p.flags_ld : nullptr;
+    const float* bias_row = p.bias ? p.bias + static_cast<long>(qrow) * p.bias_ld : nullptr;
+    const int nkt = p.nk / 32;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) stage_load(kt + 1);
+        if (live) {
+            const int k0 = kt * 32;
+            const unsigned short* K = smem + (kt & 1) * BUF;
+            const unsigned short* V = K + TL::ROWMAJ;
+            const unsigned short* KT = V + TL::ROWMAJ;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u16x8 kf = *reinterpret_cast<const u16x8*>(K + ql * TL::RS + 16 * ks + 8 * hi);
+                const u16x8 vf = *reinterpret_cast<const u16x8*>(V + ql * TL::RS + 16 * ks + 8 * hi);
+                s = Mfma32<T>::run(__builtin_bit_cast(frag, kf), qf[ks], s);
+                dp = Mfma32<T>::run(__builtin_bit_cast(frag, vf), dof[ks], dp);
+            }
+            float sv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = s[r] * c2;
+            if (flag_row && flag_row[kt]) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias_row + k0 + 8 * g + 4 * hi);
+                    sv[4 * g + 0] += bv.x * LOG2E;
+                    sv[4 * g + 1] += bv.y * LOG2E;
+                    sv[4 * g + 2] += bv.z * LOG2E;
+                    sv[4 * g + 3] += bv.w * LOG2E;
+                }
+            }
+            u16x8 pb[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = from_f32<T>(exp2f(sv[r] - lse) * (dp[r] - delta));
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const u16x8 a = lds_t_frag(KT + (d * 32 + ql) * TL::TS, s2, hi);
+                    acc[d] = Mfma32<T>::run(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, pb[s2]), acc[d]);
+                }
+        }
+        if (kt + 1 < nkt) stage_store((kt + 1) & 1);
+        __syncthreads();
+    }
+    if (!live) return;
+    unsigned short* op = p.dq + b * p.dq_bs + static_cast<long>(q0 + ql) * p.dq_ld + h * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u16x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(acc[d][4 * g + e] * p.scale);
+            *reinterpret_cast<u16x4*>(op + d * 32 + 8 * g + 4 * hi) = w;
         }
 }
 
@@ -763,14 +1092,18 @@ extern "C" pf_status pf_attention_bwd(const pf_attn_bwd_desc* d, void* stream) {
     hipStream_t st = as_stream(stream);
     const dim3 block(256), gq(cdiv(d->nq, 128), d->H, d->B), gk(cdiv(d->nk, 128), d->H, d->B);
     const bool tail = d->nq % 32 != 0 || d->nk % 32 != 0;        // ragged token counts: guarded loads, masked tails
-    PF_DISPATCH_16(d->dtype, "pf_attention_bwd",
-        if (d->D == 64) {
-            if (tail) { hipLaunchKernelGGL((k_attn_bwd_dq<T, 64, true>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv<T, 64, true>), gk, block, 0, st, p); }
-            else { hipLaunchKernelGGL((k_attn_bwd_dq<T, 64, false>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv<T, 64, false>), gk, block, 0, st, p); }
-        } else {
-            if (tail) { hipLaunchKernelGGL((k_attn_bwd_dq<T, 32, true>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv<T, 32, true>), gk, block, 0, st, p); }
-            else { hipLaunchKernelGGL((k_attn_bwd_dq<T, 32, false>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv<T, 32, false>), gk, block, 0, st, p); }
-        });
+    // LDS-staged kernels: whole 32-token tiles, 16-byte rows for the cooperative tile loads.  PF_ATTN_BWD_IMPL=direct: A/B switch
+    static const bool want_lds = [] { const char* e = getenv("PF_ATTN_BWD_IMPL"); return !(e && e[0] == 'd'); }();
+    const bool lds = want_lds && !tail && d->qt_ld % 8 == 0 && d->kt_ld % 8 == 0 && d->dot_ld % 8 == 0 && d->qt_bs % 8 == 0 &&
+                     d->kt_bs % 8 == 0 && d->dot_bs % 8 == 0;
+#define PF_BWD(DD)                                                                                                          \
+    do {                                                                                                                    \
+        if (lds) { hipLaunchKernelGGL((k_attn_bwd_dq_lds<T, DD>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv_lds<T, DD>), gk, block, 0, st, p); } \
+        else if (tail) { hipLaunchKernelGGL((k_attn_bwd_dq<T, DD, true>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv<T, DD, true>), gk, block, 0, st, p); } \
+        else { hipLaunchKernelGGL((k_attn_bwd_dq<T, DD, false>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv<T, DD, false>), gk, block, 0, st, p); } \
+    } while (0)
+    PF_DISPATCH_16(d->dtype, "pf_attention_bwd", if (d->D == 64) PF_BWD(64); else PF_BWD(32));
+#undef PF_BWD
     PF_CHECK_LAUNCH("pf_attention_bwd");
     return PF_OK;
 }
