@@ -85,51 +85,71 @@ class LoRARef:
         alpha = getattr(lora, "network_alpha", None)
         self.scale = 1.0 if alpha is None else float(alpha) / self.down.shape[0]
 
-    def operands(self, dev, dtype):
-        r = self.down.shape[0]
-        pad = (r + 63) // 64 * 64
-        d = torch.zeros(pad, self.down.shape[1], device=dev, dtype=dtype)
-        d[:r] = self.down.detach().to(device=dev, dtype=F32).to(dtype)
-        u = torch.zeros(pad, self.up.shape[0], device=dev, dtype=dtype)
-        u[:r] = self.up.detach().to(device=dev, dtype=F32).t().to(dtype)
-        return d, u                                                          # down padded [64, K], up^T padded [64, N]
-
 
 def lora_of(attn, lin, name):
     lora = getattr(lin, "lora_layer", None) or engine._processor_lora(attn, name)
     return None if lora is None else LoRARef(lora)
 
 
-def _pad_tokens(x16, xt16):
-    """Token counts of the reduction GEMMs must be multiples of 64 (pf_conv_gemm's channel rule): zero rows / columns."""
+class LoRAGroup:
+    """The LoRA pairs of projections that read the SAME input x (q / k / v of a self-attention; k / v of the text
+    cross-attention; a single projection) and whose output gradients sit side by side in one [T, sum N_i] tensor.
+    Their gradients come out of four thin GEMMs for the whole group:
+        P^T = D X^T          D = the down matrices stacked                      [R, K] x [T, K]^T -> [R, T]
+        Q^T = U_bd dY^T      U_bd = the up^T matrices on a block diagonal      [R, N] x [T, N]^T -> [R, T]
+        d_up   = dY^T P      [N, T] x [R, T]^T -> [N, R]    (pair i: rows of block i, columns of block i)
+        d_down = Q^T X       [R, T] x [K, T]^T -> [R, K]    (pair i: rows of block i)
+    with R = sum of the ranks (rounded up to 4) and the reductions over tokens on token-contiguous operands."""
+
+    def __init__(self, refs, widths, dev, dtype):
+        self.refs, self.widths = refs, widths
+        self.live = [(i, r) for i, r in enumerate(refs) if r is not None]
+        if not self.live:
+            return
+        K = self.live[0][1].down.shape[1]
+        N = sum(widths)
+        ranks = [r.down.shape[0] for _, r in self.live]
+        self.R = (sum(ranks) + 3) // 4 * 4
+        D = torch.zeros(self.R, K, device=dev, dtype=F32)
+        U = torch.zeros(self.R, N, device=dev, dtype=F32)
+        self.slots = []
+        row = 0
+        for (i, ref), rk in zip(self.live, ranks):
+            col = sum(widths[:i])
+            D[row:row + rk] = ref.down.detach().to(device=dev, dtype=F32)
+            U[row:row + rk, col:col + widths[i]] = ref.up.detach().to(device=dev, dtype=F32).t()
+            self.slots.append((ref, row, rk, col, widths[i]))
+            row += rk
+        self.D, self.U = D.to(dtype), U.to(dtype)
+
+    def grads(self, x16, xt16, dy16, dyt16, sink):
+        """x16 [T, K] / xt16 [K, T], dy16 [T, N] / dyt16 [N, T] (16-bit, T a multiple of 64)."""
+        if not self.live:
+            return
+        T = x16.shape[0]
+        pt = ops.conv_gemm(self.D, x16, T, w_in=self.R)                                        # [R, T]
+        qt = ops.conv_gemm(self.U, dy16, T, w_in=self.R)                                       # [R, T]
+        d_up = ops.conv_gemm(dyt16, pt, self.R, w_in=dyt16.shape[0], out_dtype=F32)            # [N, R]
+        d_down = ops.conv_gemm(qt, xt16, xt16.shape[0], w_in=self.R, out_dtype=F32)            # [R, K]
+        sink.scaled_pair(d_up, d_down, self.slots)
+
+
+def pad_tokens(x16):
+    """Token counts of the reduction GEMMs are multiples of 64 (pf_conv_gemm's channel rule): zero rows change nothing."""
     T = x16.shape[0]
     Tp = (T + 63) // 64 * 64
     if Tp == T:
-        return x16, xt16
+        return x16
     xp = torch.zeros(Tp, x16.shape[1], device=x16.device, dtype=x16.dtype)
     xp[:T].copy_(x16)
-    xtp = ops.transpose_tokens(xp.view(1, Tp, -1)).view(-1, Tp)
-    return xp, xtp
+    return xp
 
 
-def lora_grads(ref, x16, xt16, dy16, dyt16, sink):
-    """Gradients of one LoRA pair from the projection's input x [T, K] and output gradient dy [T, N] (16-bit, with their
-    token-contiguous transposes): d_up = s dy^T (x down^T), d_down = s (dy up)^T x -- four thin GEMMs with the rank padded
-    to 64, the reductions over tokens on token-contiguous operands."""
-    if ref is None:
-        return
-    dev, dtype = x16.device, x16.dtype
-    x16, xt16 = _pad_tokens(x16, xt16)
-    dy16, dyt16 = _pad_tokens(dy16, dyt16)
+def with_transpose(x16):
+    """(x padded to a token count of 64 n, its token-contiguous transpose)."""
+    x16 = pad_tokens(x16)
     T = x16.shape[0]
-    down, upt = ref.operands(dev, dtype)
-    r = ref.down.shape[0]
-    pt = ops.conv_gemm(down, x16, T, w_in=down.shape[0])                     # (x down^T)^T   [64, T]
-    qt = ops.conv_gemm(upt, dy16, T, w_in=upt.shape[0])                      # (dy up)^T      [64, T]
-    d_up = ops.conv_gemm(dyt16, pt, pt.shape[0], w_in=dyt16.shape[0], out_dtype=F32)       # [N, 64]
-    d_down = ops.conv_gemm(qt, xt16, xt16.shape[0], w_in=qt.shape[0], out_dtype=F32)       # [64, K]
-    sink(ref.up, d_up[:, :r], ref.scale)
-    sink(ref.down, d_down[:r], ref.scale)
+    return x16, ops.transpose_tokens(x16.view(1, T, -1)).view(-1, T)
 
 
 # ---------------------------------------------------------------------------------------------- per-layer training packs
@@ -160,7 +180,14 @@ def _attn_train(a, attn, dev, dtype, self_attn, key):
         t.wkv = _w16(wkv, dev, dtype)
     t.wv = _w16(wv, dev, dtype)
     t.wo, t.wo_t, t.bo = _w16(wo, dev, dtype), _t16(wo, dev, dtype), a.bo
-    t.lora = {n: lora_of(attn, lin, n + "_lora") for n, lin in (("to_q", attn.to_q), ("to_k", attn.to_k), ("to_v", attn.to_v), ("to_out", attn.to_out[0]))}
+    ref = {n: lora_of(attn, lin, n + "_lora") for n, lin in (("to_q", attn.to_q), ("to_k", attn.to_k), ("to_v", attn.to_v), ("to_out", attn.to_out[0]))}
+    Cc = wq.shape[0]
+    if self_attn:
+        t.lora_qkv = LoRAGroup([ref["to_q"], ref["to_k"], ref["to_v"]], [Cc, Cc, Cc], dev, dtype)
+    else:
+        t.lora_q = LoRAGroup([ref["to_q"]], [Cc], dev, dtype)
+        t.lora_kv = LoRAGroup([ref["to_k"], ref["to_v"]], [Cc, Cc], dev, dtype)
+    t.lora_out = LoRAGroup([ref["to_out"]], [Cc], dev, dtype)
     return t
 
 
@@ -304,7 +331,7 @@ def transformer_backward(t, x, text, dout, sink):
 
     # ---- backward
     d, state = _normalise(dout.reshape(T, Cc))
-    scaled = lambda p_, g_, s_: sink(p_, _unscale(g_.contiguous(), state), s_)
+    lsink = ScaledSink(sink, state)
     dtok3 = ops.linear(engine.to16(d, dt16), tw.w_out_t, out_dtype=F32)                  # proj_out (its residual: d -> dx below)
     # feed-forward
     dg = ops.linear(engine.to16(dtok3, dt16), tw.w2_t)
@@ -314,8 +341,8 @@ def transformer_backward(t, x, text, dout, sink):
     # text cross-attention
     d16 = engine.to16(dtok2, dt16)
     da2 = ops.linear(d16, a2w.wo_t).view(n, hw, Cc)
-    lora_grads(a2w.lora["to_out"], a2.view(T, Cc), ops.transpose_tokens(a2.view(1, T, Cc)).view(Cc, T), d16,
-               ops.transpose_tokens(d16.view(1, T, Cc)).view(Cc, T), scaled)
+    if a2w.lora_out.live:
+        a2w.lora_out.grads(*with_transpose(a2.view(T, Cc)), *with_transpose(d16), lsink)
     delta2 = ops.attention_delta(a2, da2, n, H, dh, hw)
     dq2 = torch.empty(n, hw, Cc, device=dev, dtype=dt16)
     dkv2 = torch.empty(n, TEXT_PAD, 2 * Cc, device=dev, dtype=dt16)
@@ -325,24 +352,17 @@ def transformer_backward(t, x, text, dout, sink):
                       q_bs=hw * Cc, k_bs=TEXT_PAD * 2 * Cc, v_bs=TEXT_PAD * 2 * Cc, do_bs=hw * Cc, dq_bs=hw * Cc,
                       dk_bs=TEXT_PAD * 2 * Cc, dv_bs=TEXT_PAD * 2 * Cc, bias=tbias, flags=tflags)
     dln2 = ops.linear(dq2.view(T, Cc), a2w.wq_t, out_dtype=F32)
-    ln2t = ops.transpose_tokens(ln2.view(1, T, Cc)).view(Cc, T)
-    lora_grads(a2w.lora["to_q"], ln2, ln2t, dq2.view(T, Cc), ops.transpose_tokens(dq2.view(1, T, Cc)).view(Cc, T), scaled)
-    if a2w.lora["to_k"] is not None or a2w.lora["to_v"] is not None:
+    if a2w.lora_q.live:
+        a2w.lora_q.grads(*with_transpose(ln2), *with_transpose(dq2.view(T, Cc)), lsink)
+    if a2w.lora_kv.live:
         Tt = n * TEXT_PAD
-        tx = textp.view(Tt, -1)
-        txt = ops.transpose_tokens(textp.view(1, Tt, -1)).view(-1, Tt)
-        dkv2t = ops.transpose_tokens(dkv2.view(1, Tt, 2 * Cc)).view(2 * Cc, Tt)
-        # contiguous copies of the two column blocks (transposing the transpose's row blocks back: [C, Tt] -> [Tt, C])
-        dkc = ops.transpose_tokens(dkv2t[:Cc].reshape(1, Cc, Tt)).view(Tt, Cc)
-        dvc = ops.transpose_tokens(dkv2t[Cc:].reshape(1, Cc, Tt)).view(Tt, Cc)
-        lora_grads(a2w.lora["to_k"], tx, txt, dkc, dkv2t[:Cc], scaled)
-        lora_grads(a2w.lora["to_v"], tx, txt, dvc, dkv2t[Cc:], scaled)
+        a2w.lora_kv.grads(*with_transpose(textp.view(Tt, -1)), *with_transpose(dkv2.view(Tt, 2 * Cc)), lsink)
     dtok1, _, _ = ops.layernorm_bwd(tok1, t.ln2.g, dln2, t.ln2.eps, dres=dtok2)
     # self-attention
     d16 = engine.to16(dtok1, dt16)
     da1 = ops.linear(d16, a1w.wo_t).view(n, hw, Cc)
-    lora_grads(a1w.lora["to_out"], a1.view(T, Cc), ops.transpose_tokens(a1.view(1, T, Cc)).view(Cc, T), d16,
-               ops.transpose_tokens(d16.view(1, T, Cc)).view(Cc, T), scaled)
+    if a1w.lora_out.live:
+        a1w.lora_out.grads(*with_transpose(a1.view(T, Cc)), *with_transpose(d16), lsink)
     delta1 = ops.attention_delta(a1, da1, n, H, dh, hw)
     dqkv = torch.empty(n, hw, 3 * Cc, device=dev, dtype=dt16)
     ld = 3 * Cc
@@ -351,18 +371,28 @@ def transformer_backward(t, x, text, dout, sink):
                       n, H, dh, hw, hw, q_ld=ld, k_ld=ld, v_ld=ld, do_ld=Cc, dq_ld=ld, dk_ld=ld, dv_ld=ld,
                       q_bs=hw * ld, k_bs=hw * ld, v_bs=hw * ld, do_bs=hw * Cc, dq_bs=hw * ld, dk_bs=hw * ld, dv_bs=hw * ld)
     dln1 = ops.linear(dqkv.view(T, 3 * Cc), a1w.wqkv_t, out_dtype=F32)
-    if any(a1w.lora[k] is not None for k in ("to_q", "to_k", "to_v")):
-        ln1t = ops.transpose_tokens(ln1.view(1, T, Cc)).view(Cc, T)
-        dqkvt = ops.transpose_tokens(dqkv.view(1, T, 3 * Cc)).view(3 * Cc, T)
-        for i, name in enumerate(("to_q", "to_k", "to_v")):
-            rows = dqkvt[i * Cc:(i + 1) * Cc]
-            cols = ops.transpose_tokens(rows.reshape(1, Cc, T)).view(T, Cc)              # contiguous column block of dqkv
-            lora_grads(a1w.lora[name], ln1, ln1t, cols, rows, scaled)
+    if a1w.lora_qkv.live:
+        a1w.lora_qkv.grads(*with_transpose(ln1), *with_transpose(dqkv.view(T, 3 * Cc)), lsink)
     dtok0, _, _ = ops.layernorm_bwd(tok0, t.ln1.g, dln1, t.ln1.eps, dres=dtok1)
     # proj_in and the GroupNorm in front of it; the block's own residual (out = proj_out(..) + x)
     dy = ops.linear(engine.to16(dtok0, dt16), tw.w_in_t, out_dtype=F32)
     dx, _ = ops.groupnorm_bwd(x, None, n, hw, t.norm.groups, t.norm.eps, t.norm.g, sc, sh, 0, dy.view(n, hw, Cc), dres=d.view(n, hw, Cc))
     return _unscale(dx, state).view(n, h, w, Cc)
+
+
+class ScaledSink:
+    """Takes a LoRA group's stacked gradients in the block's normalised units, scales them back (two launches per
+    group) and hands the per-pair blocks to the parameter sink."""
+
+    def __init__(self, sink, state):
+        self.sink, self.state = sink, state
+
+    def scaled_pair(self, d_up, d_down, slots):
+        _unscale(d_up, self.state)
+        _unscale(d_down, self.state)
+        for ref, row, rk, col, width in slots:
+            self.sink(ref.up, d_up[col:col + width, row:row + rk], ref.scale)
+            self.sink(ref.down, d_down[row:row + rk], ref.scale)
 
 
 def downsample_backward(d, dout, pano_pad, dev_dtype):
