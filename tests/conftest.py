@@ -49,7 +49,7 @@ def golden(name):
 
 
 def rel_l2(a, b):
-    a, b = a.double().flatten(), b.double().flatten()
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
