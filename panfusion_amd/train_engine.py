@@ -239,6 +239,8 @@ def text_bias(nq, L, dev):
 def pad_text(text, dtype):
     """text [n, L, Dt] -> [n, TEXT_PAD, Dt] 16-bit with zero rows behind the L tokens."""
     n, L, Dt = text.shape
+    if L > TEXT_PAD:
+        raise ValueError("prompts of %d tokens exceed the %d-key text tile of the training path" % (L, TEXT_PAD))
     out = torch.zeros(n, TEXT_PAD, Dt, device=text.device, dtype=dtype)
     out[:, :L] = text.to(dtype)
     return out
@@ -548,6 +550,7 @@ class DenoiserFunction(torch.autograd.Function):
         ctx.tape, ctx.pers, ctx.pano, ctx.params = tape, pers, pano, params
         ctx.has_sample = sample is not None
         ctx.sample_shape = None if sample is None else tuple(sample.shape)
+        ctx.pano_shape = tuple(pano_sample.shape)
         if sample is None:
             return pano_sample
         return sample, pano_sample
@@ -561,8 +564,8 @@ class DenoiserFunction(torch.autograd.Function):
                 if d_sample is None:
                     d_sample = torch.zeros(ctx.sample_shape, device=d_pano.device, dtype=F32)
                 d_eps[ctx.pers] = d_sample.flatten(0, 1).float().contiguous()
-            if d_pano is None:
-                d_pano = torch.zeros((ctx.sample_shape[0], 1) + tuple(ctx.pano.h.shape[0:0]), device=d_sample.device)
+            if d_pano is None:                  # (a loss on the views only)
+                d_pano = torch.zeros(ctx.pano_shape, device=d_sample.device, dtype=F32)
             d_eps[ctx.pano] = d_pano.flatten(0, 1).float().contiguous()
             sink = ParamGrads()
             backward(ctx.tape, d_eps, sink)
