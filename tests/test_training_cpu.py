@@ -235,3 +235,51 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
     assert rel_l2(want_s, s0.detach()) > 1e-3                      # the step moved the outputs
     assert rel_l2(s1.detach(), want_s) < 5e-5 and rel_l2(ps1.detach(), want_ps) < 5e-5
     assert hip.packed("unet", args[1].device) is pack_before and pack_before.down[0].resnets[0].train is res_before
+
+
+def test_training_reaches_lora_in_the_attention_processor_layout(fake_denoiser_backend):
+    """The LoRA matrices of a reference checkpoint sit in ``attn.processor.to_{q,k,v,out}_lora`` (set_attn_processor,
+    PanoGenerator.py:132-151; no diffusers forward ever migrates them here): the training path must find them there --
+    same gradients as with the same matrices in ``<linear>.lora_layer``."""
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    from panfusion_amd.models.sd2_unet_params import UNetParams, fill_synthetic
+    from oracle import sd2_unet as U
+    from conftest import TINY, golden
+    g = golden("mvgen_tiny.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    cams = {k: v[None] for k, v in cam4().items()}
+    args = (t("latents")[:1], t("pano_latent")[:1], torch.full((1, 4), 981), t("prompt_embd")[:1], t("pano_prompt_embd")[:1], cams)
+    grads = {}
+    for layout in ("lora_layer", "processor"):
+        unets = []
+        for seed in (5, 6):
+            u = UNetParams(**U.tiny_config(**TINY))
+            u.add_lora(4, layout="lora_layer")
+            fill_synthetic(u, seed)                       # same seeded values for both layouts ...
+            if layout == "processor":                     # ... moved into processors
+                v = UNetParams(**U.tiny_config(**TINY))
+                v.add_lora(4, layout="processor")
+                sd = {}
+                for k, p in u.state_dict().items():
+                    for n in ("to_q", "to_k", "to_v"):
+                        k = k.replace(".%s.lora_layer." % n, ".processor.%s_lora." % n)
+                    k = k.replace(".to_out.0.lora_layer.", ".processor.to_out_lora.")
+                    sd[k] = p
+                v.load_state_dict(sd)
+                u = v
+            unets.append(u)
+        model = MultiViewBaseModel(unets[0], unets[1], None, None, True, compute_dtype=torch.float32, precision="fast",
+                                   differentiable=True)
+        for i, blk in enumerate([*model.cp_blocks_encoder, model.cp_blocks_mid, *model.cp_blocks_decoder]):
+            fill_synthetic(blk, 10 + i)
+        s, ps = model(*args)
+        (s.square().mean() + ps.square().mean()).backward()
+        names = {id(p): k for k, p in model.named_parameters()}
+        tens = model.trainable_tensors()
+        assert len(tens) == 603 and all(p.grad is not None for p in tens)
+        grads[layout] = {names[id(p)].replace(".processor.to_out_lora.", ".to_out.0.lora_layer.")
+                         .replace(".processor.to_q_lora.", ".to_q.lora_layer.").replace(".processor.to_k_lora.", ".to_k.lora_layer.")
+                         .replace(".processor.to_v_lora.", ".to_v.lora_layer."): p.grad for p in tens}
+    assert set(grads["lora_layer"]) == set(grads["processor"])
+    for k, want in grads["lora_layer"].items():
+        assert rel_l2(grads["processor"][k], want) < 1e-6, k
