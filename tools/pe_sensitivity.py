@@ -1,5 +1,15 @@
+"""How far the spherical PE of the EPA block (SphericalPE, models/modules/transformer.py:166-186) amplifies coordinate
+differences: C = 320 has 80 frequencies up to 2^79, C = 64 / 128 / 256 go to 2^15 / 2^31 / 2^63.  A view-pixel
+coordinate that is 0 on one side and 5e-17 on the other (axis-aligned cameras: cos(90 deg) residues whose fate the
+summation order of the host BLAS decides) flips sin / cos of the high bands completely.  The product's coordinates
+(pf_e2p_grid, want_lonlat) against the oracle's (reference get_coords), and the PE on both.  Needs a GPU.
+
+    python tools/pe_sensitivity.py
+"""
 import sys, torch, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import cam4
 from oracle import geometry as G, mvgen as MV
 from panfusion_amd import ops
