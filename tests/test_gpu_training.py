@@ -321,3 +321,52 @@ def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, to
 def test_transpose_tokens(dtype, B, T, Cc):
     x = rnd(B, T, Cc, seed=1).to(dtype)
     assert torch.equal(ops().transpose_tokens(x), x.transpose(1, 2).contiguous())
+
+
+def test_full_width_training_step_vs_oracle_autograd():
+    """The training step AT SD-2-BASE WIDTHS (320 / 640 / 1280 channels, 5 / 10 / 20 / 20 heads of 64, 1024-wide prompts, rank-4
+    LoRA; 2 views of 32^2 latents + a 32x64 panorama latent so that CPU autograd through the oracle stays in seconds): outputs and
+    the gradient of every EPA tensor and every LoRA matrix, fp16 operands in the mixed scheme."""
+    from oracle import mvgen as MV
+    from oracle import sd2_unet as U
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    cfg = dict(U.SD2_BASE)
+    unet, pano_unet = U.UNet2DConditionModel(**cfg), U.UNet2DConditionModel(**cfg)
+    unet.add_lora(4)
+    pano_unet.add_lora(4)
+    U.init_synthetic(unet, 201)
+    U.init_synthetic(pano_unet, 202)
+    om = MV.DualBranchDenoiser(unet, pano_unet, None, None, True)
+    for i, blk in enumerate((om.cp_blocks_encoder, om.cp_blocks_mid, om.cp_blocks_decoder)):
+        U.init_synthetic(blk, 203 + i)
+    MV.randomize_epa(om, 206)
+    g = torch.Generator().manual_seed(17)
+    b, m = 1, 2
+    args = (torch.randn(b, m, 4, 32, 32, generator=g), torch.randn(b, 1, 4, 32, 64, generator=g), torch.full((b, m), 500, dtype=torch.long),
+            torch.randn(b, m, 77, 1024, generator=g), torch.randn(b, 1, 77, 1024, generator=g),
+            {"FoV": torch.full((b, m), 90), "theta": torch.tensor([[36.0, 180.0]], dtype=torch.float64),
+             "phi": torch.tensor([[52.6, -10.8]], dtype=torch.float64)})
+    noise_s, noise_p = torch.randn(args[0].shape, generator=g), torch.randn(args[1].shape, generator=g)
+    loss = lambda s, p, dev: torch.nn.functional.mse_loss(s, noise_s.to(dev)) + torch.nn.functional.mse_loss(p, noise_p.to(dev))
+    s, ps = om(*args)
+    loss(s, ps, "cpu").backward()                       # the reference's training loss (PanFusion.py:91-96)
+    keys = [k for k, p in om.named_parameters() if "lora" in k or k.startswith("cp_blocks")]
+    want = {k: p.grad.clone() for k, p in om.named_parameters() if k in set(keys)}
+    for p in om.parameters():
+        p.grad = None
+    hip = MultiViewBaseModel(om.unet, om.pano_unet, None, None, True, compute_dtype=torch.float16, precision="mixed", differentiable=True)
+    hip.load_state_dict({k: v for k, v in om.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    dev_args = tuple(a.to(DEV) if isinstance(a, torch.Tensor) else a for a in args)
+    s2, ps2 = hip(*dev_args)
+    eo = max(rel_l2(s2.cpu(), s), rel_l2(ps2.cpu(), ps))
+    loss(s2, ps2, DEV).backward()
+    got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    assert len(keys) == 603 and all(k in got for k in keys)
+    cat = lambda d: torch.cat([d[k].detach().cpu().float().flatten() for k in keys])
+    allg = rel_l2(cat(got), cat(want))
+    lora = [k for k in keys if "lora" in k]
+    errs = sorted(((rel_l2(got[k].cpu().float(), want[k]), k) for k in keys), reverse=True)
+    print("\nfull-width training step: outputs %.2e   all gradients %.2e   LoRA only %.2e   worst tensors: %s"
+          % (eo, allg, rel_l2(torch.cat([got[k].cpu().float().flatten() for k in lora]), torch.cat([want[k].flatten() for k in lora])),
+             "  ".join("%.1e %s" % (e, k.replace("transformer_blocks.0.", "").replace(".lora_layer", "")) for e, k in errs[:3])))
+    assert eo < 1e-3 and allg < 4e-3 and errs[0][0] < 2e-2, (eo, allg, errs[:3])
