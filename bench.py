@@ -149,6 +149,74 @@ def cpu_baseline(cfg, ctx_dim, lat_hw, pano_hw, m, cams_deg, flop_per_step):
                          per_scale[0], per_scale[1], per_scale[2], t_geo)}
 
 
+def training_step_leg(dev, dtype, cfg, precision=None, views_latent=32, pano_hw=(64, 128), steps=3, want_trace=False):
+    """The reference's TRAINING step through the same boundary (PanFusion.training_step, PanFusion.py:64-98; one sample per
+    GPU, 20 views of 256^2 + the 512 x 1024 panorama, README.md:199, PanoDataset.py:224,227): forward on the inference
+    kernels, backward on train_engine's tape into the 91 EPA tensors and the 512 LoRA matrices, AdamW step.  Not the
+    metric of this file: a reported extra (`training_step`), timed after everything else."""
+    import numpy as np
+    import torch
+    from panfusion_amd import ops
+    from panfusion_amd.utils.pano import icosahedron_sample_camera
+    model = build_model(dev, dtype, cfg, precision=precision)
+    model.differentiable = True
+    th, ph = icosahedron_sample_camera()
+    m = len(th)
+    g = lambda s: torch.Generator().manual_seed(s)
+    lat = views_latent
+    latents = torch.randn(1, m, 4, lat, lat, generator=g(0)).to(dev)
+    pano_latent = torch.randn(1, 1, 4, *pano_hw, generator=g(1)).to(dev)
+    noise, pano_noise = torch.randn(latents.shape, generator=g(2)).to(dev), torch.randn(pano_latent.shape, generator=g(3)).to(dev)
+    prompt = torch.randn(1, m, 77, cfg["cross_attention_dim"], generator=g(4)).to(dev)
+    pano_prompt = torch.randn(1, 1, 77, cfg["cross_attention_dim"], generator=g(5)).to(dev)
+    cams = {"FoV": torch.full((1, m), 90), "theta": torch.tensor(np.degrees(th), dtype=torch.float64)[None],
+            "phi": torch.tensor(np.degrees(ph), dtype=torch.float64)[None]}
+    t = torch.full((1, m), 500, device=dev)
+    params = model.trainable_tensors()
+    opt = torch.optim.AdamW(params, lr=1e-5)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pred, pano_pred = model(latents, pano_latent, t, prompt, pano_prompt, cams)
+        loss = torch.nn.functional.mse_loss(pred, noise) + torch.nn.functional.mse_loss(pano_pred, pano_noise)
+        loss.backward()
+        opt.step()
+        return loss
+
+    step()                                              # tables, packs, kernel attributes
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    with torch.no_grad():
+        model(latents, pano_latent, t, prompt, pano_prompt, cams)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            model(latents, pano_latent, t, prompt, pano_prompt, cams)
+        torch.cuda.synchronize()
+        dt_f = (time.perf_counter() - t1) / steps
+    out = {"ms_per_step": dt * 1e3, "forward_only_ms": dt_f * 1e3, "steps": steps, "loss": float(loss.detach()),
+           "trainable_tensors": len(params), "with_gradient": sum(p_.grad is not None for p_ in params),
+           "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "precision": model.precision,
+           "workload": "%d views of %d^2 + %dx%d panorama, one sample, SD-2-base widths, rank-4 LoRA, AdamW" % (m, lat * 8, pano_hw[0] * 8, pano_hw[1] * 8)}
+    if want_trace:
+        ops.TRACE = []
+        step()
+        torch.cuda.synchronize()
+        fam = {}
+        for name, fl, e0, e1, tag in ops.TRACE:
+            a = fam.setdefault(name, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        ops.TRACE = None
+        out["kernels"] = {k: {"launches": v[2], "ms": v[1] * 1e3, "tflops": v[0] / v[1] / 1e12} for k, v in fam.items()}
+    return out
+
+
 def usable_cores():
     """Host cores this process may actually use (affinity mask and cgroup CPU quota), capped at 64:
     the oracle's small-batch fp32 kernels do not scale past that."""
@@ -177,6 +245,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["mixed", "fast"], help="override the scheme of --dtype")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-training-leg", action="store_true", help="skip the extra `training_step` measurement (N = 1 only)")
     ap.add_argument("--trace-out", default=None, help="write the per-shape table of the instrumented step here")
     ap.add_argument("--small", action="store_true", help="reduced widths/sizes (debug only, not the metric)")
     ap.add_argument("--cfg5", action="store_true",
@@ -326,6 +395,14 @@ def main():
                "roofline": roofline}
         if not args.no_cpu_baseline and world == 1 and not args.small:
             res["cpu_baseline"] = cpu_baseline(cfg, cfg["cross_attention_dim"], lat_hw, pano_hw, m, cams_deg, flop)
+        if not args.no_training_leg and world == 1 and not (args.small or args.cfg4 or args.cfg5):
+            # extra, after the metric and its baseline: the training step through the same boundary
+            try:
+                del loop, model
+                torch.cuda.empty_cache()
+                res["training_step"] = training_step_leg(dev, dtype, cfg, args.precision)
+            except Exception as exc:                     # never lose the metric line to the extra
+                res["training_step"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
