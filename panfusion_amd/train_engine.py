@@ -24,8 +24,14 @@ import torch
 
 from . import engine, ops, training
 
+import os
+
 NS = engine.NS
 F32 = torch.float32
+# The linear maps that carry the gradient STREAM onto itself (proj_out / proj_in, the 1x1 shortcut, the stride-2 conv: the
+# transposes of the forward's stream-path GEMMs) run split-precision like their forward counterparts (engine.exact_gemm):
+# their operand roundings accumulate along the identity path of the residual network.  PF_TRAIN_EXACT=0: single pass (A/B).
+EXACT = os.environ.get("PF_TRAIN_EXACT", "1") != "0"
 
 
 # ---------------------------------------------------------------------------------------------- weights of the backward GEMMs
@@ -47,6 +53,18 @@ def _t16(w, dev, dtype):
 
 def _w16(w, dev, dtype):
     return w.detach().to(device=dev, dtype=F32).to(dtype).contiguous()
+
+
+def _t3(w, dev, dtype):
+    """W [N, K] -> the split-precision packing of W^T (engine._split_weight) for a stream-path data gradient."""
+    return engine._split_weight(w.detach().to(device=dev, dtype=F32).t().contiguous(), 1, dev, dtype)
+
+
+def stream_linear(d, w_t, w_t3, n_out, dtype):
+    """d fp32 [T, K] (a gradient stream) times W: split precision when the packed W^T triple exists, else one 16-bit pass."""
+    if w_t3 is not None:
+        return engine.exact_gemm(engine.split_operand(d, dtype=dtype), w_t3, n_out, w_in=d.shape[0], out_dtype=F32)
+    return ops.linear(engine.to16(d, dtype), w_t, out_dtype=F32)
 
 
 def conv3_dgrad(dy, wflip, cin, mode, dtype):
@@ -160,8 +178,11 @@ def resnet_train(r, dev):
         src = r.src
         tw = NS(w1=flip_conv3_weight(src.conv1.weight.to(dev), r.dtype), w2=flip_conv3_weight(src.conv2.weight.to(dev), r.dtype), ws=None)
         sc = getattr(src, "conv_shortcut", None)
+        tw.ws3 = None
         if sc is not None:
             tw.ws = _t16(sc.weight.reshape(r.cout, r.cin), dev, r.dtype)            # [cin, cout]
+            if EXACT:
+                tw.ws3 = _t3(sc.weight.reshape(r.cout, r.cin), dev, r.dtype)
         r.train = tw
     return tw
 
@@ -202,6 +223,10 @@ def transformer_train(t, dev):
         tw.w_in, tw.w_in_t = _w16(src.proj_in.weight.reshape(src.proj_in.weight.shape[0], -1), dev, t.dtype), \
             _t16(src.proj_in.weight.reshape(src.proj_in.weight.shape[0], -1), dev, t.dtype)
         tw.w_out_t = _t16(src.proj_out.weight.reshape(src.proj_out.weight.shape[0], -1), dev, t.dtype)
+        tw.w_in_t3 = tw.w_out_t3 = None
+        if EXACT:
+            tw.w_in_t3 = _t3(src.proj_in.weight.reshape(src.proj_in.weight.shape[0], -1), dev, t.dtype)
+            tw.w_out_t3 = _t3(src.proj_out.weight.reshape(src.proj_out.weight.shape[0], -1), dev, t.dtype)
         ff1, ff2 = blk.ff.net[0].proj, blk.ff.net[2]
         tw.w1, tw.w1_t, tw.b1 = _w16(ff1.weight, dev, t.dtype), _t16(ff1.weight, dev, t.dtype), engine._bias(ff1, dev)
         tw.w2, tw.w2_t = _w16(ff2.weight, dev, t.dtype), _t16(ff2.weight, dev, t.dtype)
@@ -265,7 +290,7 @@ def resnet_backward(r, x, skip, rowvec, dout):
     dh1, _ = ops.groupnorm_bwd(h1, None, n, hw, r.norm2.groups, r.norm2.eps, r.norm2.g, sc2, sh2, 1, dy2.view(n, hw, r.cout))
     dy1 = conv3_dgrad(dh1.view(n, h, w, r.cout), tw.w1, cin, "s1", r.dtype)              # gradient of silu(gn1(x | skip))
     if tw.ws is not None:
-        dsc = ops.linear(engine.to16(d, r.dtype).view(M, r.cout), tw.ws, out_dtype=F32)  # shortcut: d Ws  [M, cin]
+        dsc = stream_linear(d.view(M, r.cout), tw.ws, tw.ws3, cin, r.dtype)             # shortcut: d Ws  [M, cin]
     else:
         assert skip is None and cin == r.cout
         dsc = d
@@ -312,7 +337,10 @@ def transformer_backward(t, x, text, dout, sink):
     # ---- recompute
     sc, sh = ops.groupnorm_scale_shift(x, None, n, hw, t.norm.groups, t.norm.eps, t.norm.g, t.norm.b)
     y = ops.scale_shift_act(x, None, n, hw, sc, sh, 0, out_dtype=dt16)
-    tok0 = ops.linear(y.view(T, Cc), tw.w_in, bias=t.b_in, out_dtype=F32)
+    if EXACT and t.w_in3 is not None:                 # as the mixed forward: proj_in carries the stream
+        tok0 = engine.exact_gemm(engine.split_operand(x, None, sc, sh, 0, dtype=dt16), t.w_in3, Cc, w_in=T, bias=t.b_in, out_dtype=F32)
+    else:
+        tok0 = ops.linear(y.view(T, Cc), tw.w_in, bias=t.b_in, out_dtype=F32)
     ln1 = ops.layernorm(tok0, t.ln1.g, t.ln1.b, t.ln1.eps, out_dtype=dt16)
     qkv3, qkvt, a1, lse1 = _self_attention(a1w, ln1, n, hw, dh)
     tok1 = ops.linear(a1.view(T, Cc), a1w.wo, bias=a1w.bo, residual=tok0)
@@ -334,7 +362,7 @@ def transformer_backward(t, x, text, dout, sink):
     # ---- backward
     d, state = _normalise(dout.reshape(T, Cc))
     lsink = ScaledSink(sink, state)
-    dtok3 = ops.linear(engine.to16(d, dt16), tw.w_out_t, out_dtype=F32)                  # proj_out (its residual: d -> dx below)
+    dtok3 = stream_linear(d, tw.w_out_t, tw.w_out_t3, Cc, dt16)                          # proj_out (its residual: d -> dx below)
     # feed-forward
     dg = ops.linear(engine.to16(dtok3, dt16), tw.w2_t)
     du = ops.geglu_bwd(u, dg)
@@ -377,7 +405,7 @@ def transformer_backward(t, x, text, dout, sink):
         a1w.lora_qkv.grads(*with_transpose(ln1), *with_transpose(dqkv.view(T, 3 * Cc)), lsink)
     dtok0, _, _ = ops.layernorm_bwd(tok0, t.ln1.g, dln1, t.ln1.eps, dres=dtok1)
     # proj_in and the GroupNorm in front of it; the block's own residual (out = proj_out(..) + x)
-    dy = ops.linear(engine.to16(dtok0, dt16), tw.w_in_t, out_dtype=F32)
+    dy = stream_linear(dtok0, tw.w_in_t, tw.w_in_t3, Cc, dt16)
     dx, _ = ops.groupnorm_bwd(x, None, n, hw, t.norm.groups, t.norm.eps, t.norm.g, sc, sh, 0, dy.view(n, hw, Cc), dres=d.view(n, hw, Cc))
     return _unscale(dx, state).view(n, h, w, Cc)
 
@@ -400,12 +428,21 @@ class ScaledSink:
 def downsample_backward(d, dout, pano_pad, dev_dtype):
     """dout fp32 [n, ho, wo, C] -> dx of the block input; panorama: pad 2 / conv s2 / crop 1 (MVGenModel.py:138-144)."""
     tw = getattr(d, "train", None)
+    cin = d.src.weight.shape[1]
     if tw is None:
-        tw = d.train = NS(w=flip_conv3_weight(d.src.weight, dev_dtype))
+        wflip = d.src.weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).reshape(cin, -1)      # [cin, 9 * cout]
+        tw = d.train = NS(w=wflip.to(device=dout.device, dtype=dev_dtype).contiguous(), w3=None)
+        if EXACT:
+            tw.w3 = engine._split_weight(wflip, 9, dout.device, dev_dtype)
     g, state = _normalise(dout)
     if pano_pad:
         g = ops.crop_width_bwd(g, 1)
-    dx = conv3_dgrad(g, tw.w.to(dout.device), d.src.weight.shape[1], "s2", dev_dtype)
+    if tw.w3 is not None:                             # the stride-2 conv maps the stream onto itself: split precision
+        n, ho, wo, cout = g.shape
+        z = ops.zero_insert2(engine.split_operand(g, dtype=dev_dtype).view(n, ho, wo, 2 * cout))
+        dx = engine.exact_gemm(z, tw.w3, cin, n_img=n, h_in=2 * ho, w_in=2 * wo, ksize=3, pad=1, out_dtype=F32).view(n, 2 * ho, 2 * wo, cin)
+    else:
+        dx = conv3_dgrad(g, tw.w, cin, "s2", dev_dtype)
     if pano_pad:
         dx = ops.pad_width_bwd(dx, 2)
     return _unscale(dx, state)
