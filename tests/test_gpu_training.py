@@ -369,4 +369,4 @@ def test_full_width_training_step_vs_oracle_autograd():
     print("\nfull-width training step: outputs %.2e   all gradients %.2e   LoRA only %.2e   worst tensors: %s"
           % (eo, allg, rel_l2(torch.cat([got[k].cpu().float().flatten() for k in lora]), torch.cat([want[k].flatten() for k in lora])),
              "  ".join("%.1e %s" % (e, k.replace("transformer_blocks.0.", "").replace(".lora_layer", "")) for e, k in errs[:3])))
-    assert eo < 1e-3 and allg < 2e-3 and errs[0][0] < 2e-2, (eo, allg, errs[:3])
+    assert eo < 1e-3 and allg < 1.5e-3 and errs[0][0] < 2e-2, (eo, allg, errs[:3])     # measured 6.7e-4 / 9.7e-4 / 6.9e-3
