@@ -48,8 +48,24 @@ def main():
         step()
     torch.cuda.synchronize()
     pr.disable()
-    st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(28)
+    print("== whole steps (the backward runs on the autograd engine's thread: one opaque run_backward line here)")
+    pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+    # the backward alone, driven from this thread
+    from panfusion_amd import train_engine as TE
+    args_ = (latents, pano, t, prompt, pprompt, cams, None, None)
+    pr = cProfile.Profile()
+    for _ in range(args.steps):
+        tape = []
+        with torch.no_grad():
+            a, b, pers, pano_br = model._forward(*args_, tape=tape)
+            d = {pers: torch.randn_like(a).flatten(0, 1).contiguous(), pano_br: torch.randn_like(b).flatten(0, 1).contiguous()}
+            torch.cuda.synchronize()
+            pr.enable()
+            TE.backward(tape, d, TE.ParamGrads())
+            torch.cuda.synchronize()
+            pr.disable()
+    print("== train_engine.backward alone")
+    pstats.Stats(pr).sort_stats("tottime").print_stats(30)
 
 
 if __name__ == "__main__":
