@@ -69,6 +69,7 @@ class MultiViewBaseModel(nn.Module):
     def repack(self):
         """Drop the packed 16-bit weights (call after changing parameters / loading a checkpoint)."""
         self._packed.clear()
+        self.__dict__.pop("_trainable_cache", None)
         if self.unet is not None:
             for blk in [*self.cp_blocks_encoder, self.cp_blocks_mid, *self.cp_blocks_decoder]:
                 blk.compute_dtype, blk.precision = self.compute_dtype, self.precision
@@ -92,6 +93,9 @@ class MultiViewBaseModel(nn.Module):
         """EPA parameters and the LoRA matrices of both UNets: what the reference optimises (PanoGenerator.py:129-160,
         MVGenModel.py:34-36), in the order DenoiserFunction returns their gradients."""
         from ... import train_engine
+        cached = getattr(self, "_trainable_cache", None)
+        if cached is not None:                       # (the module tree is static; load_state_dict copies in place)
+            return cached
         out, seen = [], set()
 
         def add(t):
@@ -112,6 +116,7 @@ class MultiViewBaseModel(nn.Module):
                         if ref is not None:
                             add(ref.down)
                             add(ref.up)
+        self._trainable_cache = out
         return out
 
     def forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras,

@@ -188,21 +188,19 @@ def resnet_train(r, dev):
 
 
 def _attn_train(a, attn, dev, dtype, self_attn, key):
-    """Forward + backward operands of one attention with the CURRENT LoRA matrices folded in."""
-    w = lambda lin, name: engine._lin_weight(lin, engine._processor_lora(attn, name)).to(dev)
-    wq, wk, wv, wo = w(attn.to_q, "to_q_lora"), w(attn.to_k, "to_k_lora"), w(attn.to_v, "to_v_lora"), w(attn.to_out[0], "to_out_lora")
-    t = NS(key=key, heads=a.heads, dim=wq.shape[0])
+    """Forward + backward operands of one attention with the CURRENT LoRA matrices folded in: taken from the inference
+    pack `a`, which MultiViewBaseModel.refold_lora brought up to date in this step's forward (W + up @ down, 16 bit)."""
+    t = NS(key=key, heads=a.heads, dim=a.dim)
+    Cc = a.dim
     if self_attn:
-        wqkv = torch.cat([wq, wk, wv], 0)
-        t.wqkv, t.wqkv_t = _w16(wqkv, dev, dtype), _t16(wqkv, dev, dtype)
+        t.wqkv = torch.cat([a.wqk, a.wv], 0)                                     # [3C, C] = (q | k | v)
+        t.wqkv_t = t.wqkv.t().contiguous()
     else:
-        wkv = torch.cat([wk, wv], 0)
-        t.wq, t.wq_t = _w16(wq, dev, dtype), _t16(wq, dev, dtype)
-        t.wkv = _w16(wkv, dev, dtype)
-    t.wv = _w16(wv, dev, dtype)
-    t.wo, t.wo_t, t.bo = _w16(wo, dev, dtype), _t16(wo, dev, dtype), a.bo
+        t.wq, t.wq_t = a.wq, a.wq.t().contiguous()
+        t.wkv = torch.cat([a.wk, a.wv], 0)
+    t.wv = a.wv
+    t.wo, t.wo_t, t.bo = a.wo, a.wo.t().contiguous(), a.bo
     ref = {n: lora_of(attn, lin, n + "_lora") for n, lin in (("to_q", attn.to_q), ("to_k", attn.to_k), ("to_v", attn.to_v), ("to_out", attn.to_out[0]))}
-    Cc = wq.shape[0]
     if self_attn:
         t.lora_qkv = LoRAGroup([ref["to_q"], ref["to_k"], ref["to_v"]], [Cc, Cc, Cc], dev, dtype)
     else:
