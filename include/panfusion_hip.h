@@ -135,6 +135,11 @@ pf_status pf_scale_shift_act(const void* x0, int c0, const void* x1, int c1, int
 pf_status pf_layernorm(const void* x, const float* pe, long pe_rows, int dtype, long rows, int C,
                        const float* gamma, const float* beta, float eps, int out_dtype, void* y, void* stream);
 
+/* Sampling of the VAE posterior (diffusers DiagonalGaussianDistribution.sample, PanoGenerator.py:214-225):
+ * moments fp32 NHWC [n][hw][2L] = (mean | logvar), eps fp32 NCHW [n][L][hw] ->
+ * z NCHW [n][L][hw] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) * scale. */
+pf_status pf_vae_sample(const float* moments, const float* eps, int n, int L, long hw, float scale, float* z, void* stream);
+
 /* GEGLU: in [rows][2*inner] = [a | gate] -> out [rows][inner] = a * gelu(gate) (erf GELU). */
 pf_status pf_geglu(const void* in, int dtype, long rows, int inner, void* out, void* stream);
 
@@ -205,7 +210,9 @@ typedef struct {
     int c0, c1;          /* channels taken from each source                                 */
     int a0_ld, a1_ld;    /* per-pixel stride in elements (>= c0 / c1)                       */
     int n_img, h_in, w_in;
-    int h_out, w_out;    /* output spatial size                                              */
+    int h_out, w_out;    /* output spatial size: (h + 2 pad - k) / stride + 1, or that of the input with ONE more zero
+                          * row and column at the bottom / right (F.pad(x, (0,1,0,1)) + conv, the VAE encoder's
+                          * Downsample2D(padding=0)): pixels past the input read as zero                       */
     int ksize;           /* 1 or 3                                                          */
     int stride;          /* 1 or 2                                                          */
     int pad;             /* 0 or 1 (zeros)                                                  */

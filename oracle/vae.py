@@ -1,4 +1,4 @@
-"""Plain-PyTorch CPU restatement of the DECODER half of diffusers==0.24.0 ``AutoencoderKL`` as the
+"""Plain-PyTorch CPU restatement of diffusers==0.24.0 ``AutoencoderKL`` (decoder; encoder for the training step) as the
 reference uses it after the sampling loop.
 
 TEST INFRASTRUCTURE (see oracle/__init__.py) -- never imported by the product.
@@ -119,6 +119,77 @@ class Decoder(nn.Module):
         return self.conv_out(F.silu(self.conv_norm_out(h)))
 
 
+class _Down(nn.Module):
+    """diffusers Downsample2D(use_conv=True, padding=0): F.pad(x, (0, 1, 0, 1)) then Conv2d(ch, ch, 3, stride=2, padding=0)."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
+
+
+class Encoder(nn.Module):
+    """diffusers Encoder of AutoencoderKL (DownEncoderBlock2D x len(block_out_channels), `layers_per_block` resnets each,
+    a down-sampler after all but the last; UNetMidBlock2D; GroupNorm -> SiLU -> conv_out to 2 * latent_channels)."""
+
+    def __init__(self, in_channels, latent_channels, block_out_channels, layers_per_block, groups):
+        super().__init__()
+        boc = tuple(block_out_channels)
+        self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        prev = boc[0]
+        for i, ch in enumerate(boc):
+            blk = _Block()
+            for j in range(layers_per_block):
+                blk.resnets.append(VAEResnet(prev if j == 0 else ch, ch, groups))
+            blk.downsamplers = nn.ModuleList([_Down(ch)]) if i != len(boc) - 1 else None
+            self.down_blocks.append(blk)
+            prev = ch
+        top = boc[-1]
+        self.mid_block = _Block()
+        self.mid_block.attentions = nn.ModuleList([VAEAttention(top, groups)])
+        self.mid_block.resnets.append(VAEResnet(top, top, groups))
+        self.mid_block.resnets.append(VAEResnet(top, top, groups))
+        self.conv_norm_out = nn.GroupNorm(groups, top, eps=1e-6)
+        self.conv_out = nn.Conv2d(top, 2 * latent_channels, 3, padding=1)
+
+    def forward(self, x):
+        h = self.conv_in(x)
+        for blk in self.down_blocks:
+            for r in blk.resnets:
+                h = r(h)
+            if blk.downsamplers is not None:
+                h = blk.downsamplers[0](h)
+        h = self.mid_block.resnets[0](h)
+        h = self.mid_block.attentions[0](h)
+        h = self.mid_block.resnets[1](h)
+        return self.conv_out(F.silu(self.conv_norm_out(h)))
+
+
+class DiagonalGaussian:
+    """diffusers DiagonalGaussianDistribution: moments (n, 2L, h, w) = (mean | logvar), logvar clamped to [-30, 20]."""
+
+    def __init__(self, moments):
+        self.mean, logvar = moments.chunk(2, dim=1)
+        self.logvar = logvar.clamp(-30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None, eps=None):
+        if eps is None:
+            eps = torch.randn(self.mean.shape, generator=generator, dtype=self.mean.dtype)
+        return self.mean + self.std * eps
+
+    def mode(self):
+        return self.mean
+
+
+class _Latent:
+    def __init__(self, dist):
+        self.latent_dist = dist
+
+
 class _Sample:
     def __init__(self, sample):
         self.sample = sample
@@ -141,6 +212,9 @@ class AutoencoderKLDecoder(nn.Module):
                               norm_num_groups=norm_num_groups, out_channels=out_channels)
         self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
         self.decoder = Decoder(latent_channels, out_channels, block_out_channels, layers_per_block, norm_num_groups)
+        # the encoder half (training: PanoGenerator.encode_image, PanoGenerator.py:214-225)
+        self.encoder = Encoder(out_channels, latent_channels, block_out_channels, layers_per_block, norm_num_groups)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
 
     @property
     def dtype(self):
@@ -148,6 +222,12 @@ class AutoencoderKLDecoder(nn.Module):
 
     def decode(self, z):
         return _Sample(self.decoder(self.post_quant_conv(z)))
+
+    def encode(self, x):
+        return _Latent(DiagonalGaussian(self.quant_conv(self.encoder(x))))
+
+
+AutoencoderKL = AutoencoderKLDecoder          # (the class carries both halves since the training row)
 
 
 def tiny_vae_config(width=32, groups=8):
@@ -172,6 +252,14 @@ def decode_views_and_pano(latents, pano_latent, vae, latent_pad=8):
     images = decode_latent(latents, vae)
     pano = G.unpad_pano(decode_latent(G.pad_pano(pano_latent, latent_pad), vae), 8 * latent_pad)
     return images, pano
+
+
+def encode_image(x_input, vae, generator=None, eps=None):
+    """PanoGenerator.py:214-225 on (b, l, 3, H, W) images in [-1, 1] -> (b, l, 4, H/8, W/8) latents:
+    ``vae.encode(x).latent_dist.sample() * scaling_factor`` (eps: the normal draw, for a deterministic comparison)."""
+    b = x_input.shape[0]
+    z = vae.encode(x_input.flatten(0, 1).to(vae.dtype)).latent_dist.sample(generator=generator, eps=eps)
+    return (z * vae.config.scaling_factor).unflatten(0, (b, -1)).to(x_input.dtype)
 
 
 def tensor_to_image(image):

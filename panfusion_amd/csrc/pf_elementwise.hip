@@ -699,6 +699,26 @@ extern "C" pf_status pf_layernorm(const void* x, const float* pe, long pe_rows, 
     return PF_OK;
 }
 
+__global__ void k_vae_sample(const float* __restrict__ mom, const float* __restrict__ eps, int n, int L, long hw, float scale,
+                             float* __restrict__ z) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;      // NCHW index
+    if (i >= static_cast<long>(n) * L * hw) return;
+    const long p = i % hw;
+    const int c = (i / hw) % L;
+    const long b = i / (hw * L);
+    const float* m = mom + (b * hw + p) * 2 * L;
+    const float logvar = fminf(fmaxf(m[L + c], -30.f), 20.f);
+    z[i] = (m[c] + expf(0.5f * logvar) * eps[i]) * scale;
+}
+
+extern "C" pf_status pf_vae_sample(const float* moments, const float* eps, int n, int L, long hw, float scale, float* z, void* stream) {
+    PF_REQUIRE(moments && eps && z && n > 0 && L > 0 && hw > 0, "pf_vae_sample: bad arguments");
+    const long total = static_cast<long>(n) * L * hw;
+    hipLaunchKernelGGL(k_vae_sample, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), moments, eps, n, L, hw, scale, z);
+    PF_CHECK_LAUNCH("pf_vae_sample");
+    return PF_OK;
+}
+
 extern "C" pf_status pf_geglu(const void* in, int dtype, long rows, int inner, void* out, void* stream) {
     PF_REQUIRE(in && out && rows > 0 && inner > 0 && inner % 8 == 0, "pf_geglu: bad arguments");
     PF_REQUIRE(aligned16(in) && aligned16(out), "pf_geglu: pointers must be 16-byte aligned");

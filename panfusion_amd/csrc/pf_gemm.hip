@@ -1162,7 +1162,12 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     {   // the output size must be what the conv arithmetic produces
         const int hl = d->h_in << d->upsample, wl = d->w_in << d->upsample;
         const int ho = (hl + 2 * d->pad - d->ksize) / d->stride + 1, wo = (wl + 2 * d->pad - d->ksize) / d->stride + 1;
-        PF_REQUIRE(ho == d->h_out && wo == d->w_out, "pf_conv_gemm: output size (%d,%d) does not match (%d,%d)", d->h_out, d->w_out, ho, wo);
+        // one more zero row / column at the bottom / right is allowed (pixels past the input read as zero anyway):
+        // diffusers Downsample2D(padding=0) = F.pad(x, (0, 1, 0, 1)) + conv3x3 stride 2 of the VAE encoder
+        const int ho1 = (hl + 2 * d->pad + 1 - d->ksize) / d->stride + 1, wo1 = (wl + 2 * d->pad + 1 - d->ksize) / d->stride + 1;
+        PF_REQUIRE((d->h_out == ho && d->w_out == wo) || (d->h_out == ho1 && d->w_out == wo1),
+                   "pf_conv_gemm: output size (%d,%d) does not match (%d,%d) [or (%d,%d) with a trailing zero row / column]",
+                   d->h_out, d->w_out, ho, wo, ho1, wo1);
     }
     GemmParams p;
     p.a0 = static_cast<const unsigned short*>(d->a0);

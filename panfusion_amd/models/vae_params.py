@@ -67,3 +67,46 @@ class VAEDecoderParams(_Holder):
     @property
     def dtype(self):
         return self.post_quant_conv.weight.dtype
+
+
+class VAEEncoderParams(_Holder):
+    """The ENCODER half (``encoder`` + ``quant_conv``) with diffusers' names: what ``PanoGenerator.encode_image``
+    (PanoGenerator.py:214-225) runs on the views and the padded panorama at the top of every training step."""
+
+    def __init__(self, latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                 norm_num_groups=32, scaling_factor=0.18215):
+        super().__init__()
+        boc, g = tuple(block_out_channels), norm_num_groups
+        self.config = _Config(scaling_factor=scaling_factor, latent_channels=latent_channels, block_out_channels=boc,
+                              layers_per_block=layers_per_block, norm_num_groups=g, out_channels=out_channels)
+        e = _Holder()
+        e.conv_in = nn.Conv2d(out_channels, boc[0], 3, padding=1)
+        e.down_blocks = nn.ModuleList()
+        prev = boc[0]
+        for i, ch in enumerate(boc):
+            b = _Holder()
+            b.resnets = nn.ModuleList([_resnet(prev if j == 0 else ch, ch, g) for j in range(layers_per_block)])
+            b.downsamplers = None
+            if i != len(boc) - 1:
+                dn = _Holder()
+                dn.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=0)
+                b.downsamplers = nn.ModuleList([dn])
+            e.down_blocks.append(b)
+            prev = ch
+        top = boc[-1]
+        mid = _Holder()
+        att = _Holder()
+        att.group_norm = nn.GroupNorm(g, top, eps=1e-6)
+        att.to_q, att.to_k, att.to_v = nn.Linear(top, top), nn.Linear(top, top), nn.Linear(top, top)
+        att.to_out = nn.ModuleList([nn.Linear(top, top), nn.Dropout(0.0)])
+        mid.attentions = nn.ModuleList([att])
+        mid.resnets = nn.ModuleList([_resnet(top, top, g), _resnet(top, top, g)])
+        e.mid_block = mid
+        e.conv_norm_out = nn.GroupNorm(g, top, eps=1e-6)
+        e.conv_out = nn.Conv2d(top, 2 * latent_channels, 3, padding=1)
+        self.encoder = e
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+
+    @property
+    def dtype(self):
+        return self.quant_conv.weight.dtype

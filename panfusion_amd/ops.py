@@ -288,6 +288,15 @@ def softmax_rows(scores, scale, out_dtype, out=None):
     return out
 
 
+def vae_sample(moments, eps, scale):
+    """moments fp32 NHWC [n, h, w, 2L] = (mean | logvar), eps fp32 NCHW [n, L, h, w] -> z fp32 NCHW
+    = (mean + exp(0.5 clamp(logvar, -30, 20)) eps) * scale."""
+    n, h, w, L2 = moments.shape
+    z = torch.empty(n, L2 // 2, h, w, device=moments.device, dtype=torch.float32)
+    check(_lib.lib().pf_vae_sample(_p(moments), _p(eps), n, L2 // 2, h * w, float(scale), _p(z), _stream()), "pf_vae_sample")
+    return z
+
+
 def tensor_to_image(x):
     """fp32 NCHW image in [-1, 1] -> uint8 NHWC (models/modules/utils.py:9-15)."""
     x = x.float().contiguous()
@@ -313,19 +322,20 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,
               a_bstride=0, w_bstride=0, out_bstride=0, res_bstride=0, a0_ld=None, a1_ld=None, c0=None, c1=None,
-              out_ld=None, res_ld=None, geglu=False, algo_k=None, split_out=False):
+              out_ld=None, res_ld=None, geglu=False, algo_k=None, split_out=False, pad_hi=0):
     """out[m, n] = sum_k A[m, k] W[n, k] (+bias +rowvec[img] +residual).  a0/a1 NHWC, the last
     dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out).  The output takes the
     residual's dtype unless out_dtype says otherwise (fp32 residual stream in, fp32 out).
     algo_k: K of the layer for the FLOP count when the launched K carries split-precision passes.
-    split_out: the result leaves as the 16-bit pair [M, hi(n_out) | lo(n_out)] (operand of engine.exact_gemm)."""
+    split_out: the result leaves as the 16-bit pair [M, hi(n_out) | lo(n_out)] (operand of engine.exact_gemm).
+    pad_hi = 1: one more zero row / column at the bottom / right (F.pad(x, (0, 1, 0, 1)) of the VAE encoder's down-convs)."""
     c0 = c0 if c0 is not None else a0.shape[-1]
     c1 = (c1 if c1 is not None else a1.shape[-1]) if a1 is not None else 0
     if w_in is None:
         w_in = a0.numel() // (a0.shape[-1] * max(batch, 1)) if ksize == 1 else None
     hl, wl = h_in << upsample, w_in << upsample
-    h_out = (hl + 2 * pad - ksize) // stride + 1
-    w_out = (wl + 2 * pad - ksize) // stride + 1
+    h_out = (hl + 2 * pad + pad_hi - ksize) // stride + 1
+    w_out = (wl + 2 * pad + pad_hi - ksize) // stride + 1
     M = n_img * h_out * w_out
     if out is not None:
         out_dtype = out.dtype

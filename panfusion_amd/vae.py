@@ -1,6 +1,7 @@
-"""VAE decode of the sampled latents on the HIP kernels -- the step right after the denoising loop
+"""The VAE on the HIP kernels: DECODE of the sampled latents -- the step right after the denoising loop
 (reference ``models/pano/PanFusion.py:166-172``, ``PanoGenerator.py:213-238``,
-``models/modules/utils.py:9-15``).
+``models/modules/utils.py:9-15``) -- and ENCODE of the training images -- the step right before the denoiser call of
+a training step (``PanFusion.py:66-71``, ``PanoGenerator.encode_image``, ``PanoGenerator.py:214-225``; VAEEncoder below).
 
 ``VAEDecoder(vae)`` takes a module tree with diffusers' ``AutoencoderKL`` attribute names (diffusers' own object,
 or ``models.vae_params.VAEDecoderParams``), repacks ``post_quant_conv`` + ``decoder`` once into the kernel layouts
@@ -170,3 +171,115 @@ def decode_views_and_pano(latents, pano_latent, decoder, latent_pad=8):
     pano = unpad_pano(decode_latent(pad_pano(pano_latent, latent_pad), decoder), 8 * latent_pad)
     to_u8 = lambda x: ops.tensor_to_image(x.flatten(0, 1)).unflatten(0, x.shape[:2])
     return to_u8(images), to_u8(pano.contiguous())
+
+
+# ---------------------------------------------------------------------------------------------- encoder (training)
+def pack_vae_encoder(vae, dev, dtype, mixed):
+    """``vae.encoder`` + ``vae.quant_conv`` (diffusers AutoencoderKL names) -> kernel layouts."""
+    e = vae.encoder
+    v = NS(dtype=dtype, mixed=mixed, stream=torch.float32 if mixed else dtype)
+    v.scaling_factor = float(vae.config.scaling_factor)
+    ci = e.conv_in
+    v.c0 = ci.weight.shape[0]
+    v.w_in, v.b_in = engine._f32(ci.weight.detach().permute(2, 3, 1, 0), dev), engine._bias(ci, dev)       # [3, 3, cin, cout]
+    res = lambda r: engine.pack_resnet_plain(r, dev, dtype, mixed)
+    v.down = []
+    for blk in e.down_blocks:
+        b = NS(resnets=[res(r) for r in blk.resnets], down=None)
+        if blk.downsamplers is not None:
+            c = blk.downsamplers[0].conv
+            b.down = NS(w=engine._conv3_weight(c, dev, dtype), b=engine._bias(c, dev), c=c.weight.shape[0], w3=None)
+            if mixed:                 # stream -> stream linear map: split precision, as the UNet's Downsample2D (engine.pack_unet)
+                b.down.w3 = engine._split_weight(c.weight.detach().float().permute(0, 2, 3, 1).reshape(c.weight.shape[0], -1), 9, dev, dtype)
+        v.down.append(b)
+    v.mid_res = [res(r) for r in e.mid_block.resnets]
+    a = e.mid_block.attentions[0]
+    att = NS(C=a.to_q.weight.shape[0], norm=engine._norm(a.group_norm, dev))
+    att.wq, att.bq = engine._w16(a.to_q.weight, dev, dtype), engine._bias(a.to_q, dev)
+    att.wk, att.bk = engine._w16(a.to_k.weight, dev, dtype), engine._bias(a.to_k, dev)
+    att.wv = engine._w16(a.to_v.weight, dev, dtype)
+    wo = a.to_out[0].weight.detach().float()
+    att.wo = engine._w16(wo, dev, dtype)
+    att.bo = (a.to_out[0].bias.detach().float() + wo @ a.to_v.bias.detach().float()).to(dev).contiguous()
+    v.att = att
+    v.norm_out = engine._norm(e.conv_norm_out, dev)
+    co = e.conv_out
+    v.c_mom = co.weight.shape[0]                                            # 2 * latent channels
+    v.w_out, v.b_out = engine._f32(co.weight.detach().permute(0, 2, 3, 1), dev), engine._bias(co, dev)
+    v.q_w, v.q_b = _conv1_as_3x3(vae.quant_conv, dev, v.c_mom)
+    return v
+
+
+class VAEEncoder:
+    """``vae.encode(x).latent_dist`` on the HIP kernels (the top of every training step, PanFusion.py:66-71):
+    ``moments(x)`` -> fp32 NHWC (mean | logvar), ``encode(x)`` -> (mean, logvar) NCHW, ``sample(x, eps)`` -> z."""
+
+    def __init__(self, vae, compute_dtype=torch.float16, precision=None):
+        self.vae, self.compute_dtype = vae, compute_dtype
+        self.precision = precision or engine.default_precision(compute_dtype)
+        self._packed = {}
+
+    def packed(self, device):
+        key = (str(device), self.compute_dtype, self.precision)
+        if key not in self._packed:
+            self._packed[key] = pack_vae_encoder(self.vae, device, self.compute_dtype, self.precision == "mixed")
+        return self._packed[key]
+
+    def repack(self):
+        self._packed.clear()
+
+    @torch.no_grad()
+    def moments(self, x, chunk=None):
+        """x (n, 3, H, W) in [-1, 1] on the GPU -> fp32 NHWC [n, H/8, W/8, 2 L] = quant_conv(encoder(x))."""
+        v = self.packed(x.device)
+        x = x.float().contiguous()
+        n, _, H, W = x.shape
+        if chunk is None:             # 2 GiB operand addressing of pf_conv_gemm: the split pair of the first level at full size
+            chunk = max(1, ((1 << 31) - 1) // (H * W * 4 * v.c0))
+        if n > chunk:
+            return torch.cat([self.moments(x[i:i + chunk], chunk) for i in range(0, n, chunk)])
+        dt = v.dtype
+        h = ops.conv_in(x, v.w_in, v.b_in, v.c0, v.stream)
+        for blk in v.down:
+            for r in blk.resnets:
+                h = engine.run_resnet_plain(r, h)
+            if blk.down is not None:                                        # F.pad(x, (0, 1, 0, 1)) + conv3x3 stride 2, no padding
+                nn_, hh, ww, Cc = h.shape
+                d = blk.down
+                kw = dict(n_img=nn_, h_in=hh, w_in=ww, ksize=3, stride=2, pad=0, pad_hi=1, bias=d.b)
+                if d.w3 is not None:
+                    y = engine.exact_gemm(engine.split_operand(h, dtype=dt), d.w3, d.c, out_dtype=v.stream, **kw)
+                else:
+                    y = ops.conv_gemm(engine.to16(h, dt), d.w, d.c, out_dtype=v.stream, **kw)
+                h = y.view(nn_, hh // 2, ww // 2, d.c)
+        h = engine.run_resnet_plain(v.mid_res[0], h)
+        h = _attention(v.att, h, dt)
+        h = engine.run_resnet_plain(v.mid_res[1], h)
+        nn_, hh, ww, Cc = h.shape
+        sc, sh = ops.groupnorm_scale_shift(h, None, nn_, hh * ww, v.norm_out.groups, v.norm_out.eps, v.norm_out.g, v.norm_out.b)
+        y = ops.scale_shift_act(h, None, nn_, hh * ww, sc, sh, 1, out_dtype=v.stream).view(nn_, hh, ww, Cc)
+        mom = ops.conv_out(y, v.w_out, v.b_out, v.c_mom)                    # fp32 NCHW [n, 2L, h, w]
+        return ops.conv_in(mom, v.q_w, v.q_b, v.c_mom, torch.float32)       # quant_conv (1x1) -> NHWC
+
+    def encode(self, x):
+        m = self.moments(x).permute(0, 3, 1, 2)
+        L = m.shape[1] // 2
+        return m[:, :L].contiguous(), m[:, L:].clamp(-30.0, 20.0).contiguous()
+
+    @torch.no_grad()
+    def sample(self, x, eps=None, generator=None, scale=1.0):
+        """``latent_dist.sample()`` (times ``scale``); eps: the standard-normal draw (n, L, H/8, W/8), drawn here if None."""
+        mom = self.moments(x)
+        n, h, w, L2 = mom.shape
+        if eps is None:
+            eps = torch.randn(n, L2 // 2, h, w, device=x.device, dtype=torch.float32, generator=generator)
+        return ops.vae_sample(mom, eps.float().contiguous(), scale)
+
+
+def encode_image(x_input, encoder, eps=None, generator=None):
+    """``PanoGenerator.encode_image(x_input, vae)`` (PanoGenerator.py:214-225): (b, l, 3, H, W) images in [-1, 1] ->
+    (b, l, 4, H/8, W/8) latents = ``latent_dist.sample() * scaling_factor``."""
+    b = x_input.shape[0]
+    v = encoder.packed(x_input.device)
+    z = encoder.sample(x_input.flatten(0, 1), None if eps is None else eps.flatten(0, 1), generator, v.scaling_factor)
+    return z.unflatten(0, (b, -1)).to(x_input.dtype)

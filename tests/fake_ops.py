@@ -181,6 +181,12 @@ def softmax_rows(scores, scale, out_dtype, out=None):
     return torch.softmax(scores.float() * scale, -1).to(out_dtype)
 
 
+def vae_sample(moments, eps, scale):
+    L = moments.shape[-1] // 2
+    m = moments.permute(0, 3, 1, 2)
+    return (m[:, :L] + torch.exp(0.5 * m[:, L:].clamp(-30, 20)) * eps) * scale
+
+
 def tensor_to_image(x):
     return ((x.float() / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
 
@@ -197,7 +203,7 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, c1=None,
-              a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, split_out=False, **kw):
+              a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, split_out=False, pad_hi=0, **kw):
     if batch > 1:          # independent problems (attention scores / P.V of the VAE): plain linears only
         assert ksize == 1 and a1 is None and bias is None and residual is None and rowvec is None and not geglu
         K = c0 or a0.shape[-1]
@@ -224,6 +230,8 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     if upsample:
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
     wt = w.float().reshape(n_out, ksize, ksize, C).permute(0, 3, 1, 2)
+    if pad_hi:
+        x = F.pad(x, (0, pad_hi, 0, pad_hi))
     y = F.conv2d(x, wt, None if bias is None else bias.float(), stride=stride, padding=pad)
     ho, wo = y.shape[2:]
     y = y.permute(0, 2, 3, 1).reshape(n_img * ho * wo, n_out)

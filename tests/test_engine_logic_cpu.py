@@ -228,7 +228,8 @@ def test_vae_decode_host_logic(fake_backend, precision, dtype, tol):
     ov = OV.AutoencoderKLDecoder(**cfg)
     U.init_synthetic(ov, 51)
     params = VAEDecoderParams(**cfg)
-    missing = params.load_state_dict(ov.state_dict(), strict=True)       # identical key sets (diffusers names)
+    params.load_state_dict({k: v for k, v in ov.state_dict().items() if k.startswith(("decoder.", "post_quant_conv."))},
+                           strict=True)                                    # identical key sets per half (diffusers names)
     dec = PV.VAEDecoder(params, compute_dtype=dtype, precision=precision)
     g = torch.Generator().manual_seed(5)
     lat, pano = torch.randn(1, 2, 4, 8, 8, generator=g), torch.randn(1, 1, 4, 8, 16, generator=g)
@@ -243,6 +244,33 @@ def test_vae_decode_host_logic(fake_backend, precision, dtype, tol):
     # uint8 images: identical except where fp32 round-off straddles a rounding boundary
     assert float((gi.int() - want_u8(wi).int()).abs().float().mean()) < (0.01 if dtype == torch.float32 else 0.5)
     assert int((gp.int() - want_u8(wp).int()).abs().max()) <= (1 if dtype == torch.float32 else 8)
+
+
+@pytest.mark.parametrize("precision,dtype,tol", [("fast", torch.float32, 2e-5), ("mixed", torch.float32, 2e-5), ("mixed", torch.float16, 2e-3)])
+def test_vae_encode_host_logic(fake_backend, precision, dtype, tol):
+    """The encoder half for the training step (PanoGenerator.encode_image, PanoGenerator.py:214-225): weight packing and
+    sequencing (down-convs with the trailing zero row / column of Downsample2D(padding=0), mid attention, moments through
+    quant_conv as a centre tap, posterior sample with a given normal draw) on the CPU test double against the oracle."""
+    from oracle import sd2_unet as U
+    from oracle import vae as OV
+    from panfusion_amd import vae as PV
+    from panfusion_amd.models.vae_params import VAEEncoderParams
+    cfg = OV.tiny_vae_config(width=64, groups=8)
+    ov = OV.AutoencoderKL(**cfg)
+    U.init_synthetic(ov, 52)
+    params = VAEEncoderParams(**cfg)
+    params.load_state_dict({k: v for k, v in ov.state_dict().items() if k.startswith(("encoder.", "quant_conv."))}, strict=True)
+    enc = PV.VAEEncoder(params, compute_dtype=dtype, precision=precision)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(1, 2, 3, 64, 64, generator=g) * 2 - 1
+    eps = torch.randn(1, 2, 4, 8, 8, generator=g)
+    with torch.no_grad():
+        dist = ov.encode(x.flatten(0, 1)).latent_dist
+        want = OV.encode_image(x, ov, eps=eps.flatten(0, 1))
+    mean, logvar = enc.encode(x.flatten(0, 1))
+    assert rel_l2(mean, dist.mean) < tol and rel_l2(logvar, dist.logvar) < tol
+    got = PV.encode_image(x, enc, eps=eps)
+    assert got.shape == (1, 2, 4, 8, 8) and rel_l2(got, want) < tol, rel_l2(got, want)
 
 
 def tiny_clip(seed=0, layers=3):

@@ -61,8 +61,16 @@ def _models(cfg, seed):
     ov = OV.AutoencoderKLDecoder(**cfg)
     U.init_synthetic(ov, seed)
     params = VAEDecoderParams(**cfg)
-    params.load_state_dict(ov.state_dict(), strict=True)
+    half = lambda keys: {k: v for k, v in ov.state_dict().items() if k.startswith(keys)}
+    params.load_state_dict(half(("decoder.", "post_quant_conv.")), strict=True)      # identical key sets per half (diffusers names)
     return ov, params
+
+
+def _encoder(ov, cfg):
+    from panfusion_amd.models.vae_params import VAEEncoderParams
+    enc = VAEEncoderParams(**cfg)
+    enc.load_state_dict({k: v for k, v in ov.state_dict().items() if k.startswith(("encoder.", "quant_conv."))}, strict=True)
+    return enc
 
 
 @pytest.mark.parametrize("dtype,precision,tol", [(torch.float16, "mixed", 1e-3), (torch.float16, "fast", 4e-3),
@@ -100,3 +108,46 @@ def test_vae_decode_sd2_widths_vs_oracle():
     err = rel_l2(got.cpu(), want)
     print("VAE decode SD-2 widths, fp16 %s: rel-L2 %.3e" % (dec.precision, err))
     assert got.shape == (1, 1, 3, 512, 512) and torch.isfinite(got).all() and err <= 1e-3
+
+
+# ------------------------------------------------------------------------------------ encoder (training images -> latents)
+@pytest.mark.parametrize("dtype,precision,tol", [(torch.float16, "mixed", 1e-3), (torch.float16, "fast", 4e-3), (torch.bfloat16, "fast", 3e-2)])
+def test_vae_encode_tiny_vs_oracle(dtype, precision, tol):
+    """PanoGenerator.encode_image (PanoGenerator.py:214-225) on the views and on the circularly padded panorama of a training
+    step (PanFusion.py:66-71): moments and the scaled sample for a given normal draw."""
+    from oracle import vae as OV
+    from panfusion_amd import vae as PV
+    cfg = OV.tiny_vae_config(width=64, groups=8)
+    ov, _ = _models(cfg, 71)
+    enc = PV.VAEEncoder(_encoder(ov, cfg), compute_dtype=dtype, precision=precision)
+    g = torch.Generator().manual_seed(8)
+    imgs, pano = torch.rand(1, 3, 3, 64, 64, generator=g) * 2 - 1, torch.rand(1, 1, 3, 64, 192, generator=g) * 2 - 1
+    for x in (imgs, pano):
+        eps = torch.randn(x.shape[0], x.shape[1], 4, x.shape[3] // 8, x.shape[4] // 8, generator=g)
+        with torch.no_grad():
+            dist = ov.encode(x.flatten(0, 1)).latent_dist
+            want = OV.encode_image(x, ov, eps=eps.flatten(0, 1))
+        mean, logvar = enc.encode(x.flatten(0, 1).to(DEV))
+        em, el = rel_l2(mean.cpu(), dist.mean), rel_l2(logvar.cpu(), dist.logvar)
+        got = PV.encode_image(x.to(DEV), enc, eps=eps.to(DEV))
+        ez = rel_l2(got.cpu(), want)
+        print("VAE encode tiny %s/%s %s: mean %.2e logvar %.2e sample %.2e" % (dtype, precision, tuple(x.shape[-2:]), em, el, ez))
+        assert got.shape == want.shape and max(em, el, ez) <= tol
+
+
+def test_vae_encode_sd2_widths_vs_oracle():
+    """The SD-2 VAE encoder at its real widths on one 256^2 training view (0.57 TFLOP): fp16 mixed vs the fp32 oracle."""
+    from oracle import vae as OV
+    from panfusion_amd import vae as PV
+    cfg = dict(OV.SD2_VAE)
+    ov, _ = _models(cfg, 72)
+    enc = PV.VAEEncoder(_encoder(ov, cfg), compute_dtype=torch.float16)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(1, 1, 3, 256, 256, generator=g) * 2 - 1
+    eps = torch.randn(1, 1, 4, 32, 32, generator=g)
+    with torch.no_grad():
+        want = OV.encode_image(x, ov, eps=eps.flatten(0, 1))
+    got = PV.encode_image(x.to(DEV), enc, eps=eps.to(DEV))
+    err = rel_l2(got.cpu(), want)
+    print("VAE encode SD-2 widths, fp16 %s: rel-L2 %.3e" % (enc.precision, err))
+    assert got.shape == (1, 1, 4, 32, 32) and err <= 1e-3

@@ -41,6 +41,31 @@ def main():
     dt = (time.perf_counter() - t0) / args.reps
     print("VAE decode of %d views + padded panorama, %s %s: %.1f ms  (~%.0f TF/s algorithmic)  peak memory %.1f GB"
           % (args.views, args.dtype, dec.precision, dt * 1e3, flop / dt / 1e12, torch.cuda.max_memory_allocated() / 2 ** 30))
+    # the encoder side of a training step (PanFusion.py:66-71): 20 views of 256^2 + the padded 512 x 1152 panorama
+    from panfusion_amd.models.vae_params import VAEEncoderParams
+    from panfusion_amd.utils.pano import pad_pano
+    with torch.device(dev):
+        eparams = VAEEncoderParams(**SD2_VAE)
+    fill_synthetic(eparams, 10)
+    enc = PV.VAEEncoder(eparams, compute_dtype={"fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype], precision=args.precision)
+    imgs = (torch.rand(1, args.views, 3, 256, 256, generator=g) * 2 - 1).to(dev)
+    pano_img = (torch.rand(1, 1, 3, 512, 1024, generator=g) * 2 - 1).to(dev)
+
+    def encode():
+        z = PV.encode_image(imgs, enc)
+        zp = PV.encode_image(pad_pano(pano_img, 64), enc)
+        return z, zp
+
+    encode()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        z, zp = encode()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.reps
+    eflop = (args.views * 0.25 + 1152 / 512) * 0.566e12     # ~0.566 TFLOP per 512^2 image through the encoder
+    print("VAE encode of %d views of 256^2 + padded 512x1152 panorama, %s %s: %.1f ms  (~%.0f TF/s algorithmic)  latents %s %s"
+          % (args.views, args.dtype, enc.precision, dt * 1e3, eflop / dt / 1e12, tuple(z.shape), tuple(zp.shape)))
 
 
 if __name__ == "__main__":
