@@ -140,6 +140,10 @@ pf_status pf_layernorm(const void* x, const float* pe, long pe_rows, int dtype, 
  * z NCHW [n][L][hw] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) * scale. */
 pf_status pf_vae_sample(const float* moments, const float* eps, int n, int L, long hw, float scale, float* z, void* stream);
 
+/* out = a * x + b * y on n fp32 elements (scheduler.add_noise of the training step, PanFusion.py:83-84:
+ * sqrt(abar_t) * latents + sqrt(1 - abar_t) * noise). */
+pf_status pf_axpby(const float* x, const float* y, float a, float b, long n, float* out, void* stream);
+
 /* GEGLU: in [rows][2*inner] = [a | gate] -> out [rows][inner] = a * gelu(gate) (erf GELU). */
 pf_status pf_geglu(const void* in, int dtype, long rows, int inner, void* out, void* stream);
 

@@ -108,3 +108,28 @@ def denoise_loop(model, latents, pano_latent, prompt_embd, pano_prompt_embd, cam
         total += rot_diff
     pano_latent, cameras = rotate_latent(pano_latent, cameras, -total)
     return latents, pano_latent
+
+
+def add_noise(sched, x, noise, t):
+    """diffusers ``scheduler.add_noise``: sqrt(abar_t) x + sqrt(1 - abar_t) noise with t (b,) broadcast over the sample."""
+    a = sched.alphas_cumprod[t].to(x.dtype)
+    shape = (-1,) + (1,) * (x.dim() - 1)
+    return a.sqrt().reshape(shape) * x + (1 - a).sqrt().reshape(shape) * noise
+
+
+def training_step(model, vae, images, pano, cameras, prompt_embd, pano_prompt_embd, draws, latent_pad=8, sched=None):
+    """Restatement of ``PanFusion.training_step`` (PanFusion.py:64-98) with the random draws given: ``eps_views`` /
+    ``eps_pano`` (VAE posterior), ``t`` (b,), ``pano_noise`` (b, 1, 4, h, w).  Returns (loss, loss_pers, loss_pano)."""
+    from . import vae as OV
+    sched = sched or DDIM()
+    latents = OV.encode_image(images, vae, eps=draws["eps_views"].flatten(0, 1))
+    b, m, _, h, w = latents.shape
+    pano_pad = G.pad_pano(pano, 8 * latent_pad)
+    pano_latent = G.unpad_pano(OV.encode_image(pano_pad, vae, eps=draws["eps_pano"].flatten(0, 1)), latent_pad)
+    t = draws["t"].long()
+    pano_noise, noise = init_noise(draws["pano_noise"], cameras, h, w)
+    noise_z, pano_noise_z = add_noise(sched, latents, noise, t), add_noise(sched, pano_latent, pano_noise, t)
+    denoise, pano_denoise = model(noise_z, pano_noise_z, t[:, None].repeat(1, m), prompt_embd, pano_prompt_embd, cameras)
+    loss_pers = torch.nn.functional.mse_loss(denoise, noise)
+    loss_pano = torch.nn.functional.mse_loss(pano_denoise, pano_noise)
+    return loss_pers + loss_pano, loss_pers, loss_pano

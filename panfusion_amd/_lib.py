@@ -90,6 +90,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_layernorm": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_int, c_void_p, c_void_p,
                              c_float, c_int, c_void_p, c_void_p]),
+    "pf_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_long, c_void_p, c_void_p]),
     "pf_vae_sample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_float, c_void_p, c_void_p]),
     "pf_geglu": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p]),
     "pf_timestep_features": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

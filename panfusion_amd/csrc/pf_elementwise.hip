@@ -711,6 +711,18 @@ __global__ void k_vae_sample(const float* __restrict__ mom, const float* __restr
     z[i] = (m[c] + expf(0.5f * logvar) * eps[i]) * scale;
 }
 
+__global__ void k_axpby(const float* __restrict__ x, const float* __restrict__ y, float a, float b, long n, float* __restrict__ out) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+}
+
+extern "C" pf_status pf_axpby(const float* x, const float* y, float a, float b, long n, float* out, void* stream) {
+    PF_REQUIRE(x && y && out && n > 0, "pf_axpby: bad arguments");
+    hipLaunchKernelGGL(k_axpby, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, y, a, b, n, out);
+    PF_CHECK_LAUNCH("pf_axpby");
+    return PF_OK;
+}
+
 extern "C" pf_status pf_vae_sample(const float* moments, const float* eps, int n, int L, long hw, float scale, float* z, void* stream) {
     PF_REQUIRE(moments && eps && z && n > 0 && L > 0 && hw > 0, "pf_vae_sample: bad arguments");
     const long total = static_cast<long>(n) * L * hw;

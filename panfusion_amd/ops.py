@@ -288,6 +288,15 @@ def softmax_rows(scores, scale, out_dtype, out=None):
     return out
 
 
+def axpby(x, y, a, b, out=None):
+    """a * x + b * y on fp32 tensors of one shape."""
+    x, y = x.float().contiguous(), y.float().contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().pf_axpby(_p(x), _p(y), float(a), float(b), x.numel(), _p(out), _stream()), "pf_axpby")
+    return out
+
+
 def vae_sample(moments, eps, scale):
     """moments fp32 NHWC [n, h, w, 2L] = (mean | logvar), eps fp32 NCHW [n, L, h, w] -> z fp32 NCHW
     = (mean + exp(0.5 clamp(logvar, -30, 20)) eps) * scale."""

@@ -192,3 +192,48 @@ class DenoiseLoop:
         """Latents with the accumulated rotation undone (PanFusion.py:164)."""
         back = int(-self.total_rot / 360 * self.W)
         return self.lat, ops.roll_width(self.pano, back)
+
+
+def add_noise(sched, x, noise, t):
+    """``scheduler.add_noise`` (diffusers DDIMScheduler / DDPMScheduler): sqrt(abar_t) x + sqrt(1 - abar_t) noise, t (b,) per sample."""
+    out = torch.empty_like(x, dtype=torch.float32)
+    for i, ti in enumerate(t.tolist()):
+        a = float(sched.alphas_cumprod[ti])
+        ops.axpby(x[i], noise[i], a ** 0.5, (1 - a) ** 0.5, out=out[i])
+    return out
+
+
+def training_step(model, vae_encoder, images, pano, cameras, prompt_embd, pano_prompt_embd, latent_pad=8, sched=None,
+                  draws=None, generator=None):
+    """The body of ``PanFusion.training_step`` (PanFusion.py:64-98) on the HIP path: VAE-encode the views and the circularly
+    padded panorama, draw the timestep and the panorama noise, project that noise into the views (``init_noise``), add
+    noise, ONE denoiser call without CFG, MSE on both predictions.  Returns (loss, loss_pers, loss_pano); ``loss.backward()``
+    then fills the gradients of ``model.trainable_tensors()`` (the model must have been built ``differentiable=True``).
+
+    images (b, m, 3, H, W), pano (b, 1, 3, Hp, Wp) in [-1, 1] on the GPU; cameras: dict of (b, m); the prompt embeddings as
+    ``embed_prompt`` leaves them (b, m, L, D) / (b, 1, L, D) (text_encoder.TextEncoder).  draws: optional dict with the
+    random draws (``eps_views``, ``eps_pano`` for the VAE posterior, ``t`` (b,), ``pano_noise`` (b, 1, 4, h, w)) -- what the
+    tests fix to compare against the oracle; anything missing is drawn here."""
+    from .utils.pano import pad_pano, unpad_pano
+    from .vae import encode_image
+    draws = draws or {}
+    sched = sched or DDIMSchedule()
+    dev = images.device
+    latents = encode_image(images, vae_encoder, eps=draws.get("eps_views"), generator=generator)
+    b, m, _, h, w = latents.shape
+    pano_latent_pad = encode_image(pad_pano(pano, 8 * latent_pad), vae_encoder, eps=draws.get("eps_pano"), generator=generator)
+    pano_latent = unpad_pano(pano_latent_pad, latent_pad).contiguous()
+    t = draws.get("t")
+    if t is None:
+        t = torch.randint(0, sched.num_train_timesteps, (b,), device=dev, generator=generator)
+    pano_noise = draws.get("pano_noise")
+    if pano_noise is None:
+        pano_noise = torch.randn(b, 1, 4, *pano_latent.shape[-2:], device=dev, generator=generator)
+    pano_noise, noise = init_noise(pano_noise.to(dev).float(), cameras, h, w)
+    noise_z = add_noise(sched, latents, noise, t)
+    pano_noise_z = add_noise(sched, pano_latent, pano_noise, t)
+    tt = t.to(dev).long()[:, None].repeat(1, m)
+    denoise, pano_denoise = model(noise_z, pano_noise_z, tt, prompt_embd, pano_prompt_embd, cameras)
+    loss_pers = torch.nn.functional.mse_loss(denoise, noise)
+    loss_pano = torch.nn.functional.mse_loss(pano_denoise, pano_noise)
+    return loss_pers + loss_pano, loss_pers, loss_pano

@@ -181,6 +181,14 @@ def softmax_rows(scores, scale, out_dtype, out=None):
     return torch.softmax(scores.float() * scale, -1).to(out_dtype)
 
 
+def axpby(x, y, a, b, out=None):
+    r = a * x.float() + b * y.float()
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
 def vae_sample(moments, eps, scale):
     L = moments.shape[-1] // 2
     m = moments.permute(0, 3, 1, 2)

@@ -370,3 +370,48 @@ def test_full_width_training_step_vs_oracle_autograd():
           % (eo, allg, rel_l2(torch.cat([got[k].cpu().float().flatten() for k in lora]), torch.cat([want[k].flatten() for k in lora])),
              "  ".join("%.1e %s" % (e, k.replace("transformer_blocks.0.", "").replace(".lora_layer", "")) for e, k in errs[:3])))
     assert eo < 1e-3 and allg < 1.5e-3 and errs[0][0] < 2e-2, (eo, allg, errs[:3])     # measured 6.7e-4 / 9.7e-4 / 6.9e-3
+
+
+def test_whole_training_step_vs_oracle():
+    """pipeline.training_step -- VAE encode of the views and the padded panorama, init_noise, add_noise, ONE denoiser call, two MSE
+    losses (PanFusion.py:64-98) -- on the GPU against the oracle restatement with the same random draws: the losses, then the
+    gradients of all 603 trainable tensors after loss.backward().  Tiny widths, fp16 operands, mixed scheme."""
+    from conftest import build_tiny_oracle
+    from oracle import ddim as OD
+    from oracle import sd2_unet as U
+    from oracle import vae as OV
+    from panfusion_amd import pipeline, vae as PV
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    from panfusion_amd.models.vae_params import VAEEncoderParams
+    g = torch.Generator().manual_seed(3)
+    cams = {k: v[None] for k, v in cam4().items()}
+    cams["theta"], cams["phi"] = cams["theta"] + 7.3, cams["phi"] + 3.1
+    images, pano = torch.rand(1, 4, 3, 128, 128, generator=g) * 2 - 1, torch.rand(1, 1, 3, 128, 256, generator=g) * 2 - 1
+    pe, ppe = torch.randn(1, 4, 7, 128, generator=g), torch.randn(1, 1, 7, 128, generator=g)
+    draws = dict(eps_views=torch.randn(1, 4, 4, 16, 16, generator=g), eps_pano=torch.randn(1, 1, 4, 16, 48, generator=g),
+                 t=torch.tensor([481]), pano_noise=torch.randn(1, 1, 4, 16, 32, generator=g))
+    om = build_tiny_oracle()
+    cfg = OV.tiny_vae_config(width=64, groups=8)
+    ov = OV.AutoencoderKL(**cfg)
+    U.init_synthetic(ov, 53)
+    want = OD.training_step(om, ov, images, pano, cams, pe, ppe, draws)
+    want[0].backward()
+    keys = [k for k, p in om.named_parameters() if "lora" in k or k.startswith("cp_blocks")]
+    wg = {k: p.grad.clone() for k, p in om.named_parameters() if k in set(keys)}
+    for p in om.parameters():
+        p.grad = None
+    params = VAEEncoderParams(**cfg)
+    params.load_state_dict({k: v for k, v in ov.state_dict().items() if k.startswith(("encoder.", "quant_conv."))}, strict=True)
+    enc = PV.VAEEncoder(params, compute_dtype=torch.float16)
+    hip = MultiViewBaseModel(om.unet, om.pano_unet, None, None, om.pano_pad, compute_dtype=torch.float16, differentiable=True)
+    hip.load_state_dict({k: v for k, v in om.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    d = lambda x: x.to(DEV)
+    got = pipeline.training_step(hip, enc, d(images), d(pano), cams, d(pe), d(ppe), draws={k: d(v) for k, v in draws.items()})
+    rel = [abs(float(a) - float(b)) / abs(float(b)) for a, b in zip(got, want)]
+    got[0].backward()
+    gg = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    cat = lambda dd: torch.cat([dd[k].detach().cpu().float().flatten() for k in keys])
+    allg = rel_l2(cat(gg), cat(wg))
+    print("\nwhole training step: loss %.6f (oracle %.6f), relative error of (loss, pers, pano) %s, all gradients %.2e"
+          % (float(got[0]), float(want[0]), ["%.1e" % r for r in rel], allg))
+    assert len(keys) == 603 and max(rel) < 1e-3 and allg < 4e-3

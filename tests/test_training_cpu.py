@@ -283,3 +283,53 @@ def test_training_reaches_lora_in_the_attention_processor_layout(fake_denoiser_b
     assert set(grads["lora_layer"]) == set(grads["processor"])
     for k, want in grads["lora_layer"].items():
         assert rel_l2(grads["processor"][k], want) < 1e-6, k
+
+
+def _training_batch(seed=3):
+    g = torch.Generator().manual_seed(seed)
+    cams = {k: v[None] for k, v in cam4().items()}
+    cams["theta"], cams["phi"] = cams["theta"] + 7.3, cams["phi"] + 3.1      # (no nearest-neighbour ties in the noise projection)
+    images, pano = torch.rand(1, 4, 3, 128, 128, generator=g) * 2 - 1, torch.rand(1, 1, 3, 128, 256, generator=g) * 2 - 1
+    pe, ppe = torch.randn(1, 4, 7, 128, generator=g), torch.randn(1, 1, 7, 128, generator=g)
+    draws = dict(eps_views=torch.randn(1, 4, 4, 16, 16, generator=g), eps_pano=torch.randn(1, 1, 4, 16, 32 + 2 * 8, generator=g),
+                 t=torch.tensor([481]), pano_noise=torch.randn(1, 1, 4, 16, 32, generator=g))
+    return images, pano, cams, pe, ppe, draws
+
+
+def test_whole_training_step_matches_the_oracle(fake_denoiser_backend, monkeypatch):
+    """pipeline.training_step = the body of PanFusion.training_step (PanFusion.py:64-98): VAE encode of the views and the padded
+    panorama, init_noise, add_noise, denoiser, the two MSE losses -- against the oracle restatement with the same draws; then
+    loss.backward() against autograd through the oracle."""
+    from oracle import ddim as OD
+    from oracle import sd2_unet as U
+    from oracle import vae as OV
+    from conftest import build_tiny_oracle
+    from panfusion_amd import pipeline, vae as PV
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    from panfusion_amd.models.vae_params import VAEEncoderParams
+    for name in ("panfusion_amd.pipeline", "panfusion_amd.vae", "panfusion_amd.utils.pano",
+                 "panfusion_amd.external.Perspective_and_Equirectangular.e2p"):
+        monkeypatch.setattr(importlib.import_module(name), "ops", fake_ops)
+    om = build_tiny_oracle()
+    cfg = OV.tiny_vae_config(width=64, groups=8)
+    ov = OV.AutoencoderKL(**cfg)
+    U.init_synthetic(ov, 53)
+    images, pano, cams, pe, ppe, draws = _training_batch()
+    want = OD.training_step(om, ov, images, pano, cams, pe, ppe, draws)
+    want[0].backward()
+    wg = {k: p.grad.clone() for k, p in om.named_parameters() if p.grad is not None and ("lora" in k or k.startswith("cp_blocks"))}
+    for p in om.parameters():
+        p.grad = None
+    params = VAEEncoderParams(**cfg)
+    params.load_state_dict({k: v for k, v in ov.state_dict().items() if k.startswith(("encoder.", "quant_conv."))}, strict=True)
+    enc = PV.VAEEncoder(params, compute_dtype=torch.float32, precision="fast")
+    hip = MultiViewBaseModel(om.unet, om.pano_unet, None, None, om.pano_pad, compute_dtype=torch.float32, precision="fast", differentiable=True)
+    hip.load_state_dict({k: v for k, v in om.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    got = pipeline.training_step(hip, enc, images, pano, cams, pe, ppe, draws=draws)
+    for a, b in zip(got, want):
+        assert abs(float(a) - float(b)) <= 2e-5 * abs(float(b)), (float(a), float(b))
+    got[0].backward()
+    gg = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    assert len(wg) == 603
+    for k, w in wg.items():
+        assert rel_l2(gg[k], w) < 1e-4, (k, rel_l2(gg[k], w))
