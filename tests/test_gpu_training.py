@@ -407,11 +407,11 @@ def test_whole_training_step_vs_oracle():
     hip.load_state_dict({k: v for k, v in om.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
     d = lambda x: x.to(DEV)
     got = pipeline.training_step(hip, enc, d(images), d(pano), cams, d(pe), d(ppe), draws={k: d(v) for k, v in draws.items()})
-    rel = [abs(float(a) - float(b)) / abs(float(b)) for a, b in zip(got, want)]
+    rel = [abs(float(a.detach()) - float(b.detach())) / abs(float(b.detach())) for a, b in zip(got, want)]
     got[0].backward()
     gg = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
     cat = lambda dd: torch.cat([dd[k].detach().cpu().float().flatten() for k in keys])
     allg = rel_l2(cat(gg), cat(wg))
     print("\nwhole training step: loss %.6f (oracle %.6f), relative error of (loss, pers, pano) %s, all gradients %.2e"
-          % (float(got[0]), float(want[0]), ["%.1e" % r for r in rel], allg))
+          % (float(got[0].detach()), float(want[0].detach()), ["%.1e" % r for r in rel], allg))
     assert len(keys) == 603 and max(rel) < 1e-3 and allg < 4e-3
