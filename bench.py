@@ -198,7 +198,30 @@ def training_step_leg(dev, dtype, cfg, precision=None, views_latent=32, pano_hw=
             model(latents, pano_latent, t, prompt, pano_prompt, cams)
         torch.cuda.synchronize()
         dt_f = (time.perf_counter() - t1) / steps
-    out = {"ms_per_step": dt * 1e3, "forward_only_ms": dt_f * 1e3, "steps": steps, "loss": float(loss.detach()),
+    # the caller side of the step: VAE encode of the 20 views + the padded panorama (PanFusion.py:66-71)
+    enc_ms = None
+    try:
+        from panfusion_amd import vae as PV
+        from panfusion_amd.models.sd2_unet_params import fill_synthetic
+        from panfusion_amd.models.vae_params import SD2_VAE, VAEEncoderParams
+        from panfusion_amd.utils.pano import pad_pano
+        with torch.device(dev):
+            eparams = VAEEncoderParams(**SD2_VAE)
+        fill_synthetic(eparams, 10)
+        enc = PV.VAEEncoder(eparams, compute_dtype=dtype, precision=precision)
+        imgs = (torch.rand(1, m, 3, lat * 8, lat * 8, generator=g(6)) * 2 - 1).to(dev)
+        pimg = (torch.rand(1, 1, 3, pano_hw[0] * 8, pano_hw[1] * 8, generator=g(7)) * 2 - 1).to(dev)
+        run = lambda: (PV.encode_image(imgs, enc), PV.encode_image(pad_pano(pimg, 64), enc))
+        run()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize()
+        enc_ms = (time.perf_counter() - t2) / steps * 1e3
+    except Exception as exc:                              # (an extra of an extra)
+        enc_ms = "%s: %s" % (type(exc).__name__, exc)
+    out = {"ms_per_step": dt * 1e3, "forward_only_ms": dt_f * 1e3, "vae_encode_ms": enc_ms, "steps": steps, "loss": float(loss.detach()),
            "trainable_tensors": len(params), "with_gradient": sum(p_.grad is not None for p_ in params),
            "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "precision": model.precision,
            "workload": "%d views of %d^2 + %dx%d panorama, one sample, SD-2-base widths, rank-4 LoRA, AdamW" % (m, lat * 8, pano_hw[0] * 8, pano_hw[1] * 8)}
