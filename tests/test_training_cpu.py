@@ -334,3 +334,59 @@ def test_whole_training_step_matches_the_oracle(fake_denoiser_backend, monkeypat
     assert len(wg) == 603
     for k, w in wg.items():
         assert rel_l2(gg[k], w) < 1e-4, (k, rel_l2(gg[k], w))
+
+
+def _ddp_denoiser_worker(rank, world, port, out):
+    import os
+    import sys
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    for name in DEN_MODS:
+        importlib.import_module(name).ops = fake_ops
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        oracle, args, _, _ = _denoiser_case()
+        hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=torch.float32,
+                                 precision="fast", differentiable=True)
+        hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+        train = {id(t) for t in hip.trainable_tensors()}
+        for p in hip.parameters():                       # the reference freezes the UNets and trains LoRA + EPA only
+            p.requires_grad_(id(p) in train)
+        ddp = torch.nn.parallel.DistributedDataParallel(hip)
+        g = torch.Generator().manual_seed(200 + rank)    # every rank its own sample (one per GPU in the reference)
+        lat, pl = torch.randn(args[0].shape, generator=g), torch.randn(args[1].shape, generator=g)
+        s, ps = ddp(lat, pl, *args[2:])
+        (s.square().mean() + ps.square().mean()).backward()
+        torch.save({k: p.grad for k, p in hip.named_parameters() if p.grad is not None}, os.path.join(out, "r%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_over_the_whole_denoiser(tmp_path):
+    """DDP (the reference's strategy, main.py:68) around the differentiable denoiser: two gloo ranks with different samples end
+    with the mean of the two single-process gradients on all 603 trainable tensors."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_ddp_denoiser_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(tmp_path / ("r%d.pt" % r)) for r in range(2)]
+    singles = []
+    for rank in range(2):                                # autograd through the oracle, one process
+        oracle, args, _, _ = _denoiser_case()
+        g = torch.Generator().manual_seed(200 + rank)
+        lat, pl = torch.randn(args[0].shape, generator=g), torch.randn(args[1].shape, generator=g)
+        s, ps = oracle(lat, pl, *args[2:])
+        (s.square().mean() + ps.square().mean()).backward()
+        singles.append({k: p.grad for k, p in oracle.named_parameters() if "lora" in k or k.startswith("cp_blocks")})
+    assert len(got[0]) == 603 and set(got[0]) == set(singles[0])
+    for k in singles[0]:
+        want = (singles[0][k] + singles[1][k]) / 2
+        assert torch.equal(got[0][k], got[1][k])
+        assert rel_l2(got[0][k], want) < 1e-4, (k, rel_l2(got[0][k], want))
