@@ -845,6 +845,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     };
 
     stamp(p, 0);
+#ifdef PF_GEMM_SETPRIO
+    // static priority for the later-dispatched half of the block (MI355X_MICROARCH.md, "two waves per SIMD", item 4):
+    // measured neutral here (-DPF_GEMM_SETPRIO=1 / 3, same-box A/B round 2: 3x3 convs 915 -> 891 / 912 TF/s, step 14.85 vs 14.76):
+    // both waves of a SIMD run the same MFMA-dense stream, there is no loader / computer pairing for a priority to help
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(PF_GEMM_SETPRIO);
+#endif
     int tile = blockIdx.x;
     set_tile(tile);
     issue_prologue();
