@@ -789,6 +789,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // are compile-time so that the steady-state body is branch free and the compiler's s_waitcnt
     // insertion sees exact counts (a conditional around the prefetch made it drain lgkmcnt to 0 right
     // after issuing it, exposing the LDS latency once per step).
+    // (-DPF_ABL_NOBARRIER / NODMA / NOLDS: timing-only ablations of this loop -- wrong results -- for tools/gpu_gemm_ablate.sh)
     auto step = [&](auto more_tag, auto dma_tag, auto wait_tag) {
         constexpr bool MORE = decltype(more_tag)::value, DMA = decltype(dma_tag)::value;
         constexpr int WAIT = decltype(wait_tag)::value;           // DMA instructions that may stay in flight at the mid-step wait
@@ -801,7 +802,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             else acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb0[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
             if (idx == LEAD - 1) {
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef PF_ABL_NOLDS
                 load_frags(cur, 1, fa1, fb1);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -814,7 +817,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             else if constexpr (WAIT == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
             else if constexpr (WAIT == 13) asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");
             else static_assert(WAIT == 0, "add the immediate");
+#ifndef PF_ABL_NOBARRIER
             __builtin_amdgcn_s_barrier();                         // next stage complete; the current slot no longer read
+#endif
             asm volatile("" ::: "memory");
         }
         __amdgpu_buffer_rsrc_t rs_a = rs_w;
@@ -825,14 +830,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             else acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
             if (MORE && idx == LEAD - 1) {
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef PF_ABL_NOLDS
                 load_frags(nx1, 0, fa0, fb0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (DMA) {
                 const int k = idx - LEAD;                         // pieces after MFMA LEAD, LEAD+2, ...
                 if (k >= 0 && (k & 1) == 0 && (k >> 1) < NPIECE) {
                     __builtin_amdgcn_sched_barrier(0);
+#ifndef PF_ABL_NODMA
                     dma_piece(rs_a, cur, k >> 1);                 // stage it+3 into the slot retired at this step's barrier
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
