@@ -766,15 +766,21 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     //   f1 <- LDS(stage it, k 32..63) | MFMA(f0) | wait DMA(it+1), barrier | f0 <- LDS(stage it+1, k 0..31)
     //   | MFMA(f1) interleaved with the DMA pieces of stage it+2
     frag fa0[MREP], fb0[NREP], fa1[MREP], fb1[NREP];
-    auto load_frags = [&](int slot, int slab, frag (&fa)[MREP], frag (&fb)[NREP]) {
+    auto load_frags_a = [&](int slot, int slab, frag (&fa)[MREP]) {
         const unsigned short* As = smem + slot * STAGE;
-        const unsigned short* Bs = As + BM * 64;
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
             fa[i] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(As + lds_off(wm * 16 * MREP + i * 16 + frow, slab * 4 + fchunk)));
+    };
+    auto load_frags_b = [&](int slot, int slab, frag (&fb)[NREP]) {
+        const unsigned short* Bs = smem + slot * STAGE + BM * 64;
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
             fb[j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Bs + lds_off(wn * 16 * NREP + j * 16 + frow, slab * 4 + fchunk)));
+    };
+    auto load_frags = [&](int slot, int slab, frag (&fa)[MREP], frag (&fb)[NREP]) {
+        load_frags_a(slot, slab, fa);
+        load_frags_b(slot, slab, fb);
     };
 
     auto issue_prologue = [&]() {
@@ -790,23 +796,28 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // insertion sees exact counts (a conditional around the prefetch made it drain lgkmcnt to 0 right
     // after issuing it, exposing the LDS latency once per step).
     // (-DPF_ABL_NOBARRIER / NODMA / NOLDS: timing-only ablations of this loop -- wrong results -- for tools/gpu_gemm_ablate.sh)
-    auto step = [&](auto more_tag, auto dma_tag, auto wait_tag) {
+    auto step_l = [&](auto more_tag, auto dma_tag, auto wait_tag, auto flead_tag) {
         constexpr bool MORE = decltype(more_tag)::value, DMA = decltype(dma_tag)::value;
         constexpr int WAIT = decltype(wait_tag)::value;           // DMA instructions that may stay in flight at the mid-step wait
-        constexpr int NM = MREP * NREP, LEAD = 4;                 // fragment requests go out after LEAD MFMAs:
+        constexpr int NM = MREP * NREP, LEAD = 4, FLEAD = decltype(flead_tag)::value;   // fragment requests go out after FLEAD MFMAs:
         // at every s_waitcnt lgkmcnt the only outstanding LDS reads are then the ones being waited for
         // (the compiler drains to 0, it does not count), and they were issued >= NM - LEAD MFMAs earlier.
 #pragma unroll
         for (int idx = 0; idx < NM; ++idx) {
             if constexpr (NW == 4) Mfma<T>::acc_agpr(fb0[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
             else acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb0[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
-            if (idx == LEAD - 1) {
+#ifdef PF_GEMM_FLEAD2          /* two bursts: A fragments after FLEAD MFMAs, B fragments after FLEAD2 (A/B build) */
+            if (idx == FLEAD - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_a(cur, 1, fa1); __builtin_amdgcn_sched_barrier(0); }
+            if (idx == PF_GEMM_FLEAD2 - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_b(cur, 1, fb1); __builtin_amdgcn_sched_barrier(0); }
+#else
+            if (idx == FLEAD - 1) {
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef PF_ABL_NOLDS
                 load_frags(cur, 1, fa1, fb1);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
+#endif
         }
         if constexpr (MORE) {
             // my pieces of the next stage have landed (the stage after it may still be in flight: WAIT), and my
@@ -828,13 +839,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         for (int idx = 0; idx < NM; ++idx) {
             if constexpr (NW == 4) Mfma<T>::acc_agpr(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
             else acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
-            if (MORE && idx == LEAD - 1) {
+#ifdef PF_GEMM_FLEAD2
+            if (MORE && idx == FLEAD - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_a(nx1, 0, fa0); __builtin_amdgcn_sched_barrier(0); }
+            if (MORE && idx == PF_GEMM_FLEAD2 - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_b(nx1, 0, fb0); __builtin_amdgcn_sched_barrier(0); }
+#else
+            if (MORE && idx == FLEAD - 1) {
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef PF_ABL_NOLDS
                 load_frags(nx1, 0, fa0, fb0);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
+#endif
             if constexpr (DMA) {
                 const int k = idx - LEAD;                         // pieces after MFMA LEAD, LEAD+2, ...
                 if (k >= 0 && (k & 1) == 0 && (k >> 1) < NPIECE) {
@@ -852,6 +868,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         nx1 = nx1 == STAGES - 1 ? 0 : nx1 + 1;
         nx2 = nx2 == STAGES - 1 ? 0 : nx2 + 1;
     };
+#ifndef PF_GEMM_FLEAD
+#define PF_GEMM_FLEAD 4
+#endif
+    auto step = [&](auto more_tag, auto dma_tag, auto wait_tag) { step_l(more_tag, dma_tag, wait_tag, std::integral_constant<int, PF_GEMM_FLEAD>()); };
 
     stamp(p, 0);
 #ifdef PF_GEMM_SETPRIO
