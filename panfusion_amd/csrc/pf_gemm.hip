@@ -766,6 +766,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     //   f1 <- LDS(stage it, k 32..63) | MFMA(f0) | wait DMA(it+1), barrier | f0 <- LDS(stage it+1, k 0..31)
     //   | MFMA(f1) interleaved with the DMA pieces of stage it+2
     frag fa0[MREP], fb0[NREP], fa1[MREP], fb1[NREP];
+#ifdef PF_ABL_DUMMY_B
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+        u16x8 z = {1, 2, 3, 4, 5, 6, 7, static_cast<unsigned short>(lane)};
+        asm volatile("" : "+v"(z));
+        fb0[j] = __builtin_bit_cast(frag, z);
+        fb1[j] = __builtin_bit_cast(frag, z);
+    }
+#endif
     auto load_frags_a = [&](int slot, int slab, frag (&fa)[MREP]) {
         const unsigned short* As = smem + slot * STAGE;
 #pragma unroll
@@ -774,13 +783,24 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     };
     auto load_frags_b = [&](int slot, int slab, frag (&fb)[NREP]) {
         const unsigned short* Bs = smem + slot * STAGE + BM * 64;
+#ifdef PF_ABL_DUMMY_B         /* timing-only: the weight-fragment reads are issued and waited for, but the MFMAs keep their first operands */
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            u16x8 v = *reinterpret_cast<const u16x8*>(Bs + lds_off(wn * 16 * NREP + j * 16 + frow, slab * 4 + fchunk));
+            asm volatile("" :: "v"(v));
+        }
+        (void)fb;
+#else
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
             fb[j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Bs + lds_off(wn * 16 * NREP + j * 16 + frow, slab * 4 + fchunk)));
+#endif
     };
     auto load_frags = [&](int slot, int slab, frag (&fa)[MREP], frag (&fb)[NREP]) {
         load_frags_a(slot, slab, fa);
+#ifndef PF_ABL_NOLDS_B        /* timing-only: what the weight fragments' share of the LDS reads costs */
         load_frags_b(slot, slab, fb);
+#endif
     };
 
     auto issue_prologue = [&]() {
@@ -856,6 +876,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
                 if (k >= 0 && (k & 1) == 0 && (k >> 1) < NPIECE) {
                     __builtin_amdgcn_sched_barrier(0);
 #ifndef PF_ABL_NODMA
+#ifdef PF_ABL_NODMA_B         /* timing-only: activation pieces only */
+                    if ((k >> 1) < APASS)
+#endif
                     dma_piece(rs_a, cur, k >> 1);                 // stage it+3 into the slot retired at this step's barrier
 #endif
                     __builtin_amdgcn_sched_barrier(0);
