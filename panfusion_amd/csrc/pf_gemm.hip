@@ -1079,7 +1079,10 @@ static int tuning(const char* name, int dflt);
 template <typename T, int NREP>
 static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
     // NW = 4 (one 128x80 wave per SIMD, accumulators in AGPRs) is implemented and correct but measured slower
-    // (K step 2520 vs 2222 clocks, epilogue 2x): a lone in-order wave exposes every lgkmcnt / vmcnt / barrier wait
+    // (K step 2520 vs 2222 clocks, epilogue 2x): a lone in-order wave exposes every lgkmcnt / vmcnt / barrier wait.
+    // PF_GEMM8_WAVES=4 selects it (A/B: it moves 28 % fewer fragment bytes through the LDS).
+    static const int nw = tuning("PF_GEMM8_WAVES", 8);
+    if (nw == 4) return launch8w<T, NREP, 4>(gp, batch, st);
     return launch8w<T, NREP, 8>(gp, batch, st);
 }
 
