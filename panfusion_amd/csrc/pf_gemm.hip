@@ -643,6 +643,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // (the activation descriptor is rebuilt from scalars at the start of every stage: carried across
     // the loop as a variable it would live in VGPRs again)
     unsigned w_off[BFULL + 1];                                    // bytes
+#ifdef PF_GEMM_BDIRECT        /* experiment: weight fragments straight from L1 / L2 into registers, no weight tile in LDS.
+                               * Correct (68 GEMM / conv tests) and 2x SLOWER (3x3 convs 850 -> 440 TF/s): a fragment-shaped load touches 16
+                               * half-used cache lines per instruction, four waves fetch the same lines, and the prefetch distance is
+                               * half a K step.  Kept as a compile-time record of the measurement. */
+    unsigned wb_off[NREP];                                        // bytes: (n of fragment j, this lane's k chunk)
+    int kw = 0;                                                   // K offset (elements) of the stage being multiplied
+#endif
     const int Ctot = p.c0 + p.c1;
     const int Hl = p.h_in << p.up, Wl = p.w_in << p.up;
 
@@ -713,6 +720,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         tap = kg / Ctot;
         cc = kg - tap * Ctot;
         set_segment();
+#ifdef PF_GEMM_BDIRECT
+        kw = kb0 * 64;
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const int n = n0 + (wave & 1) * 16 * NREP + j * 16 + (lane & 15);
+            wb_off[j] = n < p.N ? static_cast<unsigned>(n * p.K + (lane >> 4) * 8) * 2u : OOB;
+        }
+#endif
     };
 
     // One stage = NPIECE DMA instructions per wave: pieces 0..3 the activation passes, then the weight
@@ -741,6 +756,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         if (k < APASS) {
             unsigned short* dst = As + (k * RPP + wave * 8) * 64;
             lds_dma(rs_a, dst, a_off[k], st_soff_a);
+#ifdef PF_GEMM_BDIRECT
+        } else if (true) {
+#endif
         } else if (k < APASS + BFULL) {
             const int j = k - APASS;
             lds_dma(rs_w, Bs + (j * RPP + wave * 8) * 64, w_off[j], st_soff_w);
@@ -781,7 +799,17 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         for (int i = 0; i < MREP; ++i)
             fa[i] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(As + lds_off(wm * 16 * MREP + i * 16 + frow, slab * 4 + fchunk)));
     };
-    auto load_frags_b = [&](int slot, int slab, frag (&fb)[NREP]) {
+    auto load_frags_b = [&](int slot, int slab, frag (&fb)[NREP], int kadd) {
+#ifdef PF_GEMM_BDIRECT
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        const int soff = __builtin_amdgcn_readfirstlane((kw + kadd + slab * 32) * 2);
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wb_off[j], soff, 0);
+            fb[j] = __builtin_bit_cast(frag, v);
+        }
+        return;
+#endif
         const unsigned short* Bs = smem + slot * STAGE + BM * 64;
 #ifdef PF_ABL_DUMMY_B         /* timing-only: the weight-fragment reads are issued and waited for, but the MFMAs keep their first operands */
 #pragma unroll
@@ -796,10 +824,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             fb[j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Bs + lds_off(wn * 16 * NREP + j * 16 + frow, slab * 4 + fchunk)));
 #endif
     };
-    auto load_frags = [&](int slot, int slab, frag (&fa)[MREP], frag (&fb)[NREP]) {
+    auto load_frags = [&](int slot, int slab, frag (&fa)[MREP], frag (&fb)[NREP], int kadd) {   // kadd: 64 for the NEXT stage (PF_GEMM_BDIRECT)
         load_frags_a(slot, slab, fa);
 #ifndef PF_ABL_NOLDS_B        /* timing-only: what the weight fragments' share of the LDS reads costs */
-        load_frags_b(slot, slab, fb);
+        load_frags_b(slot, slab, fb, kadd);
 #endif
     };
 
@@ -828,12 +856,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             else acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb0[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
 #ifdef PF_GEMM_FLEAD2          /* two bursts: A fragments after FLEAD MFMAs, B fragments after FLEAD2 (A/B build) */
             if (idx == FLEAD - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_a(cur, 1, fa1); __builtin_amdgcn_sched_barrier(0); }
-            if (idx == PF_GEMM_FLEAD2 - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_b(cur, 1, fb1); __builtin_amdgcn_sched_barrier(0); }
+            if (idx == PF_GEMM_FLEAD2 - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_b(cur, 1, fb1, 0); __builtin_amdgcn_sched_barrier(0); }
 #else
             if (idx == FLEAD - 1) {
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef PF_ABL_NOLDS
-                load_frags(cur, 1, fa1, fb1);
+                load_frags(cur, 1, fa1, fb1, 0);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -842,7 +870,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         if constexpr (MORE) {
             // my pieces of the next stage have landed (the stage after it may still be in flight: WAIT), and my
             // reads of the current slot have returned -- it is refilled right after the barrier
+#ifdef PF_GEMM_BDIRECT
+            if constexpr (true) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
             if constexpr (WAIT == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
             else if constexpr (WAIT == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
             else if constexpr (WAIT == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
             else if constexpr (WAIT == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
@@ -861,12 +893,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             else acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
 #ifdef PF_GEMM_FLEAD2
             if (MORE && idx == FLEAD - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_a(nx1, 0, fa0); __builtin_amdgcn_sched_barrier(0); }
-            if (MORE && idx == PF_GEMM_FLEAD2 - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_b(nx1, 0, fb0); __builtin_amdgcn_sched_barrier(0); }
+            if (MORE && idx == PF_GEMM_FLEAD2 - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_b(nx1, 0, fb0, 64); __builtin_amdgcn_sched_barrier(0); }
 #else
             if (MORE && idx == FLEAD - 1) {
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef PF_ABL_NOLDS
-                load_frags(nx1, 0, fa0, fb0);
+                load_frags(nx1, 0, fa0, fb0, 64);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -890,6 +922,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         cur = cur == STAGES - 1 ? 0 : cur + 1;
         nx1 = nx1 == STAGES - 1 ? 0 : nx1 + 1;
         nx2 = nx2 == STAGES - 1 ? 0 : nx2 + 1;
+#ifdef PF_GEMM_BDIRECT
+        kw += 64;
+#endif
     };
 #ifndef PF_GEMM_FLEAD
 #define PF_GEMM_FLEAD 4
@@ -913,7 +948,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
 #pragma unroll
             for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (first && n_it > 1) {                          // stage 0 landed, stage 1 may still fly
+#ifdef PF_GEMM_BDIRECT
+            if constexpr (true) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             if constexpr (NPIECE == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+#endif
             else if constexpr (NPIECE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if constexpr (NPIECE == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
             else if constexpr (NPIECE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -926,7 +965,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         if (first) stamp(p, 1);
         first = false;
         if (n_it > 2) dma_stage(2);                       // third stage in flight (slot 2 staged the previous tile's epilogue)
-        load_frags(0, 0, fa0, fb0);
+        load_frags(0, 0, fa0, fb0, 0);
         cur = 0; nx1 = 1; nx2 = 2;
         // The slot of stage `it` is retired at the mid-step barrier of step `it` (its last fragments are
         // requested in the first half), and stage it+3 is requested into it right behind that barrier: with
