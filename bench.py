@@ -268,7 +268,8 @@ def main():
     ap.add_argument("--precision", default=None, choices=["mixed", "fast"], help="override the scheme of --dtype")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-training-leg", action="store_true", help="skip the extra `training_step` measurement (N = 1 only)")
+    ap.add_argument("--no-training-leg", action="store_true",
+                    help="skip the extra `training_step` measurement (N = 1 only; --no-cpu-baseline skips it too)")
     ap.add_argument("--trace-out", default=None, help="write the per-shape table of the instrumented step here")
     ap.add_argument("--small", action="store_true", help="reduced widths/sizes (debug only, not the metric)")
     ap.add_argument("--cfg5", action="store_true",
@@ -418,7 +419,9 @@ def main():
                "roofline": roofline}
         if not args.no_cpu_baseline and world == 1 and not args.small:
             res["cpu_baseline"] = cpu_baseline(cfg, cfg["cross_attention_dim"], lat_hw, pano_hw, m, cams_deg, flop)
-        if not args.no_training_leg and world == 1 and not (args.small or args.cfg4 or args.cfg5):
+        # (skipped with --no-cpu-baseline as well: that flag marks the quick / profiled runs of tools/*.sh -- under
+        # rocprofv3 --pmc the ~6000 launches of a training step take tens of minutes)
+        if not args.no_training_leg and not args.no_cpu_baseline and world == 1 and not (args.small or args.cfg4 or args.cfg5):
             # extra, after the metric and its baseline: the training step through the same boundary
             try:
                 del loop, model

@@ -12,23 +12,23 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v am
 echo "== bench (default = fp16 mixed)"
 timeout 900 python bench.py --trace-out gpurun_out/${TAG}_shapes.txt > gpurun_out/${TAG}_bench.log 2>&1; tail -n 1 gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json; cut -c1-300 gpurun_out/${TAG}_bench.json
 echo "== bench secondary lines (all-16-bit fp16 / bf16)"
-timeout 600 python bench.py --precision fast --no-cpu-baseline 2>&1 | tail -n 1 > gpurun_out/${TAG}_bench_fp16_fast.json; cut -c1-200 gpurun_out/${TAG}_bench_fp16_fast.json
-timeout 600 python bench.py --dtype bf16 --no-cpu-baseline 2>&1 | tail -n 1 > gpurun_out/${TAG}_bench_bf16_fast.json; cut -c1-200 gpurun_out/${TAG}_bench_bf16_fast.json
+timeout 600 python bench.py --precision fast --no-cpu-baseline --no-training-leg 2>&1 | tail -n 1 > gpurun_out/${TAG}_bench_fp16_fast.json; cut -c1-200 gpurun_out/${TAG}_bench_fp16_fast.json
+timeout 600 python bench.py --dtype bf16 --no-cpu-baseline --no-training-leg 2>&1 | tail -n 1 > gpurun_out/${TAG}_bench_bf16_fast.json; cut -c1-200 gpurun_out/${TAG}_bench_bf16_fast.json
 cd /tmp
 echo "== rocprofv3 --kernel-trace --stats of the default bench command"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_g -o bench -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_rocprof_graphs.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_g -o bench -- python $R/bench.py --no-cpu-baseline --no-training-leg > $R/gpurun_out/${TAG}_rocprof_graphs.log 2>&1
 cp $(find $R/gpurun_out/${TAG}_g -name '*kernel_stats.csv' | head -1) $R/gpurun_out/${TAG}_kernel_stats_default_cmd.csv 2>/dev/null
 find $R/gpurun_out/${TAG}_g -type f -size +1M -delete
 head -n 8 $R/gpurun_out/${TAG}_kernel_stats_default_cmd.csv | cut -c1-160
 echo "== serial (one stream, no graphs) per-kernel table"
-PF_STREAMS=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_s -o bench -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-graphs > $R/gpurun_out/${TAG}_rocprof_serial.log 2>&1
+PF_STREAMS=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_s -o bench -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-training-leg --no-graphs > $R/gpurun_out/${TAG}_rocprof_serial.log 2>&1
 T=$(find $R/gpurun_out/${TAG}_s -name '*kernel_trace.csv' | head -1)
 python $R/tools/prof_summary.py trace $T $R/gpurun_out/${TAG}_kernels_serial.txt 10
 find $R/gpurun_out/${TAG}_s -type f -size +1M -delete
 head -n 14 $R/gpurun_out/${TAG}_kernels_serial.txt
 echo "== PMC traffic passes (separate passes, --kernel-trace only)"
 for C in FETCH_SIZE WRITE_SIZE; do
-  PF_STREAMS=1 timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_$C -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graphs > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
+  PF_STREAMS=1 timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_$C -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-training-leg --no-graphs > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
   P=$(find $R/gpurun_out/${TAG}_pmc_$C -name '*counter_collection.csv' | head -1)
   python $R/tools/prof_summary.py pmc $P $R/gpurun_out/${TAG}_pmc_$C.txt
   find $R/gpurun_out/${TAG}_pmc_$C -type f -size +1M -delete
