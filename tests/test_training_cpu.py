@@ -390,3 +390,37 @@ def test_ddp_over_the_whole_denoiser(tmp_path):
         want = (singles[0][k] + singles[1][k]) / 2
         assert torch.equal(got[0][k], got[1][k])
         assert rel_l2(got[0][k], want) < 1e-4, (k, rel_l2(got[0][k], want))
+
+
+def test_lora_on_a_subset_of_the_projections(fake_denoiser_backend):
+    """LoRA groups with holes: only to_q / to_v of the self-attentions and only to_k of the text attentions carry matrices
+    (the stacked down / block-diagonal up operands of train_engine.LoRAGroup must keep every pair in its own rows and columns)."""
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    oracle, args, w_s, w_p = _denoiser_case()
+    kept = 0
+    for unet in (oracle.unet, oracle.pano_unet):
+        for mod in unet.modules():
+            if all(hasattr(mod, a) for a in ("to_q", "to_k", "to_v", "to_out")):
+                is_self = mod.to_k.in_features == mod.to_q.in_features
+                keep = {"to_q", "to_v"} if is_self else {"to_k"}
+                for name, lin in (("to_q", mod.to_q), ("to_k", mod.to_k), ("to_v", mod.to_v), ("to_out", mod.to_out[0])):
+                    if name not in keep:
+                        lin.lora_layer = None
+                    else:
+                        kept += 1
+    s, ps = oracle(*args)
+    ((s * w_s).sum() + (ps * w_p).sum()).backward()
+    want = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None and ("lora" in k or k.startswith("cp_blocks"))}
+    for p in oracle.parameters():
+        p.grad = None
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=torch.float32,
+                             precision="fast", differentiable=True)
+    hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    assert len(hip.trainable_tensors()) == 91 + 2 * kept
+    s2, ps2 = hip(*args)
+    assert rel_l2(s2, s) < 2e-5
+    ((s2 * w_s).sum() + (ps2 * w_p).sum()).backward()
+    got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    assert set(k for k in got if "lora" in k) == set(k for k in want if "lora" in k) and len(want) == 91 + 2 * kept
+    for k, w in want.items():
+        assert rel_l2(got[k], w) < 1e-4, (k, rel_l2(got[k], w))
