@@ -424,3 +424,34 @@ def test_lora_on_a_subset_of_the_projections(fake_denoiser_backend):
     assert set(k for k in got if "lora" in k) == set(k for k in want if "lora" in k) and len(want) == 91 + 2 * kept
     for k, w in want.items():
         assert rel_l2(got[k], w) < 1e-4, (k, rel_l2(got[k], w))
+
+
+def test_denoiser_training_batch_of_two_with_different_cameras(fake_denoiser_backend):
+    """b = 2 with DIFFERENT camera sets per sample (per-sample EPA tables: one attention launch per sample in recompute and
+    backward) and different timesteps: gradients against autograd through the oracle."""
+    from conftest import build_tiny_oracle, golden
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    g = golden("mvgen_tiny.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    c = cam4()
+    cams = {"FoV": torch.stack([c["FoV"], c["FoV"]]), "theta": torch.stack([c["theta"], c["theta"] + 33.0]),
+            "phi": torch.stack([c["phi"], c["phi"] - 5.0])}
+    args = (t("latents"), t("pano_latent"), torch.tensor([[981] * 4, [301] * 4]), t("prompt_embd"), t("pano_prompt_embd"), cams)
+    gen = torch.Generator().manual_seed(2)
+    w_s, w_p = torch.randn(args[0].shape, generator=gen), torch.randn(args[1].shape, generator=gen)
+    oracle = build_tiny_oracle()
+    s, ps = oracle(*args)
+    ((s * w_s).sum() + (ps * w_p).sum()).backward()
+    want = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None and ("lora" in k or k.startswith("cp_blocks"))}
+    for p in oracle.parameters():
+        p.grad = None
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=torch.float32,
+                             precision="fast", differentiable=True)
+    hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    s2, ps2 = hip(*args)
+    assert rel_l2(s2, s) < 2e-5 and rel_l2(ps2, ps) < 2e-5
+    ((s2 * w_s).sum() + (ps2 * w_p).sum()).backward()
+    got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    assert len(want) == 603
+    for k, w in want.items():
+        assert rel_l2(got[k], w) < 1e-4, (k, rel_l2(got[k], w))
