@@ -128,7 +128,8 @@ class MultiViewBaseModel(nn.Module):
             from ... import train_engine
             params = [t for t in self.trainable_tensors() if t.requires_grad]
             if params:
-                return train_engine.DenoiserFunction.apply(self, args, *params)
+                out = train_engine.DenoiserFunction.apply(self, args, *params)
+                return out if isinstance(out, tuple) else (None, out)       # PanoOnly: (sample = None, pano_sample) as the reference
         return self._forward(*args)
 
     @torch.no_grad()

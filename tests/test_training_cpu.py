@@ -455,3 +455,31 @@ def test_denoiser_training_batch_of_two_with_different_cameras(fake_denoiser_bac
     assert len(want) == 603
     for k, w in want.items():
         assert rel_l2(got[k], w) < 1e-4, (k, rel_l2(got[k], w))
+
+
+def test_pano_only_model_trains(fake_denoiser_backend):
+    """PanoOnly (PanoOnly.py:13,39-41: unet = None, latents = None, cameras = None): the panorama branch alone under training --
+    gradients of the panorama UNet's LoRA matrices; there are no EPA blocks to train."""
+    from conftest import build_tiny_oracle, golden
+    from oracle import mvgen as MV
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    g = golden("mvgen_tiny.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    full = build_tiny_oracle()
+    oracle = MV.DualBranchDenoiser(None, full.pano_unet, None, None, True)
+    args = (None, t("pano_latent")[:1], torch.tensor([481]), None, t("pano_prompt_embd")[:1], None)
+    w_p = torch.randn(args[1].shape, generator=torch.Generator().manual_seed(4))
+    _, ps = oracle(*args)
+    (ps * w_p).sum().backward()
+    want = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None and "lora" in k}
+    for p in oracle.parameters():
+        p.grad = None
+    hip = MultiViewBaseModel(None, full.pano_unet, None, None, True, compute_dtype=torch.float32, precision="fast", differentiable=True)
+    assert len(hip.trainable_tensors()) == 256
+    none, ps2 = hip(*args)
+    assert none is None and rel_l2(ps2, ps) < 2e-5
+    (ps2 * w_p).sum().backward()
+    got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    assert len(want) == 256
+    for k, w in want.items():
+        assert rel_l2(got[k], w) < 1e-4, (k, rel_l2(got[k], w))
