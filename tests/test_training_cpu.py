@@ -170,7 +170,8 @@ def _denoiser_case(seed=0):
     return oracle, args, w_s, w_p
 
 
-def test_denoiser_training_step_matches_autograd(fake_denoiser_backend):
+@pytest.mark.parametrize("precision", ["fast", "mixed"])
+def test_denoiser_training_step_matches_autograd(fake_denoiser_backend, precision):
     """One training step of the dual-branch denoiser (forward on the engine, backward on train_engine's tape) against torch
     autograd through the oracle denoiser (reference MultiViewBaseModel + EPA on the restated UNets with UNFUSED LoRA):
     gradients of every EPA parameter and every LoRA matrix of both UNets.  fp32 test double: agreement at round-off."""
@@ -182,7 +183,7 @@ def test_denoiser_training_step_matches_autograd(fake_denoiser_backend):
     for p in oracle.parameters():
         p.grad = None
     hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=torch.float32,
-                             precision="fast", differentiable=True)
+                             precision=precision, differentiable=True)     # mixed: fp32 streams, split-precision operands / weights
     hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
     s2, ps2 = hip(*args)
     assert s2.requires_grad and rel_l2(s2, s) < 2e-5 and rel_l2(ps2, ps) < 2e-5
