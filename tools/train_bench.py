@@ -8,9 +8,7 @@ train_engine's tape, gradients for the 91 EPA tensors and the 512 LoRA matrices.
 import argparse
 import os
 import sys
-import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
