@@ -19,6 +19,12 @@ from ... import engine
 from .modules import WarpAttn, camera_groups
 
 
+def _repack_hook(module, incompatible):
+    """load_state_dict post hook (module-level: a lambda would make the module unpicklable -- torch.save(model),
+    mp.spawn / Lightning ddp_spawn passing the module)."""
+    module.repack()
+
+
 class MultiViewBaseModel(nn.Module):
     def __init__(self, unet, pano_unet, pers_cn=None, pano_cn=None, pano_pad=True,
                  compute_dtype=torch.float16, precision=None, differentiable=False):
@@ -44,7 +50,7 @@ class MultiViewBaseModel(nn.Module):
         self._side = None
         # packed 16-bit weights go stale when a checkpoint is loaded -- also through a parent module (the
         # reference's LightningModule), where an overridden load_state_dict would never run
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.repack())
+        self.register_load_state_dict_post_hook(_repack_hook)
 
         if self.unet is not None:      # EPA block widths, reference MVGenModel.py:19-32
             self.cp_blocks_encoder = nn.ModuleList(
@@ -64,6 +70,9 @@ class MultiViewBaseModel(nn.Module):
         if key not in self._packed:
             pack = engine.pack_controlnet if which.endswith("_cn") else engine.pack_unet
             self._packed[key] = pack(getattr(self, which), device, self.compute_dtype, self.precision == "mixed")
+            # the LoRA state this pack was folded from (refold_lora compares against it; ADVICE r2: without it the
+            # first call after an in-place parameter change saw "no change")
+            self._packed[key].lora_key = self._lora_versions()
         return self._packed[key]
 
     def repack(self):
@@ -93,9 +102,12 @@ class MultiViewBaseModel(nn.Module):
         """EPA parameters and the LoRA matrices of both UNets: what the reference optimises (PanoGenerator.py:129-160,
         MVGenModel.py:34-36), in the order DenoiserFunction returns their gradients."""
         from ... import train_engine
+        # cache keyed on the LoRA modules found in the tree (ids): attaching / replacing LoRA layers after the first call
+        # (set_attn_processor, lora_layer assignment) rebuilds the list instead of silently training the old tensors
+        fp = self._lora_fingerprint()
         cached = getattr(self, "_trainable_cache", None)
-        if cached is not None:                       # (the module tree is static; load_state_dict copies in place)
-            return cached
+        if cached is not None and cached[0] == fp:
+            return cached[1]
         out, seen = [], set()
 
         def add(t):
@@ -116,8 +128,34 @@ class MultiViewBaseModel(nn.Module):
                         if ref is not None:
                             add(ref.down)
                             add(ref.up)
-        self._trainable_cache = out
+        self._trainable_cache = (fp, out)
         return out
+
+    def _attn_projections(self):
+        """(attention module, name, linear) of every attention projection of both UNets; the set of attention MODULES is
+        fixed by the UNet architecture, only their lora_layer / processor attributes can change: listed once."""
+        hit = self.__dict__.get("_attn_proj_cache")
+        if hit is None:
+            hit = []
+            for unet in (self.unet, self.pano_unet):
+                if unet is None:
+                    continue
+                for mod in unet.modules():
+                    if all(hasattr(mod, a) for a in ("to_q", "to_k", "to_v", "to_out")):
+                        hit += [(mod, "to_q", mod.to_q), (mod, "to_k", mod.to_k), (mod, "to_v", mod.to_v), (mod, "to_out", mod.to_out[0])]
+            self.__dict__["_attn_proj_cache"] = hit
+        return hit
+
+    def _lora_fingerprint(self):
+        """ids of the LoRA modules currently attached (either diffusers location)."""
+        fp = []
+        for mod, name, lin in self._attn_projections():
+            lora = getattr(lin, "lora_layer", None) or engine._processor_lora(mod, name + "_lora")
+            fp.append(id(lora) if lora is not None else 0)
+        return tuple(fp)
+
+    def _lora_versions(self):
+        return tuple((id(t), t._version) for t in self.trainable_tensors())
 
     def forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras,
                 pers_layout_cond=None, pano_layout_cond=None):
@@ -134,27 +172,30 @@ class MultiViewBaseModel(nn.Module):
 
     @torch.no_grad()
     def refold_lora(self):
-        """Bring the packed attention projections up to date when a LoRA matrix changed since the last call (optimizer
-        steps bump the version counters): the forward kernels read W + up @ down folded into one 16-bit weight.  Only
-        the 4 x 32 projections per UNet are re-folded; the frozen weights (and the backward operands train_engine keeps
-        next to them) stay."""
-        key = tuple(t._version for t in self.trainable_tensors())
-        if getattr(self, "_lora_key", key) != key:
-            for (which, *_), u in self._packed.items():
-                if which.endswith("_cn"):
-                    continue
-                for t in engine.all_transformers(u):
-                    blk = t.src.transformer_blocks[0]
-                    dev = t.w_in.device
-                    t.attn1 = engine.pack_attention(blk.attn1, dev, t.dtype, True)
-                    t.attn2 = engine.pack_attention(blk.attn2, dev, t.dtype, False)
-                u.__dict__.pop("text_kv_cache", None)          # K / V^T of the prompt depend on to_k / to_v
-        self._lora_key = key
+        """Bring the packed attention projections up to date when a LoRA matrix changed since the pack was built / last
+        re-folded (optimizer steps and in-place copies bump the version counters): the forward kernels read
+        W + up @ down folded into one 16-bit weight.  Only the 4 x 32 projections per UNet are re-folded; the frozen
+        weights (and the backward operands train_engine keeps next to them) stay.  Called at the top of EVERY forward --
+        also the no_grad ones (validation / predict after fit, DenoiseLoop): the key is a tuple of ~600 ints."""
+        if not self._packed:
+            return
+        key = self._lora_versions()
+        for (which, *_), u in self._packed.items():
+            if which.endswith("_cn") or getattr(u, "lora_key", key) == key:
+                continue
+            for t in engine.all_transformers(u):
+                blk = t.src.transformer_blocks[0]
+                dev = t.w_in.device
+                t.attn1 = engine.pack_attention(blk.attn1, dev, t.dtype, True)
+                t.attn2 = engine.pack_attention(blk.attn2, dev, t.dtype, False)
+            u.__dict__.pop("text_kv_cache", None)          # K / V^T of the prompt depend on to_k / to_v
+            u.lora_key = key
 
     @torch.no_grad()
     def _forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras,
                  pers_layout_cond=None, pano_layout_cond=None, tape=None):
         """tape: a list that receives (layer, inputs) records for train_engine.backward (training forward)."""
+        self.refold_lora()
         if self.pers_cn is None:
             pers_layout_cond = None                 # reference MVGenModel.py:62-65
         if self.pano_cn is None:

@@ -39,6 +39,11 @@ def camera_groups(cameras, b):
                for i in range(b)]
 
 
+def _repack_hook(module, incompatible):
+    """load_state_dict post hook; module-level so that the block stays picklable."""
+    module.repack()
+
+
 class WarpAttn(nn.Module):
     def __init__(self, dim, compute_dtype=torch.float16, precision=None):
         super().__init__()
@@ -50,7 +55,7 @@ class WarpAttn(nn.Module):
         self._tables = engine.EPATables()
         # checkpoints loaded through a PARENT module never reach a load_state_dict override of this class
         # (nn.Module recurses via _load_from_state_dict): the post hook fires either way
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.repack())
+        self.register_load_state_dict_post_hook(_repack_hook)
 
     def packed(self, device):
         # (the parameters' version counters: an optimizer step between two training forwards re-packs)

@@ -238,6 +238,41 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
     assert hip.packed("unet", args[1].device) is pack_before and pack_before.down[0].resnets[0].train is res_before
 
 
+def test_no_grad_forward_after_optimizer_step_sees_the_new_lora(fake_denoiser_backend):
+    """validation / predict after fit (torch.no_grad, DenoiseLoop) goes straight to _forward -- it must re-fold
+    the LoRA-carrying projections too, not mix the current EPA weights with the LoRA from before the step.  Also the
+    in-place case: packs built by an inference forward, parameters changed with p.data.copy_ (no load_state_dict)."""
+    import pickle
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    oracle, args, w_s, w_p = _denoiser_case()
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=torch.float32,
+                             precision="fast", differentiable=True)
+    hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    opt = torch.optim.SGD(hip.trainable_tensors(), lr=0.5)
+    s0, ps0 = hip(*args)
+    ((s0 * w_s).sum() + (ps0 * w_p).sum()).backward()
+    opt.step()
+    for name in ("cp_blocks_encoder", "cp_blocks_mid", "cp_blocks_decoder"):
+        getattr(oracle, name).load_state_dict(getattr(hip, name).state_dict())
+    with torch.no_grad():
+        want_s, want_ps = oracle(*args)
+        s1, ps1 = hip(*args)                               # inference forward right after the step
+    assert rel_l2(want_s, s0.detach()) > 1e-3
+    assert rel_l2(s1, want_s) < 5e-5 and rel_l2(ps1, want_ps) < 5e-5
+    # in-place change of a LoRA matrix between two inference forwards
+    with torch.no_grad():
+        lora = [t for t in hip.trainable_tensors() if t.dim() == 2 and min(t.shape) == 4][0]
+        lora.data.copy_(lora.data * 3.0)
+        lora._version  # noqa: B018  (data.copy_ does not bump the counter: bump it the way an in-place op on the parameter does)
+        lora.mul_(1.0)
+        want_s2, want_ps2 = oracle(*args)
+        s2, ps2 = hip(*args)
+    assert rel_l2(want_s2, want_s) > 1e-5
+    assert rel_l2(s2, want_s2) < 5e-5 and rel_l2(ps2, want_ps2) < 5e-5
+    # the module (and an EPA block alone) survive pickling: no lambdas among the load_state_dict hooks (ADVICE r2)
+    pickle.dumps(hip.cp_blocks_mid)
+
+
 def test_training_reaches_lora_in_the_attention_processor_layout(fake_denoiser_backend):
     """The LoRA matrices of a reference checkpoint sit in ``attn.processor.to_{q,k,v,out}_lora`` (set_attn_processor,
     PanoGenerator.py:132-151; no diffusers forward ever migrates them here): the training path must find them there --

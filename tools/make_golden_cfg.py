@@ -1,0 +1,113 @@
+"""Golden outputs of the CPU oracle at the EXACT BASELINE.json configurations (VERDICT r2 "Next round" item 1).
+
+Runs in the build container (CPU, minutes per case); the ``-m gpu`` tests of tests/test_gpu_configs.py rebuild the
+same seeded weights / inputs on the GPU box (oracle/fixtures.py) and compare the HIP path with what is stored here.
+
+    python tools/make_golden_cfg.py cfg2 cfg1 cfg4 cfg5        # any subset
+
+  cfg2  -> tests/golden/cfg2_eps.npz       m = 20 icosahedron views x CFG pair, first-step denoiser call at SD-2-base
+                                           widths: both epsilon outputs + 8-channel slices of both streams after each of
+                                           the 7 EPA blocks (the 20-view EPA softmax has K = 20 480 keys)
+  cfg1  -> tests/golden/cfg1_ddim10.npz    configs[0]: m = 4, 256^2 views, 10 DDIM steps at full widths: latents after
+                                           every step (drift per step)
+  cfg4  -> tests/golden/cfg4_eps.npz       128x256 panorama latent + 20 views, one CFG sample
+  cfg5  -> tests/golden/cfg5_eps.npz       cfg2's geometry + panorama ControlNet on a 512x1024 layout image, one CFG sample
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ddim as oddim  # noqa: E402
+from oracle import fixtures as FX  # noqa: E402
+from oracle import mvgen as MV  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+NSLICE = 8
+
+
+def epa_slices(model):
+    """Forward hooks on the 7 EPA blocks: channels ::C/8 of sample -1 / view 0 of both outputs."""
+    got, hooks = {}, []
+    blocks = [*model.cp_blocks_encoder, model.cp_blocks_mid, *model.cp_blocks_decoder]
+
+    def make(i):
+        def hook(mod, args, out):
+            p, e = out
+            st = p.shape[1] // NSLICE
+            m = p.shape[0] // e.shape[0]
+            got["epa%d_pers" % i] = p[-m, ::st].numpy().copy()          # view 0 of the last (conditional) sample
+            got["epa%d_pano" % i] = e[-1, ::st].numpy().copy()
+        return hook
+    for i, blk in enumerate(blocks):
+        hooks.append(blk.register_forward_hook(make(i)))
+    return got, hooks
+
+
+def call(model, args, **extra):
+    with torch.no_grad(), FX.chunked_attention():
+        return model(args["latents"], args["pano_latent"], args["timestep"], args["prompt_embd"],
+                     args["pano_prompt_embd"], args["cameras"], **extra)
+
+
+def cfg2():
+    model = FX.build_full_width()
+    args = FX.first_step_call(FX.ico_cameras(), (64, 64), (64, 128), cfg_pair=True)
+    got, hooks = epa_slices(model)
+    t0 = time.time()
+    s, ps = call(model, args)
+    print("cfg2 oracle forward %.0f s" % (time.time() - t0), flush=True)
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(OUT, "cfg2_eps.npz"), sample=s.numpy(), pano_sample=ps.numpy(), **got)
+
+
+def cfg1():
+    model = FX.build_full_width()
+    cams = FX.horizon4_cameras()
+    latents, pano_latent, pe, ppe = FX.loop_inputs(cams, (32, 32), (64, 128))
+    sched = oddim.DDIM()
+    traj_v, traj_p = [], []
+    total = 0.0
+    t0 = time.time()
+    with FX.chunked_attention():
+        for t in sched.set_timesteps(10):
+            latents, pano_latent, cams = oddim.denoise_step(model, sched, t, latents, pano_latent, pe, ppe, cams)
+            total += 90.0
+            traj_v.append(latents.numpy().copy())
+            traj_p.append(oddim.rotate_latent(pano_latent, cams, -total)[0].numpy().copy())     # un-rotated frame
+            print("cfg1 step t=%d  %.0f s" % (int(t), time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(OUT, "cfg1_ddim10.npz"), latents=np.stack(traj_v), pano_latent=np.stack(traj_p))
+
+
+def cfg4():
+    model = FX.build_full_width()
+    args = FX.first_step_call(FX.ico_cameras(), (64, 64), (128, 256), cfg_pair=False)
+    t0 = time.time()
+    s, ps = call(model, args)
+    print("cfg4 oracle forward %.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(OUT, "cfg4_eps.npz"), sample=s.numpy(), pano_sample=ps.numpy())
+
+
+def cfg5():
+    model = FX.build_full_width(controlnet=True)
+    args = FX.first_step_call(FX.ico_cameras(), (64, 64), (64, 128), cfg_pair=False)
+    cond = torch.roll(FX.layout_image((64, 128)), 1024 // 4, dims=-1)       # rolled with the panorama (PanFusion.py:152-153)
+    t0 = time.time()
+    s, ps = call(model, args, pano_layout_cond=cond)
+    s0, ps0 = call(model, args)
+    print("cfg5 oracle forward x2 %.0f s; ControlNet moves pano eps by %.3e" % (
+        time.time() - t0, float((ps - ps0).norm() / ps0.norm())), flush=True)
+    np.savez_compressed(os.path.join(OUT, "cfg5_eps.npz"), sample=s.numpy(), pano_sample=ps.numpy())
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(int(os.environ.get("PF_THREADS", os.cpu_count() or 8)))
+    for name in (sys.argv[1:] or ["cfg2", "cfg1", "cfg4", "cfg5"]):
+        globals()[name]()
+        print(name, "done", flush=True)
