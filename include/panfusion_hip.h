@@ -118,6 +118,13 @@ pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, int c1, int
                              float* scale, float* shift, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* The same scale / shift from the per-column-pair moments a pf_conv_gemm epilogue left in pf_conv_desc.gn_partial: source s
+ * is fp32 [n_img * hw / rows_s][2][c_s / 2] (rows_s = pf_conv_gemm_gn_rows of the launch that produced it); part1 = NULL: one
+ * source.  (c0 + c1) / groups, c0 and c1 must be even.  No pass over the activation itself. */
+pf_status pf_groupnorm_from_partials(const float* part0, int c0, int rows0, const float* part1, int c1, int rows1,
+                                     int n_img, int hw, int groups, float eps, const float* gamma, const float* beta,
+                                     float* scale, float* shift, void* stream);
+
 /* y = act(x*scale + shift), act 0 = identity, 1 = SiLU (scale = shift = NULL: y = act(x)).  Same concat
  * convention.  dtype = type of the sources (16-bit or PF_F32).  Output:
  *   out_dtype 16-bit, out_split 0:  y [n_img][hw][C]
@@ -128,6 +135,12 @@ pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, int c1, int
 pf_status pf_scale_shift_act(const void* x0, int c0, const void* x1, int c1, int dtype,
                              int n_img, int hw, const float* scale, const float* shift, int act,
                              int out_dtype, int out_split, void* y, void* stream);
+/* fp32 sources, 16-bit y as above, PLUS the un-normalised input as the split pair raw_pair [n_img][hw][hi(C) | lo(C)]
+ * in the same pass (the A operand of a ResnetBlock2D's split-precision conv_shortcut next to norm1 + SiLU of the same
+ * tensor: one read of the fp32 stream instead of two). */
+pf_status pf_scale_shift_act_pair(const void* x0, int c0, const void* x1, int c1, int n_img, int hw,
+                                  const float* scale, const float* shift, int act, int out_dtype, void* y,
+                                  void* raw_pair, void* stream);
 
 /* y = LayerNorm(x + pe) * gamma + beta over the last dim; x,y [rows][C]; pe (optional) fp32
  * [pe_rows][C], row r uses pe row (r % pe_rows) (transformer.py:155-158; eps 1e-5).
@@ -242,6 +255,12 @@ typedef struct {
                           * of a following split-precision GEMM without a separate split pass            */
     void* workspace;     /* split-K scratch (may be NULL: no split) of pf_conv_gemm_workspace_size   */
     size_t workspace_bytes;
+    float* gn_partial;   /* optional by-product (NULL: none): GroupNorm moments of the OUTPUT for the next layer's
+                          * norm (diffusers ResnetBlock2D.norm1 / norm2, Transformer2DModel.norm; call sites
+                          * MVGenModel.py:102-144,174-198,224-277), so that no statistics pass re-reads the tensor:
+                          * fp32 [M / R][2][n_out / 2] = (sum, sum of squares) of each column PAIR (2 k, 2 k + 1) over each run of R output rows,
+                          * R = pf_conv_gemm_gn_rows(desc) (> 0: possible for this problem; images are whole runs).
+                          * Consumed by pf_groupnorm_from_partials.  Fixed summation order, no atomics.      */
 } pf_conv_desc;
 
 enum { PF_EPILOGUE_NONE = 0, PF_EPILOGUE_GEGLU = 1, PF_EPILOGUE_SPLIT = 2 };
@@ -250,6 +269,9 @@ enum { PF_EPILOGUE_NONE = 0, PF_EPILOGUE_GEGLU = 1, PF_EPILOGUE_SPLIT = 2 };
  * cannot fill the 256 CUs (the 8x8 / 16x16 levels and the whole panorama branch); 0 = not wanted.
  * The slabs are summed in split order by a second kernel: results do not depend on scheduling. */
 size_t pf_conv_gemm_workspace_size(const pf_conv_desc* desc);
+/* Rows per moment run R of pf_conv_desc.gn_partial for this problem, or 0 when the kernel that serves it cannot emit
+ * the moments (split-K plans, batches, GEGLU / pair epilogues, images that are not whole runs of R rows). */
+int pf_conv_gemm_gn_rows(const pf_conv_desc* desc);
 /* Diagnostics only: while `device_buffer` (capacity_blocks x 32 uint64) is set, every pf_conv_gemm launch
  * with at most capacity_blocks workgroups records 4 shader-clock stamps per workgroup (entry, first
  * operand tile landed, K loop done, exit; the 8-wave kernel adds per-wave K-loop time split into

@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("batch", c_int),
         ("a_bstride", c_long), ("w_bstride", c_long), ("out_bstride", c_long), ("res_bstride", c_long),
         ("epilogue", c_int), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("gn_partial", c_void_p),
     ]
 
 
@@ -109,6 +110,11 @@ SIGNATURES = {
                                  c_long, c_int, c_int, c_void_p, c_void_p]),
     "pf_conv_gemm": (c_int, [C.POINTER(ConvDesc), c_void_p]),
     "pf_conv_gemm_workspace_size": (c_size_t, [C.POINTER(ConvDesc)]),
+    "pf_conv_gemm_gn_rows": (c_int, [C.POINTER(ConvDesc)]),
+    "pf_groupnorm_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_scale_shift_act_pair": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p]),
     "pf_debug_gemm_profile": (c_int, [c_void_p, c_long]),
     "pf_conv_in": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                            c_void_p, c_void_p]),

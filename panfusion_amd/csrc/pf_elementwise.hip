@@ -111,22 +111,34 @@ __global__ __launch_bounds__(256) void k_gn_partial(const typename In8<TI>::elem
     }
 }
 
-// Stage 2 (one block per image): chunk partials -> fp64 moments per group (256/groups lanes share a
-// group, combined in a fixed order), folded with gamma/beta into per-(image, channel) scale / shift.
+// Stage 2: chunk partials -> fp64 moments per group, folded with gamma/beta into per-(image, channel) scale / shift.
+// grid (image, group block of GPB groups): 256 / GPB lanes share a group (4 independent loads in flight each),
+// combined in a fixed order.  (Round 3: one block per image walked the chunks serially -- 24 us per launch on the
+// 2-image panorama branch, 0.9 ms per step in 122 launches.)
+constexpr int GN_GPB = 8;
 __global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ partial, int nchunks, int groups, int C,
                               int hw, float eps, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* __restrict__ scale,
                               float* __restrict__ shift) {
     __shared__ double red[2][256];
-    __shared__ float g_mean[64], g_rstd[64];
+    __shared__ float g_mean[GN_GPB], g_rstd[GN_GPB];
     const int img = blockIdx.x, t = threadIdx.x;
     const int cpg = C / groups;
-    const int lpg = groups <= 256 ? 256 / groups : 1;
-    const int g = t / lpg, l = t % lpg;
+    constexpr int lpg = 256 / GN_GPB;
+    const int gl = t / lpg, l = t % lpg, g = blockIdx.y * GN_GPB + gl;
     double s = 0.0, q = 0.0;
     if (g < groups) {
-        for (int k = l; k < nchunks; k += lpg) {
-            const float2 v = *reinterpret_cast<const float2*>(partial + ((static_cast<long>(img) * nchunks + k) * groups + g) * 2);
+        const float* base = partial + (static_cast<long>(img) * nchunks * groups + g) * 2;
+        int k = l;
+        for (; k + 3 * lpg < nchunks; k += 4 * lpg) {
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float2*>(base + static_cast<long>(k + u * lpg) * groups * 2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
+        }
+        for (; k < nchunks; k += lpg) {
+            const float2 v = *reinterpret_cast<const float2*>(base + static_cast<long>(k) * groups * 2);
             s += v.x;
             q += v.y;
         }
@@ -140,12 +152,73 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ p
         const double mean = s / cnt;
         double var = q / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
-        g_mean[g] = static_cast<float>(mean);
-        g_rstd[g] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+        g_mean[gl] = static_cast<float>(mean);
+        g_rstd[gl] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
     }
     __syncthreads();
-    for (int c = t; c < C; c += 256) {
-        const int gg = c / cpg;
+    const int cbeg = blockIdx.y * GN_GPB * cpg, cend = min(C, cbeg + GN_GPB * cpg);
+    for (int c = cbeg + t; c < cend; c += 256) {
+        const int gg = (c - cbeg) / cpg;
+        const float sc = g_rstd[gg] * gamma[c];
+        scale[static_cast<long>(img) * C + c] = sc;
+        shift[static_cast<long>(img) * C + c] = beta[c] - g_mean[gg] * sc;
+    }
+}
+
+// The same from the per-column-PAIR moments a GEMM epilogue left behind (pf_conv_desc.gn_partial): source s holds
+// [n_img * ppi_s][2][c_s / 2] (sum, sum of squares of columns (2 k, 2 k + 1) over runs of hw / ppi_s rows); the channel
+// concat (x0 | x1) is the concat of the two column ranges; groups hold an even number of channels and c0 is even, so a pair
+// never straddles a group or the two sources.  grid (image, group block): every thread owns pairs of the block's GN_GPB
+// groups and walks the image's parts with 4 loads in flight (coalesced across threads), fp64 accumulation.
+__global__ __launch_bounds__(256) void k_gn_finalize_cols(const float* __restrict__ part0, int c0, int ppi0,
+                                   const float* __restrict__ part1, int c1, int ppi1, int groups, int hw, float eps,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    constexpr int PMAX = 512;                         // pairs of GN_GPB groups (C <= 4096 at 32 groups)
+    __shared__ double chs[PMAX], chq[PMAX];
+    __shared__ float g_mean[GN_GPB], g_rstd[GN_GPB];
+    const int img = blockIdx.x, t = threadIdx.x;
+    const int C = c0 + c1, cpg = C / groups, ppg = cpg / 2;       // pairs per group
+    const int P0 = c0 / 2, P1 = c1 / 2;
+    const int pbeg = blockIdx.y * GN_GPB * ppg, pend = min(C / 2, pbeg + GN_GPB * ppg);
+    for (int pr = pbeg + t; pr < pend; pr += 256) {
+        const bool first = pr < P0;
+        const int pp = first ? pr : pr - P0, Ps = first ? P0 : P1, ppi = first ? ppi0 : ppi1;
+        const float* base = (first ? part0 : part1) + static_cast<long>(img) * ppi * 2 * Ps + pp;
+        double s = 0.0, q = 0.0;
+        int k = 0;
+        for (; k + 3 < ppi; k += 4) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = base[static_cast<long>(k + u) * 2 * Ps];
+                b[u] = base[static_cast<long>(k + u) * 2 * Ps + Ps];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += a[u]; q += b[u]; }
+        }
+        for (; k < ppi; ++k) {
+            s += base[static_cast<long>(k) * 2 * Ps];
+            q += base[static_cast<long>(k) * 2 * Ps + Ps];
+        }
+        chs[pr - pbeg] = s;
+        chq[pr - pbeg] = q;
+    }
+    __syncthreads();
+    if (t < GN_GPB && blockIdx.y * GN_GPB + t < groups) {
+        double s = 0.0, q = 0.0;
+        for (int j = 0; j < ppg; ++j) { s += chs[t * ppg + j]; q += chq[t * ppg + j]; }
+        const double cnt = static_cast<double>(hw) * cpg;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        g_mean[t] = static_cast<float>(mean);
+        g_rstd[t] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    }
+    __syncthreads();
+    const int cbeg = blockIdx.y * GN_GPB * cpg, cend = min(C, cbeg + GN_GPB * cpg);
+    for (int c = cbeg + t; c < cend; c += 256) {
+        const int gg = (c - cbeg) / cpg;
         const float sc = g_rstd[gg] * gamma[c];
         scale[static_cast<long>(img) * C + c] = sc;
         shift[static_cast<long>(img) * C + c] = beta[c] - g_mean[gg] * sc;
@@ -159,8 +232,11 @@ template <typename TI, typename T, int OUT>
 __global__ __launch_bounds__(256) void k_scale_shift_act(const typename In8<TI>::elem* __restrict__ x0, int c0,
                                   const typename In8<TI>::elem* __restrict__ x1, int c1, int hw,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                  int act, void* __restrict__ yv) {
+                                  int act, void* __restrict__ yv, unsigned short* __restrict__ raw_pair) {
     typedef typename In8<TI>::elem elem;
+    // raw_pair (optional): the UN-normalised input as the split pair [pix][hi(C) | lo(C)] -- the A operand of the resnet's
+    // split-precision shortcut GEMM, written from the registers that already hold the fp32 input (its own pass re-read 629 MB
+    // per 960-channel decoder resnet at 64 x 64)
     // grid (octet pairs of one image, image): 32-bit index arithmetic only, two octet loads in flight per thread
     const unsigned C = c0 + c1, OCT = C / 8, per_img = static_cast<unsigned>(hw) * OCT;
     const unsigned img = blockIdx.y;
@@ -181,6 +257,15 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const typename In8<TI>:
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         if (j0 + u >= per_img) break;
+        if (raw_pair) {
+            unsigned short* y = raw_pair + pix[u] * (2 * C) + cc[u];
+            const u16x8 hi = pack8<T>(v[u]);
+            float lo[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo[j] = v[u][j] - to_f32<T>(hi[j]);
+            *reinterpret_cast<u16x8*>(y) = hi;
+            *reinterpret_cast<u16x8*>(y + C) = pack8<T>(lo);
+        }
         float f[8];
         if (scale) {
             const float4* sc = reinterpret_cast<const float4*>(scale + static_cast<long>(img) * C + cc[u]);
@@ -633,15 +718,47 @@ extern "C" pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, 
         hipLaunchKernelGGL(k_gn_partial<TI>, dim3(nchunks, n_img), dim3(256), smem, st,
                            static_cast<const In8<TI>::elem*>(x0), c0, static_cast<const In8<TI>::elem*>(x1), c1,
                            hw, groups, ppc, partial));
-    hipLaunchKernelGGL(k_gn_finalize, dim3(n_img), dim3(256), 0, st, partial, nchunks, groups, C, hw, eps,
+    hipLaunchKernelGGL(k_gn_finalize, dim3(n_img, cdiv(groups, GN_GPB)), dim3(256), 0, st, partial, nchunks, groups, C, hw, eps,
                        gamma, beta, scale, shift);
     PF_CHECK_LAUNCH("pf_groupnorm_stats");
     return PF_OK;
 }
 
+extern "C" pf_status pf_groupnorm_from_partials(const float* part0, int c0, int rows0, const float* part1, int c1, int rows1,
+                                                int n_img, int hw, int groups, float eps, const float* gamma,
+                                                const float* beta, float* scale, float* shift, void* stream) {
+    if (!part1) { c1 = 0; rows1 = rows0; }
+    const int C = c0 + c1;
+    PF_REQUIRE(part0 && gamma && beta && scale && shift, "pf_groupnorm_from_partials: null pointer");
+    PF_REQUIRE(n_img > 0 && hw > 0 && groups > 0 && groups <= 64 && C % groups == 0 && c0 > 0,
+               "pf_groupnorm_from_partials: bad sizes");
+    PF_REQUIRE(rows0 > 0 && rows1 > 0 && hw % rows0 == 0 && hw % rows1 == 0,
+               "pf_groupnorm_from_partials: an image (%d rows) must be whole runs of %d / %d rows", hw, rows0, rows1);
+    PF_REQUIRE((C / groups) % 2 == 0 && c0 % 2 == 0 && c1 % 2 == 0, "pf_groupnorm_from_partials: groups and sources must hold even numbers of channels (moments are per column pair)");
+    PF_REQUIRE(GN_GPB * (C / groups) <= 1024, "pf_groupnorm_from_partials: C=%d too large for %d groups", C, groups);
+    hipLaunchKernelGGL(k_gn_finalize_cols, dim3(n_img, cdiv(groups, GN_GPB)), dim3(256), 0, as_stream(stream),
+                       part0, c0, hw / rows0, part1, c1, hw / rows1, groups, hw, eps, gamma, beta, scale, shift);
+    PF_CHECK_LAUNCH("pf_groupnorm_from_partials");
+    return PF_OK;
+}
+
+static pf_status scale_shift_act_impl(const void* x0, int c0, const void* x1, int c1, int dtype,
+                                      int n_img, int hw, const float* scale, const float* shift,
+                                      int act, int out_dtype, int out_split, void* y, void* raw_pair, void* stream);
 extern "C" pf_status pf_scale_shift_act(const void* x0, int c0, const void* x1, int c1, int dtype,
                                         int n_img, int hw, const float* scale, const float* shift,
                                         int act, int out_dtype, int out_split, void* y, void* stream) {
+    return scale_shift_act_impl(x0, c0, x1, c1, dtype, n_img, hw, scale, shift, act, out_dtype, out_split, y, nullptr, stream);
+}
+extern "C" pf_status pf_scale_shift_act_pair(const void* x0, int c0, const void* x1, int c1, int n_img, int hw,
+                                             const float* scale, const float* shift, int act, int out_dtype, void* y,
+                                             void* raw_pair, void* stream) {
+    PF_REQUIRE(raw_pair && aligned16(raw_pair), "pf_scale_shift_act_pair: raw_pair must be a 16-byte aligned pointer");
+    return scale_shift_act_impl(x0, c0, x1, c1, PF_F32, n_img, hw, scale, shift, act, out_dtype, 0, y, raw_pair, stream);
+}
+static pf_status scale_shift_act_impl(const void* x0, int c0, const void* x1, int c1, int dtype,
+                                      int n_img, int hw, const float* scale, const float* shift,
+                                      int act, int out_dtype, int out_split, void* y, void* raw_pair, void* stream) {
     if (!x1) c1 = 0;
     const int C = c0 + c1;
     PF_REQUIRE(x0 && y, "pf_scale_shift_act: null pointer");
@@ -652,13 +769,15 @@ extern "C" pf_status pf_scale_shift_act(const void* x0, int c0, const void* x1, 
     PF_REQUIRE(out_dtype == PF_BF16 || out_dtype == PF_F16 || (out_dtype == PF_F32 && !out_split),
                "pf_scale_shift_act: out_dtype must be 16-bit (optionally split) or PF_F32");
     PF_REQUIRE(dtype == PF_F32 || out_dtype == PF_F32 || dtype == out_dtype, "pf_scale_shift_act: 16-bit input and output types must agree");
+    PF_REQUIRE(!raw_pair || (dtype == PF_F32 && out_dtype != PF_F32 && !out_split), "pf_scale_shift_act_pair: fp32 sources, plain 16-bit output");
     const long per_img = static_cast<long>(hw) * (C / 8);
     PF_REQUIRE(per_img < (1L << 31) && n_img <= 65535, "pf_scale_shift_act: image too large / too many images");
     const dim3 grid(cdiv(per_img, 512), n_img), block(256);
     hipStream_t st = as_stream(stream);
 #define PF_SSA(TI, T, OUT) hipLaunchKernelGGL((k_scale_shift_act<TI, T, OUT>), grid, block, 0, st,                      \
                                               static_cast<const In8<TI>::elem*>(x0), c0,                                \
-                                              static_cast<const In8<TI>::elem*>(x1), c1, hw, scale, shift, act, y)
+                                              static_cast<const In8<TI>::elem*>(x1), c1, hw, scale, shift, act, y,       \
+                                              static_cast<unsigned short*>(raw_pair))
     const int out_kind = out_dtype == PF_F32 ? 2 : (out_split ? 1 : 0);
     // T = the 16-bit type on whichever side has one (bf16 when both sides are fp32: unused)
     const int t16 = out_dtype != PF_F32 ? out_dtype : (dtype != PF_F32 ? dtype : PF_BF16);

@@ -49,6 +49,8 @@ struct GemmParams {
     unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors of the 8-wave kernel (< 2 GiB)
     int adv_img, adv_y, adv_x;              // (image, row, column) advance of one DMA pass of output rows (8-wave kernel)
     unsigned long long* prof;      // diagnostics (pf_debug_gemm_profile): 4 s_memtime stamps per block, or NULL
+    float* gn_partial;             // [M / gn_rows][2][N / 2] fp32 per-column-pair (sum, sum of squares) of the finished output over
+    int gn_rows;                   // the gn_rows fragment rows of one wavefront (GroupNorm moments of the NEXT layer), or NULL
 };
 
 // phase stamp of wave 0 / lane 0 of a block: [block][4] = kernel entry, first tile landed, K loop done, exit
@@ -151,6 +153,109 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
         for (int e = 0; e < 4; ++e) w4[e] = from_f32<T>(v[e]);
         *reinterpret_cast<u16x4*>(o) = w4;
     }
+}
+
+// GroupNorm moments of the layer's OUTPUT as a by-product of the epilogue (the consumer's statistics pass re-read
+// the whole tensor: 210 MB per fp32 stream tensor at 64 x 64 x 320 x 40 views).  A lane holds 4 consecutive
+// columns of the rows (lane & 15) + 16 i of its wavefront's fragment rows: per-lane sums over i, then an
+// all-reduce over the 16 lanes of a DPP row (row_ror 8 / 4 / 2 / 1: VALU only, no LDS), and lane 0 of every row
+// writes its 4 columns.  One partial row per (wavefront row group): [part][2][N], part = first row / gn_rows --
+// fixed summation order, no atomics: results do not depend on scheduling.
+__device__ __forceinline__ float row16_allreduce(float v) {
+#define PF_ROR(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xF, 0xF, false))
+    v += PF_ROR(8);
+    v += PF_ROR(4);
+    v += PF_ROR(2);
+    v += PF_ROR(1);
+#undef PF_ROR
+    return v;
+}
+// Moments are kept per column PAIR (2 c, 2 c + 1): every GroupNorm group of the UNets / VAE has an even number of channels
+// and pairs never straddle a group.  They are computed in a phase of their own BEFORE the block epilogue, column block by
+// column block, while nothing but the accumulators is live -- folded into the epilogue's own loops the 20 + 20 running sums
+// pushed the 8-wave kernel from 244 registers into scratch, and every reload drained the DMA queue of the next tile
+// (K loop + 15 %, epilogue x 1.8: profiles/r3c_gemm_gn.txt).  The phase re-reads the tile's residual (the epilogue proper
+// reads it again, from L2); bias and the image's time-embedding row are one float4 each per column block -- an image is
+// whole runs of gn_rows rows (gn_rows_for), so a wavefront's rows belong to ONE image.
+template <typename T, int MREP, int NREP, int RES>            // RES: 0 none, 1 fp32 residual, 2 16-bit residual
+__device__ __forceinline__ void gn_moments_phase_r(const GemmParams& p, long bz, const f32x4 (&acc)[MREP][NREP],
+                                                   int m0, int n0, int row_base, int col_base, int lane) {
+    const int cq4 = 4 * (lane >> 4), rl = lane & 15;
+    const int NP = p.N >> 1;
+    const int mw = m0 + row_base;                                 // first row of this wavefront
+    if (mw >= p.M) return;
+    float* base = p.gn_partial + static_cast<long>(mw / p.gn_rows) * 2 * NP;
+    const float* rv = p.rowvec ? p.rowvec + static_cast<long>(mw / p.rows_per_img) * p.rowvec_ld : nullptr;
+    const int nb = n0 + col_base + cq4;                           // (whole N tiles: gn_rows_for) column of block j: nb + 16 j
+    // operands are requested in batches (a few memory latencies for the whole phase, not one per column block): bias + row
+    // vector of all column blocks first, then the residual of HALF the fragment rows at a time (40 registers; all 80 at once
+    // sent the kernel back to scratch)
+    float4 c[NREP];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+        c[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb + 16 * j) : float4{0.f, 0.f, 0.f, 0.f};
+        if (rv) {
+            const float4 r = *reinterpret_cast<const float4*>(rv + nb + 16 * j);
+            c[j].x += r.x; c[j].y += r.y; c[j].z += r.z; c[j].w += r.w;
+        }
+    }
+    constexpr bool res32 = RES == 1, res16 = RES == 2;
+    float sm[NREP][2], sq[NREP][2];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) { sm[j][0] = sm[j][1] = 0.f; sq[j][0] = sq[j][1] = 0.f; }
+    constexpr int HR = MREP >= 2 ? MREP / 2 : 1;                  // fragment rows per batch
+#pragma unroll
+    for (int i0 = 0; i0 < MREP; i0 += HR) {
+        float4 r32[res32 ? HR : 1][NREP];
+        u16x4 r16[res16 ? HR : 1][NREP];
+        if constexpr (res32) {
+#pragma unroll
+            for (int ii = 0; ii < HR; ++ii) {
+                const float* rp = static_cast<const float*>(p.residual) + bz * p.res_bs + static_cast<long>(min(mw + (i0 + ii) * 16 + rl, p.M - 1)) * p.res_ld + nb;
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) r32[ii][j] = *reinterpret_cast<const float4*>(rp + 16 * j);
+            }
+        } else if constexpr (res16) {
+#pragma unroll
+            for (int ii = 0; ii < HR; ++ii) {
+                const unsigned short* rp = static_cast<const unsigned short*>(p.residual) + bz * p.res_bs + static_cast<long>(min(mw + (i0 + ii) * 16 + rl, p.M - 1)) * p.res_ld + nb;
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) r16[ii][j] = *reinterpret_cast<const u16x4*>(rp + 16 * j);
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < HR; ++ii) {
+            const int i = i0 + ii;
+            const float live = mw + i * 16 + rl < p.M ? 1.f : 0.f;        // (rows past M: clamped copies)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) {
+                float x0 = acc[i][j][0] + c[j].x, x1 = acc[i][j][1] + c[j].y, x2 = acc[i][j][2] + c[j].z, x3 = acc[i][j][3] + c[j].w;
+                if constexpr (res32) { x0 += r32[ii][j].x; x1 += r32[ii][j].y; x2 += r32[ii][j].z; x3 += r32[ii][j].w; }
+                else if constexpr (res16) { x0 += to_f32<T>(r16[ii][j][0]); x1 += to_f32<T>(r16[ii][j][1]); x2 += to_f32<T>(r16[ii][j][2]); x3 += to_f32<T>(r16[ii][j][3]); }
+                x0 *= live; x1 *= live; x2 *= live; x3 *= live;
+                sm[j][0] += x0 + x1; sm[j][1] += x2 + x3;
+                sq[j][0] += x0 * x0 + x1 * x1; sq[j][1] += x2 * x2 + x3 * x3;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                        // (one batch of residual registers at a time)
+    }
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+        const float s0 = row16_allreduce(sm[j][0]), s1 = row16_allreduce(sm[j][1]);
+        const float q0 = row16_allreduce(sq[j][0]), q1 = row16_allreduce(sq[j][1]);
+        if (rl == 0) {
+            *reinterpret_cast<float2*>(base + ((nb + 16 * j) >> 1)) = float2{s0, s1};
+            *reinterpret_cast<float2*>(base + NP + ((nb + 16 * j) >> 1)) = float2{q0, q1};
+        }
+    }
+}
+
+template <typename T, int MREP, int NREP>
+__device__ __forceinline__ void gn_moments_phase(const GemmParams& p, long bz, const f32x4 (&acc)[MREP][NREP],
+                                                 int m0, int n0, int row_base, int col_base, int lane) {
+    if (!p.residual) gn_moments_phase_r<T, MREP, NREP, 0>(p, bz, acc, m0, n0, row_base, col_base, lane);
+    else if (p.res_f32) gn_moments_phase_r<T, MREP, NREP, 1>(p, bz, acc, m0, n0, row_base, col_base, lane);
+    else gn_moments_phase_r<T, MREP, NREP, 2>(p, bz, acc, m0, n0, row_base, col_base, lane);
 }
 
 // Block epilogue.  All arithmetic (bias, per-image row vector, residual, GEGLU) runs in the MFMA
@@ -370,10 +475,18 @@ __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4
 // region the staged tile may use.  HALVES > 1: staged in row slices through a smaller region;
 // after_ring() runs right after the barrier that retires the operand ring -- the persistent kernel
 // requests the next tile's first stages there, into ring slots the staging region does not overlap.
-template <typename T, int MREP, int NREP, int NT, int BM, int BN, int HALVES = 1, typename F = NoOp>
+template <typename T, int MREP, int NREP, int NT, int BM, int BN, int HALVES = 1, bool STATS = false, typename F = NoOp>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, long bz, f32x4 (&acc)[MREP][NREP],
                                               unsigned short* smem16, int m0, int n0, int row_base, int col_base,
                                               int lane, int t, F after_ring = F()) {
+    if constexpr (STATS) {
+        // GroupNorm-moment instantiation of the kernel (pf_conv_desc.gn_partial; a separate instantiation so that the
+        // default kernels keep their code and register allocation untouched).  Ahead of the ring barrier and of the next
+        // tile's DMA requests: the phase's own loads would otherwise queue behind them in vmcnt order (it cost 8 k clocks
+        // per tile there), and the waves that arrive early spend their barrier wait on it.
+        gn_moments_phase<T, MREP, NREP>(p, bz, acc, m0, n0, row_base, col_base, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();                                              // every wave is done reading the operand ring
     stamp(p, 4);
     after_ring();
@@ -410,7 +523,7 @@ generic:
     }
 }
 
-template <typename T, int MREP, int NREP>
+template <typename T, int MREP, int NREP, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -581,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
         }
         return;
     }
-    epilogue_tile<T, MREP, NREP, 256, BM, BN>(p, bz, acc, smem, m0, n0, wm * 16 * MREP, wn * 16 * NREP, lane, t);
+    epilogue_tile<T, MREP, NREP, 256, BM, BN, 1, STATS>(p, bz, acc, smem, m0, n0, wm * 16 * MREP, wn * 16 * NREP, lane, t);
     stamp(p, 3);
 }
 
@@ -597,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
 // by the lower 32 lanes of all 8 waves), so one immediate serves all.
 // Tile boundary: right after the barrier that retires the ring the block decodes its next tile and requests
 // that tile's first two stages into slots 0 / 1; the epilogue runs meanwhile in two row slices through slot 2.
-template <typename T, int NREP, int NW>
+template <typename T, int NREP, int NW, bool STATS = false>
 __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // NW = 8: 4 x 2 waves, 64x80 per wave, two waves per SIMD.  NW = 4: 2 x 2 waves, 128x80 per wave, ONE wave
     // per SIMD with the whole register file (160 accumulator + 104 fragment registers): twice the MFMAs per
@@ -1007,7 +1120,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             // of the tile loop and stay live -- in registers the K loop has none to spare of)
             int e_lane = lane, e_t = t;
             asm volatile("" : "+v"(e_lane), "+v"(e_t));
-            epilogue_tile<T, MREP, NREP, NT, BM, BN, 2>(p, bz, acc, smem + 2 * STAGE, em0, en0, wm * 16 * MREP, wn * 16 * NREP,
+            epilogue_tile<T, MREP, NREP, NT, BM, BN, 2, STATS>(p, bz, acc, smem + 2 * STAGE, em0, en0, wm * 16 * MREP, wn * 16 * NREP,
                                                         e_lane, e_t, [&]() { if (has_next) { set_tile(next); issue_prologue(); } });
             if (!has_next) break;
         }
@@ -1048,8 +1161,8 @@ static inline ProfState prof_snapshot() {
 }
 
 
-template <typename T, int MREP, int NREP>
-static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
+template <typename T, int MREP, int NREP, bool STATS = false>
+static pf_status launch_s(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     GemmParams p = gp;
     p.mtiles = static_cast<int>(cdiv(p.M - p.m_begin, BM));
@@ -1059,11 +1172,11 @@ static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     const size_t smem = static_cast<size_t>(2) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP, STATS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP, STATS>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(256), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm");
     if (p.splits > 1) {
         const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
@@ -1073,9 +1186,14 @@ static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
     return PF_OK;
 }
 
+template <typename T, int MREP, int NREP>
+static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
+    return gp.gn_partial ? launch_s<T, MREP, NREP, true>(gp, batch, st) : launch_s<T, MREP, NREP, false>(gp, batch, st);
+}
+
 static int tuning(const char* name, int dflt);
-template <typename T, int NREP, int NW>
-static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
+template <typename T, int NREP, int NW, bool STATS = false>
+static pf_status launch8w_s(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 256, BN = 32 * NREP;
     GemmParams p = gp;
     p.mtiles = static_cast<int>(cdiv(p.M - p.m_begin, BM));
@@ -1091,7 +1209,7 @@ static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
     const size_t smem = static_cast<size_t>(3) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm8<T, NREP, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm8<T, NREP, NW, STATS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
@@ -1104,7 +1222,7 @@ static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
         if (gx >= 8) gx = gx / 8 * 8;
         grid = std::min(grid, gx);
     }
-    hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW>), dim3(grid, p.splits, batch), dim3(64 * NW), smem, st, p);
+    hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW, STATS>), dim3(grid, p.splits, batch), dim3(64 * NW), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm (8-wave)");
     if (p.splits > 1) {
         const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
@@ -1112,6 +1230,12 @@ static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
         PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
     }
     return PF_OK;
+}
+
+template <typename T, int NREP, int NW>
+static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
+    if constexpr (NW == 8) { if (gp.gn_partial) return launch8w_s<T, NREP, NW, true>(gp, batch, st); }
+    return launch8w_s<T, NREP, NW, false>(gp, batch, st);
 }
 
 static int tuning(const char* name, int dflt);
@@ -1220,6 +1344,56 @@ static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_spli
     return g;
 }
 
+// descriptor -> kernel parameters (no validation here)
+static void params_from_desc(const pf_conv_desc* d, GemmParams& p) {
+    const int c1 = d->a1 ? d->c1 : 0;
+    const int Ctot = d->c0 + c1;
+    p.a0 = static_cast<const unsigned short*>(d->a0);
+    p.a1 = static_cast<const unsigned short*>(d->a1);
+    p.c0 = d->c0; p.c1 = c1; p.a0_ld = d->a0_ld; p.a1_ld = d->a1 ? d->a1_ld : 0;
+    p.h_in = d->h_in; p.w_in = d->w_in; p.h_out = d->h_out; p.w_out = d->w_out;
+    p.ksize = d->ksize; p.stride = d->stride; p.pad = d->pad; p.up = d->upsample;
+    p.w = static_cast<const unsigned short*>(d->w);
+    p.rows_per_img = d->h_out * d->w_out;
+    p.M = d->n_img * p.rows_per_img; p.N = d->n_out; p.K = d->ksize * d->ksize * Ctot;
+    p.bias = d->bias; p.rowvec = d->rowvec; p.rowvec_ld = d->rowvec_ld;
+    p.residual = d->residual; p.res_ld = d->res_ld;
+    p.res_f32 = d->residual != nullptr && d->res_dtype == PF_F32;
+    p.out = d->out; p.out_ld = d->out_ld; p.out_f32 = d->out_dtype == PF_F32;
+    p.geglu = d->epilogue == PF_EPILOGUE_GEGLU;
+    p.split_out = d->epilogue == PF_EPILOGUE_SPLIT;
+    p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;
+    p.mtiles = p.ntiles = 0;
+    p.prof = nullptr;
+    p.batch = d->batch;
+    p.gn_partial = nullptr; p.gn_rows = 0;
+    p.m_begin = 0; p.splits = 1; p.kb_per_split = 0; p.partial = nullptr;
+    p.a0_bytes = p.a1_bytes = p.w_bytes = 0; p.adv_img = p.adv_y = p.adv_x = 0;
+}
+
+// Rows per GroupNorm-moment part (pf_conv_desc.gn_partial) of this problem under plan g: the fragment rows of one
+// wavefront -- or 0 where the moments cannot be produced: split K (the reduce kernel writes the output), a batch,
+// images that are not whole parts, or an operand mix that takes the per-fragment (generic) epilogue.
+static int gn_rows_for(const GemmParams& p, const GemmPlan& g, int batch) {
+    if (batch != 1 || g.splits > 1 || g.m_split > 0 || p.geglu || p.split_out) return 0;
+    // Layers with a residual are left to the consumer's statistics pass by default: the moment phase has to read the
+    // residual tile a second time, which costs an HBM-bound layer as much as that pass saves (fp32-residual linear at
+    // 163840 x 320: 141 -> 171 us, the pass it replaces 42 us; VAE decode 107 -> 122 ms; profiles/r3d_gemm_gn.txt).
+    // Without a residual (resnet conv1 -> norm2, the up-sampling conv) the phase costs 2-3 us against a 25-40 us pass.
+    if (p.residual && tuning("PF_GN_EPILOGUE_RES", 0) == 0) return 0;
+    if (g.big && tuning("PF_GEMM8_WAVES", 8) == 4) return 0;       // (the one-wave-per-SIMD A/B instantiation has no moment variant)
+    const int rows = g.big ? 64 : 16 * g.mrep;
+    const int BM = g.big ? 256 : 32 * g.mrep;
+    if (p.rows_per_img % rows != 0 || p.N % (32 * g.nrep) != 0) return 0;      // whole runs per image, whole N tiles
+    if (p.out_f32) {
+        const bool ok = !p.rowvec && (p.out_ld & 3) == 0 && (!p.residual || (p.res_f32 && (p.res_ld & 3) == 0));
+        return ok ? rows : 0;
+    }
+    const bool staged = !p.res_f32 && (p.out_ld & 7) == 0 && (p.N & 7) == 0 && !(p.rowvec && p.residual) &&
+                        !(p.rowvec && p.rows_per_img < BM);
+    return staged ? rows : 0;
+}
+
 }  // namespace pf
 
 using namespace pf;
@@ -1270,25 +1444,14 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
                    d->h_out, d->w_out, ho, wo, ho1, wo1);
     }
     GemmParams p;
-    p.a0 = static_cast<const unsigned short*>(d->a0);
-    p.a1 = static_cast<const unsigned short*>(d->a1);
-    p.c0 = d->c0; p.c1 = c1; p.a0_ld = d->a0_ld; p.a1_ld = d->a1 ? d->a1_ld : 0;
-    p.h_in = d->h_in; p.w_in = d->w_in; p.h_out = d->h_out; p.w_out = d->w_out;
-    p.ksize = d->ksize; p.stride = d->stride; p.pad = d->pad; p.up = d->upsample;
-    p.w = static_cast<const unsigned short*>(d->w);
-    p.rows_per_img = d->h_out * d->w_out;
-    p.M = d->n_img * p.rows_per_img; p.N = d->n_out; p.K = d->ksize * d->ksize * Ctot;
-    p.bias = d->bias; p.rowvec = d->rowvec; p.rowvec_ld = d->rowvec_ld;
-    p.residual = d->residual; p.res_ld = d->res_ld;
-    p.res_f32 = d->residual != nullptr && d->res_dtype == PF_F32;
-    p.out = d->out; p.out_ld = d->out_ld; p.out_f32 = d->out_dtype == PF_F32;
-    p.geglu = d->epilogue == PF_EPILOGUE_GEGLU;
-    p.split_out = d->epilogue == PF_EPILOGUE_SPLIT;
-    p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;
-    p.mtiles = p.ntiles = 0;
-    p.prof = nullptr;
-    p.batch = d->batch;
+    params_from_desc(d, p);
     GemmPlan g = plan_gemm(p.M, p.N, p.K, d->batch, d->workspace != nullptr);
+    if (d->gn_partial) {
+        const int r = gn_rows_for(p, g, d->batch);
+        PF_REQUIRE(r > 0 && aligned16(d->gn_partial), "pf_conv_gemm: gn_partial given but this problem cannot emit GroupNorm moments (ask pf_conv_gemm_gn_rows first)");
+        p.gn_partial = d->gn_partial;
+        p.gn_rows = r;
+    }
     {   // extents for the buffer descriptors of the 8-wave kernel (32-bit offsets, < 2 GiB)
         const long npix = static_cast<long>(d->n_img) * d->h_in * d->w_in;
         const long a0b = ((npix - 1) * p.a0_ld + p.c0) * 2, a1b = p.a1 ? ((npix - 1) * p.a1_ld + p.c1) * 2 : 0;
@@ -1333,6 +1496,13 @@ extern "C" pf_status pf_debug_gemm_profile(void* device_buffer, long capacity_bl
     const ProfState* s = device_buffer ? new ProfState{static_cast<unsigned long long*>(device_buffer), capacity_blocks} : nullptr;
     g_prof_state.store(s, std::memory_order_release);
     return PF_OK;
+}
+
+extern "C" int pf_conv_gemm_gn_rows(const pf_conv_desc* d) {
+    if (!d || d->batch < 1 || d->n_out < 1 || d->n_img < 1) return 0;
+    GemmParams p;
+    params_from_desc(d, p);
+    return gn_rows_for(p, plan_gemm(p.M, p.N, p.K, d->batch, true), d->batch);
 }
 
 extern "C" size_t pf_conv_gemm_workspace_size(const pf_conv_desc* d) {

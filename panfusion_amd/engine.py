@@ -36,6 +36,9 @@ def default_precision(dtype):
     return "mixed" if dtype == torch.float16 else "fast"
 
 
+RAW_PAIR_FUSED = os.environ.get("PF_RAW_PAIR", "1") != "0"      # A/B: 0 = the shortcut operand by its own split pass
+
+
 def stream_dtype(dtype, precision):
     return torch.float32 if precision == "mixed" else dtype
 
@@ -383,25 +386,33 @@ def pack_epa(block, dev, dtype, mixed=False):
 # ---------------------------------------------------------------------------- layer runners
 def run_resnet(r, x, skip, temb_all, groups_eps=None):
     """x [n, h, w, C] (+ skip concatenated along channels) -> [n, h, w, cout], stream dtype in and out.
-    GN -> SiLU -> conv3x3 (+bias +temb) -> GN -> SiLU -> conv3x3 (+bias) + shortcut(x)."""
+    GN -> SiLU -> conv3x3 (+bias +temb) -> GN -> SiLU -> conv3x3 (+bias) + shortcut(x).
+    GroupNorm moments: conv1's epilogue leaves the moments of h1 behind for norm2, conv2's those of the block output for
+    whichever norm reads it next (ops.conv_gemm(gn_stats=True)); norm1 uses what x / skip carry, else its own pass."""
     n, h, w, _ = x.shape
     hw = h * w
     sc, sh = ops.groupnorm_scale_shift(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, r.norm1.b)
-    y = ops.scale_shift_act(x, skip, n, hw, sc, sh, 1, out_dtype=r.dtype)
+    pair = None
+    if r.ws3 is not None and x.dtype == torch.float32 and RAW_PAIR_FUSED:
+        # mixed scheme: the shortcut's split operand [hi | lo] of (x | skip) comes out of the same pass as norm1 + SiLU
+        y, pair = ops.scale_shift_act(x, skip, n, hw, sc, sh, 1, out_dtype=r.dtype, raw_pair=True)
+    else:
+        y = ops.scale_shift_act(x, skip, n, hw, sc, sh, 1, out_dtype=r.dtype)
     rowvec = temb_all[:, r.temb_off:] if temb_all is not None else None
-    h1 = ops.conv_gemm(y, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec)
-    h1 = h1.view(n, hw, r.cout)
+    h1 = ops.conv_gemm(y, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec, gn_stats=True)
+    h1 = ops.carry(h1.view(n, hw, r.cout), h1)
     sc, sh = ops.groupnorm_scale_shift(h1, None, n, hw, r.norm2.groups, r.norm2.eps, r.norm2.g, r.norm2.b)
     y2 = ops.scale_shift_act(h1, None, n, hw, sc, sh, 1, out_dtype=r.dtype)
     if r.ws3 is not None:         # mixed scheme: the shortcut maps the stream linearly -> split precision, fp32 out
-        short = exact_gemm(split_operand(x, skip, dtype=r.dtype), r.ws3, r.cout, w_in=n * hw, bias=r.bs,
-                           out_dtype=r.stream)
+        if pair is None:
+            pair = split_operand(x, skip, dtype=r.dtype)
+        short = exact_gemm(pair, r.ws3, r.cout, w_in=n * hw, bias=r.bs, out_dtype=r.stream)
     elif r.ws is not None:
         short = ops.conv_gemm(x, r.ws, r.cout, a1=skip, n_img=n, h_in=h, w_in=w, ksize=1, bias=r.bs)
     else:
         short = x.view(n * hw, r.cout)
-    out = ops.conv_gemm(y2, r.w2, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b2, residual=short)
-    return out.view(n, h, w, r.cout)
+    out = ops.conv_gemm(y2, r.w2, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b2, residual=short, gn_stats=True)
+    return ops.carry(out.view(n, h, w, r.cout), out)
 
 
 def text_kv(a, text):
@@ -456,14 +467,15 @@ def run_transformer(t, x, text, kv=None):
         # the token stream's last value feeds proj_out only: FF2's epilogue emits it directly as the [hi | lo]
         # pair of the split-precision proj_out (no fp32 round trip, no separate split pass)
         pair = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok, split_out=True)
-        out = exact_gemm(pair, t.w_out3, Cc, w_in=n * hw, bias=t.b_out, residual=x.view(n * hw, Cc))
+        out = exact_gemm(pair, t.w_out3, Cc, w_in=n * hw, bias=t.b_out, residual=x.view(n * hw, Cc), gn_stats=True)
     elif t.w_out3 is not None:           # A/B switch PF_FF2_PAIR=0: fp32 token stream + a separate split pass
         tok = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok)
-        out = exact_gemm(split_operand(tok, dtype=t.dtype), t.w_out3, Cc, w_in=n * hw, bias=t.b_out, residual=x.view(n * hw, Cc))
+        out = exact_gemm(split_operand(tok, dtype=t.dtype), t.w_out3, Cc, w_in=n * hw, bias=t.b_out, residual=x.view(n * hw, Cc),
+                         gn_stats=True)
     else:
         tok = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=tok)
-        out = ops.linear(tok, t.w_out, bias=t.b_out, residual=x.view(n * hw, Cc))
-    return out.view(n, h, w, Cc)
+        out = ops.linear(tok, t.w_out, bias=t.b_out, residual=x.view(n * hw, Cc), gn_stats=True)
+    return ops.carry(out.view(n, h, w, Cc), out)
 
 
 class Branch:
@@ -535,8 +547,8 @@ class Branch:
         x = to16(self._padded(self.h, 1), self.u.dtype)
         n, h, w, Cc = x.shape
         y = ops.conv_gemm(x, up.w, up.c, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1, bias=up.b,
-                          out_dtype=self.u.stream)
-        y = y.view(n, 2 * h, 2 * w, up.c)
+                          out_dtype=self.u.stream, gn_stats=not self.pad)
+        y = ops.carry(y.view(n, 2 * h, 2 * w, up.c), y)
         self.h = ops.crop_width(y, 2) if self.pad else y
 
     def head(self):                     # GN + SiLU un-padded; conv_out padded by 1   (:279-294)
@@ -595,7 +607,7 @@ def _epa_tail(e, attn_out, x, Cc):
     y = ops.linear(attn_out.view(-1, Cc), e.wo, bias=e.bo, residual=x)
     ln2 = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps, out_dtype=e.cdtype)
     g = ops.linear(ln2, e.w_ff1, bias=e.b_ff1, geglu=True)
-    return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y)
+    return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y, gn_stats=True)
 
 
 def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None, pers_hw=None):
@@ -729,4 +741,4 @@ def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None, side=None, pers_hw=N
     else:
         out_e = tail(attend(qk_e, qk_p[:, Cc:], vt_p, E, mP, "e"), te)
         out_p = tail(attend(qk_p, qk_e[:, Cc:], vt_e, mP, E, "p"), tp)
-    return out_p.view(bm, ph, pw, Cc), out_e.view(b, eh, ew, Cc)
+    return ops.carry(out_p.view(bm, ph, pw, Cc), out_p), ops.carry(out_e.view(b, eh, ew, Cc), out_e)

@@ -207,8 +207,13 @@ class MultiViewBaseModel(nn.Module):
         cn_res = {}                                 # id(branch) -> (12 skip residuals, mid residual)
         shard = getattr(self, "shard", None)      # set by sharding.ShardedDenoiseLoop: latents hold only
         if tape is not None:
-            if shard is not None or pers_layout_cond is not None or pano_layout_cond is not None:
-                raise NotImplementedError("the training path covers the un-sharded denoiser without ControlNet conditions")
+            if shard is not None:
+                raise NotImplementedError("the training path covers the un-sharded denoiser")
+            # Layout conditions under training (PanFusion.py:85-89): the ControlNet runs as in inference and its 12 + 1
+            # residuals enter the tape as constants -- gradients flow THROUGH the additions into the EPA blocks and the
+            # LoRA matrices (identity w.r.t. the skip / mid activations), the ControlNet's own parameters take none
+            # (conditioned fine-tuning with a frozen ControlNet; the reference's layout_cond=True additionally trains the
+            # ControlNet itself at lr x 0.1, PanoGenerator.py:153-157 -- its weight gradients are not implemented here).
             from ... import train_engine
             make_branch = lambda *a, **k: train_engine.TrainBranch(tape, *a, **k)
         else:

@@ -5,6 +5,7 @@ hands raw device pointers + sizes to ``libpanfusion_hip.so`` on the caller's
 current stream.  No function has a torch / CPU fallback.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -137,13 +138,36 @@ def epa_tables(fov, theta, phi, ph, pw, eh, ew, device):
 
 
 # ---------------------------------------------------------------------------- norms / pointwise
+GN_FROM_EPILOGUE = os.environ.get("PF_GN_EPILOGUE", "1") != "0"      # A/B: 0 = always the separate statistics pass
+
+
+def carry(dst, src):
+    """dst = a view / reshape of src: hand over the GroupNorm moments a GEMM epilogue attached to src (`_pf_gn`)."""
+    st = getattr(src, "_pf_gn", None)
+    if st is not None:
+        dst._pf_gn = st
+    return dst
+
+
 def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
-    """x0 [n, hw, c0] (+ x1 [n, hw, c1] concatenated along channels) -> (scale, shift) [n, C] fp32."""
+    """x0 [n, hw, c0] (+ x1 [n, hw, c1] concatenated along channels) -> (scale, shift) [n, C] fp32.
+    When every source still carries the per-column moments the GEMM that produced it left behind (conv_gemm(gn_stats=True)
+    -> tensor attribute `_pf_gn` = (partials, rows per part)), the statistics come from those -- no pass over the tensors."""
     c0 = x0.shape[-1]
     c1 = x1.shape[-1] if x1 is not None else 0
     Cc = c0 + c1
     scale = torch.empty(n_img, Cc, device=x0.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
+    st0 = getattr(x0, "_pf_gn", None)
+    st1 = getattr(x1, "_pf_gn", None) if x1 is not None else None
+    usable = st0 is not None and (x1 is None or st1 is not None) and (Cc // groups) % 2 == 0 and c0 % 2 == 0
+    if usable and (hw % st0[1] or (st1 is not None and hw % st1[1])):
+        usable = False                # (a linear layer's moment runs need not respect this consumer's image boundaries)
+    if usable:
+        check(_lib.lib().pf_groupnorm_from_partials(_p(st0[0]), c0, st0[1], _p(st1[0]) if st1 else None, c1,
+                                                    st1[1] if st1 else st0[1], n_img, hw, groups, eps, _p(gamma), _p(beta),
+                                                    _p(scale), _p(shift), _stream()), "pf_groupnorm_from_partials")
+        return scale, shift
     nbytes = _lib.lib().pf_groupnorm_workspace_size(n_img, hw, Cc)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, device=x0.device, dtype=torch.uint8)
@@ -153,15 +177,23 @@ def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
     return scale, shift
 
 
-def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None, out_dtype=None, split=False):
+def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None, out_dtype=None, split=False, raw_pair=False):
     """y = act(x * scale + shift) over the channel concat (x0 | x1); scale = shift = None: y = act(x).
     Sources 16-bit or fp32.  out_dtype: 16-bit type (default: the sources') or fp32; split=True: the
-    16-bit pair [.., hi(C) | lo(C)] (A operand of a split-precision GEMM, engine.exact_gemm)."""
+    16-bit pair [.., hi(C) | lo(C)] (A operand of a split-precision GEMM, engine.exact_gemm).
+    raw_pair=True (fp32 sources, plain 16-bit y): also returns the UN-normalised input as that pair, written in the
+    same pass -> (y, pair)."""
     c0 = x0.shape[-1]
     c1 = x1.shape[-1] if x1 is not None else 0
     out_dtype = out_dtype or x0.dtype
     if out is None:
         out = torch.empty(n_img, hw, (c0 + c1) * (2 if split else 1), device=x0.device, dtype=out_dtype)
+    if raw_pair:
+        assert x0.dtype == torch.float32 and not split and out_dtype != torch.float32
+        pair = torch.empty(n_img, hw, 2 * (c0 + c1), device=x0.device, dtype=out_dtype)
+        check(_lib.lib().pf_scale_shift_act_pair(_p(x0), c0, _p(x1), c1, n_img, hw, _p(scale), _p(shift), int(act),
+                                                 dt(out_dtype), _p(out), _p(pair), _stream()), "pf_scale_shift_act_pair")
+        return out, pair
     check(_lib.lib().pf_scale_shift_act(_p(x0), c0, _p(x1), c1, dt(x0), n_img, hw, _p(scale), _p(shift),
                                         int(act), dt(out_dtype), int(split), _p(out), _stream()), "pf_scale_shift_act")
     return out
@@ -331,13 +363,15 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,
               a_bstride=0, w_bstride=0, out_bstride=0, res_bstride=0, a0_ld=None, a1_ld=None, c0=None, c1=None,
-              out_ld=None, res_ld=None, geglu=False, algo_k=None, split_out=False, pad_hi=0):
+              out_ld=None, res_ld=None, geglu=False, algo_k=None, split_out=False, pad_hi=0, gn_stats=False):
     """out[m, n] = sum_k A[m, k] W[n, k] (+bias +rowvec[img] +residual).  a0/a1 NHWC, the last
     dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out).  The output takes the
     residual's dtype unless out_dtype says otherwise (fp32 residual stream in, fp32 out).
     algo_k: K of the layer for the FLOP count when the launched K carries split-precision passes.
     split_out: the result leaves as the 16-bit pair [M, hi(n_out) | lo(n_out)] (operand of engine.exact_gemm).
-    pad_hi = 1: one more zero row / column at the bottom / right (F.pad(x, (0, 1, 0, 1)) of the VAE encoder's down-convs)."""
+    pad_hi = 1: one more zero row / column at the bottom / right (F.pad(x, (0, 1, 0, 1)) of the VAE encoder's down-convs).
+    gn_stats: the result feeds a GroupNorm -- where the kernel serving this problem can, its epilogue leaves the per-column
+    moments of the output behind (attribute `_pf_gn` of the returned tensor, read by groupnorm_scale_shift)."""
     c0 = c0 if c0 is not None else a0.shape[-1]
     c1 = (c1 if c1 is not None else a1.shape[-1]) if a1 is not None else 0
     if w_in is None:
@@ -374,9 +408,17 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     nbytes = _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
     ws = torch.empty(nbytes, device=a0.device, dtype=torch.uint8) if nbytes else None   # split-K slabs
     d.workspace, d.workspace_bytes = _p(ws), nbytes
+    gn = None
+    if gn_stats and GN_FROM_EPILOGUE and batch == 1:
+        rows = _lib.lib().pf_conv_gemm_gn_rows(C.byref(d))
+        if rows > 0:
+            gn = (torch.empty(M // rows, 2, n_out // 2, device=a0.device, dtype=torch.float32), rows)
+            d.gn_partial = _p(gn[0])
     _traced("k_conv_gemm", 2.0 * M * n_out * (algo_k or ksize * ksize * (c0 + c1)) * batch,
             lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"),
             "M%d N%d K%d k%d s%d u%d b%d" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch))
+    if gn is not None:
+        out._pf_gn = gn
     return out
 
 
@@ -394,12 +436,13 @@ def gemm_workspace_bytes(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, k
     return _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
 
 
-def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False, split_out=False):
+def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False, split_out=False, gn_stats=False):
     """x [rows, K] 16-bit, w [N, K] 16-bit.  geglu: w / bias rows interleaved (value_j, gate_j),
-    returns [rows, N/2] = value * gelu(gate)."""
+    returns [rows, N/2] = value * gelu(gate).  gn_stats: see conv_gemm (the moment runs are runs of token rows; the
+    consumer's images must be whole runs, which groupnorm_scale_shift's entry point checks)."""
     rows, K = x.shape
     return conv_gemm(x, w, w.shape[0], w_in=rows, bias=bias, residual=residual, out=out, out_dtype=out_dtype,
-                     geglu=geglu, split_out=split_out)
+                     geglu=geglu, split_out=split_out, gn_stats=gn_stats)
 
 
 def interleave_geglu(w, b=None):

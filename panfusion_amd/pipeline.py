@@ -8,6 +8,8 @@ captured into one hipGraph per rotation offset (the geometry is 4-periodic,
 SURVEY.md §4) and replayed; the CFG+DDIM update is a separate fused kernel
 whose scalar coefficients change every step.
 """
+import os
+
 import torch
 
 from . import ops
@@ -124,7 +126,10 @@ class DenoiseLoop:
                 self._denoise(cams)                  # warm-up: builds tables, sets kernel attributes
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # PF_VIEW_PRIORITY: capture on the caller's (high-priority) stream, so that the view branch = the critical
+                # path keeps that priority and the panorama side stream (default priority) only fills what it leaves idle
+                cap = torch.cuda.current_stream() if os.environ.get("PF_VIEW_PRIORITY") else None
+                with torch.cuda.graph(graph, stream=cap):
                     out = self._denoise(cams)
             g = (graph, out, self._graph_keepalive())
             self.graphs[key] = g
@@ -204,7 +209,7 @@ def add_noise(sched, x, noise, t):
 
 
 def training_step(model, vae_encoder, images, pano, cameras, prompt_embd, pano_prompt_embd, latent_pad=8, sched=None,
-                  draws=None, generator=None):
+                  draws=None, generator=None, pers_layout_cond=None, pano_layout_cond=None):
     """The body of ``PanFusion.training_step`` (PanFusion.py:64-98) on the HIP path: VAE-encode the views and the circularly
     padded panorama, draw the timestep and the panorama noise, project that noise into the views (``init_noise``), add
     noise, ONE denoiser call without CFG, MSE on both predictions.  Returns (loss, loss_pers, loss_pano); ``loss.backward()``
@@ -213,7 +218,11 @@ def training_step(model, vae_encoder, images, pano, cameras, prompt_embd, pano_p
     images (b, m, 3, H, W), pano (b, 1, 3, Hp, Wp) in [-1, 1] on the GPU; cameras: dict of (b, m); the prompt embeddings as
     ``embed_prompt`` leaves them (b, m, L, D) / (b, 1, L, D) (text_encoder.TextEncoder).  draws: optional dict with the
     random draws (``eps_views``, ``eps_pano`` for the VAE posterior, ``t`` (b,), ``pano_noise`` (b, 1, 4, h, w)) -- what the
-    tests fix to compare against the oracle; anything missing is drawn here."""
+    tests fix to compare against the oracle; anything missing is drawn here.
+    pers_layout_cond / pano_layout_cond: ``batch.get('images_layout_cond')`` / ``batch.get('pano_layout_cond')`` as the
+    reference passes them (PanFusion.py:85-89).  The ControlNets then run with FROZEN parameters: the gradients reach the EPA
+    blocks and the LoRA matrices through the residual additions; the ControlNet's own weight gradients (the reference's
+    trainable set under layout_cond=True, PanoGenerator.py:153-157) are not implemented."""
     from .utils.pano import pad_pano, unpad_pano
     from .vae import encode_image
     draws = draws or {}
@@ -233,7 +242,8 @@ def training_step(model, vae_encoder, images, pano, cameras, prompt_embd, pano_p
     noise_z = add_noise(sched, latents, noise, t)
     pano_noise_z = add_noise(sched, pano_latent, pano_noise, t)
     tt = t.to(dev).long()[:, None].repeat(1, m)
-    denoise, pano_denoise = model(noise_z, pano_noise_z, tt, prompt_embd, pano_prompt_embd, cameras)
+    denoise, pano_denoise = model(noise_z, pano_noise_z, tt, prompt_embd, pano_prompt_embd, cameras,
+                                  pers_layout_cond, pano_layout_cond)
     loss_pers = torch.nn.functional.mse_loss(denoise, noise)
     loss_pano = torch.nn.functional.mse_loss(pano_denoise, pano_noise)
     return loss_pers + loss_pano, loss_pers, loss_pano

@@ -80,7 +80,48 @@ def _cat(x0, x1):
     return x0 if x1 is None else torch.cat([x0, x1], -1)
 
 
+def carry(dst, src):
+    st = getattr(src, "_pf_gn", None)
+    if st is not None:
+        dst._pf_gn = st
+    return dst
+
+
+GN_FROM_PARTIALS = [0, 0]       # [statistics taken from GEMM-epilogue moments, statistics by a pass over the tensor] (test probes)
+
+
 def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
+    st0 = getattr(x0, "_pf_gn", None)
+    st1 = getattr(x1, "_pf_gn", None) if x1 is not None else None
+    c0 = x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    usable = st0 is not None and (x1 is None or st1 is not None) and ((c0 + c1) // groups) % 2 == 0 and c0 % 2 == 0
+    if usable and (hw % st0[1] or (st1 is not None and hw % st1[1])):
+        usable = False
+    if usable:
+        # the product's path: per-column-PAIR moments over runs of `rows` output rows, as pf_conv_gemm's epilogue leaves them
+        GN_FROM_PARTIALS[0] += 1
+        s, q = [], []
+        for st in (st0, st1):
+            if st is None:
+                continue
+            part, rows = st
+            assert hw % rows == 0 and part.shape[0] == n_img * hw // rows
+            pp = part.double().reshape(n_img, hw // rows, 2, -1).sum(1)            # [n, 2, c/2]
+            s.append(pp[:, 0])
+            q.append(pp[:, 1])
+        s, q = torch.cat(s, -1), torch.cat(q, -1)                                  # [n, C/2]
+        C = 2 * s.shape[-1]
+        cpg2 = C // groups // 2
+        sg, qg = s.reshape(n_img, groups, cpg2).sum(-1), q.reshape(n_img, groups, cpg2).sum(-1)
+        cnt = float(hw * (C // groups))
+        mean = sg / cnt
+        var = (qg / cnt - mean * mean).clamp_min(0)
+        rstd = (var + eps).rsqrt()
+        scale = (rstd.repeat_interleave(C // groups, 1) * gamma.double()).float()
+        shift = (beta.double() - mean.repeat_interleave(C // groups, 1) * scale.double()).float()
+        return scale, shift
+    GN_FROM_PARTIALS[1] += 1
     x = _cat(x0, x1).float().reshape(n_img, hw, -1)
     C = x.shape[-1]
     xg = x.reshape(n_img, hw, groups, C // groups)
@@ -92,11 +133,14 @@ def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
     return scale, shift
 
 
-def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None, out_dtype=None, split=False):
+def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None, out_dtype=None, split=False, raw_pair=False):
     x = _cat(x0, x1).float().reshape(n_img, hw, -1)
     y = x if scale is None else x * scale[:, None] + shift[:, None]
     y = F.silu(y) if act else y
     out_dtype = out_dtype or x0.dtype
+    if raw_pair:
+        hi = x.to(out_dtype)
+        return y.to(out_dtype), torch.cat([hi, (x - hi.float()).to(out_dtype)], -1)
     if split:
         hi = y.to(out_dtype)
         return torch.cat([hi, (y - hi.float()).to(out_dtype)], -1)
@@ -211,7 +255,8 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, c1=None,
-              a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, split_out=False, pad_hi=0, **kw):
+              a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, split_out=False, pad_hi=0,
+              gn_stats=False, **kw):
     if batch > 1:          # independent problems (attention scores / P.V of the VAE): plain linears only
         assert ksize == 1 and a1 is None and bias is None and residual is None and rowvec is None and not geglu
         K = c0 or a0.shape[-1]
@@ -247,6 +292,12 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
         y = y + rowvec[:, :n_out].float().repeat_interleave(ho * wo, 0)
     if residual is not None:
         y = y + residual.float().reshape(-1, residual.shape[-1])[:, :n_out]
+    gn = None
+    if gn_stats and not geglu and not split_out and n_out % 2 == 0:
+        rows = next((r for r in (64, 32, 16) if (ho * wo) % r == 0), 0)           # (the kernels: 64 / 32 fragment rows per wavefront)
+        if rows:
+            yr = y.double().reshape(-1, rows, n_out // 2, 2)
+            gn = (torch.stack([yr.sum((1, 3)), (yr * yr).sum((1, 3))], 1).float(), rows)      # [M / rows, 2, N / 2]
     if geglu:                                     # rows interleaved (value_j, gate_j)
         y = y[:, 0::2] * F.gelu(y[:, 1::2])
     if split_out:
@@ -259,13 +310,15 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
             out.view(-1, out.shape[-1])[:, :y.shape[-1]] = y
         else:
             out.copy_(y.reshape(out.shape))
-        return out
+        y = out
+    if gn is not None:
+        y._pf_gn = gn
     return y
 
 
-def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False, split_out=False):
+def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False, split_out=False, gn_stats=False):
     return conv_gemm(x, w, w.shape[0], w_in=x.shape[0], bias=bias, residual=residual, out=out, out_dtype=out_dtype,
-                     geglu=geglu, split_out=split_out)
+                     geglu=geglu, split_out=split_out, gn_stats=gn_stats)
 
 
 def interleave_geglu(w, b=None):

@@ -633,3 +633,115 @@ def test_py360_e2p_random_cases_vs_oracle():
                 assert np.array_equal(got, want), (trial, mode, int((got != want).sum()))
             else:       # float32 bilinear: weights differ by the device's atan2 / sqrt ulps -> a few float32 ulp of the result
                 assert np.allclose(got, want, rtol=0, atol=2e-6), (trial, mode, float(np.abs(got - want).max()))
+
+
+# ------------------------------------------------------------------------------------ round 3: GroupNorm moments from the GEMM epilogue
+def _moments_ref(y, rows):
+    """[M, N] fp32 -> [M / rows, 2, N / 2]: per column PAIR (sum, sum of squares) over runs of `rows` rows."""
+    yr = y.double().reshape(-1, rows, y.shape[1] // 2, 2)
+    return torch.stack([yr.sum((1, 3)), (yr * yr).sum((1, 3))], 1).float()
+
+
+GN_CASES = [
+    # (n_img, h, w, cin, cout, ksize, what): the operand mixes of the layers that feed a GroupNorm.  (Sizes chosen so that
+    # the plan is NOT a split-K one: those write the output from the reduce kernel and report pf_conv_gemm_gn_rows = 0.)
+    (40, 32, 32, 128, 320, 3, "rowvec16"),     # resnet conv1: bias + time-embedding row, 16-bit out (8-wave kernel, MODE 1)
+    (40, 32, 32, 128, 320, 3, "res32"),        # resnet conv2: bias + fp32 residual, fp32 out (8-wave kernel, fp32 epilogue)
+    (40, 32, 32, 128, 320, 3, "res16"),        # all-16-bit scheme: bias + 16-bit residual (MODE 2)
+    (40, 32, 32, 128, 256, 3, "plain16"),      # VAE resnet conv1 (MODE 0), 128-wide N tiles
+    (40, 32, 32, 128, 320, 3, "plain32"),      # up-sampling conv: fp32 out, no residual
+    (40, 32, 32, 64, 128, 3, "res32"),         # VAE widths, fp32 stream
+    (2, 16, 24, 64, 128, 3, "rowvec16"),       # small problem: 4-wave kernel
+    (2, 16, 24, 64, 128, 3, "res32"),
+    (1, 1, 40960, 320, 320, 1, "res32"),       # proj_out / EPA FF2 as linear layers (image structure is the consumer's)
+    (1, 1, 163840, 320, 320, 1, "res32"),
+    (3, 8, 20, 64, 64, 3, "rowvec16"),         # 160 rows per image: the 32-row runs of the 64-row-tile kernel
+    (2, 64, 132, 320, 320, 3, "res32"),        # the padded panorama at 64 x (128 + 4)
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", GN_CASES)
+def test_conv_gemm_leaves_groupnorm_moments(dtype, case):
+    """pf_conv_desc.gn_partial: the epilogue's per-column-pair moments == moments of the tensor it wrote, the output is
+    unchanged by asking for them, and GroupNorm scale / shift from them == the statistics pass over the tensor."""
+    o = ops()
+    n, h, w, cin, cout, ks, what = case
+    x, xf = q16(rnd(n, h, w, cin, seed=60), dtype)
+    wt, wf = q16(rnd(cout, ks * ks * cin, seed=61) / (ks * ks * cin) ** 0.5, dtype)
+    b = rnd(cout, seed=62).to(DEV)
+    M = n * h * w
+    kw = dict(n_img=n, h_in=h, w_in=w, ksize=ks, pad=ks // 2, bias=b)
+    if what == "rowvec16":
+        kw["rowvec"] = rnd(n, cout + 64, seed=63).to(DEV)[:, 32:32 + cout]        # strided view, like temb_all[:, off:]
+    elif what == "res32":
+        kw["residual"] = (rnd(M, cout, seed=64) * 2 + 0.3).to(DEV)
+    elif what == "res16":
+        kw["residual"] = q16(rnd(M, cout, seed=64), dtype)[0]
+    elif what == "plain32":
+        kw["out_dtype"] = torch.float32
+    base = o.conv_gemm(x, wt, cout, **kw)
+    got = o.conv_gemm(x, wt, cout, gn_stats=True, **kw)
+    assert torch.equal(base, got), "asking for the moments changed the output"
+    st = getattr(got, "_pf_gn", None)
+    assert st is not None, "no moments for %s" % (case,)
+    part, rows = st
+    assert (h * w) % rows == 0 and part.shape == (M // rows, 2, cout // 2)
+    # the moments are taken on the fp32 values BEFORE the 16-bit rounding of a 16-bit output
+    ref = _moments_ref(got.float().cpu(), rows)
+    tol = 3e-3 if (dtype == torch.bfloat16 and got.dtype != torch.float32) else (6e-4 if got.dtype != torch.float32 else 2e-5)
+    # sums cancel (zero-mean columns): compare them on the scale of sqrt(count * sum of squares), the Cauchy-Schwarz bound
+    norm = (ref[:, 1] * 2 * rows).sqrt().clamp_min(1e-6)
+    d = float(((part[:, 0].float().cpu() - ref[:, 0]) / norm).abs().max())
+    assert d <= tol, "moment sums off by %.3e of their scale (tolerance %.1e)" % (d, tol)
+    check("moment squares", part[:, 1], ref[:, 1], tol * 4)
+    # consumer: GroupNorm over (this tensor) and over (this tensor | a second source without moments -> falls back)
+    groups = 32 if cout % 64 == 0 else 16
+    gam, bet = (rnd(cout, seed=65) * 0.2 + 1).to(DEV), (rnd(cout, seed=66) * 0.1).to(DEV)
+    hw = h * w if ks == 3 else 4096
+    nimg = M // hw
+    t3 = o.carry(got.view(nimg, hw, cout), got)
+    sc, sh = o.groupnorm_scale_shift(t3, None, nimg, hw, groups, 1e-5, gam, bet)
+    plain = got.view(nimg, hw, cout).clone()                                     # (a clone carries no moments: statistics pass)
+    sc0, sh0 = o.groupnorm_scale_shift(plain, None, nimg, hw, groups, 1e-5, gam, bet)
+    check("scale from moments", sc, sc0, 2e-3 if got.dtype != torch.float32 else 2e-5)
+    want = F.group_norm(got.float().cpu().view(nimg, hw, cout).permute(0, 2, 1), groups, gam.cpu(), bet.cpu(), 1e-5).permute(0, 2, 1)
+    y = o.scale_shift_act(t3, None, nimg, hw, sc, sh, 0, out_dtype=torch.float32)
+    check("groupnorm from moments", y, want, 1e-3 if got.dtype != torch.float32 else 2e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_groupnorm_moments_of_a_channel_concat(dtype):
+    """norm1 of a decoder resnet: GroupNorm over (x | skip), both carrying moments from DIFFERENT kernels / run lengths."""
+    o = ops()
+    n, h, w = 24, 32, 32
+    gen = lambda c, s: q16(rnd(n, h, w, c, seed=s), dtype)[0]
+    wt = lambda co, ci, s: q16(rnd(co, 9 * ci, seed=s) / (9 * ci) ** 0.5, dtype)[0]
+    a = o.conv_gemm(gen(64, 70), wt(320, 64, 71), 320, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, out_dtype=torch.float32, gn_stats=True)
+    b = o.conv_gemm(gen(128, 72), wt(64, 128, 73), 64, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, out_dtype=torch.float32, gn_stats=True)
+    assert getattr(a, "_pf_gn", None) is not None and getattr(b, "_pf_gn", None) is not None, (getattr(a, "_pf_gn", None), getattr(b, "_pf_gn", None))
+    C = 384
+    gam, bet = (rnd(C, seed=74) * 0.2 + 1).to(DEV), (rnd(C, seed=75) * 0.1).to(DEV)
+    a3, b3 = o.carry(a.view(n, h * w, 320), a), o.carry(b.view(n, h * w, 64), b)
+    sc, sh = o.groupnorm_scale_shift(a3, b3, n, h * w, 32, 1e-5, gam, bet)
+    y = o.scale_shift_act(a3, b3, n, h * w, sc, sh, 1, out_dtype=torch.float32)
+    cat = torch.cat([a.view(n, h * w, 320), b.view(n, h * w, 64)], -1).float().cpu()
+    want = F.silu(F.group_norm(cat.permute(0, 2, 1), 32, gam.cpu(), bet.cpu(), 1e-5)).permute(0, 2, 1)
+    check("concat groupnorm from moments", y, want, 2e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_scale_shift_act_with_raw_pair(dtype):
+    """norm1 + SiLU of an fp32 stream tensor and, from the same pass, the un-normalised [hi | lo] pair (shortcut operand)."""
+    o = ops()
+    n, hw, c0, c1 = 3, 200, 192, 64
+    x0, x1 = (rnd(n, hw, c0, seed=80) * 3 + 0.2).to(DEV), (rnd(n, hw, c1, seed=81) * 3).to(DEV)
+    gam, bet = (rnd(c0 + c1, seed=82) * 0.2 + 1).to(DEV), (rnd(c0 + c1, seed=83) * 0.1).to(DEV)
+    sc, sh = o.groupnorm_scale_shift(x0, x1, n, hw, 32, 1e-5, gam, bet)
+    y_ref = o.scale_shift_act(x0, x1, n, hw, sc, sh, 1, out_dtype=dtype)
+    p_ref = o.scale_shift_act(x0, x1, n, hw, None, None, 0, out_dtype=dtype, split=True)
+    y, pair = o.scale_shift_act(x0, x1, n, hw, sc, sh, 1, out_dtype=dtype, raw_pair=True)
+    assert torch.equal(y, y_ref) and torch.equal(pair, p_ref)
+    C = c0 + c1
+    rec = pair[..., :C].float() + pair[..., C:].float()
+    check("pair reconstructs the input", rec, torch.cat([x0, x1], -1), 2e-6 if dtype == torch.float16 else 4e-5)

@@ -238,6 +238,43 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
     assert hip.packed("unet", args[1].device) is pack_before and pack_before.down[0].resnets[0].train is res_before
 
 
+def test_training_step_with_layout_condition_frozen_controlnet(fake_denoiser_backend):
+    """PanFusion.training_step with ``pano_layout_cond`` (PanFusion.py:85-89): the panorama ControlNet's residuals enter the
+    tape as constants; EPA + LoRA gradients == torch autograd through the oracle with the ControlNet's parameters frozen."""
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    from oracle import mvgen as MV
+    from oracle import sd2_unet as U
+    oracle0, args, w_s, w_p = _denoiser_case()
+    cn = U.ControlNetModel.from_unet(oracle0.pano_unet)
+    U.init_synthetic(cn.controlnet_cond_embedding, 71)
+    U.init_synthetic(cn.controlnet_down_blocks, 72)
+    U.init_synthetic(cn.controlnet_mid_block, 73)
+    cn.requires_grad_(False)
+    oracle = MV.DualBranchDenoiser(oracle0.unet, oracle0.pano_unet, None, cn, oracle0.pano_pad)
+    oracle.load_state_dict({k: v for k, v in oracle0.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    pl = args[1]
+    cond = torch.rand(1, 1, 3, pl.shape[-2] * 8, pl.shape[-1] * 8, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    s, ps = oracle(*args, pano_layout_cond=cond)
+    s0, ps0 = oracle(*args)
+    assert rel_l2(ps, ps0) > 1e-2                                  # the condition does something
+    ((s * w_s).sum() + (ps * w_p).sum()).backward()
+    want = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None}
+    for p in oracle.parameters():
+        p.grad = None
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, cn, oracle.pano_pad, compute_dtype=torch.float32,
+                             precision="mixed", differentiable=True)
+    hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    s2, ps2 = hip(*args, pano_layout_cond=cond)
+    assert s2.requires_grad and rel_l2(s2, s) < 2e-5 and rel_l2(ps2, ps) < 2e-5
+    ((s2 * w_s).sum() + (ps2 * w_p).sum()).backward()
+    got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    keys = [k for k in want if "lora" in k or k.startswith("cp_blocks")]
+    assert len(keys) == 2 * 16 * 2 * 4 * 2 + 7 * 13
+    assert not [k for k in got if k.startswith("pano_cn")]         # frozen: no ControlNet gradients
+    for k in keys:
+        assert k in got and rel_l2(got[k], want[k]) < 1e-4, (k, rel_l2(got[k], want[k]) if k in got else None)
+
+
 def test_no_grad_forward_after_optimizer_step_sees_the_new_lora(fake_denoiser_backend):
     """validation / predict after fit (torch.no_grad, DenoiseLoop) goes straight to _forward -- it must re-fold
     the LoRA-carrying projections too, not mix the current EPA weights with the LoRA from before the step.  Also the

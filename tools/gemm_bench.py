@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--phases", action="store_true", help="per-block phase stamps (pf_debug_gemm_profile)")
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--gn", action="store_true", help="ask the epilogue for GroupNorm moments (pf_conv_desc.gn_partial)")
     ap.add_argument("--stream32", action="store_true", help="fp32 residual in / fp32 out where the shape has a residual (mixed scheme)")
     args = ap.parse_args()
     dev = "cuda"
@@ -55,7 +56,8 @@ def main():
         TS = torch.float32 if (args.stream32 and ex.get("res")) else T16
         res = torch.randn(M, n_store, device=dev, generator=g).to(TS) if ex.get("res") else None
         out = torch.empty(M, n_store, device=dev, dtype=TS)
-        kw = dict(n_img=n, h_in=h, w_in=w, ksize=ks, pad=ks // 2, bias=b, residual=res, out=out, geglu=bool(ex.get("geglu")))
+        kw = dict(n_img=n, h_in=h, w_in=w, ksize=ks, pad=ks // 2, bias=b, residual=res, out=out, geglu=bool(ex.get("geglu")),
+                  gn_stats=args.gn and not ex.get("geglu"))
         for _ in range(3):
             ops.conv_gemm(x, wt, cout, **kw)
         torch.cuda.synchronize()
