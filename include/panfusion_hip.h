@@ -118,6 +118,15 @@ pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, int c1, int
                              float* scale, float* shift, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* GroupNorm statistics of the tensor x [n_img][h][w][C] as if its width had been padded circularly by wrap_pad columns first
+ * (the first and last wrap_pad columns count twice): what GroupNorm sees inside pad_pano(x, 2) -> ResnetBlock2D -> unpad_pano
+ * of the panorama branch (MVGenModel.py:110-115), without the padded copy.  Workspace as pf_groupnorm_stats (hw = h * w). */
+pf_status pf_groupnorm_stats_wrap(const void* x0, int c0, const void* x1, int c1, int dtype,
+                                  int n_img, int h, int w, int wrap_pad, int groups, float eps,
+                                  const float* gamma, const float* beta,
+                                  float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+
 /* The same scale / shift from the per-column-pair moments a pf_conv_gemm epilogue left in pf_conv_desc.gn_partial: source s
  * is fp32 [n_img * hw / rows_s][2][c_s / 2] (rows_s = pf_conv_gemm_gn_rows of the launch that produced it); part1 = NULL: one
  * source.  (c0 + c1) / groups, c0 and c1 must be even.  No pass over the activation itself. */
@@ -261,6 +270,14 @@ typedef struct {
                           * fp32 [M / R][2][n_out / 2] = (sum, sum of squares) of each column PAIR (2 k, 2 k + 1) over each run of R output rows,
                           * R = pf_conv_gemm_gn_rows(desc) (> 0: possible for this problem; images are whole runs).
                           * Consumed by pf_groupnorm_from_partials.  Fixed summation order, no atomics.      */
+    int wrap_pad;        /* 0..2: the input is read as if its WIDTH had been padded circularly by wrap_pad columns on both
+                          * sides first (pad_pano, utils/pano.py:74-99), in pre-upsampling columns; the zero padding `pad`
+                          * applies outside that virtual tensor.  No padded copy exists.                              */
+    int crop;            /* 0..2: output columns cropped by `crop` on both sides (unpad_pano, utils/pano.py:102-105):
+                          * w_out = ((w_in + 2 wrap_pad) << upsample + 2 pad - ksize) / stride + 1 - 2 crop.
+                          * Together: pad_pano(x, p) -> conv -> unpad_pano(., c) of the panorama branch in one launch
+                          * (MVGenModel.py:110-115 resnets p = c = 2 [conv1: wrap 2 / crop 0, conv2: wrap 0 / crop 2 on the
+                          * padded intermediate], :138-144 down-sampling 2 / 1, :272-277 up-sampling 1 / 2).           */
 } pf_conv_desc;
 
 enum { PF_EPILOGUE_NONE = 0, PF_EPILOGUE_GEGLU = 1, PF_EPILOGUE_SPLIT = 2 };

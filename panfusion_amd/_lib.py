@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("batch", c_int),
         ("a_bstride", c_long), ("w_bstride", c_long), ("out_bstride", c_long), ("res_bstride", c_long),
         ("epilogue", c_int), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
-        ("gn_partial", c_void_p),
+        ("gn_partial", c_void_p), ("wrap_pad", c_int), ("crop", c_int),
     ]
 
 
@@ -87,6 +87,8 @@ SIGNATURES = {
     "pf_groupnorm_workspace_size": (c_size_t, [c_int, c_int, c_int]),
     "pf_groupnorm_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pf_groupnorm_stats_wrap": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pf_scale_shift_act": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_layernorm": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_int, c_void_p, c_void_p,

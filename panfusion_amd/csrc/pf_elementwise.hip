@@ -11,6 +11,7 @@
 // (models/pano/PanFusion.py:159-162).
 #include "pf_common.h"
 #include <math.h>
+#include <algorithm>
 
 namespace pf {
 
@@ -48,7 +49,9 @@ __device__ __forceinline__ void store8_f32(float* ptr, const float (&f)[8]) {
 template <typename TI>
 __global__ __launch_bounds__(256) void k_gn_partial(const typename In8<TI>::elem* __restrict__ x0, int c0,
                              const typename In8<TI>::elem* __restrict__ x1, int c1, int hw, int groups,
-                             int pix_per_chunk, float* __restrict__ partial) {
+                             int pix_per_chunk, float* __restrict__ partial, int wimg, int wrap) {
+    // wrap > 0: the moments of the tensor circularly padded by `wrap` columns (image width wimg) without building it -- the
+    // first and last `wrap` columns count twice (GroupNorm inside pad_pano .. unpad_pano, MVGenModel.py:110-115)
     typedef typename In8<TI>::elem elem;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = c0 + c1, OCT = C / 8, cpg = C / groups;
@@ -82,13 +85,19 @@ __global__ __launch_bounds__(256) void k_gn_partial(const typename In8<TI>::elem
                     if (pp < p1) In8<TI>::load(base + static_cast<long>(pp) * ld, v[u]);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u) {
+                    float wgt = 1.f;
+                    if (wrap > 0) {
+                        const int col = (p + u * pix_par) % wimg;
+                        wgt = (col < wrap || col >= wimg - wrap) ? 2.f : 1.f;
+                    }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float f = v[u][j];
-                        s[j] += f;
-                        q[j] += f * f;
+                        s[j] += f * wgt;
+                        q[j] += f * f * wgt;
                     }
+                }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -168,44 +177,65 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ p
 // The same from the per-column-PAIR moments a GEMM epilogue left behind (pf_conv_desc.gn_partial): source s holds
 // [n_img * ppi_s][2][c_s / 2] (sum, sum of squares of columns (2 k, 2 k + 1) over runs of hw / ppi_s rows); the channel
 // concat (x0 | x1) is the concat of the two column ranges; groups hold an even number of channels and c0 is even, so a pair
-// never straddles a group or the two sources.  grid (image, group block): every thread owns pairs of the block's GN_GPB
-// groups and walks the image's parts with 4 loads in flight (coalesced across threads), fp64 accumulation.
+// never straddles a group or the two sources.  grid (image, block of gpb groups).  The block's threads are laid out as
+// (slice of the parts) x (pair): with few pairs per block (VAE: 2 per group) and thousands of parts per image (512 x 512 / 64)
+// a thread per pair walking all parts took 250 us per call -- the host picks gpb so that 256 / (gpb * pairs per group)
+// slices share the walk (4 loads in flight each), fp64 accumulation, fixed combination order.
 __global__ __launch_bounds__(256) void k_gn_finalize_cols(const float* __restrict__ part0, int c0, int ppi0,
-                                   const float* __restrict__ part1, int c1, int ppi1, int groups, int hw, float eps,
+                                   const float* __restrict__ part1, int c1, int ppi1, int groups, int gpb, int hw, float eps,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ scale, float* __restrict__ shift) {
-    constexpr int PMAX = 512;                         // pairs of GN_GPB groups (C <= 4096 at 32 groups)
+    constexpr int PMAX = 512;                         // pairs of one block (gpb * pairs per group)
+    __shared__ double red_s[256], red_q[256];
     __shared__ double chs[PMAX], chq[PMAX];
     __shared__ float g_mean[GN_GPB], g_rstd[GN_GPB];
     const int img = blockIdx.x, t = threadIdx.x;
     const int C = c0 + c1, cpg = C / groups, ppg = cpg / 2;       // pairs per group
     const int P0 = c0 / 2, P1 = c1 / 2;
-    const int pbeg = blockIdx.y * GN_GPB * ppg, pend = min(C / 2, pbeg + GN_GPB * ppg);
-    for (int pr = pbeg + t; pr < pend; pr += 256) {
-        const bool first = pr < P0;
-        const int pp = first ? pr : pr - P0, Ps = first ? P0 : P1, ppi = first ? ppi0 : ppi1;
-        const float* base = (first ? part0 : part1) + static_cast<long>(img) * ppi * 2 * Ps + pp;
+    const int pbeg = blockIdx.y * gpb * ppg, pend = min(C / 2, pbeg + gpb * ppg);
+    const int npairs = pend - pbeg;
+    const int slices = npairs <= 128 ? 256 / npairs : 1;
+    for (int p0 = 0; p0 < npairs; p0 += 256) {                    // (one round unless a block holds more than 256 pairs)
+        const int pl = slices > 1 ? t % npairs : p0 + t, slice = slices > 1 ? t / npairs : 0;
         double s = 0.0, q = 0.0;
-        int k = 0;
-        for (; k + 3 < ppi; k += 4) {
-            float a[4], b[4];
+        if (pl < npairs && slice < slices) {
+            const int pr = pbeg + pl;
+            const bool first = pr < P0;
+            const int pp = first ? pr : pr - P0, Ps = first ? P0 : P1, ppi = first ? ppi0 : ppi1;
+            const float* base = (first ? part0 : part1) + static_cast<long>(img) * ppi * 2 * Ps + pp;
+            int k = slice;
+            for (; k + 3 * slices < ppi; k += 4 * slices) {
+                float a[4], b[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = base[static_cast<long>(k + u) * 2 * Ps];
-                b[u] = base[static_cast<long>(k + u) * 2 * Ps + Ps];
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = base[static_cast<long>(k + u * slices) * 2 * Ps];
+                    b[u] = base[static_cast<long>(k + u * slices) * 2 * Ps + Ps];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s += a[u]; q += b[u]; }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { s += a[u]; q += b[u]; }
+            for (; k < ppi; k += slices) {
+                s += base[static_cast<long>(k) * 2 * Ps];
+                q += base[static_cast<long>(k) * 2 * Ps + Ps];
+            }
         }
-        for (; k < ppi; ++k) {
-            s += base[static_cast<long>(k) * 2 * Ps];
-            q += base[static_cast<long>(k) * 2 * Ps + Ps];
+        if (slices > 1) {
+            red_s[t] = s;
+            red_q[t] = q;
+            __syncthreads();
+            if (t < npairs) {
+                double ss = 0.0, qq = 0.0;
+                for (int sl = 0; sl < slices; ++sl) { ss += red_s[sl * npairs + t]; qq += red_q[sl * npairs + t]; }
+                chs[t] = ss;
+                chq[t] = qq;
+            }
+        } else if (pl < npairs) {
+            chs[pl] = s;
+            chq[pl] = q;
         }
-        chs[pr - pbeg] = s;
-        chq[pr - pbeg] = q;
     }
     __syncthreads();
-    if (t < GN_GPB && blockIdx.y * GN_GPB + t < groups) {
+    if (t < gpb && blockIdx.y * gpb + t < groups) {
         double s = 0.0, q = 0.0;
         for (int j = 0; j < ppg; ++j) { s += chs[t * ppg + j]; q += chq[t * ppg + j]; }
         const double cnt = static_cast<double>(hw) * cpg;
@@ -216,7 +246,7 @@ __global__ __launch_bounds__(256) void k_gn_finalize_cols(const float* __restric
         g_rstd[t] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
     }
     __syncthreads();
-    const int cbeg = blockIdx.y * GN_GPB * cpg, cend = min(C, cbeg + GN_GPB * cpg);
+    const int cbeg = blockIdx.y * gpb * cpg, cend = min(C, cbeg + gpb * cpg);
     for (int c = cbeg + t; c < cend; c += 256) {
         const int gg = (c - cbeg) / cpg;
         const float sc = g_rstd[gg] * gamma[c];
@@ -281,7 +311,8 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const typename In8<TI>:
         }
         if (act) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = f[j] / (1.0f + expf(-f[j]));
+            for (int j = 0; j < 8; ++j) f[j] = f[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-f[j]));   // (v_exp + v_rcp: 1-2 ulp; the
+                                                   // libm expf + IEEE division made the pass ALU-bound on tensors too large for the Infinity Cache)
         }
         if (OUT == 0) {
             *reinterpret_cast<u16x8*>(static_cast<unsigned short*>(yv) + pix[u] * C + cc[u]) = pack8<T>(f);
@@ -623,16 +654,20 @@ __global__ void k_conv_in(const float* __restrict__ x, int n, int cin, int h, in
 }
 
 // conv_out: x NHWC 16-bit [n][h][w][cin] -> y fp32 NCHW [n][cout<=8][h][w]; weights fp32
-// [cout][3][3][cin].  One wavefront per output pixel, lanes over the channel octets of each tap.
-template <typename TI>
+// [cout][3][3][cin].  LPP lanes per output pixel (the smallest power of two >= cin / 8, lanes over the channel octets of
+// each tap), 64 / LPP pixels per wavefront: at the VAE's 128 channels a whole wavefront per pixel left 48 of 64 lanes idle
+// (12.8 ms of a 107 ms decode in three launches, profiles/r3h_vae_kernels.txt).
+template <typename TI, int LPP>
 __global__ void k_conv_out(const typename In8<TI>::elem* __restrict__ x, int n, int cin, int h, int w,
                            const float* __restrict__ wgt, const float* __restrict__ bias, int cout,
                            int wrap, float* __restrict__ y) {
-    const int lane = threadIdx.x & 63;
-    const long pix = blockIdx.x * static_cast<long>(blockDim.x >> 6) + (threadIdx.x >> 6);
+    constexpr int PPW = 64 / LPP;                                 // pixels per wavefront
+    const int lane = threadIdx.x & 63, sub = lane % LPP;
+    const long pix = (blockIdx.x * static_cast<long>(blockDim.x >> 6) + (threadIdx.x >> 6)) * PPW + lane / LPP;
     const long npix = static_cast<long>(n) * h * w;
-    if (pix >= npix) return;
-    const int xx = pix % w, yy = (pix / w) % h, b = pix / (static_cast<long>(w) * h);
+    const bool live = pix < npix;
+    const long pc = live ? pix : npix - 1;
+    const int xx = pc % w, yy = (pc / w) % h, b = pc / (static_cast<long>(w) * h);
     const int OCT = cin / 8;
     float acc[8];
 #pragma unroll
@@ -641,9 +676,9 @@ __global__ void k_conv_out(const typename In8<TI>::elem* __restrict__ x, int n, 
         const int yi = yy + tap / 3 - 1;
         int xi = xx + tap % 3 - 1;
         if (wrap) xi = (xi + w) % w;
-        if (yi < 0 || yi >= h || xi < 0 || xi >= w) continue;   // wave-uniform
+        if (yi < 0 || yi >= h || xi < 0 || xi >= w) continue;   // (uniform per pixel = per LPP-lane group)
         const typename In8<TI>::elem* src = x + ((static_cast<long>(b) * h + yi) * w + xi) * cin;
-        for (int oct = lane; oct < OCT; oct += 64) {
+        for (int oct = sub; oct < OCT; oct += LPP) {
             float f[8];
             In8<TI>::load(src + oct * 8, f);
 #pragma unroll
@@ -659,8 +694,10 @@ __global__ void k_conv_out(const typename In8<TI>::elem* __restrict__ x, int n, 
 #pragma unroll
     for (int co = 0; co < 8; ++co) {
         if (co >= cout) break;
-        float s = wave_sum(acc[co]);
-        if (lane == 0) y[((static_cast<long>(b) * cout + co) * h + yy) * w + xx] = s + (bias ? bias[co] : 0.f);
+        float s = acc[co];
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (sub == 0 && live) y[((static_cast<long>(b) * cout + co) * h + yy) * w + xx] = s + (bias ? bias[co] : 0.f);
     }
 }
 
@@ -695,10 +732,27 @@ extern "C" size_t pf_groupnorm_workspace_size(int n_img, int hw, int C) {
     return static_cast<size_t>(n_img) * nchunks * 64 * 2 * sizeof(float);   // up to 64 groups
 }
 
+static pf_status groupnorm_stats_impl(const void* x0, int c0, const void* x1, int c1, int dtype,
+                                      int n_img, int hw, int groups, float eps, const float* gamma,
+                                      const float* beta, float* scale, float* shift, void* workspace,
+                                      size_t ws_bytes, void* stream, int wimg, int wrap);
 extern "C" pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, int c1, int dtype,
                                         int n_img, int hw, int groups, float eps, const float* gamma,
                                         const float* beta, float* scale, float* shift, void* workspace,
                                         size_t ws_bytes, void* stream) {
+    return groupnorm_stats_impl(x0, c0, x1, c1, dtype, n_img, hw, groups, eps, gamma, beta, scale, shift, workspace, ws_bytes, stream, 0, 0);
+}
+extern "C" pf_status pf_groupnorm_stats_wrap(const void* x0, int c0, const void* x1, int c1, int dtype,
+                                             int n_img, int h, int w, int wrap_pad, int groups, float eps, const float* gamma,
+                                             const float* beta, float* scale, float* shift, void* workspace,
+                                             size_t ws_bytes, void* stream) {
+    PF_REQUIRE(h > 0 && w > 0 && wrap_pad >= 0 && 2 * wrap_pad <= w, "pf_groupnorm_stats_wrap: bad image size / padding");
+    return groupnorm_stats_impl(x0, c0, x1, c1, dtype, n_img, h * w, groups, eps, gamma, beta, scale, shift, workspace, ws_bytes, stream, w, wrap_pad);
+}
+static pf_status groupnorm_stats_impl(const void* x0, int c0, const void* x1, int c1, int dtype,
+                                      int n_img, int hw, int groups, float eps, const float* gamma,
+                                      const float* beta, float* scale, float* shift, void* workspace,
+                                      size_t ws_bytes, void* stream, int wimg, int wrap) {
     const int C = c0 + (x1 ? c1 : 0);
     if (!x1) c1 = 0;
     PF_REQUIRE(x0 && gamma && beta && scale && shift && workspace, "pf_groupnorm_stats: null pointer");
@@ -717,8 +771,9 @@ extern "C" pf_status pf_groupnorm_stats(const void* x0, int c0, const void* x1, 
     PF_DISPATCH_IN(dtype, "pf_groupnorm_stats",
         hipLaunchKernelGGL(k_gn_partial<TI>, dim3(nchunks, n_img), dim3(256), smem, st,
                            static_cast<const In8<TI>::elem*>(x0), c0, static_cast<const In8<TI>::elem*>(x1), c1,
-                           hw, groups, ppc, partial));
-    hipLaunchKernelGGL(k_gn_finalize, dim3(n_img, cdiv(groups, GN_GPB)), dim3(256), 0, st, partial, nchunks, groups, C, hw, eps,
+                           hw, groups, ppc, partial, wimg, wrap));
+    const int hw_counted = wrap > 0 ? hw / wimg * (wimg + 2 * wrap) : hw;         // pixels of the virtually padded tensor
+    hipLaunchKernelGGL(k_gn_finalize, dim3(n_img, cdiv(groups, GN_GPB)), dim3(256), 0, st, partial, nchunks, groups, C, hw_counted, eps,
                        gamma, beta, scale, shift);
     PF_CHECK_LAUNCH("pf_groupnorm_stats");
     return PF_OK;
@@ -735,9 +790,12 @@ extern "C" pf_status pf_groupnorm_from_partials(const float* part0, int c0, int 
     PF_REQUIRE(rows0 > 0 && rows1 > 0 && hw % rows0 == 0 && hw % rows1 == 0,
                "pf_groupnorm_from_partials: an image (%d rows) must be whole runs of %d / %d rows", hw, rows0, rows1);
     PF_REQUIRE((C / groups) % 2 == 0 && c0 % 2 == 0 && c1 % 2 == 0, "pf_groupnorm_from_partials: groups and sources must hold even numbers of channels (moments are per column pair)");
-    PF_REQUIRE(GN_GPB * (C / groups) <= 1024, "pf_groupnorm_from_partials: C=%d too large for %d groups", C, groups);
-    hipLaunchKernelGGL(k_gn_finalize_cols, dim3(n_img, cdiv(groups, GN_GPB)), dim3(256), 0, as_stream(stream),
-                       part0, c0, hw / rows0, part1, c1, hw / rows1, groups, hw, eps, gamma, beta, scale, shift);
+    const int ppi = std::max(hw / rows0, hw / rows1);
+    int gpb = ppi <= 32 ? 8 : ppi <= 128 ? 4 : ppi <= 512 ? 2 : 1;       // fewer groups per block = more slices walking the parts
+    while (gpb > 1 && gpb * (C / groups) / 2 > 512) gpb >>= 1;
+    PF_REQUIRE(gpb * (C / groups) / 2 <= 512, "pf_groupnorm_from_partials: C=%d too large for %d groups", C, groups);
+    hipLaunchKernelGGL(k_gn_finalize_cols, dim3(n_img, cdiv(groups, gpb)), dim3(256), 0, as_stream(stream),
+                       part0, c0, hw / rows0, part1, c1, hw / rows1, groups, gpb, hw, eps, gamma, beta, scale, shift);
     PF_CHECK_LAUNCH("pf_groupnorm_from_partials");
     return PF_OK;
 }
@@ -1046,9 +1104,13 @@ extern "C" pf_status pf_conv_out(const void* x, int dtype, int n, int cin, int h
     PF_REQUIRE(cin % 8 == 0 && cout > 0 && cout <= 8, "pf_conv_out: cin %% 8 == 0 and cout <= 8 required");
     PF_REQUIRE(aligned16(x) && aligned16(wgt), "pf_conv_out: 16-byte alignment required");
     const long npix = static_cast<long>(n) * h * w;
+    const int oct = cin / 8;
+    const int lpp = oct <= 8 ? 8 : oct <= 16 ? 16 : oct <= 32 ? 32 : 64;     // lanes per output pixel
+#define PF_CONV_OUT(L) hipLaunchKernelGGL((k_conv_out<TI, L>), dim3(cdiv(npix, 4 * (64 / L))), dim3(256), 0, as_stream(stream), \
+                                          static_cast<const In8<TI>::elem*>(x), n, cin, h, w, wgt, bias, cout, wrap, y)
     PF_DISPATCH_IN(dtype, "pf_conv_out",
-        hipLaunchKernelGGL(k_conv_out<TI>, dim3(cdiv(npix, 4)), dim3(256), 0, as_stream(stream),
-                           static_cast<const In8<TI>::elem*>(x), n, cin, h, w, wgt, bias, cout, wrap, y));
+        if (lpp == 8) PF_CONV_OUT(8); else if (lpp == 16) PF_CONV_OUT(16); else if (lpp == 32) PF_CONV_OUT(32); else PF_CONV_OUT(64));
+#undef PF_CONV_OUT
     PF_CHECK_LAUNCH("pf_conv_out");
     return PF_OK;
 }

@@ -33,6 +33,9 @@ struct GemmParams {
     int c0, c1, a0_ld, a1_ld;
     int h_in, w_in, h_out, w_out;
     int ksize, stride, pad, up;
+    int wrap, crop;              // virtual circular padding of the input WIDTH by `wrap` columns (pre-upsample) and output columns
+                                 // cropped by `crop` on both sides: pad_pano -> conv -> unpad_pano of the panorama branch without
+                                 // the padded copies (utils/pano.py:74-105, MVGenModel.py:98-144,224-294)
     const unsigned short* w;
     int M, N, K;                 // K = ksize*ksize*(c0+c1); a launch covers output rows [m_begin, M)
     int m_begin;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
             const int yo = rem / p.w_out;
             a_img[i] = img;
             a_y[i] = yo * p.stride - p.pad;
-            a_x[i] = (rem - yo * p.w_out) * p.stride - p.pad;
+            a_x[i] = (rem - yo * p.w_out + p.crop) * p.stride - p.pad;
         } else {
             a_img[i] = 0; a_y[i] = -(1 << 20); a_x[i] = 0;     // never in range
         }
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
         w_off[j] = n < p.N ? static_cast<unsigned>(n * p.K + lchunk8) * 2u : OOB;
     }
     const int Ctot = p.c0 + p.c1;
-    const int Hl = p.h_in << p.up, Wl = p.w_in << p.up;
+    const int Hl = p.h_in << p.up, Wl = (p.w_in + 2 * p.wrap) << p.up;
 
     // K walk (wave-uniform state): K-block kb = (tap, source, 64-channel block); no divisions in the loop
     const int nkb = p.K / 64;
@@ -603,9 +606,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
         const int ld = seg1 ? p.a1_ld : p.a0_ld;
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
-            const int yi = a_y[i] + ky, xi = a_x[i] + kx;
+            const int yi = a_y[i] + ky, xi = a_x[i] + kx;             // xi: column in the (virtually wrap-padded, upsampled) input
             const bool ok = yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
-            const int pix = (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up);
+            int sx = (xi >> p.up) - p.wrap;                            // source column: the padding is circular
+            sx += sx < 0 ? p.w_in : 0;
+            sx -= sx >= p.w_in ? p.w_in : 0;
+            const int pix = (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + sx;
             a_off[i] = ok ? static_cast<unsigned>(pix * ld + lchunk8) * 2u : OOB;
         }
     };
@@ -764,7 +770,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     int kw = 0;                                                   // K offset (elements) of the stage being multiplied
 #endif
     const int Ctot = p.c0 + p.c1;
-    const int Hl = p.h_in << p.up, Wl = p.w_in << p.up;
+    const int Hl = p.h_in << p.up, Wl = (p.w_in + 2 * p.wrap) << p.up;
 
     // K walk (wave-uniform): K-block = (tap, source, 64-channel block).  Per-thread activation offsets
     // change only when the tap or the source changes ("segment"); inside a segment only soffset moves.
@@ -781,9 +787,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         const int ld = seg1 ? p.a1_ld : p.a0_ld;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
-            const int yi = a_y[i] + ky, xi = a_x[i] + kx;
+            const int yi = a_y[i] + ky, xi = a_x[i] + kx;             // xi: column in the (virtually wrap-padded, upsampled) input
             const bool ok = yi >= 0 && yi < Hl && xi >= 0 && xi < Wl;
-            const int pix = (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + (xi >> p.up);
+            int sx = (xi >> p.up) - p.wrap;                            // source column: the padding is circular
+            sx += sx < 0 ? p.w_in : 0;
+            sx -= sx >= p.w_in ? p.w_in : 0;
+            const int pix = (a_img[i] * p.h_in + (yi >> p.up)) * p.w_in + sx;
             a_off[i] = ok ? static_cast<unsigned>(pix * ld + lchunk8) * 2u : OOB;
         }
     };
@@ -812,7 +821,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
                 const bool ok = m0 + i * RPP + lrow < p.M;
                 a_img[i] = ok ? img : 0;
                 a_y[i] = ok ? yo * p.stride - p.pad : -(1 << 20);
-                a_x[i] = xo * p.stride - p.pad;
+                a_x[i] = (xo + p.crop) * p.stride - p.pad;
                 xo += p.adv_x;
                 if (xo >= p.w_out) { xo -= p.w_out; ++yo; }
                 yo += p.adv_y;
@@ -1353,6 +1362,7 @@ static void params_from_desc(const pf_conv_desc* d, GemmParams& p) {
     p.c0 = d->c0; p.c1 = c1; p.a0_ld = d->a0_ld; p.a1_ld = d->a1 ? d->a1_ld : 0;
     p.h_in = d->h_in; p.w_in = d->w_in; p.h_out = d->h_out; p.w_out = d->w_out;
     p.ksize = d->ksize; p.stride = d->stride; p.pad = d->pad; p.up = d->upsample;
+    p.wrap = d->wrap_pad; p.crop = d->crop;
     p.w = static_cast<const unsigned short*>(d->w);
     p.rows_per_img = d->h_out * d->w_out;
     p.M = d->n_img * p.rows_per_img; p.N = d->n_out; p.K = d->ksize * d->ksize * Ctot;
@@ -1433,12 +1443,14 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     if (d->epilogue == PF_EPILOGUE_GEGLU)
         PF_REQUIRE(d->n_out % 4 == 0 && d->out_dtype == d->dtype && !d->residual && d->out_ld >= d->n_out / 2 && d->out_ld % 2 == 0,
                    "pf_conv_gemm: GEGLU epilogue needs n_out %% 4 == 0, 16-bit output, no residual, out_ld >= n_out/2");
+    PF_REQUIRE(d->wrap_pad >= 0 && d->wrap_pad <= 2 && d->crop >= 0 && d->crop <= 2 && d->wrap_pad <= d->w_in,
+               "pf_conv_gemm: wrap_pad and crop must be in 0..2");
     {   // the output size must be what the conv arithmetic produces
-        const int hl = d->h_in << d->upsample, wl = d->w_in << d->upsample;
-        const int ho = (hl + 2 * d->pad - d->ksize) / d->stride + 1, wo = (wl + 2 * d->pad - d->ksize) / d->stride + 1;
+        const int hl = d->h_in << d->upsample, wl = (d->w_in + 2 * d->wrap_pad) << d->upsample;
+        const int ho = (hl + 2 * d->pad - d->ksize) / d->stride + 1, wo = (wl + 2 * d->pad - d->ksize) / d->stride + 1 - 2 * d->crop;
         // one more zero row / column at the bottom / right is allowed (pixels past the input read as zero anyway):
         // diffusers Downsample2D(padding=0) = F.pad(x, (0, 1, 0, 1)) + conv3x3 stride 2 of the VAE encoder
-        const int ho1 = (hl + 2 * d->pad + 1 - d->ksize) / d->stride + 1, wo1 = (wl + 2 * d->pad + 1 - d->ksize) / d->stride + 1;
+        const int ho1 = (hl + 2 * d->pad + 1 - d->ksize) / d->stride + 1, wo1 = (wl + 2 * d->pad + 1 - d->ksize) / d->stride + 1 - 2 * d->crop;
         PF_REQUIRE((d->h_out == ho && d->w_out == wo) || (d->h_out == ho1 && d->w_out == wo1),
                    "pf_conv_gemm: output size (%d,%d) does not match (%d,%d) [or (%d,%d) with a trailing zero row / column]",
                    d->h_out, d->w_out, ho, wo, ho1, wo1);

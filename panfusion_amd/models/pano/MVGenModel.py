@@ -246,7 +246,11 @@ class MultiViewBaseModel(nn.Module):
         side = None
         if two and self.two_streams and main is not None and not view_only and not pano_only and tape is None:
             if self._side is None:
-                self._side = torch.cuda.Stream(dev)
+                # PF_PANO_PRIORITY=1: the panorama branch's stream gets HIGH priority.  Its ~1400 small kernels are the
+                # critical path at the deep levels (the view stream idles 3-4 ms per step at the joins there,
+                # profiles/r3f_streams.txt): with priority their workgroups take the first compute units that come free
+                # instead of queueing behind a whole round of the view branch's persistent GEMM blocks.
+                self._side = torch.cuda.Stream(dev, priority=-1 if os.environ.get("PF_PANO_PRIORITY", "0") == "1" else 0)
             side = self._side
         keep = []                                   # tensors produced on one stream and read on the other stay
                                                     # referenced until the next join (allocator reuse is per stream)
