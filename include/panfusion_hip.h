@@ -278,6 +278,12 @@ typedef struct {
                           * Together: pad_pano(x, p) -> conv -> unpad_pano(., c) of the panorama branch in one launch
                           * (MVGenModel.py:110-115 resnets p = c = 2 [conv1: wrap 2 / crop 0, conv2: wrap 0 / crop 2 on the
                           * padded intermediate], :138-144 down-sampling 2 / 1, :272-277 up-sampling 1 / 2).           */
+    int* tickets;        /* optional (NULL: the split-K slabs are combined by a second kernel): n_tickets int32 arrival counters,
+                          * ALL ZERO when the call is enqueued and zero again when it has run, not shared with a launch that may
+                          * run concurrently -- the K-slice workgroup that arrives last combines the slabs inside the launch
+                          * (same sums in split order as the second kernel: bit-identical).  n_tickets >= tiles x batch of the
+                          * split launch (<= 1024 for every plan this library makes).                                  */
+    int n_tickets;
 } pf_conv_desc;
 
 enum { PF_EPILOGUE_NONE = 0, PF_EPILOGUE_GEGLU = 1, PF_EPILOGUE_SPLIT = 2 };

@@ -48,6 +48,8 @@ struct GemmParams {
     int mtiles, ntiles;
     int splits, kb_per_split;      // split-K: blockIdx.y walks K-blocks [y*kb_per_split, ...)
     float* partial;                // [split][batch][M][N] fp32 when splits > 1
+    int* tickets;                  // splits > 1: arrival counters, one per (batch, tile), all zero between launches; NULL = the
+                                   // slabs are combined by a second kernel (k_splitk_reduce)
     int batch;
     unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors of the 8-wave kernel (< 2 GiB)
     int adv_img, adv_y, adv_x;              // (image, row, column) advance of one DMA pass of output rows (8-wave kernel)
@@ -526,6 +528,63 @@ generic:
     }
 }
 
+// Split-K combine INSIDE the GEMM launch (no second kernel: the 8 x 8 / 16 x 16 levels and the whole panorama branch paid
+// one ~8 us launch per split layer, 200+ per step, most of them on the latency-bound chains the branch joins wait for).
+// Every K-slice block publishes its fp32 slab and draws a ticket; the block that draws the last one combines the slabs IN
+// SPLIT ORDER (the same sums as k_splitk_reduce: results do not depend on arrival order) and runs the epilogue.
+// Inter-workgroup visibility (cdna_hip_programming.md section 6 Guideline 16, write-through form): sc1 slab stores ->
+// s_waitcnt vmcnt(0) in every wave -> barrier -> lane 0: relaxed agent-scope fetch_add; the last arriver: lane 0
+// agent-scope acquire fence (drops this CU's L1) -> barrier -> plain loads.  Nobody waits for anybody:
+// no residency assumption, no deadlock.  The last arriver zeroes the counter for the next launch that is handed the slot.
+// fp32 slab store of a split-K partial: WRITE-THROUGH (sc1) when the slabs are combined inside the launch -- the bytes leave
+// the XCD's L2 with the store itself, so publishing needs no agent-scope release fence (buffer_wbl2 writes back EVERY dirty
+// line of the L2, the concurrently running branch's outputs included: with one fence per K-slice workgroup the step lost
+// 4.4 ms, profiles/r3k_ab_splitk.txt).
+__device__ __forceinline__ void slab_store(const GemmParams& p, long elem, const f32x4& v) {
+    if (p.tickets) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        const unsigned long long a = reinterpret_cast<unsigned long long>(p.partial);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a >> 32));
+        float* base = reinterpret_cast<float*>(static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFFu, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, static_cast<int>(static_cast<unsigned>(elem * 4)), 0, /* sc1 */ 16);
+    } else {
+        *reinterpret_cast<float4*>(p.partial + elem) = float4{v[0], v[1], v[2], v[3]};
+    }
+}
+
+template <typename T, int BM, int BN, int NT>
+__device__ __forceinline__ void splitk_finish(const GemmParams& p, long bz, int tile_lin, int m0, int n0, int* flag, int t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have left the wave
+    __syncthreads();                                              // (also: every wave is done with the operand ring -> `flag` may live there)
+    int* ticket = p.tickets + (bz * p.mtiles * p.ntiles + tile_lin);
+    if (t == 0) {                                                 // (write-through slabs + drained stores: no release fence)
+        const int drawn = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = drawn == p.splits - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    __syncthreads();                                              // (flag read by everyone before the ring is reused)
+    if (!last) return;
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    constexpr int QPR = BN / 4;
+    const int Ms = p.M - p.m_begin;
+    const long slab = static_cast<long>(p.batch) * Ms * p.N;
+    for (int q = t; q < BM * QPR; q += NT) {
+        const int r = q / QPR, m = m0 + r, n4 = n0 + (q - r * QPR) * 4;
+        if (m >= p.M || n4 >= p.N) continue;
+        const float* src = p.partial + (bz * Ms + (m - p.m_begin)) * p.N + n4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.splits; ++s) {
+            const float4 x = *reinterpret_cast<const float4*>(src + s * slab);
+            v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+        }
+        epilogue_store<T>(p, bz, m, n4, v);
+    }
+    if (t == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename T, int MREP, int NREP, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
@@ -694,10 +753,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
             for (int j = 0; j < NREP; ++j) {
                 const int n4 = n0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
                 if (n4 >= p.N) continue;
-                float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * (p.M - p.m_begin) + (m - p.m_begin)) * p.N + n4;
-                *reinterpret_cast<float4*>(o) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                slab_store(p, ((static_cast<long>(blockIdx.y) * p.batch + bz) * (p.M - p.m_begin) + (m - p.m_begin)) * p.N + n4, acc[i][j]);
             }
         }
+        if (p.tickets) splitk_finish<T, BM, BN, 256>(p, bz, tid_lin, m0, n0, reinterpret_cast<int*>(smem), t);
         return;
     }
     epilogue_tile<T, MREP, NREP, 256, BM, BN, 1, STATS>(p, bz, acc, smem, m0, n0, wm * 16 * MREP, wn * 16 * NREP, lane, t);
@@ -1113,10 +1172,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
                 for (int j = 0; j < NREP; ++j) {
                     const int n4 = en0 + wn * 16 * NREP + j * 16 + 4 * (lane >> 4);
                     if (n4 >= p.N) continue;
-                    float* o = p.partial + ((static_cast<long>(blockIdx.y) * p.batch + bz) * (p.M - p.m_begin) + (m - p.m_begin)) * p.N + n4;
-                    *reinterpret_cast<float4*>(o) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    slab_store(p, ((static_cast<long>(blockIdx.y) * p.batch + bz) * (p.M - p.m_begin) + (m - p.m_begin)) * p.N + n4, acc[i][j]);
                 }
             }
+            if (p.tickets) splitk_finish<T, BM, BN, NT>(p, bz, tile, em0, en0, reinterpret_cast<int*>(smem + 2 * STAGE), t);
             if (!has_next) break;
             __syncthreads();                              // every wave is done reading the operand ring
             set_tile(next);
@@ -1187,7 +1246,7 @@ static pf_status launch_s(const GemmParams& gp, int batch, hipStream_t st) {
     }
     hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP, STATS>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(256), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm");
-    if (p.splits > 1) {
+    if (p.splits > 1 && !p.tickets) {
         const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
         hipLaunchKernelGGL((k_splitk_reduce<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, p);
         PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
@@ -1233,7 +1292,7 @@ static pf_status launch8w_s(const GemmParams& gp, int batch, hipStream_t st) {
     }
     hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW, STATS>), dim3(grid, p.splits, batch), dim3(64 * NW), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm (8-wave)");
-    if (p.splits > 1) {
+    if (p.splits > 1 && !p.tickets) {
         const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
         hipLaunchKernelGGL((k_splitk_reduce<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, p);
         PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
@@ -1377,7 +1436,7 @@ static void params_from_desc(const pf_conv_desc* d, GemmParams& p) {
     p.prof = nullptr;
     p.batch = d->batch;
     p.gn_partial = nullptr; p.gn_rows = 0;
-    p.m_begin = 0; p.splits = 1; p.kb_per_split = 0; p.partial = nullptr;
+    p.m_begin = 0; p.splits = 1; p.kb_per_split = 0; p.partial = nullptr; p.tickets = nullptr;
     p.a0_bytes = p.a1_bytes = p.w_bytes = 0; p.adv_img = p.adv_y = p.adv_x = 0;
 }
 
@@ -1474,6 +1533,21 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     }
     p.splits = g.splits; p.kb_per_split = g.kb_per_split;
     p.partial = static_cast<float*>(d->workspace);
+    // In-launch combine: implemented, bit-identical (tests/test_gpu_kernels.py), and OFF by default -- it does not pay at these
+    // tile sizes: the last-arriving workgroup reads splits x 164 KB of slabs through one CU (~65 GB/s per block cross-XCD,
+    // MI355X_MICROARCH.md "handoff-payload") while the second kernel spreads the same reads over the whole chip: the step went
+    // 65.3 -> 67.8 ms with write-through slabs, -> 72.9 ms with a release fence per workgroup (profiles/r3k_ab_splitk.txt,
+    // r3l_ab_splitk.txt).  PF_SPLITK_INKERNEL=1 enables it for A/B.
+    if (d->tickets && tuning("PF_SPLITK_INKERNEL", 0) && d->workspace_bytes < (1ULL << 32)) {      // (32-bit slab offsets)
+        // enough zeroed counters for every (batch, tile) of the split launch?  (tile counts of split plans: <= 320 of the
+        // 4-wave kernel, <= 255 of the 8-wave one)
+        const int bm = g.big ? 256 : 32 * g.mrep, bn = 32 * g.nrep;
+        const long rows = g.big && g.m_split > 0 ? p.M - g.m_split : p.M;
+        const long need = cdiv(rows, bm) * cdiv(p.N, bn) * d->batch;
+        PF_REQUIRE(d->n_tickets >= need && (reinterpret_cast<uintptr_t>(d->tickets) & 3) == 0,
+                   "pf_conv_gemm: %ld arrival counters needed, %d given", need, d->n_tickets);
+        p.tickets = d->tickets;
+    }
     p.m_begin = 0;
     hipStream_t st = as_stream(stream);
     if (g.big && g.m_split > 0) {           // two launches: full rounds unsplit, then the tail rows with split K

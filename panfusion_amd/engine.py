@@ -37,6 +37,7 @@ def default_precision(dtype):
 
 
 RAW_PAIR_FUSED = os.environ.get("PF_RAW_PAIR", "1") != "0"      # A/B: 0 = the shortcut operand by its own split pass
+VIRTUAL_PAD = os.environ.get("PF_VIRTUAL_PAD", "1") != "0"      # A/B: 0 = materialised pad_pano / unpad_pano copies around the panorama convs
 
 
 def stream_dtype(dtype, precision):
@@ -384,14 +385,20 @@ def pack_epa(block, dev, dtype, mixed=False):
 
 
 # ---------------------------------------------------------------------------- layer runners
-def run_resnet(r, x, skip, temb_all, groups_eps=None):
+def run_resnet(r, x, skip, temb_all, groups_eps=None, wrap=0):
     """x [n, h, w, C] (+ skip concatenated along channels) -> [n, h, w, cout], stream dtype in and out.
     GN -> SiLU -> conv3x3 (+bias +temb) -> GN -> SiLU -> conv3x3 (+bias) + shortcut(x).
-    GroupNorm moments: conv1's epilogue leaves the moments of h1 behind for norm2, conv2's those of the block output for
-    whichever norm reads it next (ops.conv_gemm(gn_stats=True)); norm1 uses what x / skip carry, else its own pass."""
+    GroupNorm moments: conv1's epilogue leaves the moments of h1 behind for norm2 (ops.conv_gemm(gn_stats=True)); norm1 uses
+    what x / skip carry, else its own pass.
+    wrap = p > 0: the panorama branch's pad_pano(x, p) -> resnet -> unpad_pano(., p) (MVGenModel.py:110-115) WITHOUT the padded
+    copies, bug-compatible with the reference: norm1's statistics count the wrapped columns twice, conv1 reads the
+    normalised x through a virtual circular padding and produces the w + 2p columns the reference has (its zero padding
+    contaminating the two outermost ones), norm2 normalises exactly that tensor, conv2 produces only the w columns that
+    survive the crop, and the 1x1 shortcut / identity acts on the un-padded x."""
     n, h, w, _ = x.shape
     hw = h * w
-    sc, sh = ops.groupnorm_scale_shift(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, r.norm1.b)
+    sc, sh = ops.groupnorm_scale_shift(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, r.norm1.b,
+                                       wrap=(w, wrap) if wrap else None)
     pair = None
     if r.ws3 is not None and x.dtype == torch.float32 and RAW_PAIR_FUSED:
         # mixed scheme: the shortcut's split operand [hi | lo] of (x | skip) comes out of the same pass as norm1 + SiLU
@@ -399,10 +406,12 @@ def run_resnet(r, x, skip, temb_all, groups_eps=None):
     else:
         y = ops.scale_shift_act(x, skip, n, hw, sc, sh, 1, out_dtype=r.dtype)
     rowvec = temb_all[:, r.temb_off:] if temb_all is not None else None
-    h1 = ops.conv_gemm(y, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec, gn_stats=True)
-    h1 = ops.carry(h1.view(n, hw, r.cout), h1)
-    sc, sh = ops.groupnorm_scale_shift(h1, None, n, hw, r.norm2.groups, r.norm2.eps, r.norm2.g, r.norm2.b)
-    y2 = ops.scale_shift_act(h1, None, n, hw, sc, sh, 1, out_dtype=r.dtype)
+    wp = w + 2 * wrap
+    h1 = ops.conv_gemm(y, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec, gn_stats=True,
+                       wrap_pad=wrap)
+    h1 = ops.carry(h1.view(n, h * wp, r.cout), h1)
+    sc, sh = ops.groupnorm_scale_shift(h1, None, n, h * wp, r.norm2.groups, r.norm2.eps, r.norm2.g, r.norm2.b)
+    y2 = ops.scale_shift_act(h1, None, n, h * wp, sc, sh, 1, out_dtype=r.dtype)
     if r.ws3 is not None:         # mixed scheme: the shortcut maps the stream linearly -> split precision, fp32 out
         if pair is None:
             pair = split_operand(x, skip, dtype=r.dtype)
@@ -411,7 +420,8 @@ def run_resnet(r, x, skip, temb_all, groups_eps=None):
         short = ops.conv_gemm(x, r.ws, r.cout, a1=skip, n_img=n, h_in=h, w_in=w, ksize=1, bias=r.bs)
     else:
         short = x.view(n * hw, r.cout)
-    out = ops.conv_gemm(y2, r.w2, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b2, residual=short, gn_stats=True)
+    out = ops.conv_gemm(y2, r.w2, r.cout, n_img=n, h_in=h, w_in=wp, ksize=3, pad=1, bias=r.b2, residual=short, gn_stats=True,
+                        crop=wrap)
     return ops.carry(out.view(n, h, w, r.cout), out)
 
 
@@ -517,7 +527,9 @@ class Branch:
 
     def resnet(self, r, skip=False):
         s = self.skips.pop() if skip else None
-        if self.pad:
+        if self.pad and VIRTUAL_PAD:
+            self.h = run_resnet(r, self.h, s, self.temb, wrap=2)
+        elif self.pad:
             out = run_resnet(r, self._padded(self.h, 2), self._padded(s, 2), self.temb)
             self.h = ops.crop_width(out, 2)
         else:
@@ -533,21 +545,31 @@ class Branch:
         self.skips.append(self.h)
 
     def downsample(self, d):            # pano: pad 2, conv s2, crop 1   (MVGenModel.py:138-144)
-        x = self._padded(self.h, 2)
+        virt = self.pad and VIRTUAL_PAD
+        x = self.h if virt else self._padded(self.h, 2)
         n, h, w, Cc = x.shape
+        geo = dict(wrap_pad=2, crop=1) if virt else {}
         if d.w3 is not None:            # mixed scheme: stream -> stream linear map, split precision
             y = exact_gemm(split_operand(x, dtype=self.u.dtype), d.w3, d.c, n_img=n, h_in=h, w_in=w, ksize=3, stride=2,
-                           pad=1, bias=d.b, out_dtype=self.u.stream)
+                           pad=1, bias=d.b, out_dtype=self.u.stream, **geo)
         else:
-            y = ops.conv_gemm(x, d.w, d.c, n_img=n, h_in=h, w_in=w, ksize=3, stride=2, pad=1, bias=d.b)
+            y = ops.conv_gemm(x, d.w, d.c, n_img=n, h_in=h, w_in=w, ksize=3, stride=2, pad=1, bias=d.b, **geo)
+        if virt:
+            self.h = y.view(n, (h - 1) // 2 + 1, y.shape[0] // (n * ((h - 1) // 2 + 1)), d.c)
+            return
         y = y.view(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, d.c)
         self.h = ops.crop_width(y, 1) if self.pad else y
 
     def upsample(self, up):             # pano: pad 1, nearest x2 + conv, crop 2   (:272-277)
-        x = to16(self._padded(self.h, 1), self.u.dtype)
+        virt = self.pad and VIRTUAL_PAD
+        x = to16(self.h if virt else self._padded(self.h, 1), self.u.dtype)
         n, h, w, Cc = x.shape
+        geo = dict(wrap_pad=1, crop=2) if virt else {}
         y = ops.conv_gemm(x, up.w, up.c, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1, bias=up.b,
-                          out_dtype=self.u.stream, gn_stats=not self.pad)
+                          out_dtype=self.u.stream, gn_stats=not self.pad, **geo)
+        if virt:
+            self.h = y.view(n, 2 * h, 2 * w, up.c)
+            return
         y = ops.carry(y.view(n, 2 * h, 2 * w, up.c), y)
         self.h = ops.crop_width(y, 2) if self.pad else y
 

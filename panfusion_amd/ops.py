@@ -140,6 +140,25 @@ def epa_tables(fov, theta, phi, ph, pw, eh, ew, device):
 # ---------------------------------------------------------------------------- norms / pointwise
 GN_FROM_EPILOGUE = os.environ.get("PF_GN_EPILOGUE", "1") != "0"      # A/B: 0 = always the separate statistics pass
 
+# Arrival counters of the in-kernel split-K combine (pf_conv_desc.tickets): one zeroed int32 ring per device, handed out in
+# slices of _TICKET_SLICE counters per split launch.  A slice is zero again when its launch has run (the last-arriving
+# workgroup resets its counter) and comes round again only _TICKET_SLICES split launches later -- several denoiser steps --
+# so no two launches that could overlap in time ever share one.  Allocated outside any graph capture (the warm-up pass).
+_TICKET_SLICE, _TICKET_SLICES = 1024, 1024
+_TICKETS = {}
+
+
+def _ticket_slice(device):
+    key = (device.type, device.index)
+    ring = _TICKETS.get(key)
+    if ring is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the split-K counter ring must be allocated before a graph capture (run one eager pass first)")
+        ring = _TICKETS[key] = [torch.zeros(_TICKET_SLICE * _TICKET_SLICES, device=device, dtype=torch.int32), 0]
+    off = ring[1]
+    ring[1] = (off + 1) % _TICKET_SLICES
+    return ring[0].data_ptr() + 4 * _TICKET_SLICE * off
+
 
 def carry(dst, src):
     """dst = a view / reshape of src: hand over the GroupNorm moments a GEMM epilogue attached to src (`_pf_gn`)."""
@@ -149,8 +168,9 @@ def carry(dst, src):
     return dst
 
 
-def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
+def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None, wrap=None):
     """x0 [n, hw, c0] (+ x1 [n, hw, c1] concatenated along channels) -> (scale, shift) [n, C] fp32.
+    wrap = (image width, p): statistics of the tensor as if its width had been padded circularly by p columns (pad_pano).
     When every source still carries the per-column moments the GEMM that produced it left behind (conv_gemm(gn_stats=True)
     -> tensor attribute `_pf_gn` = (partials, rows per part)), the statistics come from those -- no pass over the tensors."""
     c0 = x0.shape[-1]
@@ -160,6 +180,13 @@ def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
     shift = torch.empty_like(scale)
     st0 = getattr(x0, "_pf_gn", None)
     st1 = getattr(x1, "_pf_gn", None) if x1 is not None else None
+    if wrap is not None and wrap[1] > 0:
+        nbytes = _lib.lib().pf_groupnorm_workspace_size(n_img, hw, Cc)
+        ws = torch.empty(nbytes, device=x0.device, dtype=torch.uint8)
+        check(_lib.lib().pf_groupnorm_stats_wrap(_p(x0), c0, _p(x1), c1, dt(x0), n_img, hw // wrap[0], wrap[0], wrap[1], groups, eps,
+                                                 _p(gamma), _p(beta), _p(scale), _p(shift), _p(ws), ws.numel(), _stream()),
+              "pf_groupnorm_stats_wrap")
+        return scale, shift
     usable = st0 is not None and (x1 is None or st1 is not None) and (Cc // groups) % 2 == 0 and c0 % 2 == 0
     if usable and (hw % st0[1] or (st1 is not None and hw % st1[1])):
         usable = False                # (a linear layer's moment runs need not respect this consumer's image boundaries)
@@ -363,7 +390,8 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,
               a_bstride=0, w_bstride=0, out_bstride=0, res_bstride=0, a0_ld=None, a1_ld=None, c0=None, c1=None,
-              out_ld=None, res_ld=None, geglu=False, algo_k=None, split_out=False, pad_hi=0, gn_stats=False):
+              out_ld=None, res_ld=None, geglu=False, algo_k=None, split_out=False, pad_hi=0, gn_stats=False,
+              wrap_pad=0, crop=0):
     """out[m, n] = sum_k A[m, k] W[n, k] (+bias +rowvec[img] +residual).  a0/a1 NHWC, the last
     dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out).  The output takes the
     residual's dtype unless out_dtype says otherwise (fp32 residual stream in, fp32 out).
@@ -371,14 +399,16 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     split_out: the result leaves as the 16-bit pair [M, hi(n_out) | lo(n_out)] (operand of engine.exact_gemm).
     pad_hi = 1: one more zero row / column at the bottom / right (F.pad(x, (0, 1, 0, 1)) of the VAE encoder's down-convs).
     gn_stats: the result feeds a GroupNorm -- where the kernel serving this problem can, its epilogue leaves the per-column
-    moments of the output behind (attribute `_pf_gn` of the returned tensor, read by groupnorm_scale_shift)."""
+    moments of the output behind (attribute `_pf_gn` of the returned tensor, read by groupnorm_scale_shift).
+    wrap_pad / crop: the input is read as if its width had been padded circularly by wrap_pad columns (pad_pano), the output
+    loses `crop` columns on both sides (unpad_pano): pad -> conv -> crop of the panorama branch without the padded copies."""
     c0 = c0 if c0 is not None else a0.shape[-1]
     c1 = (c1 if c1 is not None else a1.shape[-1]) if a1 is not None else 0
     if w_in is None:
         w_in = a0.numel() // (a0.shape[-1] * max(batch, 1)) if ksize == 1 else None
-    hl, wl = h_in << upsample, w_in << upsample
+    hl, wl = h_in << upsample, (w_in + 2 * wrap_pad) << upsample
     h_out = (hl + 2 * pad + pad_hi - ksize) // stride + 1
-    w_out = (wl + 2 * pad + pad_hi - ksize) // stride + 1
+    w_out = (wl + 2 * pad + pad_hi - ksize) // stride + 1 - 2 * crop
     M = n_img * h_out * w_out
     if out is not None:
         out_dtype = out.dtype
@@ -405,9 +435,12 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     d.batch = batch
     d.a_bstride, d.w_bstride, d.out_bstride, d.res_bstride = a_bstride, w_bstride, out_bstride, res_bstride
     d.epilogue = 1 if geglu else (2 if split_out else 0)
+    d.wrap_pad, d.crop = wrap_pad, crop
     nbytes = _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
     ws = torch.empty(nbytes, device=a0.device, dtype=torch.uint8) if nbytes else None   # split-K slabs
     d.workspace, d.workspace_bytes = _p(ws), nbytes
+    if nbytes:                                   # a split-K plan: combined inside the launch by the last-arriving workgroup
+        d.tickets, d.n_tickets = _ticket_slice(a0.device), _TICKET_SLICE
     gn = None
     if gn_stats and GN_FROM_EPILOGUE and batch == 1:
         rows = _lib.lib().pf_conv_gemm_gn_rows(C.byref(d))

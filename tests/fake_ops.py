@@ -90,7 +90,12 @@ def carry(dst, src):
 GN_FROM_PARTIALS = [0, 0]       # [statistics taken from GEMM-epilogue moments, statistics by a pass over the tensor] (test probes)
 
 
-def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None):
+def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None, wrap=None):
+    if wrap is not None and wrap[1] > 0:          # statistics of the circularly padded tensor
+        w, p = wrap
+        x = _cat(x0, x1).float().reshape(n_img, hw // w, w, -1)
+        x = torch.cat([x[:, :, -p:], x, x[:, :, :p]], 2)
+        return groupnorm_scale_shift(x.reshape(n_img, -1, x.shape[-1]), None, n_img, (hw // w) * (w + 2 * p), groups, eps, gamma, beta)
     st0 = getattr(x0, "_pf_gn", None)
     st1 = getattr(x1, "_pf_gn", None) if x1 is not None else None
     c0 = x0.shape[-1]
@@ -256,7 +261,7 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, c1=None,
               a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, split_out=False, pad_hi=0,
-              gn_stats=False, **kw):
+              gn_stats=False, wrap_pad=0, crop=0, **kw):
     if batch > 1:          # independent problems (attention scores / P.V of the VAE): plain linears only
         assert ksize == 1 and a1 is None and bias is None and residual is None and rowvec is None and not geglu
         K = c0 or a0.shape[-1]
@@ -280,12 +285,16 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     if w_in is None:
         w_in = x.shape[0]
     x = x.reshape(n_img, h_in, w_in, C).permute(0, 3, 1, 2)
+    if wrap_pad:                                  # virtual pad_pano of the input width (pre-upsampling columns)
+        x = torch.cat([x[..., -wrap_pad:], x, x[..., :wrap_pad]], -1)
     if upsample:
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
     wt = w.float().reshape(n_out, ksize, ksize, C).permute(0, 3, 1, 2)
     if pad_hi:
         x = F.pad(x, (0, pad_hi, 0, pad_hi))
     y = F.conv2d(x, wt, None if bias is None else bias.float(), stride=stride, padding=pad)
+    if crop:                                      # unpad_pano of the output
+        y = y[..., crop:-crop]
     ho, wo = y.shape[2:]
     y = y.permute(0, 2, 3, 1).reshape(n_img * ho * wo, n_out)
     if rowvec is not None:

@@ -748,3 +748,137 @@ def test_scale_shift_act_with_raw_pair(dtype):
     C = c0 + c1
     rec = pair[..., :C].float() + pair[..., C:].float()
     check("pair reconstructs the input", rec, torch.cat([x0, x1], -1), 2e-6 if dtype == torch.float16 else 4e-5)
+
+
+# ------------------------------------------------------------------------------------ round 3: pad_pano / unpad_pano folded into the conv
+WRAP_CASES = [
+    # (n, h, w, cin, cout, what): the three padded module kinds of the panorama branch at the benchmark sizes and small ones
+    (2, 64, 128, 320, 320, "resnet"),      # 8-wave kernel, M = 2 x 64 x 132
+    (2, 16, 32, 128, 128, "resnet"),       # 4-wave kernel
+    (2, 8, 16, 256, 256, "resnet"),        # split-K plan
+    (2, 64, 128, 320, 320, "down"),
+    (2, 16, 32, 128, 128, "down"),
+    (2, 32, 64, 128, 128, "up"),
+    (2, 8, 16, 256, 256, "up"),
+    (3, 6, 10, 64, 64, "resnet"),          # ragged tiles
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", WRAP_CASES)
+def test_conv_gemm_virtual_circular_padding(dtype, case):
+    """pf_conv_desc.wrap_pad / crop == the panorama branch's pad_pano -> conv -> unpad_pano with materialised copies
+    (utils/pano.py:74-105; MVGenModel.py:110-115 resnet convs, :138-144 down-sampling, :272-277 up-sampling): BIT-identical
+    outputs (same products in the same order, only the addressing differs)."""
+    o = ops()
+    n, h, w, cin, cout, what = case
+    x, _ = q16(rnd(n, h, w, cin, seed=90), dtype)
+    wt, _ = q16(rnd(cout, 9 * cin, seed=91) / (9 * cin) ** 0.5, dtype)
+    b = rnd(cout, seed=92).to(DEV)
+    if what == "resnet":
+        # conv1: virtual pad 2, all w + 4 columns;  conv2: reads the padded intermediate, writes the w central columns
+        ref1 = o.conv_gemm(o.pad_width(x, 2), wt, cout, n_img=n, h_in=h, w_in=w + 4, ksize=3, pad=1, bias=b)
+        got1 = o.conv_gemm(x, wt, cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=b, wrap_pad=2)
+        assert got1.shape == ref1.shape and torch.equal(got1, ref1)
+        mid = ref1.view(n, h, w + 4, cout)
+        wt2, _ = q16(rnd(cout, 9 * cout, seed=93) / (9 * cout) ** 0.5, dtype)
+        res = (rnd(n * h * w, cout, seed=94)).to(DEV)
+        ref2 = o.crop_width(o.conv_gemm(mid, wt2, cout, n_img=n, h_in=h, w_in=w + 4, ksize=3, pad=1, bias=b,
+                                         residual=o.pad_width(res.view(n, h, w, cout), 2).view(-1, cout)).view(n, h, w + 4, cout), 2)
+        got2 = o.conv_gemm(mid, wt2, cout, n_img=n, h_in=h, w_in=w + 4, ksize=3, pad=1, bias=b, residual=res, crop=2)
+        # (the cropped problem has fewer rows: it may take another tile / split-K plan than the padded one -- same products,
+        # another fp32 summation order)
+        check("conv2 with the crop folded in", got2.view(n, h, w, cout), ref2, 1e-6)
+    elif what == "down":
+        ref = o.crop_width(o.conv_gemm(o.pad_width(x, 2), wt, cout, n_img=n, h_in=h, w_in=w + 4, ksize=3, stride=2, pad=1, bias=b)
+                           .view(n, h // 2, w // 2 + 2, cout), 1)
+        got = o.conv_gemm(x, wt, cout, n_img=n, h_in=h, w_in=w, ksize=3, stride=2, pad=1, bias=b, wrap_pad=2, crop=1)
+        check("down-sampling conv", got.view(n, h // 2, w // 2, cout), ref, 1e-6 if got.dtype == torch.float32 else TOL[dtype])
+    else:
+        ref = o.crop_width(o.conv_gemm(o.pad_width(x, 1), wt, cout, n_img=n, h_in=h, w_in=w + 2, ksize=3, pad=1, upsample=1, bias=b)
+                           .view(n, 2 * h, 2 * w + 4, cout), 2)
+        got = o.conv_gemm(x, wt, cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1, bias=b, wrap_pad=1, crop=2)
+        check("up-sampling conv", got.view(n, 2 * h, 2 * w, cout), ref, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_groupnorm_statistics_of_the_virtually_padded_tensor(dtype):
+    o = ops()
+    n, h, w, c0, c1 = 2, 16, 32, 128, 64
+    x0 = (rnd(n, h, w, c0, seed=95) * 2 + 0.4).to(DEV).to(dtype)
+    x1 = (rnd(n, h, w, c1, seed=96) * 2).to(DEV).to(dtype)
+    gam, bet = (rnd(c0 + c1, seed=97) * 0.2 + 1).to(DEV), (rnd(c0 + c1, seed=98) * 0.1).to(DEV)
+    p0, p1 = o.pad_width(x0, 2), o.pad_width(x1, 2)
+    sc_ref, sh_ref = o.groupnorm_scale_shift(p0.view(n, -1, c0), p1.view(n, -1, c1), n, h * (w + 4), 32, 1e-5, gam, bet)
+    sc, sh = o.groupnorm_scale_shift(x0.view(n, -1, c0), x1.view(n, -1, c1), n, h * w, 32, 1e-5, gam, bet, wrap=(w, 2))
+    check("scale", sc, sc_ref, 1e-5)
+    check("shift", sh, sh_ref, 2e-5)
+
+
+# ------------------------------------------------------------------------------------ round 3: split-K combined inside the launch
+SPLITK_INKERNEL_CASES = [
+    # (n, h, w, cin, cout, ksize, extras)
+    (40, 8, 8, 1280, 1280, 3, "res32"),        # 8-wave kernel, split K (the 8 x 8 level of the view branch)
+    (40, 16, 16, 1280, 1280, 3, "rowvec16"),   # tail split: full rounds unsplit + split tail rows
+    (2, 8, 20, 1280, 1280, 3, "res32"),        # the panorama's innermost level: 4-wave kernel, deep split
+    (2, 16, 36, 640, 1280, 3, "plain16"),
+    (1, 1, 4096, 1920, 640, 1, "res32"),       # long-K linear on few rows
+    (3, 6, 10, 256, 64, 3, "res16"),           # ragged tiles
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", SPLITK_INKERNEL_CASES)
+def test_split_k_combined_in_kernel_equals_the_reduce_kernel(dtype, case, monkeypatch):
+    """pf_conv_desc.tickets: the last-arriving K-slice workgroup combines the slabs in split order -- BIT-identical to the
+    second-kernel combine, run after run (arrival order must not matter), and the counters are zero again afterwards."""
+    o = ops()
+    n, h, w, cin, cout, ks, what = case
+    x, _ = q16(rnd(n, h, w, cin, seed=110), dtype)
+    wt, _ = q16(rnd(cout, ks * ks * cin, seed=111) / (ks * ks * cin) ** 0.5, dtype)
+    b = rnd(cout, seed=112).to(DEV)
+    M = n * h * w
+    kw = dict(n_img=n, h_in=h, w_in=w, ksize=ks, pad=ks // 2, bias=b)
+    if what == "rowvec16":
+        kw["rowvec"] = rnd(n, cout, seed=113).to(DEV)
+    elif what == "res32":
+        kw["residual"] = rnd(M, cout, seed=114).to(DEV)
+    elif what == "res16":
+        kw["residual"] = q16(rnd(M, cout, seed=114), dtype)[0]
+    assert o.gemm_workspace_bytes(x, wt, cout, n_img=n, h_in=h, w_in=w, ksize=ks, pad=ks // 2) > 0, "not a split-K plan: %s" % (case,)
+    monkeypatch.setenv("PF_SPLITK_INKERNEL", "0")
+    ref = o.conv_gemm(x, wt, cout, **kw)
+    monkeypatch.setenv("PF_SPLITK_INKERNEL", "1")
+    for _ in range(6):
+        got = o.conv_gemm(x, wt, cout, **kw)
+        assert torch.equal(got, ref)
+    torch.cuda.synchronize()
+    ring = o._TICKETS[("cuda", torch.cuda.current_device())][0]
+    assert int(ring.abs().sum()) == 0, "arrival counters not reset"
+
+
+def test_split_k_in_kernel_under_concurrent_streams():
+    """Uneven load: split-K launches of two streams interleave on the chip (the panorama branch runs beside the view
+    branch); every result must equal the serial one."""
+    import os
+    os.environ["PF_SPLITK_INKERNEL"] = "1"                     # (off by default: it does not pay; kept correct and tested)
+    o = ops()
+    dtype = torch.float16
+    mk = lambda n, hh, ww, ci, co, seed: (q16(rnd(n, hh, ww, ci, seed=seed), dtype)[0],
+                                           q16(rnd(co, 9 * ci, seed=seed + 1) / (9 * ci) ** 0.5, dtype)[0], n, hh, ww, co)
+    probs = [mk(40, 8, 8, 1280, 1280, 120), mk(2, 8, 20, 1280, 1280, 122), mk(2, 16, 36, 640, 1280, 124), mk(40, 8, 8, 2560, 1280, 126)]
+    run = lambda pr: o.conv_gemm(pr[0], pr[1], pr[5], n_img=pr[2], h_in=pr[3], w_in=pr[4], ksize=3, pad=1)
+    want = [run(pr) for pr in probs]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(8):
+        with torch.cuda.stream(s1):
+            a = [run(probs[0]), run(probs[3])]
+        with torch.cuda.stream(s2):
+            bb = [run(probs[1]), run(probs[2])]
+        outs.append((a, bb))
+    torch.cuda.synchronize()
+    os.environ.pop("PF_SPLITK_INKERNEL", None)
+    for a, bb in outs:
+        assert torch.equal(a[0], want[0]) and torch.equal(a[1], want[3]) and torch.equal(bb[0], want[1]) and torch.equal(bb[1], want[2])
