@@ -280,7 +280,7 @@ struct NoOp { __device__ void operator()() const {} };
 template <typename T, int MREP, int NREP, int NT, int BM, int BN, int HALVES, int MODE>
 __device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x4 (&acc)[MREP][NREP], unsigned short* smem16,
                                               int m0, int n0, int row_base, int col_base, int lane, int t) {
-    constexpr int SLD = BN + 8;                                   // 16-bit elements per staged row
+    constexpr int SLD = (MODE == 3 ? BN / 2 : BN) + 8;            // 16-bit elements per staged row (GEGLU: half as many columns)
     constexpr int BMH = BM / HALVES;                              // staged rows per slice
     constexpr int WR = 16 * MREP, WRH = WR / HALVES, IH = MREP / HALVES;
     constexpr int G = 2, NG = MREP / G;                           // fragment rows per operand group
@@ -507,7 +507,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, long bz, f32x
     }
     const bool staged = !p.out_f32 && !p.res_f32 && !p.split_out && (p.out_ld & 7) == 0 && (n_store & 7) == 0 && (p.N & 3) == 0;
     if (staged && !(p.rowvec && p.residual) && !(p.geglu && (p.rowvec || p.residual))) {
-        if (p.geglu) epilogue_fast<T, MREP, NREP, NT, BM, BN, HALVES, 3>(p, bz, acc, smem16, m0, n0, row_base, col_base, lane, t);
+        // GEGLU halves the columns: the whole 256 x 80 tile fits the staging slot at once -- one barrier pair instead of two
+        // (the FF1 tile of a K = 320 layer spends 3 x 1.2 k of its 24.6 k clocks waiting at them)
+        if (p.geglu) epilogue_fast<T, MREP, NREP, NT, BM, BN, 1, 3>(p, bz, acc, smem16, m0, n0, row_base, col_base, lane, t);
         else if (p.rowvec && p.rows_per_img < BM) goto generic;
         else if (p.rowvec) epilogue_fast<T, MREP, NREP, NT, BM, BN, HALVES, 1>(p, bz, acc, smem16, m0, n0, row_base, col_base, lane, t);
         else if (p.residual) epilogue_fast<T, MREP, NREP, NT, BM, BN, HALVES, 2>(p, bz, acc, smem16, m0, n0, row_base, col_base, lane, t);

@@ -249,3 +249,28 @@ def test_controlnet_layout_condition(oracle_model, dtype):
     es, ep = rel_l2(s.cpu(), ws), rel_l2(ps.cpu(), wp)
     print("ControlNet rel-L2 %s: views %.3e pano %.3e" % (dtype, es, ep))
     assert es <= TOL[dtype] and ep <= TOL[dtype], (es, ep)
+
+
+def test_rotation_step_that_does_not_divide_360_keeps_caches_bounded(oracle_model):
+    """rot_diff = 7 never revisits a rotation offset: every step brings a new camera set.  The loop
+    must keep working past MAX_GRAPHS captured graphs (eager launches from then on), the per-block geometry-table cache
+    must stay within its LRU bound (tables used by a captured graph pinned), and the results must equal a loop that never
+    used graphs."""
+    from panfusion_amd.engine import EPATables
+    from panfusion_amd.pipeline import DenoiseLoop
+    g, lat, pl, pe, ppe = tiny_inputs()
+    model = hip_model_from(oracle_model, torch.float16)
+    cam1 = {k: v[None] for k, v in cam4().items()}
+    steps = DenoiseLoop.MAX_GRAPHS + EPATables.MAX_ENTRIES + 4
+    outs = []
+    for graphs in (True, False):
+        loop = DenoiseLoop(model, lat[:1].to(DEV), pl[:1].to(DEV), pe.to(DEV), ppe.to(DEV), cam1, steps=steps, rot_diff=7.0,
+                           use_graphs=graphs)
+        outs.append([x.cpu() for x in loop.run()])
+        if graphs:
+            assert len(loop.graphs) == DenoiseLoop.MAX_GRAPHS
+        for blk in [*model.cp_blocks_encoder, model.cp_blocks_mid, *model.cp_blocks_decoder]:
+            cache = blk._tables
+            assert len(cache.cache) <= max(EPATables.MAX_ENTRIES, len(cache.pins)), (len(cache.cache), len(cache.pins))
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert rel_l2(outs[0][0], outs[1][0]) <= 1e-6 and rel_l2(outs[0][1], outs[1][1]) <= 1e-6
