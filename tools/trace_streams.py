@@ -58,6 +58,7 @@ def main():
     cuts = [r["e"] for r in by[main_id] if "k_attention_lds<pf::F16, 32" in r["Kernel_Name"] or "k_attention_lds<F16, 32" in short(r["Kernel_Name"])]
     bounds = [t0] + cuts + [t1]
     print("\nsegment  start..end ms   view busy  pano busy  view idle  both-running", file=out)
+    segs = []
     for a, b in zip(bounds, bounds[1:]):
         def busy_in(ks):
             return sum(max(0, min(r["e"], b) - max(r["s"], a)) for r in ks) / 1e6
@@ -76,6 +77,24 @@ def main():
             n += d
             last = t
         print("  %6.2f .. %6.2f   %8.2f   %8.2f   %8.2f   %8.2f" % ((a - t0) / 1e6, (b - t0) / 1e6, vb, pb, (b - a) / 1e6 - vb, both / 1e6), file=out)
+        segs.append((a, b, (b - a) / 1e6 - vb))
+    # the segments where the view stream waits: what the panorama stream is doing there (kernel families, time = end - start
+    # of each kernel, i.e. including the wait for compute units)
+    for a, b, idle in segs:
+        if idle < 0.4 or len(segs) - segs.index((a, b, idle)) > 9:      # last step only
+            continue
+        fam = collections.defaultdict(lambda: [0, 0.0])
+        for k, v in by.items():
+            if k == main_id:
+                continue
+            for r in v:
+                if r["s"] >= a and r["e"] <= b:
+                    f = fam[short(r["Kernel_Name"]) + " grid " + r.get("Grid_Size_X", "")]
+                    f[0] += 1
+                    f[1] += (r["e"] - r["s"]) / 1e3
+        print("\nsegment %.2f .. %.2f ms (view idle %.2f ms): panorama-stream kernels" % ((a - t0) / 1e6, (b - t0) / 1e6, idle), file=out)
+        for n, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:14]:
+            print("    %-70s %3d  %8.1f us" % (n, v[0], v[1]), file=out)
 
 
 if __name__ == "__main__":
