@@ -396,6 +396,28 @@ pf_status pf_groupnorm_bwd(const void* x0, int c0, const void* x1, int c1, int d
                            const float* dy, const float* dres, float* dx0, float* dx1, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* Parameter gradients of a TRAINABLE GroupNorm (+ SiLU): the ControlNet's own parameters train when layout conditions
+ * are on (reference models/pano/PanoGenerator.py:153-157 `get_cn`: list(cn.parameters()) at lr x 0.1; autograd through
+ * diffusers' GroupNorm at MVGenModel.py:68-83).  Forward y = act(x * scale + shift) as for pf_groupnorm_bwd;
+ * unit_scale / unit_shift fp32 [n][c0+c1]: the same statistics with gamma = 1, beta = 0 (xhat = x * unit_scale +
+ * unit_shift).  dgamma_dbeta fp32 [2 * (c0+c1)] = (sum dz * xhat | sum dz), dz = dy * act'(x * scale + shift), summed
+ * over images and pixels in a fixed order. */
+size_t pf_groupnorm_param_grads_workspace_size(int n_img, int hw, int C);
+pf_status pf_groupnorm_param_grads(const void* x0, int c0, const void* x1, int c1, int dtype, int n_img, int hw,
+                                   const float* scale, const float* shift, const float* unit_scale, const float* unit_shift,
+                                   int act, const float* dy, float* dgamma_dbeta, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+
+/* dz = dy * silu'(z), z 16-bit or PF_F32 [n] (a pre-activation the forward kept), dy / dz fp32: the SiLUs of the ControlNet's
+ * conditioning embedding and of the timestep embedding under autograd (diffusers ControlNetConditioningEmbedding /
+ * TimestepEmbedding, reached from MVGenModel.py:68-83). */
+pf_status pf_silu_bwd(const void* z, int dtype, const float* dy, long n, float* dz, void* stream);
+
+/* im2col of a 3x3 / pad 1 convolution, stride 1 or 2: x [n][h][w][C] 16-bit -> y [n*ho*wo][9][C] (tap = 3 ky + kx, zero
+ * outside the image; ho = (h-1)/stride+1).  The weight gradient of a trainable convolution (torch autograd through
+ * nn.Conv2d in the ControlNet) is then one token-reducing pf_conv_gemm: dW [cout][9 C] = dY^T y. */
+pf_status pf_im2col3(const void* x, int dtype, int n, int h, int w, int C, int stride, void* y, void* stream);
+
 /* Data movement of the backward pass (NHWC):
  *   pf_zero_insert2   y [n][2h][2w][C] = x at the even positions, zero elsewhere (16-bit): the data gradient of a
  *                     stride-2 convolution is the stride-1 convolution of this with the flipped kernel;

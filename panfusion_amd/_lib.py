@@ -132,6 +132,11 @@ SIGNATURES = {
     "pf_groupnorm_bwd_workspace_size": (c_size_t, [c_int, c_int, c_int]),
     "pf_groupnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pf_groupnorm_param_grads_workspace_size": (c_size_t, [c_int, c_int, c_int]),
+    "pf_groupnorm_param_grads": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pf_silu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_long, c_void_p, c_void_p]),
+    "pf_im2col3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_zero_insert2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_sum2x2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_pad_width_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -855,6 +855,88 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const void* __restrict__ x
     reinterpret_cast<float4*>(dst)[1] = float4{o[4], o[5], o[6], o[7]};
 }
 
+// ---- parameter gradients of a trainable GroupNorm (the ControlNet: every parameter trains, PanoGenerator.py:153-157) ----------
+// y = act(gamma * xhat + beta), xhat = x * uscale + ushift per (image, channel) (the statistics as pf_groupnorm_stats leaves them
+// for gamma = 1, beta = 0), z = x * scale + shift the pre-activation of the affine forward.  With dz = dy * act'(z):
+//   dgamma[c] = sum dz * xhat,   dbeta[c] = sum dz        over images and pixels.
+// One partial row [dgamma | dbeta] per (image, pixel chunk); the rows are added in a fixed order by the column-sum kernels.
+template <typename TI>
+__global__ __launch_bounds__(256) void k_gn_param_partial(const void* __restrict__ x0, int c0, const void* __restrict__ x1, int c1,
+                                                          int hw, int pix_per_chunk, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ uscale,
+                                                          const float* __restrict__ ushift, int act, const float* __restrict__ dy,
+                                                          float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [2][pix_par][C]
+    const int C = c0 + c1, OCT = C / 8;
+    const int OCTB = OCT < 256 ? OCT : 256;
+    const int pix_par = 256 / OCTB;
+    const int img = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * pix_per_chunk, p1 = min(p0 + pix_per_chunk, hw);
+    const int t = threadIdx.x, slot = t / OCTB, olane = t % OCTB;
+    for (int ob = 0; ob < OCT; ob += OCTB) {
+        const int oct = ob + olane;
+        if (slot < pix_par && oct < OCT) {
+            const int c = oct * 8;
+            float ag[8], ab[8], sc[8], sh[8], us[8], uh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ag[j] = ab[j] = 0.f;
+            load8_any<float>(scale, static_cast<long>(img) * C + c, sc);
+            load8_any<float>(shift, static_cast<long>(img) * C + c, sh);
+            load8_any<float>(uscale, static_cast<long>(img) * C + c, us);
+            load8_any<float>(ushift, static_cast<long>(img) * C + c, uh);
+            for (int pp = p0 + slot; pp < p1; pp += pix_par) {
+                const long pix = static_cast<long>(img) * hw + pp;
+                float v[8], d[8];
+                if (c < c0) load8_any<TI>(x0, pix * c0 + c, v); else load8_any<TI>(x1, pix * c1 + (c - c0), v);
+                load8_any<float>(dy, pix * C + c, d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dz = d[j] * act_grad(v[j] * sc[j] + sh[j], act);
+                    ag[j] += dz * (v[j] * us[j] + uh[j]);
+                    ab[j] += dz;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sm[(0 * pix_par + slot) * C + c + j] = ag[j];
+                sm[(1 * pix_par + slot) * C + c + j] = ab[j];
+            }
+        }
+    }
+    __syncthreads();
+    float* row = partial + (static_cast<long>(img) * gridDim.x + chunk) * 2 * C;
+    for (int i = t; i < 2 * C; i += 256) {
+        const int q = i / C, c = i - q * C;
+        float s = 0.f;
+        for (int sl = 0; sl < pix_par; ++sl) s += sm[(q * pix_par + sl) * C + c];
+        row[i] = s;
+    }
+}
+
+// dz = dy * silu'(z): z 16-bit or fp32 (the pre-activation the forward kept), dy / dz fp32.
+template <typename S>
+__global__ void k_silu_bwd(const void* __restrict__ z, const float* __restrict__ dy, long n, float* __restrict__ dz) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i < n) dz[i] = dy[i] * act_grad(ld_any<S>(z, i), 1);
+}
+
+// im2col of a 3x3 / pad 1 convolution (stride 1 or 2): y [n * ho * wo][9][C] = the nine zero-padded taps of x [n][h][w][C]
+// (16-bit octets).  The weight gradient of the convolution is then ONE token-reducing GEMM dW [cout][9 C] = dY^T cols.
+__global__ void k_im2col3(const u16x8* __restrict__ x, int n, int h, int w, int OCT, int stride, int ho, int wo, u16x8* __restrict__ y) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    const long total = static_cast<long>(n) * ho * wo * 9 * OCT;
+    if (i >= total) return;
+    const int o = i % OCT;
+    const int tap = (i / OCT) % 9;
+    const long pix = i / (9L * OCT);
+    const int xo = pix % wo, yo = (pix / wo) % ho;
+    const long img = pix / (static_cast<long>(ho) * wo);
+    const int yy = yo * stride + tap / 3 - 1, xx = xo * stride + tap % 3 - 1;
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = x[((img * h + yy) * w + xx) * OCT + o];
+    y[i] = v;
+}
+
 // ---- data movement of the backward pass ---------------------------------------------------------------------------
 // zero insertion (data gradient of a stride-2 convolution = stride-1 convolution of the zero-stuffed gradient with the
 // flipped kernel): y[n][2i][2j] = x[n][i][j], zero elsewhere; 16-bit octets.
@@ -1248,6 +1330,73 @@ extern "C" pf_status pf_groupnorm_bwd(const void* x0, int c0, const void* x1, in
     else PF_REQUIRE(false, "pf_groupnorm_bwd: unsupported dtype %d", dtype);
 #undef PF_GNB
     PF_CHECK_LAUNCH("pf_groupnorm_bwd");
+    return PF_OK;
+}
+
+extern "C" size_t pf_groupnorm_param_grads_workspace_size(int n_img, int hw, int C) {
+    if (n_img <= 0 || hw <= 0 || C <= 0) return 0;
+    int ppc;
+    const long rows = static_cast<long>(n_img) * gn_bwd_chunks(hw, &ppc);
+    return static_cast<size_t>(rows) * 2 * C * sizeof(float) + pf_colsum_workspace_size(rows, 2 * C);
+}
+
+extern "C" pf_status pf_groupnorm_param_grads(const void* x0, int c0, const void* x1, int c1, int dtype, int n_img, int hw,
+                                              const float* scale, const float* shift, const float* unit_scale, const float* unit_shift,
+                                              int act, const float* dy, float* dgamma_dbeta, void* workspace, size_t workspace_bytes,
+                                              void* stream) {
+    PF_REQUIRE(x0 && scale && shift && unit_scale && unit_shift && dy && dgamma_dbeta && workspace && n_img > 0 && hw > 0,
+               "pf_groupnorm_param_grads: bad arguments");
+    if (!x1) c1 = 0;
+    const int C = c0 + c1;
+    PF_REQUIRE(c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0, "pf_groupnorm_param_grads: channels (%d,%d) must be multiples of 8", c0, c1);
+    PF_REQUIRE(n_img <= 65535, "pf_groupnorm_param_grads: at most 65535 images per call");
+    PF_REQUIRE(act == 0 || act == 1, "pf_groupnorm_param_grads: act must be 0 (none) or 1 (SiLU)");
+    PF_REQUIRE(workspace_bytes >= pf_groupnorm_param_grads_workspace_size(n_img, hw, C), "pf_groupnorm_param_grads: workspace too small");
+    PF_REQUIRE(aligned16(x0) && (!x1 || aligned16(x1)) && aligned16(dy) && aligned16(scale) && aligned16(shift) && aligned16(unit_scale) &&
+               aligned16(unit_shift) && aligned16(workspace), "pf_groupnorm_param_grads: pointers must be 16-byte aligned");
+    int ppc;
+    const int chunks = gn_bwd_chunks(hw, &ppc);
+    const long rows = static_cast<long>(n_img) * chunks;
+    float* partial = static_cast<float*>(workspace);
+    const int OCT = C / 8, OCTB = OCT < 256 ? OCT : 256, pix_par = 256 / OCTB;
+    const size_t smem = static_cast<size_t>(2) * pix_par * C * sizeof(float);
+    PF_REQUIRE(smem <= 64 * 1024, "pf_groupnorm_param_grads: %d channels exceed the 64 KiB staging buffer", C);
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(chunks, n_img), block(256);
+#define PF_GNP(TI) hipLaunchKernelGGL(k_gn_param_partial<TI>, grid, block, smem, st, x0, c0, x1, c1, hw, ppc, scale, shift, unit_scale, unit_shift, act, dy, partial)
+    if (dtype == PF_F32) PF_GNP(float);
+    else if (dtype == PF_F16) PF_GNP(F16);
+    else if (dtype == PF_BF16) PF_GNP(Bf16);
+    else PF_REQUIRE(false, "pf_groupnorm_param_grads: unsupported dtype %d", dtype);
+#undef PF_GNP
+    PF_CHECK_LAUNCH("pf_groupnorm_param_grads");
+    const size_t used = static_cast<size_t>(rows) * 2 * C * sizeof(float);
+    return pf_colsum(partial, PF_F32, rows, 2 * C, 2 * C, dgamma_dbeta, reinterpret_cast<char*>(workspace) + used, workspace_bytes - used, stream);
+}
+
+extern "C" pf_status pf_silu_bwd(const void* z, int dtype, const float* dy, long n, float* dz, void* stream) {
+    PF_REQUIRE(z && dy && dz && n > 0, "pf_silu_bwd: bad arguments");
+    const dim3 grid(cdiv(n, 256)), block(256);
+    hipStream_t st = as_stream(stream);
+    if (dtype == PF_F32) hipLaunchKernelGGL(k_silu_bwd<AnyF32>, grid, block, 0, st, z, dy, n, dz);
+    else if (dtype == PF_F16) hipLaunchKernelGGL(k_silu_bwd<AnyF16>, grid, block, 0, st, z, dy, n, dz);
+    else if (dtype == PF_BF16) hipLaunchKernelGGL(k_silu_bwd<AnyBf16>, grid, block, 0, st, z, dy, n, dz);
+    else PF_REQUIRE(false, "pf_silu_bwd: unsupported dtype %d", dtype);
+    PF_CHECK_LAUNCH("pf_silu_bwd");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_im2col3(const void* x, int dtype, int n, int h, int w, int C, int stride, void* y, void* stream) {
+    PF_REQUIRE(x && y && x != y && n > 0 && h > 0 && w > 0 && C > 0 && C % 8 == 0, "pf_im2col3: bad arguments");
+    PF_REQUIRE(dtype == PF_F16 || dtype == PF_BF16, "pf_im2col3: 16-bit tensors only");
+    PF_REQUIRE(stride == 1 || stride == 2, "pf_im2col3: stride must be 1 or 2");
+    PF_REQUIRE(aligned16(x) && aligned16(y), "pf_im2col3: pointers must be 16-byte aligned");
+    const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+    const long total = static_cast<long>(n) * ho * wo * 9 * (C / 8);
+    PF_REQUIRE(cdiv(total, 256) < (1L << 31), "pf_im2col3: tensor too large for one launch");
+    hipLaunchKernelGGL(k_im2col3, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), static_cast<const u16x8*>(x), n, h, w, C / 8, stride, ho, wo,
+                       static_cast<u16x8*>(y));
+    PF_CHECK_LAUNCH("pf_im2col3");
     return PF_OK;
 }
 

@@ -214,6 +214,7 @@ def pack_transformer(tf, dev, dtype, mixed=False):
 def pack_unet(unet, dev, dtype, mixed=False):
     """Walks the diffusers attribute tree exactly as MVGenModel.py does."""
     u = NS()
+    u.src = unet                               # (train_engine reaches the trainable ControlNet's parameters through it)
     u.dtype, u.mixed = dtype, mixed
     u.stream = torch.float32 if mixed else dtype
     ci = unet.conv_in
@@ -338,12 +339,14 @@ def run_cond_embedding(c, cond):
     return x
 
 
-def run_controlnet(c, latent, timestep, text, cond):
+def run_controlnet(c, latent, timestep, text, cond, make_branch=None, embed=None, rec=None):
     """ControlNetModel.forward(sample, timestep, encoder_hidden_states, controlnet_cond) on NHWC:
     -> (12 skip residuals [n, h, w, C], mid residual).  Plain zero-padded convolutions (the reference
-    calls it on the un-padded panorama latent, MVGenModel.py:76-83)."""
-    br = Branch(c, latent, timestep, text, pano=False, pad=False)
-    br.h = ops.add(br.h, run_cond_embedding(c, cond))
+    calls it on the un-padded panorama latent, MVGenModel.py:76-83).
+    make_branch / embed / rec: the training forward (train_engine.controlnet_forward) substitutes a taping branch and a
+    conditioning embedding that keeps its pre-activations, and gets the zero-convs' inputs back in rec."""
+    br = (make_branch or Branch)(c, latent, timestep, text, pano=False, pad=False)
+    br.h = ops.add(br.h, (embed or run_cond_embedding)(c, cond))
     br.skips = [br.h]
     for blk in c.down:
         for j, r in enumerate(blk.resnets):
@@ -363,6 +366,8 @@ def run_controlnet(c, latent, timestep, text, cond):
         n, h, w, Cc = x.shape
         return ops.conv_gemm(to16(x, c.dtype), z.w, z.c, n_img=n, h_in=h, w_in=w, ksize=1, bias=z.b).view(n, h, w, z.c)
 
+    if rec is not None:
+        rec.br, rec.skips, rec.h_mid = br, list(br.skips), br.h
     return [zero_conv(z, s) for z, s in zip(c.zero_down, br.skips)], zero_conv(c.zero_mid, br.h)
 
 

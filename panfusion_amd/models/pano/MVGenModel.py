@@ -67,13 +67,22 @@ class MultiViewBaseModel(nn.Module):
     # ------------------------------------------------------------------ weights
     def packed(self, which, device):
         key = (which, str(device), self.compute_dtype, self.precision)
+        if which.endswith("_cn") and key in self._packed and self._packed[key].param_key != self._cn_versions(which):
+            del self._packed[key]                   # a ControlNet that trains: its weights moved since the pack was built
         if key not in self._packed:
             pack = engine.pack_controlnet if which.endswith("_cn") else engine.pack_unet
             self._packed[key] = pack(getattr(self, which), device, self.compute_dtype, self.precision == "mixed")
             # the LoRA state this pack was folded from (refold_lora compares against it; ADVICE r2: without it the
             # first call after an in-place parameter change saw "no change")
             self._packed[key].lora_key = self._lora_versions()
+            if which.endswith("_cn"):
+                self._packed[key].param_key = self._cn_versions(which)
         return self._packed[key]
+
+    def _cn_versions(self, which):
+        """Version counters of a ControlNet's parameters (optimizer steps and in-place copies bump them): the whole pack is
+        rebuilt when one moved -- every weight of a training ControlNet changes in a step, there is nothing to re-fold."""
+        return tuple(t._version for t in getattr(self, which).parameters())
 
     def repack(self):
         """Drop the packed 16-bit weights (call after changing parameters / loading a checkpoint)."""
@@ -128,6 +137,13 @@ class MultiViewBaseModel(nn.Module):
                         if ref is not None:
                             add(ref.down)
                             add(ref.up)
+        # the ControlNets: all of their parameters (PanoGenerator.py:153-157 get_cn -> list(cn.parameters())); which of them
+        # actually train is the caller's requires_grad (the reference freezes nothing of a ControlNet it added)
+        self._n_lora_epa = len(out)
+        for cn in (self.pers_cn, self.pano_cn):
+            if cn is not None:
+                for t in cn.parameters():
+                    add(t)
         self._trainable_cache = (fp, out)
         return out
 
@@ -155,7 +171,8 @@ class MultiViewBaseModel(nn.Module):
         return tuple(fp)
 
     def _lora_versions(self):
-        return tuple((id(t), t._version) for t in self.trainable_tensors())
+        tensors = self.trainable_tensors()
+        return tuple((id(t), t._version) for t in tensors[:self._n_lora_epa])       # (not the ControlNets': packed())
 
     def forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras,
                 pers_layout_cond=None, pano_layout_cond=None):
@@ -209,15 +226,24 @@ class MultiViewBaseModel(nn.Module):
         if tape is not None:
             if shard is not None:
                 raise NotImplementedError("the training path covers the un-sharded denoiser")
-            # Layout conditions under training (PanFusion.py:85-89): the ControlNet runs as in inference and its 12 + 1
-            # residuals enter the tape as constants -- gradients flow THROUGH the additions into the EPA blocks and the
-            # LoRA matrices (identity w.r.t. the skip / mid activations), the ControlNet's own parameters take none
-            # (conditioned fine-tuning with a frozen ControlNet; the reference's layout_cond=True additionally trains the
-            # ControlNet itself at lr x 0.1, PanoGenerator.py:153-157 -- its weight gradients are not implemented here).
+            # Layout conditions under training (PanFusion.py:85-89).  A ControlNet with parameters that require gradients
+            # (the reference's layout_cond=True: every ControlNet parameter trains at lr x 0.1, PanoGenerator.py:153-157)
+            # runs on a tape of its own (train_engine.controlnet_forward); the tape of the branch it feeds notes where its
+            # 12 + 1 residuals were added, and the backward hands the skip / mid gradients found there to
+            # train_engine.controlnet_backward.  A frozen ControlNet runs as in inference: its residuals are constants,
+            # gradients flow THROUGH the additions into the EPA blocks and the LoRA matrices.
             from ... import train_engine
             make_branch = lambda *a, **k: train_engine.TrainBranch(tape, *a, **k)
         else:
             make_branch = engine.Branch
+        cn_recs = {}                                # id(branch) -> train_engine record of a trainable ControlNet's forward
+
+        def controlnet(which, br, latent, t, cond):
+            c = self.packed(which, dev)
+            if tape is not None and any(p_.requires_grad for p_ in getattr(self, which).parameters()):
+                cn_res[id(br)], cn_recs[id(br)] = train_engine.controlnet_forward(c, latent, t, br.text, cond)
+            else:
+                cn_res[id(br)] = engine.run_controlnet(c, latent, t, br.text, cond)
         if two:                                   # this rank's views, cameras all m of them
             b, m = latents.shape[:2]
             flat_cams = {k: v.reshape(-1) for k, v in cameras.items()}
@@ -234,9 +260,7 @@ class MultiViewBaseModel(nn.Module):
                                self._prompt16(prompt_embd), pano=False, pad=False)
             branches.append(pers)
             if pers_layout_cond is not None:        # reference :66-74 (ControlNet on the view branch)
-                cn_res[id(pers)] = engine.run_controlnet(
-                    self.packed("pers_cn", dev), latents.flatten(0, 1), timestep.reshape(-1), pers.text,
-                    pers_layout_cond.flatten(0, 1))
+                controlnet("pers_cn", pers, latents.flatten(0, 1), timestep.reshape(-1), pers_layout_cond.flatten(0, 1))
         else:
             pano_t = timestep
         # view-sharded rank without the panorama branch (sharding layout "pano_rank"): the view branch only;
@@ -282,9 +306,7 @@ class MultiViewBaseModel(nn.Module):
                                    self._prompt16(pano_prompt_embd), pano=True, pad=self.pano_pad)
                 pano.precompute_text_kv()
                 if pano_layout_cond is not None:    # reference :75-83: plain convolutions on the un-padded latent
-                    cn_res[id(pano)] = engine.run_controlnet(
-                        self.packed("pano_cn", dev), pano_latent.flatten(0, 1), pano_t, pano.text,
-                        pano_layout_cond.flatten(0, 1))
+                    controlnet("pano_cn", pano, pano_latent.flatten(0, 1), pano_t, pano_layout_cond.flatten(0, 1))
             branches.append(pano)
 
         def each_branch(fn):
@@ -336,6 +358,8 @@ class MultiViewBaseModel(nn.Module):
         def add_skips(br):
             if id(br) in cn_res:
                 br.skips = [engine.ops.add(sk, r) for sk, r in zip(br.skips, cn_res[id(br)][0])]
+                if id(br) in cn_recs:
+                    tape.append(("cn_skips", br, cn_recs[id(br)]))
         each_branch(add_skips)
 
         # mid (reference :172-207)
@@ -347,6 +371,8 @@ class MultiViewBaseModel(nn.Module):
                 br.resnet(r)
             if id(br) in cn_res:
                 br.h = engine.ops.add(br.h, cn_res[id(br)][1])
+                if id(br) in cn_recs:
+                    tape.append(("cn_mid", br, cn_recs[id(br)]))
         each_branch(middle)
         if two:
             fuse(self.cp_blocks_mid)

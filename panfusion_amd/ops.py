@@ -659,6 +659,39 @@ def groupnorm_bwd(x0, x1, n_img, hw, groups, eps, gamma, scale, shift, act, dy, 
     return dx0, dx1
 
 
+def groupnorm_param_grads(x0, x1, n_img, hw, scale, shift, unit_scale, unit_shift, act, dy):
+    """(dgamma, dbeta) fp32 [c0 + c1] of a trainable GroupNorm (+ SiLU) whose forward was scale_shift_act(x, scale, shift):
+    unit_scale / unit_shift = groupnorm_scale_shift of the same input with gamma = 1, beta = 0 (xhat = x * unit_scale + unit_shift)."""
+    c0 = x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    Cc = c0 + c1
+    out = torch.empty(2 * Cc, device=x0.device, dtype=torch.float32)
+    nbytes = _lib.lib().pf_groupnorm_param_grads_workspace_size(n_img, hw, Cc)
+    ws = torch.empty(nbytes, device=x0.device, dtype=torch.uint8)
+    check(_lib.lib().pf_groupnorm_param_grads(_p(x0), c0, _p(x1), c1, dt(x0), n_img, hw, _p(scale), _p(shift), _p(unit_scale),
+                                              _p(unit_shift), int(act), _p(dy), _p(out), _p(ws), nbytes, _stream()),
+          "pf_groupnorm_param_grads")
+    return out[:Cc], out[Cc:]
+
+
+def silu_bwd(z, dy):
+    """dy * silu'(z): z 16-bit or fp32 (any shape, contiguous), dy fp32 of the same shape -> fp32."""
+    assert z.is_contiguous() and dy.is_contiguous() and dy.dtype == torch.float32 and z.shape == dy.shape
+    out = torch.empty_like(dy)
+    check(_lib.lib().pf_silu_bwd(_p(z), dt(z), _p(dy), z.numel(), _p(out), _stream()), "pf_silu_bwd")
+    return out
+
+
+def im2col3(x, stride=1):
+    """x NHWC 16-bit [n, h, w, C] -> [n * ho * wo, 9 * C]: the nine zero-padded taps of a 3x3 / pad 1 convolution (tap-major,
+    channels fastest: the column order of the packed conv weights [cout, ky, kx, cin])."""
+    n, h, w, Cc = x.shape
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = torch.empty(n * ho * wo, 9 * Cc, device=x.device, dtype=x.dtype)
+    check(_lib.lib().pf_im2col3(_p(x), dt(x), n, h, w, Cc, stride, _p(out), _stream()), "pf_im2col3")
+    return out
+
+
 def zero_insert2(x):
     """x NHWC 16-bit [n, h, w, C] -> [n, 2h, 2w, C] with x at the even positions (stride-2 conv data gradient)."""
     n, h, w, Cc = x.shape

@@ -94,6 +94,52 @@ def _unscale(t, state):
     return ops.scale_by_state(t, state, 2, out=t)
 
 
+# ---------------------------------------------------------------------------------------------- weight gradients
+# The layers of a TRAINABLE network: the ControlNet under layout conditions (PanoGenerator.py:153-157 -- every ControlNet
+# parameter trains at lr x 0.1; its forward is called at MVGenModel.py:68-83).  The UNets themselves stay frozen.
+_WGRAD_CHUNK = 1 << 30        # bytes of im2col columns per weight-gradient GEMM (pf_conv_gemm addresses operands below 2 GiB)
+_UNIT = {}
+
+
+def _unit_affine(C, dev):
+    key = (C, str(dev))
+    hit = _UNIT.get(key)
+    if hit is None:
+        hit = _UNIT[key] = (torch.ones(C, device=dev, dtype=F32), torch.zeros(C, device=dev, dtype=F32))
+    return hit
+
+
+def conv3_wgrad(d16, x16, stride=1):
+    """Weight gradient of a 3x3 / pad 1 convolution in torch layout [cout, cin, 3, 3]: d16 [n, ho, wo, cout] the 16-bit
+    output gradient, x16 [n, h, w, cin] the 16-bit input.  im2col (pf_im2col3) + ONE token-reducing MFMA GEMM per chunk of
+    images (training.weight_grad: dW = dY^T cols)."""
+    n, ho, wo, cout = d16.shape
+    cin = x16.shape[-1]
+    step = max(1, min(n, _WGRAD_CHUNK // (ho * wo * 9 * cin * 2)))
+    g = None
+    for i in range(0, n, step):
+        cols = ops.im2col3(x16[i:i + step], stride)
+        part = training.weight_grad(d16[i:i + step].reshape(-1, cout), cols)
+        g = part if g is None else ops.add(g, part)
+    return g.view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+
+
+def gn_param_grads(norm, x, skip, n, hw, sc, sh, act, dy):
+    """(dgamma, dbeta) of a GroupNorm (+ SiLU) whose affine forward was (sc, sh); norm: the packed norm (groups, eps)."""
+    C = x.shape[-1] + (skip.shape[-1] if skip is not None else 0)
+    ones, zeros = _unit_affine(C, x.device)
+    usc, ush = ops.groupnorm_scale_shift(x, skip, n, hw, norm.groups, norm.eps, ones, zeros)
+    return ops.groupnorm_param_grads(x, skip, n, hw, sc, sh, usc, ush, act, dy)
+
+
+def _scaled(wsink, state):
+    """wsink for gradients computed in a layer's normalised units: scales them back before they reach the parameter sink."""
+    def put(param, grad):
+        g = grad.to(F32).contiguous()
+        wsink(param, _unscale(g, state))
+    return put
+
+
 # ---------------------------------------------------------------------------------------------- LoRA
 class LoRARef:
     """One rank-r LoRA pair of a projection: W' = W + s * up @ down (engine._lin_weight folds it for the forward)."""
@@ -270,8 +316,10 @@ def pad_text(text, dtype):
 
 
 # ---------------------------------------------------------------------------------------------- layer backward passes
-def resnet_backward(r, x, skip, rowvec, dout):
-    """x [n, h, w, cx] (+ skip [n, h, w, cs]) as the forward saw them, dout fp32 [n, h, w, cout] -> (dx, dskip) fp32."""
+def resnet_backward(r, x, skip, rowvec, dout, wsink=None):
+    """x [n, h, w, cx] (+ skip [n, h, w, cs]) as the forward saw them, dout fp32 [n, h, w, cout] -> (dx, dskip) fp32.
+    wsink (trainable resnet, the ControlNet's): also the gradients of norm1 / conv1 / norm2 / conv2 / conv_shortcut into
+    wsink(param, grad), and a third result: the gradient [n, cout] of this resnet's slice of the time-embedding projection."""
     tw = resnet_train(r, x.device)
     n, h, w, cx = x.shape
     hw, M = h * w, n * h * w
@@ -294,10 +342,36 @@ def resnet_backward(r, x, skip, rowvec, dout):
         dsc = d
     dx, dskip = ops.groupnorm_bwd(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, sc1, sh1, 1,
                                   dy1.view(n, hw, cin), dres=dsc.view(n, hw, cin))
+    dtemb = None
+    if wsink is not None:
+        src, put = r.src, _scaled(wsink, state)
+        d16 = engine.to16(d, r.dtype)
+        y2 = ops.scale_shift_act(h1, None, n, hw, sc2, sh2, 1, out_dtype=r.dtype).view(n, h, w, r.cout)
+        put(src.conv2.weight, conv3_wgrad(d16, y2))
+        put(src.conv2.bias, ops.colsum(d.view(M, r.cout)))
+        g2, b2 = gn_param_grads(r.norm2, h1, None, n, hw, sc2, sh2, 1, dy2.view(n, hw, r.cout))
+        put(src.norm2.weight, g2)
+        put(src.norm2.bias, b2)
+        dh16 = engine.to16(dh1.view(n, h, w, r.cout), r.dtype)
+        put(src.conv1.weight, conv3_wgrad(dh16, y1.view(n, h, w, cin)))
+        per_img = torch.stack([ops.colsum(dh1[i]) for i in range(n)], 0)                # [n, cout]: conv1's bias, temb rows
+        put(src.conv1.bias, ops.colsum(per_img))
+        dtemb = _unscale(per_img, state)
+        g1, b1 = gn_param_grads(r.norm1, x, skip, n, hw, sc1, sh1, 1, dy1.view(n, hw, cin))
+        put(src.norm1.weight, g1)
+        put(src.norm1.bias, b1)
+        if tw.ws is not None:
+            ones, zeros = _unit_affine(cin, x.device)
+            xs16 = ops.scale_shift_act(x, skip, n, hw, ones.expand(n, cin).contiguous(), zeros.expand(n, cin).contiguous(), 0,
+                                       out_dtype=r.dtype)                                 # (x | skip) as one 16-bit operand
+            put(src.conv_shortcut.weight, training.weight_grad(d16.view(M, r.cout), xs16.view(M, cin)))
+            put(src.conv_shortcut.bias, ops.colsum(d.view(M, r.cout)))
     _unscale(dx, state)
     if dskip is not None:
         _unscale(dskip, state)
         dskip = dskip.view(n, h, w, -1)
+    if wsink is not None:
+        return dx.view(n, h, w, cx), dskip, dtemb
     return dx.view(n, h, w, cx), dskip
 
 
@@ -321,8 +395,9 @@ def _self_attention(tw, ln, n, hw, dh):
     return qkv3, qkvt, a, lse
 
 
-def transformer_backward(t, x, text, dout, sink):
-    """x [n, h, w, C] as the forward saw it, text [n, L, Dt], dout fp32 [n, h, w, C] -> dx fp32; LoRA gradients into sink."""
+def transformer_backward(t, x, text, dout, sink, wsink=None):
+    """x [n, h, w, C] as the forward saw it, text [n, L, Dt], dout fp32 [n, h, w, C] -> dx fp32; LoRA gradients into sink.
+    wsink (trainable transformer, the ControlNet's): the gradient of every parameter of the block into wsink(param, grad)."""
     dev = x.device
     tw = transformer_train(t, dev)
     a1w, a2w = tw.attn1, tw.attn2
@@ -360,15 +435,34 @@ def transformer_backward(t, x, text, dout, sink):
     # ---- backward
     d, state = _normalise(dout.reshape(T, Cc))
     lsink = ScaledSink(sink, state)
+    put = _scaled(wsink, state) if wsink is not None else None
+    src = t.src
+    blk = src.transformer_blocks[0]
+    wg = training.weight_grad
     dtok3 = stream_linear(d, tw.w_out_t, tw.w_out_t3, Cc, dt16)                          # proj_out (its residual: d -> dx below)
     # feed-forward
-    dg = ops.linear(engine.to16(dtok3, dt16), tw.w2_t)
+    d3_16 = engine.to16(dtok3, dt16)
+    dg = ops.linear(d3_16, tw.w2_t)
     du = ops.geglu_bwd(u, dg)
     dln3 = ops.linear(du, tw.w1_t, out_dtype=F32)
-    dtok2, _, _ = ops.layernorm_bwd(tok2, t.ln3.g, dln3, t.ln3.eps, dres=dtok3)
+    dtok2, g_ln3, b_ln3 = ops.layernorm_bwd(tok2, t.ln3.g, dln3, t.ln3.eps, dres=dtok3)
+    if put is not None:
+        g = ops.geglu(u)                                                                 # [T, 4C]
+        tok3 = ops.linear(g, tw.w2, bias=t.b_ff2, residual=tok2)                         # the input of proj_out
+        put(src.proj_out.weight, wg(engine.to16(d, dt16), engine.to16(tok3, dt16)))
+        put(src.proj_out.bias, ops.colsum(d))
+        put(blk.ff.net[2].weight, wg(d3_16, g))
+        put(blk.ff.net[2].bias, ops.colsum(dtok3))
+        put(blk.ff.net[0].proj.weight, wg(du, ln3))
+        put(blk.ff.net[0].proj.bias, ops.colsum(du))
+        put(blk.norm3.weight, g_ln3)
+        put(blk.norm3.bias, b_ln3)
     # text cross-attention
     d16 = engine.to16(dtok2, dt16)
     da2 = ops.linear(d16, a2w.wo_t).view(n, hw, Cc)
+    if put is not None:
+        put(blk.attn2.to_out[0].weight, wg(d16, a2.view(T, Cc)))
+        put(blk.attn2.to_out[0].bias, ops.colsum(dtok2))
     if a2w.lora_out.live:
         a2w.lora_out.grads(*with_transpose(a2.view(T, Cc)), *with_transpose(d16), lsink)
     delta2 = ops.attention_delta(a2, da2, n, H, dh, hw)
@@ -385,10 +479,21 @@ def transformer_backward(t, x, text, dout, sink):
     if a2w.lora_kv.live:
         Tt = n * TEXT_PAD
         a2w.lora_kv.grads(*with_transpose(textp.view(Tt, -1)), *with_transpose(dkv2.view(Tt, 2 * Cc)), lsink)
-    dtok1, _, _ = ops.layernorm_bwd(tok1, t.ln2.g, dln2, t.ln2.eps, dres=dtok2)
+    dtok1, g_ln2, b_ln2 = ops.layernorm_bwd(tok1, t.ln2.g, dln2, t.ln2.eps, dres=dtok2)
+    if put is not None:
+        put(blk.attn2.to_q.weight, wg(dq2.view(T, Cc), ln2))
+        Tt = n * TEXT_PAD
+        dwkv = wg(dkv2.view(Tt, 2 * Cc), textp.view(Tt, -1))                             # [2C, Dt] = (k | v) rows
+        put(blk.attn2.to_k.weight, dwkv[:Cc])
+        put(blk.attn2.to_v.weight, dwkv[Cc:])
+        put(blk.norm2.weight, g_ln2)
+        put(blk.norm2.bias, b_ln2)
     # self-attention
     d16 = engine.to16(dtok1, dt16)
     da1 = ops.linear(d16, a1w.wo_t).view(n, hw, Cc)
+    if put is not None:
+        put(blk.attn1.to_out[0].weight, wg(d16, a1.view(T, Cc)))
+        put(blk.attn1.to_out[0].bias, ops.colsum(dtok1))
     if a1w.lora_out.live:
         a1w.lora_out.grads(*with_transpose(a1.view(T, Cc)), *with_transpose(d16), lsink)
     delta1 = ops.attention_delta(a1, da1, n, H, dh, hw)
@@ -401,9 +506,21 @@ def transformer_backward(t, x, text, dout, sink):
     dln1 = ops.linear(dqkv.view(T, 3 * Cc), a1w.wqkv_t, out_dtype=F32)
     if a1w.lora_qkv.live:
         a1w.lora_qkv.grads(*with_transpose(ln1), *with_transpose(dqkv.view(T, 3 * Cc)), lsink)
-    dtok0, _, _ = ops.layernorm_bwd(tok0, t.ln1.g, dln1, t.ln1.eps, dres=dtok1)
+    dtok0, g_ln1, b_ln1 = ops.layernorm_bwd(tok0, t.ln1.g, dln1, t.ln1.eps, dres=dtok1)
     # proj_in and the GroupNorm in front of it; the block's own residual (out = proj_out(..) + x)
     dy = stream_linear(dtok0, tw.w_in_t, tw.w_in_t3, Cc, dt16)
+    if put is not None:
+        dwqkv = wg(dqkv.view(T, 3 * Cc), ln1)                                            # [3C, C] = (q | k | v) rows
+        put(blk.attn1.to_q.weight, dwqkv[:Cc])
+        put(blk.attn1.to_k.weight, dwqkv[Cc:2 * Cc])
+        put(blk.attn1.to_v.weight, dwqkv[2 * Cc:])
+        put(blk.norm1.weight, g_ln1)
+        put(blk.norm1.bias, b_ln1)
+        put(src.proj_in.weight, wg(engine.to16(dtok0, dt16), y.view(T, Cc)))
+        put(src.proj_in.bias, ops.colsum(dtok0))
+        g_n, b_n = gn_param_grads(t.norm, x, None, n, hw, sc, sh, 0, dy.view(n, hw, Cc))
+        put(src.norm.weight, g_n)
+        put(src.norm.bias, b_n)
     dx, _ = ops.groupnorm_bwd(x, None, n, hw, t.norm.groups, t.norm.eps, t.norm.g, sc, sh, 0, dy.view(n, hw, Cc), dres=d.view(n, hw, Cc))
     return _unscale(dx, state).view(n, h, w, Cc)
 
@@ -423,8 +540,9 @@ class ScaledSink:
             self.sink(ref.down, d_down[row:row + rk], ref.scale)
 
 
-def downsample_backward(d, dout, pano_pad, dev_dtype):
-    """dout fp32 [n, ho, wo, C] -> dx of the block input; panorama: pad 2 / conv s2 / crop 1 (MVGenModel.py:138-144)."""
+def downsample_backward(d, dout, pano_pad, dev_dtype, wsink=None, x=None):
+    """dout fp32 [n, ho, wo, C] -> dx of the block input; panorama: pad 2 / conv s2 / crop 1 (MVGenModel.py:138-144).
+    wsink + x (the conv's input [n, h, w, cin]): also the gradients of the trainable conv's weight and bias."""
     tw = getattr(d, "train", None)
     cin = d.src.weight.shape[1]
     if tw is None:
@@ -435,6 +553,11 @@ def downsample_backward(d, dout, pano_pad, dev_dtype):
     g, state = _normalise(dout)
     if pano_pad:
         g = ops.crop_width_bwd(g, 1)
+    if wsink is not None:
+        assert not pano_pad and x is not None
+        put = _scaled(wsink, state)
+        put(d.src.weight, conv3_wgrad(engine.to16(g, dev_dtype), engine.to16(x, dev_dtype), stride=2))
+        put(d.src.bias, ops.colsum(g.view(-1, g.shape[-1])))
     if tw.w3 is not None:                             # the stride-2 conv maps the stream onto itself: split precision
         n, ho, wo, cout = g.shape
         z = ops.zero_insert2(engine.split_operand(g, dtype=dev_dtype).view(n, ho, wo, 2 * cout))
@@ -496,8 +619,9 @@ class TrainBranch(engine.Branch):
         self.tape.append(("push", self))
 
     def downsample(self, d):
+        x = self.h
         super().downsample(d)
-        self.tape.append(("down", self, d))
+        self.tape.append(("down", self, d, x))
 
     def upsample(self, up):
         super().upsample(up)
@@ -532,11 +656,21 @@ class ParamGrads:
         return None if hit is None else hit[1].to(device=param.device, dtype=param.dtype)      # (modules may live on the host)
 
 
-def backward(tape, d_eps, sink):
-    """Walk the tape backwards.  d_eps: {branch: fp32 NCHW gradient of that branch's predicted noise}."""
-    dh, dskips = {}, {}
+def backward(tape, d_eps, sink, dh=None, dskips=None, wsink=None, dtemb=None):
+    """Walk the tape backwards.  d_eps: {branch: fp32 NCHW gradient of that branch's predicted noise}.
+    dh / dskips: gradients to start from (a ControlNet's tape starts at its mid output and its 12 skip tensors);
+    wsink: the taped network's own weights train -- parameter gradients into wsink, each resnet's time-embedding gradient
+    appended to dtemb as (offset, [n, cout])."""
+    dh = {} if dh is None else dh
+    dskips = {} if dskips is None else dskips
     for entry in reversed(tape):
         kind, br = entry[0], entry[1]
+        if kind == "cn_mid":                          # h += mid residual (MVGenModel.py:200-203): its gradient is dh as it stands
+            entry[2].d_mid = dh[br]
+            continue
+        if kind == "cn_skips":                        # skips += residuals (:154-170): every skip's gradient is known by now
+            controlnet_backward(entry[2], list(dskips[br]), entry[2].d_mid, sink)
+            continue
         if kind == "fuse":
             _, pers, pano, block, xp, xe, groups, m = entry
             dp, de, grads = block.backward_nhwc(xp, xe, groups, m, dh[pers], dh[pano])
@@ -550,12 +684,12 @@ def backward(tape, d_eps, sink):
         elif kind == "up":
             dh[br] = upsample_backward(entry[2], dh[br], pad, br.u.dtype)
         elif kind == "down":
-            dh[br] = downsample_backward(entry[2], dh[br], pad, br.u.dtype)
+            dh[br] = downsample_backward(entry[2], dh[br], pad, br.u.dtype, wsink, entry[3] if wsink is not None else None)
         elif kind == "push":
             g = dskips[br].pop()
             dh[br] = ops.add(dh[br], g) if dh.get(br) is not None else g
         elif kind == "attention":
-            dh[br] = transformer_backward(entry[2], entry[3], br.text, dh[br], sink)
+            dh[br] = transformer_backward(entry[2], entry[3], br.text, dh[br], sink, wsink)
         elif kind == "resnet":
             _, _, r, x, s = entry
             rowvec = br.temb[:, r.temb_off:]
@@ -563,13 +697,159 @@ def backward(tape, d_eps, sink):
             if pad:                                   # pad 2 / resnet / crop 2 (MVGenModel.py:110-115)
                 d = ops.crop_width_bwd(d, 2)
                 x, s = ops.pad_width(x, 2), (ops.pad_width(s, 2) if s is not None else None)
-            dx, ds = resnet_backward(r, x, s, rowvec, d)
+            if wsink is not None:
+                dx, ds, dt = resnet_backward(r, x, s, rowvec, d, wsink)
+                dtemb.append((r.temb_off, dt))
+            else:
+                dx, ds = resnet_backward(r, x, s, rowvec, d)
             if pad:
                 dx, ds = ops.pad_width_bwd(dx, 2), (ops.pad_width_bwd(ds, 2) if ds is not None else None)
             dh[br] = dx
             if s is not None:
                 dskips.setdefault(br, []).append(ds)
-    return dh
+    return dh, dskips
+
+
+# ---------------------------------------------------------------------------------------------- the trainable ControlNet
+def cond_embedding_train(c, cond, rec):
+    """engine.run_cond_embedding (diffusers ControlNetConditioningEmbedding.forward) keeping every layer's 16-bit input
+    (rec.xs) and pre-activation (rec.zs) for the backward; channel counts zero-padded to multiples of 64 as there."""
+    n, _, H, W = cond.shape
+    dev = cond.device
+    z = ops.conv_in(cond.float(), c.ce_w0, c.ce_b0, c.ce_c0, c.dtype, wrap=False)
+    rec.zs, rec.xs = [z], []
+    x = ops.silu(z)
+    h, w = H, W
+    for i, L in enumerate(c.ce_layers):
+        ho, wo = (h - 1) // L.stride + 1, (w - 1) // L.stride + 1
+        out = torch.zeros(n, ho, wo, engine._pad64(L.cout), device=dev, dtype=c.dtype)
+        ops.conv_gemm(x, L.w, L.cout, n_img=n, h_in=h, w_in=w, ksize=3, stride=L.stride, pad=1, bias=L.b,
+                      c0=L.cin_pad, out=out.view(-1, out.shape[-1]))
+        rec.xs.append(x)
+        if i + 1 < len(c.ce_layers):
+            rec.zs.append(out)
+            x = ops.silu(out)
+        else:
+            x = out
+        h, w = ho, wo
+    return x
+
+
+def controlnet_forward(c, latent, timestep, text, cond):
+    """The ControlNet's forward of a training step: engine.run_controlnet on a taping branch.  -> (residuals, record)."""
+    rec = NS(c=c, tape=[], latent=latent, timestep=timestep, cond=cond)
+    res = engine.run_controlnet(c, latent, timestep, text, cond, rec=rec,
+                                make_branch=lambda *a, **k: TrainBranch(rec.tape, *a, **k),
+                                embed=lambda c_, cond_: cond_embedding_train(c_, cond_, rec))
+    return res, rec
+
+
+def _nhwc8(x_nchw, dtype):
+    """NCHW fp32 with < 8 channels (the 4-channel latent, the 3-channel layout image) -> NHWC 16-bit, channels zero-padded
+    to 8: the operand of pf_im2col3 for the weight gradient of a boundary convolution."""
+    n, ch, h, w = x_nchw.shape
+    out = torch.zeros(n, h, w, 8, device=x_nchw.device, dtype=dtype)
+    out[..., :ch] = x_nchw.permute(0, 2, 3, 1).to(dtype)
+    return out
+
+
+def _padded_flip(conv, cin_pad, cout_pad, dev, dtype):
+    """Data-gradient operand (flip_conv3_weight) of a conv whose channel counts are zero-padded to the buffers' strides."""
+    co, ci = conv.weight.shape[:2]
+    w = torch.zeros(cout_pad, cin_pad, 3, 3, device=dev, dtype=F32)
+    w[:co, :ci] = conv.weight.detach().to(device=dev, dtype=F32)
+    return flip_conv3_weight(w, dtype)
+
+
+def cond_embedding_backward(c, rec, d_out, sink):
+    """d_out fp32 [n, h, w, c0]: gradient of the conditioning embedding's output -> gradients of its 8 convolutions."""
+    ce = c.src.controlnet_cond_embedding
+    convs = [*ce.blocks, ce.conv_out]
+    d = d_out
+    for i in reversed(range(len(c.ce_layers))):
+        L, conv, x = c.ce_layers[i], convs[i], rec.xs[i]
+        cin_pad, cout_pad = x.shape[-1], d.shape[-1]
+        g, state = _normalise(d)
+        put = _scaled(sink, state)
+        put(conv.weight, conv3_wgrad(engine.to16(g, c.dtype), x, stride=L.stride)[:L.cout, :conv.weight.shape[1]])
+        put(conv.bias, ops.colsum(g.view(-1, cout_pad))[:L.cout])
+        wflip = getattr(L, "wflip", None)
+        if wflip is None:
+            wflip = L.wflip = _padded_flip(conv, cin_pad, cout_pad, x.device, c.dtype)
+        dx = conv3_dgrad(g, wflip, cin_pad, "s2" if L.stride == 2 else "s1", c.dtype)
+        d = _unscale(ops.silu_bwd(rec.zs[i], dx), state)
+    g, state = _normalise(d)                              # the boundary conv 3 -> 16 (fp32 kernel in the forward)
+    put = _scaled(sink, state)
+    co, ci = ce.conv_in.weight.shape[:2]
+    put(ce.conv_in.weight, conv3_wgrad(engine.to16(g, c.dtype), _nhwc8(rec.cond.float(), c.dtype))[:co, :ci])
+    put(ce.conv_in.bias, ops.colsum(g.view(-1, g.shape[-1]))[:co])
+
+
+def time_embedding_backward(c, timestep, dtemb, sink):
+    """dtemb fp32 [n, temb_total]: gradient of the concatenated time_emb_proj outputs (engine.Branch.temb) -> gradients of
+    every resnet's time_emb_proj and of TimestepEmbedding's two linears (Linear - SiLU - Linear, then SiLU - proj)."""
+    dt = c.dtype
+    te = c.src.time_embedding
+    feats = ops.timestep_features(timestep, c.t_dim, dt)
+    e1 = ops.linear(feats, c.w_t1, bias=c.b_t1)
+    s1 = ops.silu(e1)
+    e2 = ops.linear(s1, c.w_t2, bias=c.b_t2)
+    s2 = ops.silu(e2)
+    g, state = _normalise(dtemb)
+    put = _scaled(sink, state)
+    g16 = engine.to16(g, dt)
+    dw, db = training.weight_grad(g16, s2), ops.colsum(g)
+    for blk in [*c.down, c.mid]:
+        for r in blk.resnets:
+            put(r.src.time_emb_proj.weight, dw[r.temb_off:r.temb_off + r.cout])
+            put(r.src.time_emb_proj.bias, db[r.temb_off:r.temb_off + r.cout])
+    ds2 = _unscale(ops.linear(g16, c.w_temb.t().contiguous(), out_dtype=F32), state)
+    g, state = _normalise(ops.silu_bwd(e2, ds2))
+    put = _scaled(sink, state)
+    g16 = engine.to16(g, dt)
+    put(te.linear_2.weight, training.weight_grad(g16, s1))
+    put(te.linear_2.bias, ops.colsum(g))
+    ds1 = _unscale(ops.linear(g16, c.w_t2.t().contiguous(), out_dtype=F32), state)
+    g, state = _normalise(ops.silu_bwd(e1, ds1))
+    put = _scaled(sink, state)
+    put(te.linear_1.weight, training.weight_grad(engine.to16(g, dt), feats))
+    put(te.linear_1.bias, ops.colsum(g))
+
+
+def controlnet_backward(rec, d_skips, d_mid, sink):
+    """Gradients of EVERY ControlNet parameter (the reference's trainable set under layout conditions,
+    PanoGenerator.py:153-157) from the gradients of its 12 skip residuals and its mid residual (fp32 NHWC)."""
+    c, br = rec.c, rec.br
+    cn = c.src
+    dt = c.dtype
+
+    def zero_conv_backward(z, mod, x, d):
+        n, h, w, Cc = x.shape
+        M = n * h * w
+        g, state = _normalise(d.reshape(M, z.c))
+        put = _scaled(sink, state)
+        g16 = engine.to16(g, dt)
+        put(mod.weight, training.weight_grad(g16, engine.to16(x, dt).view(M, Cc)))
+        put(mod.bias, ops.colsum(g))
+        wt = getattr(z, "wt", None)
+        if wt is None:
+            wt = z.wt = z.w.t().contiguous()
+        return _unscale(ops.linear(g16, wt, out_dtype=F32), state).view(n, h, w, Cc)
+
+    dh = {br: zero_conv_backward(c.zero_mid, cn.controlnet_mid_block, rec.h_mid, d_mid)}
+    dsk = {br: [zero_conv_backward(z, mod, x, d) for z, mod, x, d in zip(c.zero_down, cn.controlnet_down_blocks, rec.skips, d_skips)]}
+    dtemb = []
+    dh, dsk = backward(rec.tape, {}, sink, dh=dh, dskips=dsk, wsink=sink, dtemb=dtemb)
+    assert len(dsk[br]) == 1                                  # the first skip: conv_in(latent) + conditioning embedding
+    d0 = ops.add(dh[br], dsk[br][0])
+    g, state = _normalise(d0)
+    put = _scaled(sink, state)
+    co, ci = cn.conv_in.weight.shape[:2]
+    put(cn.conv_in.weight, conv3_wgrad(engine.to16(g, dt), _nhwc8(rec.latent.float(), dt))[:, :ci])
+    put(cn.conv_in.bias, ops.colsum(g.view(-1, co)))
+    cond_embedding_backward(c, rec, d0, sink)
+    dtemb.sort(key=lambda e: e[0])
+    time_embedding_backward(c, rec.timestep, torch.cat([t for _, t in dtemb], 1).contiguous(), sink)
 
 
 class DenoiserFunction(torch.autograd.Function):

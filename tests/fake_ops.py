@@ -475,6 +475,31 @@ def groupnorm_bwd(x0, x1, n_img, hw, groups, eps, gamma, scale, shift, act, dy, 
     return g[..., :c0].contiguous(), (g[..., c0:].contiguous() if x1 is not None else None)
 
 
+def groupnorm_param_grads(x0, x1, n_img, hw, scale, shift, unit_scale, unit_shift, act, dy):
+    x = _cat(x0, x1).float().reshape(n_img, hw, -1)
+    z = x * scale[:, None, :] + shift[:, None, :]
+    dz = dy.reshape(n_img, hw, -1).float()
+    if act:
+        sg = torch.sigmoid(z)
+        dz = dz * sg * (1 + z * (1 - sg))
+    xhat = x * unit_scale[:, None, :] + unit_shift[:, None, :]
+    return (dz * xhat).sum((0, 1)), dz.sum((0, 1))
+
+
+def silu_bwd(z, dy):
+    zf = z.float()
+    sg = torch.sigmoid(zf)
+    return dy * sg * (1 + zf * (1 - sg))
+
+
+def im2col3(x, stride=1):
+    n, h, w, Cc = x.shape
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
+    taps = [xp[:, ky:ky + stride * (ho - 1) + 1:stride, kx:kx + stride * (wo - 1) + 1:stride] for ky in range(3) for kx in range(3)]
+    return torch.stack(taps, 3).reshape(n * ho * wo, 9 * Cc)
+
+
 def zero_insert2(x):
     n, h, w, C = x.shape
     y = torch.zeros(n, 2 * h, 2 * w, C, dtype=x.dtype)

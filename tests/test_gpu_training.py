@@ -316,6 +316,114 @@ def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, to
     assert eo < tol_out and allg < tol_grad and errs[0][0] < 4 * tol_grad, (eo, allg, errs[:4])
 
 
+# ------------------------------------------------------------------------------------ the trainable ControlNet
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("n,hw,c0,c1,groups,act", [(3, 24 * 17, 64, 32, 32, 1), (2, 1024, 320, 0, 32, 1), (1, 64, 1280, 1280, 32, 0),
+                                                   (2, 300, 640, 320, 32, 1), (1, 8192, 320, 0, 32, 1)])
+def test_groupnorm_parameter_gradients(xdtype, n, hw, c0, c1, groups, act):
+    """pf_groupnorm_param_grads against autograd of F.group_norm (+ SiLU) w.r.t. gamma and beta."""
+    from panfusion_amd import train_engine as TE
+    from panfusion_amd.engine import NS
+    o = ops()
+    x0 = (rnd(n, hw, c0, seed=1, scale=2.0) + 0.5).to(xdtype)
+    x1 = rnd(n, hw, c1, seed=2).to(xdtype) if c1 else None
+    C = c0 + c1
+    gamma, beta = (rnd(C, seed=3) * 0.2 + 1).requires_grad_(True), (rnd(C, seed=4) * 0.1).requires_grad_(True)
+    dy = rnd(n, hw, C, seed=5)
+    xr = (torch.cat([x0, x1], -1) if c1 else x0).float()
+    z = F.group_norm(xr.transpose(1, 2), groups, gamma, beta, 1e-5).transpose(1, 2)
+    (F.silu(z) if act else z).backward(dy)
+    sc, sh = o.groupnorm_scale_shift(x0, x1, n, hw, groups, 1e-5, gamma.detach(), beta.detach())
+    dg, db = TE.gn_param_grads(NS(groups=groups, eps=1e-5), x0, x1, n, hw, sc, sh, act, dy)
+    assert rel_l2(dg.cpu(), gamma.grad.cpu()) < 2e-5 and rel_l2(db.cpu(), beta.grad.cpu()) < 2e-5, \
+        (rel_l2(dg.cpu(), gamma.grad.cpu()), rel_l2(db.cpu(), beta.grad.cpu()))
+
+
+def test_silu_backward_and_im2col():
+    o = ops()
+    for zd in (torch.float32, torch.float16, torch.bfloat16):
+        z = rnd(3, 1000, 64, seed=1, scale=3.0).to(zd)
+        dy = rnd(3, 1000, 64, seed=2)
+        zr = z.float().requires_grad_(True)
+        F.silu(zr).backward(dy)
+        assert rel_l2(o.silu_bwd(z, dy).cpu(), zr.grad.cpu()) < 1e-6
+    for dtype in D16:
+        for (n, h, w, Cc, stride) in [(2, 8, 12, 64, 1), (1, 16, 16, 8, 2), (3, 6, 10, 72, 2), (1, 5, 7, 16, 1)]:
+            if stride == 2 and (h % 2 or w % 2):
+                continue
+            x = rnd(n, h, w, Cc, seed=3).to(dtype)
+            ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+            cols = F.unfold(x.permute(0, 3, 1, 2).float(), 3, padding=1, stride=stride)          # [n, C * 9, ho * wo], (c, ky, kx)
+            want = cols.view(n, Cc, 9, ho * wo).permute(0, 3, 2, 1).reshape(n * ho * wo, 9 * Cc).to(dtype)
+            assert torch.equal(o.im2col3(x, stride), want), (n, h, w, Cc, stride)
+
+
+@pytest.mark.parametrize("dtype", D16)
+@pytest.mark.parametrize("n,h,w,cin,cout,stride", [(2, 8, 12, 64, 128, 1), (1, 16, 32, 128, 64, 2), (3, 32, 32, 64, 64, 1)])
+def test_conv_weight_gradient(dtype, n, h, w, cin, cout, stride):
+    """dW of a 3x3 convolution = im2col + ONE token-reducing MFMA GEMM (train_engine.conv3_wgrad), chunked over images,
+    against autograd of F.conv2d."""
+    from panfusion_amd import train_engine as TE
+    wt = (rnd(cout, cin, 3, 3, seed=1) * (9 * cin) ** -0.5).requires_grad_(True)
+    x = rnd(n, cin, h, w, seed=2)
+    y = F.conv2d(x, wt, None, stride=stride, padding=1)
+    dy = rnd(*y.shape, seed=3)
+    y.backward(dy)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dtype)
+    got = TE.conv3_wgrad(nhwc(dy), nhwc(x), stride)
+    assert got.shape == wt.shape and rel_l2(got.cpu(), wt.grad.cpu()) < TOL[dtype], rel_l2(got.cpu(), wt.grad.cpu())
+    saved = TE._WGRAD_CHUNK
+    TE._WGRAD_CHUNK = 1                                     # one image per GEMM: the partial gradients add up
+    try:
+        assert rel_l2(TE.conv3_wgrad(nhwc(dy), nhwc(x), stride).cpu(), wt.grad.cpu()) < TOL[dtype]
+    finally:
+        TE._WGRAD_CHUNK = saved
+
+
+def test_trainable_controlnet_training_step_vs_oracle_autograd():
+    """The reference's layout_cond=True training (PanoGenerator.py:153-157, 165-168; PanFusion.py:85-89) on the GPU, fp16
+    operands in the mixed scheme, tiny widths: the gradient of EVERY ControlNet parameter (conditioning embedding, conv_in, time
+    embedding, resnets, transformers, down-samplers, 13 zero-convs: 340 tensors) plus the EPA / LoRA gradients against torch
+    autograd through the oracle on the CPU.  Tolerance: all ControlNet gradients as one vector <= 3e-3."""
+    from oracle import mvgen as MV
+    from oracle import sd2_unet as U
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    oracle0, _, args = _tiny_denoiser(torch.float16, "mixed")
+    cn = U.ControlNetModel.from_unet(oracle0.pano_unet)
+    U.init_synthetic(cn.controlnet_cond_embedding, 71)
+    U.init_synthetic(cn.controlnet_down_blocks, 72)
+    U.init_synthetic(cn.controlnet_mid_block, 73)
+    oracle = MV.DualBranchDenoiser(oracle0.unet, oracle0.pano_unet, None, cn, oracle0.pano_pad)
+    oracle.load_state_dict({k: v for k, v in oracle0.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    pl = args[1]
+    gen = torch.Generator().manual_seed(9)
+    cond = torch.rand(1, 1, 3, pl.shape[-2] * 8, pl.shape[-1] * 8, generator=gen) * 2 - 1
+    noise_s, noise_p = torch.randn(args[0].shape, generator=gen), torch.randn(args[1].shape, generator=gen)
+    loss = lambda s, p, dev: F.mse_loss(s, noise_s.to(dev)) + F.mse_loss(p, noise_p.to(dev))      # PanFusion.py:91-96
+    s, ps = oracle(*args, pano_layout_cond=cond)
+    loss(s, ps, "cpu").backward()
+    want = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None}
+    for p in oracle.parameters():
+        p.grad = None
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, cn, oracle.pano_pad, compute_dtype=torch.float16, precision="mixed",
+                             differentiable=True)
+    hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    dev_args = tuple(a.to(DEV) if isinstance(a, torch.Tensor) else a for a in args)
+    s2, ps2 = hip(*dev_args, pano_layout_cond=cond.to(DEV))
+    eo = max(rel_l2(s2.detach().cpu(), s.detach()), rel_l2(ps2.detach().cpu(), ps.detach()))
+    loss(s2, ps2, DEV).backward()
+    got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    cn_keys = [k for k in want if k.startswith("pano_cn.")]
+    other = [k for k in want if "lora" in k or k.startswith("cp_blocks")]
+    assert len(cn_keys) == len(list(cn.parameters())) and not [k for k in cn_keys + other if k not in got]
+    cat = lambda d, keys: torch.cat([d[k].detach().cpu().float().flatten() for k in keys])
+    e_cn, e_other = rel_l2(cat(got, cn_keys), cat(want, cn_keys)), rel_l2(cat(got, other), cat(want, other))
+    errs = sorted(((rel_l2(got[k].cpu().float(), want[k]), k) for k in cn_keys), reverse=True)
+    print("\ntrainable ControlNet: outputs %.2e   %d ControlNet gradients as one vector %.2e   EPA + LoRA %.2e   worst tensors: %s"
+          % (eo, len(cn_keys), e_cn, e_other, "  ".join("%.1e %s" % (e, k.replace("transformer_blocks.0.", "")) for e, k in errs[:4])))
+    assert eo < 1e-3 and e_cn < 3e-3 and e_other < 3e-3 and errs[0][0] < 3e-2, (eo, e_cn, e_other, errs[:4])
+
+
 @pytest.mark.parametrize("dtype", D16)
 @pytest.mark.parametrize("B,T,Cc", [(2, 128, 64), (3, 1000, 320), (1, 77, 1028), (1, 20480, 960), (2, 16, 192)])
 def test_transpose_tokens(dtype, B, T, Cc):
