@@ -130,16 +130,19 @@ def cpu_baseline(cfg, ctx_dim, lat_hw, pano_hw, m, cams_deg, flop_per_step):
                       % (cores, m, lat_hw[0], lat_hw[1], pano_hw[0], pano_hw[1], flop_per_step / 2e12, t_sample, t_geo, 2 * t_sample)}
 
 
-def training_step_leg(dev, dtype, cfg, precision=None, views_latent=32, pano_hw=(64, 128), steps=3, want_trace=False):
+def training_step_leg(dev, dtype, cfg, precision=None, views_latent=32, pano_hw=(64, 128), steps=3, want_trace=False,
+                      layout_cond=False):
     """The reference's TRAINING step through the same boundary (PanFusion.training_step, PanFusion.py:64-98; one sample per
     GPU, 20 views of 256^2 + the 512 x 1024 panorama, README.md:199, PanoDataset.py:224,227): forward on the inference
     kernels, backward on train_engine's tape into the 91 EPA tensors and the 512 LoRA matrices, AdamW step.  Not the
-    metric of this file: a reported extra (`training_step`), timed after everything else."""
+    metric of this file: a reported extra (`training_step`), timed after everything else.
+    layout_cond: the reference's layout-conditioned training (PanoGenerator.py:153-157, 165-174): the panorama ControlNet is
+    added and ALL of its parameters train, next to the EPA blocks; the LoRA matrices do not (`train_lora and not add_cn`)."""
     import numpy as np
     import torch
     from panfusion_amd import ops
     from panfusion_amd.utils.pano import icosahedron_sample_camera
-    model = build_model(dev, dtype, cfg, precision=precision)
+    model = build_model(dev, dtype, cfg, layout_cond=layout_cond, precision=precision)
     model.differentiable = True
     th, ph = icosahedron_sample_camera()
     m = len(th)
@@ -154,11 +157,19 @@ def training_step_leg(dev, dtype, cfg, precision=None, views_latent=32, pano_hw=
             "phi": torch.tensor(np.degrees(ph), dtype=torch.float64)[None]}
     t = torch.full((1, m), 500, device=dev)
     params = model.trainable_tensors()
+    kw = {}
+    if layout_cond:
+        cn_ids = {id(p_) for p_ in model.pano_cn.parameters()}
+        epa_ids = {id(p_) for blk in [*model.cp_blocks_encoder, model.cp_blocks_mid, *model.cp_blocks_decoder] for p_ in blk.parameters()}
+        for p_ in params:
+            p_.requires_grad_(id(p_) in cn_ids or id(p_) in epa_ids)
+        params = [p_ for p_ in params if p_.requires_grad]
+        kw["pano_layout_cond"] = (torch.rand(1, 1, 3, pano_hw[0] * 8, pano_hw[1] * 8, generator=g(8)) * 2 - 1).to(dev)
     opt = torch.optim.AdamW(params, lr=1e-5)
 
     def step():
         opt.zero_grad(set_to_none=True)
-        pred, pano_pred = model(latents, pano_latent, t, prompt, pano_prompt, cams)
+        pred, pano_pred = model(latents, pano_latent, t, prompt, pano_prompt, cams, **kw)
         loss = torch.nn.functional.mse_loss(pred, noise) + torch.nn.functional.mse_loss(pano_pred, pano_noise)
         loss.backward()
         opt.step()
@@ -172,11 +183,11 @@ def training_step_leg(dev, dtype, cfg, precision=None, views_latent=32, pano_hw=
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     with torch.no_grad():
-        model(latents, pano_latent, t, prompt, pano_prompt, cams)
+        model(latents, pano_latent, t, prompt, pano_prompt, cams, **kw)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(steps):
-            model(latents, pano_latent, t, prompt, pano_prompt, cams)
+            model(latents, pano_latent, t, prompt, pano_prompt, cams, **kw)
         torch.cuda.synchronize()
         dt_f = (time.perf_counter() - t1) / steps
     # the caller side of the step: VAE encode of the 20 views + the padded panorama (PanFusion.py:66-71)
@@ -205,7 +216,9 @@ def training_step_leg(dev, dtype, cfg, precision=None, views_latent=32, pano_hw=
     out = {"ms_per_step": dt * 1e3, "forward_only_ms": dt_f * 1e3, "vae_encode_ms": enc_ms, "steps": steps, "loss": float(loss.detach()),
            "trainable_tensors": len(params), "with_gradient": sum(p_.grad is not None for p_ in params),
            "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "precision": model.precision,
-           "workload": "%d views of %d^2 + %dx%d panorama, one sample, SD-2-base widths, rank-4 LoRA, AdamW" % (m, lat * 8, pano_hw[0] * 8, pano_hw[1] * 8)}
+           "workload": "%d views of %d^2 + %dx%d panorama, one sample, SD-2-base widths, %s, AdamW"
+                       % (m, lat * 8, pano_hw[0] * 8, pano_hw[1] * 8,
+                          "panorama ControlNet (all parameters) + EPA trainable" if layout_cond else "rank-4 LoRA")}
     if want_trace:
         ops.TRACE = []
         step()

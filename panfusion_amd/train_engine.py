@@ -16,6 +16,9 @@ residual stream) and applies the layer's backward:
   panorama      circular pad / crop around every conv-bearing module (MVGenModel.py:110-115): fold / zero-margin kernels
   head          conv_out's data gradient = the boundary conv kernel (conv_in) on rearranged weights, then GN+SiLU backward
   EPA fusion    training.epa_recompute / epa_backward
+  ControlNet    (layout conditions, PanoGenerator.py:153-157: ALL of its parameters train) a tape of its own, walked by the same
+                layer backward passes with a weight sink: conv / linear weight gradients (im2col + token-reducing GEMM), GroupNorm /
+                LayerNorm parameters, time embedding, conditioning embedding, the 13 zero-convs (controlnet_backward)
 
 Every entry normalises its incoming gradient by a power of two on the device (max |d| in [1, 2)) before it becomes a
 16-bit operand and scales its results back (training.py: an MSE over 1e5 latent elements hands down 1e-5).

@@ -480,6 +480,59 @@ def test_full_width_training_step_vs_oracle_autograd():
     assert eo < 1e-3 and allg < 1.5e-3 and errs[0][0] < 2e-2, (eo, allg, errs[:3])     # measured 6.7e-4 / 9.7e-4 / 6.9e-3
 
 
+def test_full_width_trainable_controlnet_vs_oracle_autograd():
+    """Layout-conditioned training AT SD-2-BASE WIDTHS (the panorama ControlNet with all 340 tensors trainable + the EPA blocks;
+    the LoRA matrices frozen as in the reference, PanoGenerator.py:173 `train_lora and not add_cn`): 2 views of 32^2 latents, a
+    32x64 panorama latent, a 256x512 layout image; every ControlNet gradient against CPU autograd through the oracle."""
+    from oracle import mvgen as MV
+    from oracle import sd2_unet as U
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    cfg = dict(U.SD2_BASE)
+    unet, pano_unet = U.UNet2DConditionModel(**cfg), U.UNet2DConditionModel(**cfg)
+    U.init_synthetic(unet, 201)
+    U.init_synthetic(pano_unet, 202)
+    cn = U.ControlNetModel.from_unet(pano_unet)
+    U.init_synthetic(cn.controlnet_cond_embedding, 207)
+    U.init_synthetic(cn.controlnet_down_blocks, 208)
+    U.init_synthetic(cn.controlnet_mid_block, 209)
+    unet.requires_grad_(False)
+    pano_unet.requires_grad_(False)
+    om = MV.DualBranchDenoiser(unet, pano_unet, None, cn, True)
+    for i, blk in enumerate((om.cp_blocks_encoder, om.cp_blocks_mid, om.cp_blocks_decoder)):
+        U.init_synthetic(blk, 203 + i)
+    MV.randomize_epa(om, 206)
+    g = torch.Generator().manual_seed(17)
+    b, m = 1, 2
+    args = (torch.randn(b, m, 4, 32, 32, generator=g), torch.randn(b, 1, 4, 32, 64, generator=g), torch.full((b, m), 500, dtype=torch.long),
+            torch.randn(b, m, 77, 1024, generator=g), torch.randn(b, 1, 77, 1024, generator=g),
+            {"FoV": torch.full((b, m), 90), "theta": torch.tensor([[36.0, 180.0]], dtype=torch.float64),
+             "phi": torch.tensor([[52.6, -10.8]], dtype=torch.float64)})
+    cond = torch.rand(b, 1, 3, 256, 512, generator=g) * 2 - 1
+    noise_s, noise_p = torch.randn(args[0].shape, generator=g), torch.randn(args[1].shape, generator=g)
+    loss = lambda s, p, dev: F.mse_loss(s, noise_s.to(dev)) + F.mse_loss(p, noise_p.to(dev))
+    s, ps = om(*args, pano_layout_cond=cond)
+    loss(s, ps, "cpu").backward()
+    want = {k: p.grad.clone() for k, p in om.named_parameters() if p.grad is not None}
+    for p in om.parameters():
+        p.grad = None
+    hip = MultiViewBaseModel(om.unet, om.pano_unet, None, cn, True, compute_dtype=torch.float16, precision="mixed", differentiable=True)
+    hip.load_state_dict({k: v for k, v in om.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    dev_args = tuple(a.to(DEV) if isinstance(a, torch.Tensor) else a for a in args)
+    s2, ps2 = hip(*dev_args, pano_layout_cond=cond.to(DEV))
+    eo = max(rel_l2(s2.cpu(), s), rel_l2(ps2.cpu(), ps))
+    loss(s2, ps2, DEV).backward()
+    got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    cn_keys = [k for k in want if k.startswith("pano_cn.")]
+    epa = [k for k in want if k.startswith("cp_blocks")]
+    assert len(cn_keys) == 340 and len(epa) == 91 and not [k for k in cn_keys + epa if k not in got]
+    cat = lambda d, keys: torch.cat([d[k].detach().cpu().float().flatten() for k in keys])
+    e_cn, e_epa = rel_l2(cat(got, cn_keys), cat(want, cn_keys)), rel_l2(cat(got, epa), cat(want, epa))
+    errs = sorted(((rel_l2(got[k].cpu().float(), want[k]), k) for k in cn_keys), reverse=True)
+    print("\nfull-width trainable ControlNet: outputs %.2e   340 ControlNet gradients as one vector %.2e   EPA %.2e   worst tensors: %s"
+          % (eo, e_cn, e_epa, "  ".join("%.1e %s" % (e, k.replace("transformer_blocks.0.", "")) for e, k in errs[:4])))
+    assert eo < 1e-3 and e_cn < 3e-3 and e_epa < 3e-3 and errs[0][0] < 3e-2, (eo, e_cn, e_epa, errs[:4])
+
+
 def test_whole_training_step_vs_oracle():
     """pipeline.training_step -- VAE encode of the views and the padded panorama, init_noise, add_noise, ONE denoiser call, two MSE
     losses (PanFusion.py:64-98) -- on the GPU against the oracle restatement with the same random draws: the losses, then the

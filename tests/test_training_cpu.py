@@ -275,46 +275,52 @@ def test_training_step_with_layout_condition_frozen_controlnet(fake_denoiser_bac
         assert k in got and rel_l2(got[k], want[k]) < 1e-4, (k, rel_l2(got[k], want[k]) if k in got else None)
 
 
-def _with_pano_controlnet(seed=71):
+def _with_controlnet(which="pano", seed=71):
+    """The tiny oracle denoiser with a ControlNet on the panorama branch (the reference's default, PanoGenerator.py:186-191) or
+    on the view branch (pers_cn, MVGenModel.py:66-74), and the matching layout images."""
     from oracle import mvgen as MV
     from oracle import sd2_unet as U
     oracle0, args, w_s, w_p = _denoiser_case()
-    cn = U.ControlNetModel.from_unet(oracle0.pano_unet)
+    cn = U.ControlNetModel.from_unet(oracle0.pano_unet if which == "pano" else oracle0.unet)
     U.init_synthetic(cn.controlnet_cond_embedding, seed)
     U.init_synthetic(cn.controlnet_down_blocks, seed + 1)
     U.init_synthetic(cn.controlnet_mid_block, seed + 2)
-    oracle = MV.DualBranchDenoiser(oracle0.unet, oracle0.pano_unet, None, cn, oracle0.pano_pad)
+    cns = (None, cn) if which == "pano" else (cn, None)
+    oracle = MV.DualBranchDenoiser(oracle0.unet, oracle0.pano_unet, *cns, oracle0.pano_pad)
     oracle.load_state_dict({k: v for k, v in oracle0.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
-    pl = args[1]
-    cond = torch.rand(1, 1, 3, pl.shape[-2] * 8, pl.shape[-1] * 8, generator=torch.Generator().manual_seed(9)) * 2 - 1
-    return oracle, cn, args, cond, w_s, w_p
+    lat = args[1] if which == "pano" else args[0]
+    cond = torch.rand(*lat.shape[:2], 3, lat.shape[-2] * 8, lat.shape[-1] * 8, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    kw = {"pano_layout_cond": cond} if which == "pano" else {"pers_layout_cond": cond}
+    return oracle, cn, cns, args, kw, w_s, w_p
 
 
-def test_training_step_with_trainable_controlnet(fake_denoiser_backend):
+@pytest.mark.parametrize("which", ["pano", "pers"])
+def test_training_step_with_trainable_controlnet(fake_denoiser_backend, which):
     """The reference's layout_cond=True training (PanoGenerator.py:153-157, 165-168: every parameter of the ControlNet trains;
     PanFusion.py:85-89 passes the layout images): gradients of ALL ControlNet parameters -- conditioning embedding, conv_in,
     time embedding, every resnet / transformer / down-sampler, the 13 zero-convs -- and still of the EPA blocks and the LoRA
-    matrices, against torch autograd through the oracle.  fp32 test double: agreement at round-off."""
+    matrices, against torch autograd through the oracle.  fp32 test double: agreement at round-off.  Both attachment points:
+    the panorama branch (one image per sample) and the view branch (m images per sample)."""
     from panfusion_amd.models.pano import MultiViewBaseModel
-    oracle, cn, args, cond, w_s, w_p = _with_pano_controlnet()
-    s, ps = oracle(*args, pano_layout_cond=cond)
+    oracle, cn, cns, args, kw, w_s, w_p = _with_controlnet(which)
+    s, ps = oracle(*args, **kw)
     ((s * w_s).sum() + (ps * w_p).sum()).backward()
     want = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None}
     for p in oracle.parameters():
         p.grad = None
-    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, cn, oracle.pano_pad, compute_dtype=torch.float32,
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, *cns, oracle.pano_pad, compute_dtype=torch.float32,
                              precision="mixed", differentiable=True)
     hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
-    s2, ps2 = hip(*args, pano_layout_cond=cond)
+    s2, ps2 = hip(*args, **kw)
     assert rel_l2(s2, s) < 2e-5 and rel_l2(ps2, ps) < 2e-5
     ((s2 * w_s).sum() + (ps2 * w_p).sum()).backward()
     got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
-    cn_keys = [k for k in want if k.startswith("pano_cn.")]
+    cn_keys = [k for k in want if k.startswith(which + "_cn.")]
     assert len(cn_keys) == len(list(cn.parameters())) and len(cn_keys) > 300
     missing = [k for k in cn_keys if k not in got]
     assert not missing, missing[:6]
     errs = sorted(((rel_l2(got[k], want[k]), k) for k in cn_keys), reverse=True)
-    print("trainable ControlNet: %d tensors, worst %s" % (len(cn_keys), "  ".join("%.1e %s" % e for e in errs[:4])))
+    print("trainable ControlNet (%s): %d tensors, worst %s" % (which, len(cn_keys), "  ".join("%.1e %s" % e for e in errs[:4])))
     assert errs[0][0] < 2e-4, errs[:6]
     for k in [k for k in want if "lora" in k or k.startswith("cp_blocks")]:
         assert k in got and rel_l2(got[k], want[k]) < 1e-4, k
@@ -323,7 +329,8 @@ def test_training_step_with_trainable_controlnet(fake_denoiser_backend):
 def test_optimizer_step_on_the_controlnet_reaches_the_next_forward(fake_denoiser_backend):
     """A training ControlNet's pack is rebuilt when its parameters moved (packed(): version counters), the UNets' packs stay."""
     from panfusion_amd.models.pano import MultiViewBaseModel
-    oracle, cn, args, cond, w_s, w_p = _with_pano_controlnet()
+    oracle, cn, cns, args, kw, w_s, w_p = _with_controlnet("pano")
+    cond = kw["pano_layout_cond"]
     hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, cn, oracle.pano_pad, compute_dtype=torch.float32,
                              precision="fast", differentiable=True)
     hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)

@@ -3,7 +3,7 @@ PanFusion.py:64-98: one mv_base_model call without CFG, MSE on both outputs; bs 
 512 x 1024 panorama -- README.md:199, PanoDataset.py:224,227): forward on the inference kernels, backward on
 train_engine's tape, gradients for the 91 EPA tensors and the 512 LoRA matrices.  SD-2-base widths, synthetic weights.
 
-    python tools/train_bench.py [--dtype fp16|bf16] [--views-latent 32|64] [--steps 3] [--small]
+    python tools/train_bench.py [--dtype fp16|bf16] [--views-latent 32|64] [--steps 3] [--small] [--layout-cond]
 """
 import argparse
 import os
@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--views-latent", type=int, default=32)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--small", action="store_true")
+    ap.add_argument("--layout-cond", action="store_true", help="layout-conditioned training: the panorama ControlNet trains (all parameters)")
     args = ap.parse_args()
     import bench
     from panfusion_amd.models.sd2_unet_params import SD2_BASE
@@ -31,7 +32,7 @@ def main():
     if args.small:
         cfg.update(block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4), cross_attention_dim=128)
         lat, pano_hw = 16, (16, 32)
-    r = bench.training_step_leg(dev, dtype, cfg, args.precision, lat, pano_hw, args.steps, want_trace=True)
+    r = bench.training_step_leg(dev, dtype, cfg, args.precision, lat, pano_hw, args.steps, want_trace=True, layout_cond=args.layout_cond)
     print("training step (%s %s): %s: %.1f ms / step (forward alone %.1f ms), loss %.4f, %d / %d trainable tensors with gradients, "
           "peak memory %.1f GB" % (args.dtype, r["precision"], r["workload"], r["ms_per_step"], r["forward_only_ms"], r["loss"],
                                    r["with_gradient"], r["trainable_tensors"], r["peak_memory_gb"]))
