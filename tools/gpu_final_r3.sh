@@ -61,3 +61,8 @@ python tools/gemm_bench.py --reps 20 2>&1 | grep -v amdgpu.ids > gpurun_out/${TA
 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_attn_microbench.txt
 python tools/elem_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_elem_microbench.txt
 tail -n 3 gpurun_out/${TAG}_gemm_microbench.txt
+echo "== training step: LoRA + EPA, and layout-conditioned (the ControlNet trains)"
+timeout 400 python tools/train_bench.py --steps 3 2>&1 | grep -v amdgpu.ids | tail -n 6 > gpurun_out/${TAG}_train_lora.txt; head -n 1 gpurun_out/${TAG}_train_lora.txt | cut -c1-300
+timeout 400 python tools/train_bench.py --layout-cond --steps 3 2>&1 | grep -v amdgpu.ids | tail -n 6 > gpurun_out/${TAG}_train_layout_cond.txt; head -n 1 gpurun_out/${TAG}_train_layout_cond.txt | cut -c1-300
+echo "== MFMA utilisation in the step (PMC)"
+bash tools/gpu_mfma_instep.sh ${TAG} 2>&1 | tail -n 14
