@@ -355,8 +355,8 @@ pf_status pf_attention_delta(const void* out, const void* dout, int dtype, int B
  * All of q, k, v, dout are ROW-major ([B][n][ld], head h at column h*D); kt, qt, dot are the transposes of k, q, dout
  * ([B][H*D][*_ld], tokens contiguous) -- the A operands of the products whose reduction runs over tokens.
  * dq [B][nq][dq_ld], dk / dv [B][nk][dk_ld / dv_ld] in `dtype`.  Token counts that are not multiples of 32 take a
- * guarded instantiation (the 4x4 level of a 256^2 view has 16 tokens); with a bias nk % 4 == 0.  Two launches: queries-stationary (dq) and keys-stationary (dk, dv); no atomics, results do
- * not depend on scheduling. */
+ * guarded instantiation (the 4x4 level of a 256^2 view has 16 tokens); with a bias nk % 4 == 0.  Two launches: queries-stationary (dq) and keys-stationary (dk, dv)
+ * (+ a reduce launch when the query range was split, see `workspace`); no atomics, results do not depend on scheduling. */
 typedef struct {
     const void* q; const void* k; const void* v; const void* dout;
     const void* qt; const void* kt; const void* dot;
@@ -372,8 +372,13 @@ typedef struct {
     const float* bias; long bias_ld;      /* as pf_attention: [nq][bias_ld] */
     const uint8_t* flags; int flags_ld;
     const float* lse; const float* delta; /* fp32 [B][H][nq] */
+    void* workspace; size_t workspace_bytes; /* optional fp32 scratch of pf_attention_bwd_workspace_size(desc) bytes: lets the
+                                              * keys-stationary launch split its query range when it has few blocks (the 128
+                                              * text keys of a cross-attention, one panorama sample); partial sums are added in a
+                                              * fixed order.  NULL: never split. */
 } pf_attn_bwd_desc;
 
+size_t pf_attention_bwd_workspace_size(const pf_attn_bwd_desc* desc);
 pf_status pf_attention_bwd(const pf_attn_bwd_desc* desc, void* stream);
 
 /* LayerNorm backward (rows of width C <= 2048, C % 8 == 0).  x (+ pe, as pf_layernorm) is the forward input, dy fp32

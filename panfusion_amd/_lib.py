@@ -64,6 +64,7 @@ class AttnBwdDesc(C.Structure):
         ("scale", c_float),
         ("bias", c_void_p), ("bias_ld", c_long), ("flags", c_void_p), ("flags_ld", c_int),
         ("lse", c_void_p), ("delta", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
     ]
 
 
@@ -126,6 +127,7 @@ SIGNATURES = {
     "pf_attention": (c_int, [C.POINTER(AttnDesc), c_void_p]),
     "pf_attention_delta": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_void_p, c_void_p]),
     "pf_attention_bwd": (c_int, [C.POINTER(AttnBwdDesc), c_void_p]),
+    "pf_attention_bwd_workspace_size": (c_size_t, [C.POINTER(AttnBwdDesc)]),
     "pf_layernorm_bwd_parts": (c_int, [c_long]),
     "pf_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_int, c_void_p, c_float, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),

@@ -34,6 +34,8 @@ struct AttnBwdParams {
     float scale, scale_log2e;
     const float* bias; long bias_ld; const uint8_t* flags; int flags_ld;
     const float *lse, *delta;
+    int qsplit;                         // > 1: the keys-stationary kernel splits the query range over qsplit blocks ...
+    float *part_k, *part_v;             // ... which leave fp32 partial sums [qsplit][B][nk][H*D], added in order by k_attn_bwd_reduce
 };
 
 constexpr float LOG2E = 1.44269504088896340736f;
@@ -294,9 +296,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(const AttnBwdParams p)
     typedef typename Mfma32<T>::frag frag;
     constexpr int BUF = 2 * TL::ROWMAJ + 2 * TL::TRANS;          // Q rows | dO rows | Q^T | dO^T
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+    // log-sum-exp and delta of the 32 staged queries travel with the tiles: read straight from global memory inside the
+    // step they sat on the critical path of every iteration (a step is about as long as one L2 round trip)
+    __shared__ __attribute__((aligned(16))) float lsd[2][64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int kl = lane & 31, hi = lane >> 5;
-    const int k0 = (blockIdx.x * 4 + wave) * 32;
+    const int qs = blockIdx.x % p.qsplit;                          // this block's share of the query tiles
+    const int k0 = ((blockIdx.x / p.qsplit) * 4 + wave) * 32;
     const bool live = k0 < p.nk;                                   // (a block's trailing waves still help staging)
     const int h = blockIdx.y;
     const long b = blockIdx.z;
@@ -326,8 +332,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(const AttnBwdParams p)
     // staging ownership: row-major chunk c -> (row c / (D/8), 8 channels at (c % (D/8)) * 8); transposed chunk c -> (row c / 4, 8 tokens at (c % 4) * 8)
     constexpr int NR = (TL::CH_R + 255) / 256, NT = (TL::CH_T + 255) / 256;
     u16x8 rq[NR], rdo[NR], rqt[NT], rdot[NT];
+    float4 rls = {0.f, 0.f, 0.f, 0.f};
     auto stage_load = [&](int qt_) {
         const int q0 = qt_ * 32;
+        if (t < 16) rls = *reinterpret_cast<const float4*>((t < 8 ? lsep : delp) + q0 + 4 * (t & 7));
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int c = t + 256 * i;
@@ -352,6 +360,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(const AttnBwdParams p)
         unsigned short* DO = Q + TL::ROWMAJ;
         unsigned short* QT = DO + TL::ROWMAJ;
         unsigned short* DOT = QT + TL::TRANS;
+        if (t < 16) *reinterpret_cast<float4*>(&lsd[buf][(t < 8 ? 0 : 32) + 4 * (t & 7)]) = rls;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int c = t + 256 * i;
@@ -376,11 +385,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(const AttnBwdParams p)
     };
 
     const int kt = k0 >> 5;
-    const int nqt = p.nq / 32;
-    stage_load(0);
-    stage_store(0);
+    const int per = (p.nq / 32 + p.qsplit - 1) / p.qsplit;
+    const int qt_begin = qs * per, nqt = min(p.nq / 32, qt_begin + per);
+    if (qt_begin < nqt) {
+        stage_load(qt_begin);
+        stage_store(qt_begin & 1);
+    }
     __syncthreads();
-    for (int qt = 0; qt < nqt; ++qt) {
+    for (int qt = qt_begin; qt < nqt; ++qt) {
         if (qt + 1 < nqt) stage_load(qt + 1);
         if (live) {
             const int q0 = qt * 32;
@@ -411,8 +423,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(const AttnBwdParams p)
             u16x8 pp[2], pd[2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 l4 = *reinterpret_cast<const float4*>(lsep + q0 + 8 * g + 4 * hi);
-                const float4 d4 = *reinterpret_cast<const float4*>(delp + q0 + 8 * g + 4 * hi);
+                const float4 l4 = *reinterpret_cast<const float4*>(&lsd[qt & 1][8 * g + 4 * hi]);
+                const float4 d4 = *reinterpret_cast<const float4*>(&lsd[qt & 1][32 + 8 * g + 4 * hi]);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -436,6 +448,19 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(const AttnBwdParams p)
         __syncthreads();
     }
     if (!live) return;
+    if (p.qsplit > 1) {                                            // fp32 partial sums of this query range
+        const long row = ((static_cast<long>(qs) * gridDim.z + b) * p.nk + k0 + kl) * (static_cast<long>(p.H) * D) + h * D;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = d * 32 + 8 * g + 4 * hi;
+                *reinterpret_cast<float4*>(p.part_k + row + c) = float4{acc_k[d][4 * g] * p.scale, acc_k[d][4 * g + 1] * p.scale,
+                                                                        acc_k[d][4 * g + 2] * p.scale, acc_k[d][4 * g + 3] * p.scale};
+                *reinterpret_cast<float4*>(p.part_v + row + c) = float4{acc_v[d][4 * g], acc_v[d][4 * g + 1], acc_v[d][4 * g + 2], acc_v[d][4 * g + 3]};
+            }
+        return;
+    }
     unsigned short* okp = p.dk + b * p.dk_bs + static_cast<long>(k0 + kl) * p.dk_ld + h * D;
     unsigned short* ovp = p.dv + b * p.dv_bs + static_cast<long>(k0 + kl) * p.dv_ld + h * D;
 #pragma unroll
@@ -593,6 +618,26 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq_lds(const AttnBwdParams p) 
             for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(acc[d][4 * g + e] * p.scale);
             *reinterpret_cast<u16x4*>(op + d * 32 + 8 * g + 4 * hi) = w;
         }
+}
+
+// dK / dV of a query-split keys-stationary launch: the qsplit fp32 partial sums added in order, written in the 16-bit type.
+template <typename T>
+__global__ void k_attn_bwd_reduce(const float* __restrict__ part_k, const float* __restrict__ part_v, int qsplit, int B, int nk, int HD,
+                                  unsigned short* __restrict__ dk, unsigned short* __restrict__ dv, int dk_ld, int dv_ld, long dk_bs, long dv_bs) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;       // (b, key, quad of channels)
+    const int Q4 = HD / 4;
+    if (i >= static_cast<long>(B) * nk * Q4) return;
+    const int c = static_cast<int>(i % Q4) * 4;
+    const long key = (i / Q4) % nk, b = i / (static_cast<long>(Q4) * nk);
+    const long slab = static_cast<long>(B) * nk * HD, off = (b * nk + key) * HD + c;
+    float4 sk = *reinterpret_cast<const float4*>(part_k + off), sv = *reinterpret_cast<const float4*>(part_v + off);
+    for (int q = 1; q < qsplit; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(part_k + q * slab + off), v = *reinterpret_cast<const float4*>(part_v + q * slab + off);
+        sk.x += a.x; sk.y += a.y; sk.z += a.z; sk.w += a.w;
+        sv.x += v.x; sv.y += v.y; sv.z += v.z; sv.w += v.w;
+    }
+    *reinterpret_cast<u16x4*>(dk + b * dk_bs + key * dk_ld + c) = u16x4{from_f32<T>(sk.x), from_f32<T>(sk.y), from_f32<T>(sk.z), from_f32<T>(sk.w)};
+    *reinterpret_cast<u16x4*>(dv + b * dv_bs + key * dv_ld + c) = u16x4{from_f32<T>(sv.x), from_f32<T>(sv.y), from_f32<T>(sv.z), from_f32<T>(sv.w)};
 }
 
 template <typename T>
@@ -1139,6 +1184,30 @@ extern "C" pf_status pf_attention_delta(const void* out, const void* dout, int d
     return PF_OK;
 }
 
+// LDS-staged kernels: whole 32-token tiles, 16-byte rows for the cooperative tile loads.  PF_ATTN_BWD_IMPL=direct: A/B switch
+static bool attn_bwd_lds(const pf_attn_bwd_desc* d) {
+    static const bool want_lds = [] { const char* e = getenv("PF_ATTN_BWD_IMPL"); return !(e && e[0] == 'd'); }();
+    const bool tail = d->nq % 32 != 0 || d->nk % 32 != 0;
+    return want_lds && !tail && d->qt_ld % 8 == 0 && d->kt_ld % 8 == 0 && d->dot_ld % 8 == 0 && d->qt_bs % 8 == 0 && d->kt_bs % 8 == 0 &&
+           d->dot_bs % 8 == 0;
+}
+
+// Query split of the keys-stationary launch: towards ~512 blocks, at least 8 query tiles (256 queries) per block.
+static int attn_bwd_qsplit(const pf_attn_bwd_desc* d) {
+    static const int on = [] { const char* e = getenv("PF_ATTN_BWD_QSPLIT"); return e ? atoi(e) : 1; }();
+    if (!on || !attn_bwd_lds(d) || (d->H * d->D) % 4 != 0) return 1;
+    const long base = cdiv(d->nk, 128) * d->H * d->B;
+    if (base >= 384) return 1;
+    const long qs = std::min<long>(cdiv(512, base), (d->nq / 32) / 8);
+    return static_cast<int>(std::max<long>(1, qs));
+}
+
+extern "C" size_t pf_attention_bwd_workspace_size(const pf_attn_bwd_desc* d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->nq <= 0 || d->nk <= 0 || (d->D != 32 && d->D != 64)) return 0;
+    const int qs = attn_bwd_qsplit(d);
+    return qs > 1 ? static_cast<size_t>(2) * qs * d->B * d->nk * d->H * d->D * sizeof(float) : 0;
+}
+
 extern "C" pf_status pf_attention_bwd(const pf_attn_bwd_desc* d, void* stream) {
     PF_REQUIRE(d, "pf_attention_bwd: null descriptor");
     PF_REQUIRE(d->q && d->k && d->v && d->dout && d->qt && d->kt && d->dot && d->dq && d->dk && d->dv && d->lse && d->delta,
@@ -1172,12 +1241,20 @@ extern "C" pf_status pf_attention_bwd(const pf_attn_bwd_desc* d, void* stream) {
     p.bias = d->bias; p.bias_ld = d->bias_ld; p.flags = d->flags; p.flags_ld = d->flags_ld;
     p.lse = d->lse; p.delta = d->delta;
     hipStream_t st = as_stream(stream);
-    const dim3 block(256), gq(cdiv(d->nq, 128), d->H, d->B), gk(cdiv(d->nk, 128), d->H, d->B);
     const bool tail = d->nq % 32 != 0 || d->nk % 32 != 0;        // ragged token counts: guarded loads, masked tails
-    // LDS-staged kernels: whole 32-token tiles, 16-byte rows for the cooperative tile loads.  PF_ATTN_BWD_IMPL=direct: A/B switch
-    static const bool want_lds = [] { const char* e = getenv("PF_ATTN_BWD_IMPL"); return !(e && e[0] == 'd'); }();
-    const bool lds = want_lds && !tail && d->qt_ld % 8 == 0 && d->kt_ld % 8 == 0 && d->dot_ld % 8 == 0 && d->qt_bs % 8 == 0 &&
-                     d->kt_bs % 8 == 0 && d->dot_bs % 8 == 0;
+    const bool lds = attn_bwd_lds(d);
+    // keys-stationary launch with few blocks (the 128 text keys of a cross-attention: H x B blocks walking all queries; one
+    // panorama sample): the query range is split over several blocks, fp32 partial sums added in a fixed order afterwards
+    const int qsplit = d->workspace ? attn_bwd_qsplit(d) : 1;
+    p.qsplit = qsplit;
+    p.part_k = p.part_v = nullptr;
+    if (qsplit > 1) {
+        const size_t half = static_cast<size_t>(qsplit) * d->B * d->nk * d->H * d->D * sizeof(float);
+        PF_REQUIRE(d->workspace_bytes >= 2 * half && aligned16(d->workspace), "pf_attention_bwd: workspace too small or misaligned (pf_attention_bwd_workspace_size)");
+        p.part_k = static_cast<float*>(d->workspace);
+        p.part_v = p.part_k + half / sizeof(float);
+    }
+    const dim3 block(256), gq(cdiv(d->nq, 128), d->H, d->B), gk(cdiv(d->nk, 128) * qsplit, d->H, d->B);
 #define PF_BWD(DD)                                                                                                          \
     do {                                                                                                                    \
         if (lds) { hipLaunchKernelGGL((k_attn_bwd_dq_lds<T, DD>), gq, block, 0, st, p); hipLaunchKernelGGL((k_attn_bwd_dkv_lds<T, DD>), gk, block, 0, st, p); } \
@@ -1186,6 +1263,12 @@ extern "C" pf_status pf_attention_bwd(const pf_attn_bwd_desc* d, void* stream) {
     } while (0)
     PF_DISPATCH_16(d->dtype, "pf_attention_bwd", if (d->D == 64) PF_BWD(64); else PF_BWD(32));
 #undef PF_BWD
+    if (qsplit > 1) {
+        const long total = static_cast<long>(d->B) * d->nk * (d->H * d->D / 4);
+        PF_DISPATCH_16(d->dtype, "pf_attention_bwd",
+            hipLaunchKernelGGL(k_attn_bwd_reduce<T>, dim3(cdiv(total, 256)), dim3(256), 0, st, p.part_k, p.part_v, qsplit, d->B, d->nk, d->H * d->D,
+                               p.dk, p.dv, p.dk_ld, p.dv_ld, p.dk_bs, p.dv_bs));
+    }
     PF_CHECK_LAUNCH("pf_attention_bwd");
     return PF_OK;
 }

@@ -589,6 +589,11 @@ def attention_bwd(q, k, v, dout, qt, kt, dot, lse, delta, dq, dk, dv, B, H, D, n
     d.bias, d.bias_ld = _p(bias), (_ld(bias) if bias is not None else 0)
     d.flags, d.flags_ld = _p(flags), (_ld(flags) if flags is not None else 0)
     d.lse, d.delta = _p(lse), _p(delta)
+    d.workspace, d.workspace_bytes = None, 0
+    nbytes = _lib.lib().pf_attention_bwd_workspace_size(C.byref(d))
+    if nbytes:
+        ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+        d.workspace, d.workspace_bytes = _p(ws), nbytes
     _traced("k_attention_bwd", 10.0 * B * H * nq * nk * D,
             lambda: check(_lib.lib().pf_attention_bwd(C.byref(d), _stream()), "pf_attention_bwd"),
             "B%d H%d D%d nq%d nk%d bias%d" % (B, H, D, nq, nk, bias is not None))

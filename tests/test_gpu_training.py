@@ -39,6 +39,9 @@ def sparse_bias(nq, nk, seed):
 @pytest.mark.parametrize("dtype", D16)
 @pytest.mark.parametrize("D,H,nq,nk,biased", [(32, 3, 128, 320, True), (32, 2, 96, 64, False), (64, 2, 160, 96, False),
                                               (32, 10, 512, 1280, True),
+                                              # few key blocks, many queries: the keys-stationary launch splits its query range
+                                              # (text cross-attention of the panorama: 128 keys; one sample's self-attention)
+                                              (64, 2, 2048, 128, True), (64, 5, 1024, 1024, False), (32, 4, 4096, 256, True),
                                               # ragged token counts (guarded instantiation): the 4x4 level of a 256^2 view, text keys
                                               (64, 2, 16, 16, False), (64, 2, 100, 128, True), (32, 2, 40, 72, False)])
 def test_attention_lse_and_backward(dtype, D, H, nq, nk, biased):
@@ -86,6 +89,14 @@ def test_attention_lse_and_backward(dtype, D, H, nq, nk, biased):
         assert err < 2.5 * TOL[dtype], (name, err)
     # the slots the call does not own stay untouched
     assert not dqkv_q[:, :, Cc:].any() and not dqkv_k[:, :, :Cc].any()
+    if nq >= 1024:                                        # split query range: partial sums are added in a fixed order
+        again = torch.zeros_like(dqkv_k)
+        o.attention_bwd(q, k, v, dout, qt_all[:, :Cc], kt_all[:, Cc:2 * Cc], o.transpose_tokens(dout), lse, delta,
+                        torch.zeros_like(dqkv_q)[:, :, :Cc], again[:, :, Cc:2 * Cc], again[:, :, 2 * Cc:], B, H, D, nq, nk,
+                        q_ld=ld, k_ld=ld, v_ld=ld, do_ld=Cc, dq_ld=ld, dk_ld=ld, dv_ld=ld,
+                        q_bs=nq * ld, k_bs=nk * ld, v_bs=nk * ld, do_bs=nq * Cc, dq_bs=nq * ld, dk_bs=nk * ld, dv_bs=nk * ld,
+                        bias=bias, flags=flags)
+        assert torch.equal(again, dqkv_k)
 
 
 @pytest.mark.parametrize("xdtype", [torch.float32, torch.float16, torch.bfloat16])
