@@ -234,12 +234,11 @@ def training_step_leg(dev, dtype, cfg, precision=None, views_latent=32, pano_hw=
         out["kernels"] = {k: {"launches": v[2], "ms": v[1] * 1e3, "tflops": v[0] / v[1] / 1e12} for k, v in fam.items()}
         shapes = {}
         for name, fl, e0, e1, tag in trace:
-            if name != "k_conv_gemm":
-                a = shapes.setdefault("%s %s" % (name, tag), [0.0, 0.0, 0])
-                a[0] += fl
-                a[1] += e0.elapsed_time(e1) * 1e-3
-                a[2] += 1
-        out["attention_shapes"] = {k: {"launches": v[2], "ms": v[1] * 1e3, "tflops": v[0] / v[1] / 1e12} for k, v in shapes.items()}
+            a = shapes.setdefault("%s %s" % (name, tag), [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        out["shapes"] = {k: {"launches": v[2], "ms": v[1] * 1e3, "tflops": v[0] / v[1] / 1e12} for k, v in shapes.items()}
     return out
 
 

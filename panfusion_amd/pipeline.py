@@ -220,9 +220,9 @@ def training_step(model, vae_encoder, images, pano, cameras, prompt_embd, pano_p
     random draws (``eps_views``, ``eps_pano`` for the VAE posterior, ``t`` (b,), ``pano_noise`` (b, 1, 4, h, w)) -- what the
     tests fix to compare against the oracle; anything missing is drawn here.
     pers_layout_cond / pano_layout_cond: ``batch.get('images_layout_cond')`` / ``batch.get('pano_layout_cond')`` as the
-    reference passes them (PanFusion.py:85-89).  The ControlNets then run with FROZEN parameters: the gradients reach the EPA
-    blocks and the LoRA matrices through the residual additions; the ControlNet's own weight gradients (the reference's
-    trainable set under layout_cond=True, PanoGenerator.py:153-157) are not implemented."""
+    reference passes them (PanFusion.py:85-89).  Every ControlNet parameter that requires a gradient gets one (the
+    reference's trainable set under layout_cond=True, PanoGenerator.py:153-157: all of them; train_engine.controlnet_backward);
+    a ControlNet frozen with requires_grad_(False) contributes its residuals as constants."""
     from .utils.pano import pad_pano, unpad_pano
     from .vae import encode_image
     draws = draws or {}

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--views-latent", type=int, default=32)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--small", action="store_true")
-    ap.add_argument("--shapes", action="store_true", help="per-shape table of the attention forward / backward launches")
+    ap.add_argument("--shapes", action="store_true", help="per-shape table of the GEMM / attention launches of one step")
     ap.add_argument("--layout-cond", action="store_true", help="layout-conditioned training: the panorama ControlNet trains (all parameters)")
     args = ap.parse_args()
     import bench
@@ -40,7 +40,7 @@ def main():
     for name, k in sorted(r["kernels"].items()):
         print("    %-18s launches %5d  %8.2f ms  %7.1f TF/s" % (name, k["launches"], k["ms"], k["tflops"]))
     if args.shapes:
-        for name, k in sorted(r["attention_shapes"].items(), key=lambda kv: -kv[1]["ms"]):
+        for name, k in sorted(r["shapes"].items(), key=lambda kv: -kv[1]["ms"]):
             print("    %-70s launches %4d  %8.3f ms  %7.1f TF/s" % (name, k["launches"], k["ms"], k["tflops"]))
 
 
