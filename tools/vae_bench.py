@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--precision", default=None)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--views", type=int, default=20)
+    ap.add_argument("--shapes", action="store_true", help="per-shape table of the decode's GEMM launches (device events, one extra pass)")
     args = ap.parse_args()
     from panfusion_amd import vae as PV
     from panfusion_amd.models.sd2_unet_params import fill_synthetic
@@ -31,16 +32,30 @@ def main():
     g = torch.Generator().manual_seed(0)
     lat = torch.randn(1, args.views, 4, 64, 64, generator=g).to(dev)
     pano = torch.randn(1, 1, 4, 64, 128, generator=g).to(dev)
-    flop = (args.views + 144 / 64) * 1.24e12                 # ~1.24 TFLOP per 512^2 image (convs 1.20 + attention 0.04)
+    from panfusion_amd import ops
+    ops.TRACE = []                                           # algorithmic FLOPs of the decode: summed over its MFMA launches
     PV.decode_views_and_pano(lat, pano, dec)
     torch.cuda.synchronize()
+    trace, ops.TRACE = ops.TRACE, None
+    flop = sum(t[1] for t in trace)
     t0 = time.perf_counter()
     for _ in range(args.reps):
         images, pano_img = PV.decode_views_and_pano(lat, pano, dec)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.reps
-    print("VAE decode of %d views + padded panorama, %s %s: %.1f ms  (~%.0f TF/s algorithmic)  peak memory %.1f GB"
-          % (args.views, args.dtype, dec.precision, dt * 1e3, flop / dt / 1e12, torch.cuda.max_memory_allocated() / 2 ** 30))
+    print("VAE decode of %d views + padded panorama, %s %s: %.1f ms  (%.1f TFLOP in its MFMA launches: %.0f TF/s)  peak memory %.1f GB"
+          % (args.views, args.dtype, dec.precision, dt * 1e3, flop / 1e12, flop / dt / 1e12, torch.cuda.max_memory_allocated() / 2 ** 30))
+    if args.shapes:
+        shapes, tot = {}, 0.0
+        for name, fl, e0, e1, tag in trace:
+            a = shapes.setdefault("%s %s" % (name, tag), [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:24]:
+            tot += v[1]
+            print("    %-64s launches %3d  %8.3f ms  %7.1f TF/s" % (k, v[2], v[1] * 1e3, v[0] / v[1] / 1e12))
+        print("    MFMA launches listed: %.1f ms of the decode" % (tot * 1e3))
     # the encoder side of a training step (PanFusion.py:66-71): 20 views of 256^2 + the padded 512 x 1152 panorama
     from panfusion_amd.models.vae_params import VAEEncoderParams
     from panfusion_amd.utils.pano import pad_pano
