@@ -423,6 +423,16 @@ pf_status pf_silu_bwd(const void* z, int dtype, const float* dy, long n, float* 
  * nn.Conv2d in the ControlNet) is then one token-reducing pf_conv_gemm: dW [cout][9 C] = dY^T y. */
 pf_status pf_im2col3(const void* x, int dtype, int n, int h, int w, int C, int stride, void* y, void* stream);
 
+/* LoRA fold, once per projection and optimizer step of a training run (the rank-4 LoRA of models/pano/PanoGenerator.py:129-151
+ * on q / k / v / out of every attention; diffusers LoRALinearLayer: y = W x + scale * up(down(x))):
+ *   out [N][out_ld] (16-bit `dtype`) = W + scale * up @ down,   W fp32 [N][K], up fp32 [N][r], down fp32 [r][K], r <= 16
+ * (r = 0: a plain fp32 -> 16-bit conversion).  Optional by-products for the backward, NULL to skip: out_t [K][out_t_ld] the
+ * transpose of the folded weight; d_out [r][d_ld] = down and u_out [r][u_ld] = up^T in 16 bit (rows / a block of the
+ * stacked matrices the LoRA gradient GEMMs read).  `out` may be a row slice of a larger packed weight. */
+pf_status pf_lora_fold(const float* w, const float* up, const float* down, int N, int K, int r, float scale, int dtype,
+                       void* out, long out_ld, void* out_t, long out_t_ld, void* d_out, long d_ld, void* u_out, long u_ld,
+                       void* stream);
+
 /* Data movement of the backward pass (NHWC):
  *   pf_zero_insert2   y [n][2h][2w][C] = x at the even positions, zero elsewhere (16-bit): the data gradient of a
  *                     stride-2 convolution is the stride-1 convolution of this with the flipped kernel;

@@ -139,6 +139,8 @@ SIGNATURES = {
                                          c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pf_silu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_long, c_void_p, c_void_p]),
     "pf_im2col3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_lora_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p, c_long,
+                             c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "pf_zero_insert2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_sum2x2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_pad_width_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -982,6 +982,59 @@ __global__ void k_im2col3(const u16x8* __restrict__ x, int n, int h, int w, int 
     y[i] = v;
 }
 
+// ---- LoRA fold: W' = W + scale * up @ down, every step of a training run ---------------------------------------------------
+// (PanoGenerator.py:129-151: rank-4 LoRA on q / k / v / out of every attention; the forward kernels read the folded 16-bit weight.)
+// One launch per projection writes, from the fp32 weight and the two thin matrices:
+//   out   [N][out_ld]    the folded weight in the 16-bit operand type (a row slice of the packed (q | k | v) buffer),
+//   out_t [K][out_t_ld]  its transpose (data-gradient operand of the backward), optional,
+//   d_out [r][d_ld]      the down matrix in 16 bit (rows of the group's stacked D), optional,
+//   u_out [r][u_ld]      the up matrix transposed in 16 bit (a block of the group's block-diagonal U), optional.
+// 64 x 64 tiles; the transpose goes through LDS so that both outputs are written in whole rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_lora_fold(const float* __restrict__ w, const float* __restrict__ up, const float* __restrict__ down,
+                                                   int N, int K, int r, float scale, unsigned short* __restrict__ out, long out_ld,
+                                                   unsigned short* __restrict__ out_t, long out_t_ld, unsigned short* __restrict__ d_out,
+                                                   long d_ld, unsigned short* __restrict__ u_out, long u_ld) {
+    __shared__ unsigned short tile[64][66];
+    __shared__ float s_up[64][16], s_down[16][64];
+    const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64, t = threadIdx.x;
+    for (int i = t; i < 64 * r; i += 256) {
+        const int a = i / r, j = i - a * r;                         // up [N][r]: row n0 + a
+        s_up[a][j] = (up && n0 + a < N) ? up[static_cast<long>(n0 + a) * r + j] : 0.f;
+        const int jj = i / 64, b = i - jj * 64;                     // down [r][K]: column k0 + b
+        s_down[jj][b] = (down && k0 + b < K) ? down[static_cast<long>(jj) * K + k0 + b] : 0.f;
+    }
+    __syncthreads();
+    const int kl = t & 63;
+    for (int nl = t >> 6; nl < 64; nl += 4) {
+        const int n = n0 + nl, k = k0 + kl;
+        unsigned short v = 0;
+        if (n < N && k < K) {
+            float acc = 0.f;
+            for (int j = 0; j < r; ++j) acc += s_up[nl][j] * s_down[j][kl];
+            v = from_f32<T>(w[static_cast<long>(n) * K + k] + scale * acc);
+            out[static_cast<long>(n) * out_ld + k] = v;
+        }
+        tile[nl][kl] = v;
+    }
+    if (out_t) {
+        __syncthreads();
+        const int nl = t & 63;
+        for (int kk = t >> 6; kk < 64; kk += 4)
+            if (n0 + nl < N && k0 + kk < K) out_t[static_cast<long>(k0 + kk) * out_t_ld + n0 + nl] = tile[nl][kk];
+    }
+    if (d_out && blockIdx.y == 0)
+        for (int i = t; i < 64 * r; i += 256) {
+            const int j = i / 64, b = i - j * 64;
+            if (k0 + b < K) d_out[static_cast<long>(j) * d_ld + k0 + b] = from_f32<T>(s_down[j][b]);
+        }
+    if (u_out && blockIdx.x == 0)
+        for (int i = t; i < 64 * r; i += 256) {
+            const int j = i / 64, a = i - j * 64;
+            if (n0 + a < N) u_out[static_cast<long>(j) * u_ld + n0 + a] = from_f32<T>(s_up[a][j]);
+        }
+}
+
 // ---- data movement of the backward pass ---------------------------------------------------------------------------
 // zero insertion (data gradient of a stride-2 convolution = stride-1 convolution of the zero-stuffed gradient with the
 // flipped kernel): y[n][2i][2j] = x[n][i][j], zero elsewhere; 16-bit octets.
@@ -1480,6 +1533,22 @@ extern "C" pf_status pf_im2col3(const void* x, int dtype, int n, int h, int w, i
     hipLaunchKernelGGL(k_im2col3, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), static_cast<const u16x8*>(x), n, h, w, C / 8, stride, ho, wo,
                        static_cast<u16x8*>(y));
     PF_CHECK_LAUNCH("pf_im2col3");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_lora_fold(const float* w, const float* up, const float* down, int N, int K, int r, float scale, int dtype,
+                                  void* out, long out_ld, void* out_t, long out_t_ld, void* d_out, long d_ld, void* u_out, long u_ld,
+                                  void* stream) {
+    PF_REQUIRE(w && out && N > 0 && K > 0, "pf_lora_fold: bad arguments");
+    PF_REQUIRE(r >= 0 && r <= 16 && (r == 0 || (up && down)), "pf_lora_fold: rank %d unsupported (0..16, with both matrices)", r);
+    PF_REQUIRE(out_ld >= K && (!out_t || out_t_ld >= N) && (!d_out || d_ld >= K) && (!u_out || u_ld >= N), "pf_lora_fold: leading dimensions too small");
+    PF_REQUIRE(cdiv(N, 64) <= 65535, "pf_lora_fold: too many rows");
+    const dim3 grid(cdiv(K, 64), cdiv(N, 64)), block(256);
+    PF_DISPATCH_16(dtype, "pf_lora_fold",
+        hipLaunchKernelGGL(k_lora_fold<T>, grid, block, 0, as_stream(stream), w, up, down, N, K, r, scale, static_cast<unsigned short*>(out), out_ld,
+                           static_cast<unsigned short*>(out_t), out_t_ld, static_cast<unsigned short*>(d_out), d_ld,
+                           static_cast<unsigned short*>(u_out), u_ld));
+    PF_CHECK_LAUNCH("pf_lora_fold");
     return PF_OK;
 }
 

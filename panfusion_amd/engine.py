@@ -53,35 +53,6 @@ def _w16(t, dev, dtype):
     return t.detach().to(device=dev, dtype=torch.float32).to(dtype).contiguous()
 
 
-def _lora_delta(lora):
-    """up @ down of a diffusers LoRALinearLayer (scale network_alpha / rank when an alpha is set)."""
-    down, up = lora.down.weight.detach().float(), lora.up.weight.detach().float()
-    delta = up @ down
-    alpha = getattr(lora, "network_alpha", None)
-    if alpha is not None:
-        delta = delta * (float(alpha) / down.shape[0])
-    return delta
-
-
-def _lin_weight(lin, processor_lora=None):
-    """Effective weight of a (LoRA-compatible) linear: W + up @ down (PanoGenerator.py:132-151, rank-4 LoRA
-    with scale 1 folded for inference).  The LoRA matrices live in ONE of two places:
-      * ``lin.lora_layer.{down,up}`` -- where diffusers 0.24 keeps them after the first Attention.forward
-        migrated them out of the processor (and where its own saved checkpoints have them);
-      * ``attn.processor.to_{q,k,v,out}_lora.{down,up}`` (``processor_lora``) -- where
-        ``unet.set_attn_processor(LoRAAttnProcessor(...))`` puts them and where a reference checkpoint
-        loads them (convert_state_dict, PanoGenerator.py:101-111).  This engine never calls the modules'
-        forward, so the migration never happens: both places are read here."""
-    w = lin.weight.detach().float()
-    own = getattr(lin, "lora_layer", None)
-    if own is not None and processor_lora is not None:
-        raise ValueError("LoRA weights found both in <linear>.lora_layer and in the attention processor")
-    lora = own if own is not None else processor_lora
-    if lora is not None:
-        w = w + _lora_delta(lora)
-    return w
-
-
 def _processor_lora(attn, name):
     """attn.processor.to_{q,k,v,out}_lora of an un-migrated diffusers LoRAAttnProcessor, or None."""
     proc = getattr(attn, "processor", None)
@@ -173,21 +144,76 @@ def run_resnet_plain(r, x):
     return run_resnet(r, x, None, None)
 
 
+def _current_lora(attn, name, lin):
+    """The LoRA layer of one projection (PanoGenerator.py:132-151, rank-4 LoRA with scale 1), or None.  The LoRA matrices live
+    in ONE of two places:
+      * ``lin.lora_layer.{down,up}`` -- where diffusers 0.24 keeps them after the first Attention.forward migrated them out
+        of the processor (and where its own saved checkpoints have them);
+      * ``attn.processor.to_{q,k,v,out}_lora.{down,up}`` -- where ``unet.set_attn_processor(LoRAAttnProcessor(...))`` puts
+        them and where a reference checkpoint loads them (convert_state_dict, PanoGenerator.py:101-111).  This engine never
+        calls the modules' forward, so the migration never happens: both places are read here."""
+    own = getattr(lin, "lora_layer", None)
+    proc = _processor_lora(attn, name + "_lora")
+    if own is not None and proc is not None:
+        raise ValueError("LoRA weights found both in <linear>.lora_layer and in the attention processor")
+    return own if own is not None else proc
+
+
+def _dev32(t, dev):
+    """fp32, contiguous, on the device -- the tensor itself when it already is (no copy of a frozen GPU weight)."""
+    t = t.detach()
+    if t.dtype == torch.float32 and t.device == torch.device(dev) and t.is_contiguous():
+        return t
+    return t.to(device=dev, dtype=torch.float32).contiguous()
+
+
 def pack_attention(attn, dev, dtype, self_attn):
+    """16-bit operands of one attention in PERSISTENT buffers: self-attention (q | k | v) rows of one [3C, C] tensor (the forward
+    reads its (q | k) prefix and its v rows, the backward all of it), cross-attention q and (k | v), the output projection.
+    ``a.proj[name]`` records where each projection's folded weight W + up @ down goes; fold_attention (re)writes them IN PLACE
+    -- after an optimizer step on the LoRA matrices (MultiViewBaseModel.refold_lora) nothing is re-allocated, captured
+    graphs and the backward's operands keep their addresses."""
     a = NS()
-    a.heads = attn.heads
-    wq = _lin_weight(attn.to_q, _processor_lora(attn, "to_q_lora"))
-    wk = _lin_weight(attn.to_k, _processor_lora(attn, "to_k_lora"))
-    wv = _lin_weight(attn.to_v, _processor_lora(attn, "to_v_lora"))
-    a.dim = wq.shape[0]
+    a.heads, a.src, a.dtype, a.self_attn = attn.heads, attn, dtype, self_attn
+    Cc, Dk = attn.to_q.weight.shape[0], attn.to_k.weight.shape[1]
+    a.dim = Cc
+    buf = lambda rows, cols: torch.empty(rows, cols, device=dev, dtype=dtype)
     if self_attn:
-        a.wqk = _w16(torch.cat([wq, wk], 0), dev, dtype)
+        a.wqkv = buf(3 * Cc, Cc)
+        a.wqk, a.wv = a.wqkv[:2 * Cc], a.wqkv[2 * Cc:]
+        dst = {"to_q": a.wqkv[:Cc], "to_k": a.wqkv[Cc:2 * Cc], "to_v": a.wv}
     else:
-        a.wq, a.wk = _w16(wq, dev, dtype), _w16(wk, dev, dtype)
-    a.wv = _w16(wv, dev, dtype)
-    a.wo = _w16(_lin_weight(attn.to_out[0], _processor_lora(attn, "to_out_lora")), dev, dtype)
+        a.wq, a.wkv = buf(Cc, Cc), buf(2 * Cc, Dk)
+        a.wk, a.wv = a.wkv[:Cc], a.wkv[Cc:]
+        dst = {"to_q": a.wq, "to_k": a.wk, "to_v": a.wv}
+    a.wo = buf(Cc, Cc)
+    dst["to_out"] = a.wo
+    a.proj = {}
+    for name, d in dst.items():
+        lin = attn.to_out[0] if name == "to_out" else getattr(attn, name)
+        # (w32: the frozen fp32 weight on the device -- the parameter itself when the module lives there)
+        a.proj[name] = NS(lin=lin, dst=d, w32=_dev32(lin.weight, dev), dst_t=None, d_dst=None, u_dst=None)
     a.bo = _bias(attn.to_out[0], dev)
+    fold_attention(a, everything=True)
     return a
+
+
+def fold_attention(a, everything=False):
+    """Write W + scale * up @ down of every LoRA-carrying projection of the packed attention `a` into its buffers (one
+    pf_lora_fold launch each: folded weight, and -- once train_engine attached them -- its transpose and the 16-bit copies of
+    the LoRA matrices the gradient GEMMs read).  everything: also the projections without LoRA (first packing / newly attached
+    backward buffers); a re-fold after an optimizer step skips them, they cannot have changed."""
+    dev = a.wo.device
+    for name, pr in a.proj.items():
+        lora = _current_lora(a.src, name, pr.lin)
+        if lora is None:
+            if everything:
+                ops.lora_fold(pr.w32, None, None, 0.0, pr.dst, out_t=pr.dst_t)
+            continue
+        alpha = getattr(lora, "network_alpha", None)
+        rank = lora.down.weight.shape[0]
+        ops.lora_fold(pr.w32, _dev32(lora.up.weight, dev), _dev32(lora.down.weight, dev),
+                      1.0 if alpha is None else float(alpha) / rank, pr.dst, out_t=pr.dst_t, d_out=pr.d_dst, u_out=pr.u_dst)
 
 
 def pack_transformer(tf, dev, dtype, mixed=False):

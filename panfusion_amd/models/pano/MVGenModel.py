@@ -191,8 +191,9 @@ class MultiViewBaseModel(nn.Module):
     def refold_lora(self):
         """Bring the packed attention projections up to date when a LoRA matrix changed since the pack was built / last
         re-folded (optimizer steps and in-place copies bump the version counters): the forward kernels read
-        W + up @ down folded into one 16-bit weight.  Only the 4 x 32 projections per UNet are re-folded; the frozen
-        weights (and the backward operands train_engine keeps next to them) stay.  Called at the top of EVERY forward --
+        W + up @ down folded into one 16-bit weight.  Only the 4 x 32 projections per UNet are re-folded, IN PLACE
+        (engine.fold_attention: one kernel launch each, which also refreshes the backward's operands once a training step has
+        attached them); the frozen weights stay.  Called at the top of EVERY forward --
         also the no_grad ones (validation / predict after fit, DenoiseLoop): the key is a tuple of ~600 ints."""
         if not self._packed:
             return
@@ -201,10 +202,8 @@ class MultiViewBaseModel(nn.Module):
             if which.endswith("_cn") or getattr(u, "lora_key", key) == key:
                 continue
             for t in engine.all_transformers(u):
-                blk = t.src.transformer_blocks[0]
-                dev = t.w_in.device
-                t.attn1 = engine.pack_attention(blk.attn1, dev, t.dtype, True)
-                t.attn2 = engine.pack_attention(blk.attn2, dev, t.dtype, False)
+                engine.fold_attention(t.attn1)          # in place: one launch per LoRA-carrying projection
+                engine.fold_attention(t.attn2)
             u.__dict__.pop("text_kv_cache", None)          # K / V^T of the prompt depend on to_k / to_v
             u.lora_key = key
 

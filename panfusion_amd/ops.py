@@ -697,6 +697,22 @@ def im2col3(x, stride=1):
     return out
 
 
+def lora_fold(w, up, down, scale, out, out_t=None, d_out=None, u_out=None):
+    """out [N, K] (16-bit, rows may be a slice of a packed weight) = w + scale * up @ down from fp32 w [N, K], up [N, r],
+    down [r, K] (up = down = None: a plain conversion); optional by-products out_t [K, >= N] (transpose), d_out [r, >= K] (down)
+    and u_out [r, >= N] (up^T) in the same 16-bit type, each a (possibly column-offset) view with contiguous rows."""
+    N, K = w.shape
+    r = 0 if up is None else up.shape[1]
+    for t_ in (w, up, down):
+        assert t_ is None or (t_.dtype == torch.float32 and t_.is_contiguous() and t_.device == out.device)
+    for t_ in (out, out_t, d_out, u_out):
+        assert t_ is None or (t_.stride(-1) == 1 and t_.dtype == out.dtype)
+    ld = lambda t_: 0 if t_ is None else t_.stride(0)
+    check(_lib.lib().pf_lora_fold(_p(w), _p(up), _p(down), N, K, r, float(scale), dt(out), _p(out), ld(out), _p(out_t), ld(out_t),
+                                  _p(d_out), ld(d_out), _p(u_out), ld(u_out), _stream()), "pf_lora_fold")
+    return out
+
+
 def zero_insert2(x):
     """x NHWC 16-bit [n, h, w, C] -> [n, 2h, 2w, C] with x at the even positions (stride-2 conv data gradient)."""
     n, h, w, Cc = x.shape

@@ -145,7 +145,7 @@ def _scaled(wsink, state):
 
 # ---------------------------------------------------------------------------------------------- LoRA
 class LoRARef:
-    """One rank-r LoRA pair of a projection: W' = W + s * up @ down (engine._lin_weight folds it for the forward)."""
+    """One rank-r LoRA pair of a projection: W' = W + s * up @ down (engine.fold_attention folds it for the forward)."""
 
     def __init__(self, lora):
         self.down, self.up = lora.down.weight, lora.up.weight               # [r, K], [N, r]
@@ -166,9 +166,11 @@ class LoRAGroup:
         Q^T = U_bd dY^T      U_bd = the up^T matrices on a block diagonal      [R, N] x [T, N]^T -> [R, T]
         d_up   = dY^T P      [N, T] x [R, T]^T -> [N, R]    (pair i: rows of block i, columns of block i)
         d_down = Q^T X       [R, T] x [K, T]^T -> [R, K]    (pair i: rows of block i)
-    with R = sum of the ranks (rounded up to 4) and the reductions over tokens on token-contiguous operands."""
+    with R = sum of the ranks (rounded up to 4) and the reductions over tokens on token-contiguous operands.
+    D and U are allocated ONCE (zero outside the blocks); their blocks are (re)written by engine.fold_attention together with
+    the folded weights -- `projs`: the packed attention's projection records, which get the views to write to."""
 
-    def __init__(self, refs, widths, dev, dtype):
+    def __init__(self, refs, widths, projs, dev, dtype):
         self.refs, self.widths = refs, widths
         self.live = [(i, r) for i, r in enumerate(refs) if r is not None]
         if not self.live:
@@ -177,17 +179,16 @@ class LoRAGroup:
         N = sum(widths)
         ranks = [r.down.shape[0] for _, r in self.live]
         self.R = (sum(ranks) + 3) // 4 * 4
-        D = torch.zeros(self.R, K, device=dev, dtype=F32)
-        U = torch.zeros(self.R, N, device=dev, dtype=F32)
+        self.D = torch.zeros(self.R, K, device=dev, dtype=dtype)
+        self.U = torch.zeros(self.R, N, device=dev, dtype=dtype)
         self.slots = []
         row = 0
         for (i, ref), rk in zip(self.live, ranks):
             col = sum(widths[:i])
-            D[row:row + rk] = ref.down.detach().to(device=dev, dtype=F32)
-            U[row:row + rk, col:col + widths[i]] = ref.up.detach().to(device=dev, dtype=F32).t()
+            projs[i].d_dst = self.D[row:row + rk]
+            projs[i].u_dst = self.U[row:row + rk, col:col + widths[i]]
             self.slots.append((ref, row, rk, col, widths[i]))
             row += rk
-        self.D, self.U = D.to(dtype), U.to(dtype)
 
     def grads(self, x16, xt16, dy16, dyt16, sink):
         """x16 [T, K] / xt16 [K, T], dy16 [T, N] / dyt16 [N, T] (16-bit, T a multiple of 64)."""
@@ -236,37 +237,52 @@ def resnet_train(r, dev):
     return tw
 
 
-def _attn_train(a, attn, dev, dtype, self_attn, key):
-    """Forward + backward operands of one attention with the CURRENT LoRA matrices folded in: taken from the inference
-    pack `a`, which MultiViewBaseModel.refold_lora brought up to date in this step's forward (W + up @ down, 16 bit)."""
-    t = NS(key=key, heads=a.heads, dim=a.dim)
+def _attn_train(a, attn, dev, dtype, self_attn):
+    """Forward + backward operands of one attention, built ONCE per inference pack `a` and kept on it: the folded weights are
+    the pack's own buffers, their transposes (data-gradient operands) and the LoRA groups' stacked matrices are allocated here
+    and registered with the pack's projection records -- from then on engine.fold_attention (MultiViewBaseModel.refold_lora, at
+    the top of every forward) rewrites all of them in place when a LoRA matrix changed.  Rebuilt only when the set of
+    attached LoRA modules changes."""
+    names = ("to_q", "to_k", "to_v", "to_out")
+    ref = {n: lora_of(attn, a.proj[n].lin, n + "_lora") for n in names}
+    ids = tuple(0 if ref[n] is None else id(ref[n].down) for n in names)
+    t = getattr(a, "train", None)
+    if t is not None and t.lora_ids == ids:
+        return t
+    t = NS(lora_ids=ids, heads=a.heads, dim=a.dim)
     Cc = a.dim
+    pr = a.proj
+    for p_ in pr.values():
+        p_.dst_t = p_.d_dst = p_.u_dst = None
     if self_attn:
-        t.wqkv = torch.cat([a.wqk, a.wv], 0)                                     # [3C, C] = (q | k | v)
-        t.wqkv_t = t.wqkv.t().contiguous()
+        t.wqkv = a.wqkv                                                          # [3C, C] = (q | k | v)
+        t.wqkv_t = torch.empty(Cc, 3 * Cc, device=dev, dtype=dtype)
+        for i, n in enumerate(names[:3]):
+            pr[n].dst_t = t.wqkv_t[:, i * Cc:(i + 1) * Cc]
+        t.lora_qkv = LoRAGroup([ref["to_q"], ref["to_k"], ref["to_v"]], [Cc, Cc, Cc], [pr[n] for n in names[:3]], dev, dtype)
     else:
-        t.wq, t.wq_t = a.wq, a.wq.t().contiguous()
-        t.wkv = torch.cat([a.wk, a.wv], 0)
+        t.wq, t.wq_t = a.wq, torch.empty(Cc, Cc, device=dev, dtype=dtype)
+        pr["to_q"].dst_t = t.wq_t
+        t.wkv = a.wkv
+        t.lora_q = LoRAGroup([ref["to_q"]], [Cc], [pr["to_q"]], dev, dtype)
+        t.lora_kv = LoRAGroup([ref["to_k"], ref["to_v"]], [Cc, Cc], [pr["to_k"], pr["to_v"]], dev, dtype)
     t.wv = a.wv
-    t.wo, t.wo_t, t.bo = a.wo, a.wo.t().contiguous(), a.bo
-    ref = {n: lora_of(attn, lin, n + "_lora") for n, lin in (("to_q", attn.to_q), ("to_k", attn.to_k), ("to_v", attn.to_v), ("to_out", attn.to_out[0]))}
-    if self_attn:
-        t.lora_qkv = LoRAGroup([ref["to_q"], ref["to_k"], ref["to_v"]], [Cc, Cc, Cc], dev, dtype)
-    else:
-        t.lora_q = LoRAGroup([ref["to_q"]], [Cc], dev, dtype)
-        t.lora_kv = LoRAGroup([ref["to_k"], ref["to_v"]], [Cc, Cc], dev, dtype)
-    t.lora_out = LoRAGroup([ref["to_out"]], [Cc], dev, dtype)
+    t.wo, t.wo_t, t.bo = a.wo, torch.empty(Cc, Cc, device=dev, dtype=dtype), a.bo
+    pr["to_out"].dst_t = t.wo_t
+    t.lora_out = LoRAGroup([ref["to_out"]], [Cc], [pr["to_out"]], dev, dtype)
+    engine.fold_attention(a, everything=True)                                    # fills the new buffers (and the weights again)
+    a.train = t
     return t
 
 
 def transformer_train(t, dev):
-    """Backward operands of a packed transformer: the frozen parts once, the LoRA-carrying attentions whenever a LoRA
-    matrix changed (optimizer steps bump the parameters' version counters)."""
+    """Backward operands of a packed transformer: the frozen parts once; the LoRA-carrying attentions' operands live on the
+    inference pack and are refreshed in place with the folded weights (_attn_train)."""
     src = t.src
     blk = src.transformer_blocks[0]
     tw = getattr(t, "train", None)
     if tw is None:
-        tw = NS(attn_key=None)
+        tw = NS()
         tw.w_in, tw.w_in_t = _w16(src.proj_in.weight.reshape(src.proj_in.weight.shape[0], -1), dev, t.dtype), \
             _t16(src.proj_in.weight.reshape(src.proj_in.weight.shape[0], -1), dev, t.dtype)
         tw.w_out_t = _t16(src.proj_out.weight.reshape(src.proj_out.weight.shape[0], -1), dev, t.dtype)
@@ -278,13 +294,8 @@ def transformer_train(t, dev):
         tw.w1, tw.w1_t, tw.b1 = _w16(ff1.weight, dev, t.dtype), _t16(ff1.weight, dev, t.dtype), engine._bias(ff1, dev)
         tw.w2, tw.w2_t = _w16(ff2.weight, dev, t.dtype), _t16(ff2.weight, dev, t.dtype)
         t.train = tw
-    loras = [p for a in (blk.attn1, blk.attn2) for n, lin in (("to_q", a.to_q), ("to_k", a.to_k), ("to_v", a.to_v), ("to_out", a.to_out[0]))
-             for ref in [lora_of(a, lin, n + "_lora")] if ref is not None for p in (ref.down, ref.up)]
-    key = tuple((p.data_ptr(), p._version) for p in loras)
-    if tw.attn_key != key:
-        tw.attn1 = _attn_train(t.attn1, blk.attn1, dev, t.dtype, True, key)
-        tw.attn2 = _attn_train(t.attn2, blk.attn2, dev, t.dtype, False, key)
-        tw.attn_key = key
+    tw.attn1 = _attn_train(t.attn1, blk.attn1, dev, t.dtype, True)
+    tw.attn2 = _attn_train(t.attn2, blk.attn2, dev, t.dtype, False)
     return tw
 
 

@@ -500,6 +500,19 @@ def im2col3(x, stride=1):
     return torch.stack(taps, 3).reshape(n * ho * wo, 9 * Cc)
 
 
+def lora_fold(w, up, down, scale, out, out_t=None, d_out=None, u_out=None):
+    f = w if up is None else w + scale * (up @ down)
+    N, K = w.shape
+    out.copy_(f.to(out.dtype))
+    if out_t is not None:
+        out_t[:K, :N].copy_(out.t())
+    if d_out is not None:
+        d_out[:, :K].copy_(down.to(out.dtype))
+    if u_out is not None:
+        u_out[:, :N].copy_(up.t().to(out.dtype))
+    return out
+
+
 def zero_insert2(x):
     n, h, w, C = x.shape
     y = torch.zeros(n, 2 * h, 2 * w, C, dtype=x.dtype)

@@ -327,6 +327,29 @@ def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, to
     assert eo < tol_out and allg < tol_grad and errs[0][0] < 4 * tol_grad, (eo, allg, errs[:4])
 
 
+@pytest.mark.parametrize("dtype", D16)
+@pytest.mark.parametrize("N,K,r", [(320, 320, 4), (1280, 1024, 4), (640, 640, 16), (96, 200, 3), (320, 320, 0)])
+def test_lora_fold_kernel(dtype, N, K, r):
+    """pf_lora_fold: W + scale * up @ down in the operand type (bit-identical to torch's fp32 sum rounded once), written into a
+    row slice of a packed weight, with its transpose and the 16-bit copies of down / up^T as by-products."""
+    o = ops()
+    w = rnd(N, K, seed=1)
+    up, down = (rnd(N, r, seed=2) * 0.1, rnd(r, K, seed=3) * 0.1) if r else (None, None)
+    packed = torch.full((N + 64, K), 7.0, device=DEV, dtype=dtype)
+    out_t = torch.full((K, N + 32), 7.0, device=DEV, dtype=dtype)
+    D = torch.zeros(max(r, 1) + 4, K + 8, device=DEV, dtype=dtype)
+    Ubd = torch.zeros(max(r, 1) + 4, N + 16, device=DEV, dtype=dtype)
+    o.lora_fold(w, up, down, 0.5, packed[64:], out_t=out_t[:, 32:], d_out=D[4:, 8:] if r else None, u_out=Ubd[4:, 16:] if r else None)
+    ref = w + 0.5 * (up @ down) if r else w
+    # (the kernel accumulates the r products in order in fp32; torch's matmul may associate differently: one ulp of fp32)
+    assert rel_l2(packed[64:].float().cpu(), ref.cpu()) < (6e-4 if dtype == torch.float16 else 5e-3)
+    assert (packed[64:].float() - ref.to(dtype).float()).abs().max() <= ref.abs().max() * (2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6)
+    assert torch.equal(out_t[:, 32:], packed[64:].t()) and (packed[:64] == 7).all() and (out_t[:, :32] == 7).all()
+    if r:
+        assert torch.equal(D[4:, 8:], down.to(dtype)) and torch.equal(Ubd[4:, 16:], up.t().to(dtype))
+        assert not D[:4].any() and not D[:, :8].any() and not Ubd[:4].any() and not Ubd[:, :16].any()
+
+
 # ------------------------------------------------------------------------------------ the trainable ControlNet
 @pytest.mark.parametrize("xdtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("n,hw,c0,c1,groups,act", [(3, 24 * 17, 64, 32, 32, 1), (2, 1024, 320, 0, 32, 1), (1, 64, 1280, 1280, 32, 0),

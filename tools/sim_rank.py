@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--precision", default=None, choices=["mixed", "fast"])
+    ap.add_argument("--shapes", type=int, default=0, help="also print the N most expensive GEMM / attention shapes of one eager step of the rank")
     args = ap.parse_args()
     import bench
     from panfusion_amd import sharding
@@ -70,6 +71,31 @@ def main():
         print("world %d rank %d  %-60s %7.2f ms/step  (graphs %s)" % (args.world, rank, "%s %s %s" % (loop.layout_desc, args.dtype, model.precision), ms, loop.use_graphs), flush=True)
         del model, loop
         torch.cuda.empty_cache()
+        if args.shapes:
+            from panfusion_amd import ops
+            model, loop = sharding.build_sharded(bench.build_model, bench.build_inputs, dev, dtype, cfg, 20, (64, 64), (64, 128),
+                                                 cams_deg, 4, False, precision=args.precision)
+            loop.prepare()
+            loop.step()
+            torch.cuda.synchronize()
+            ops.TRACE = []
+            loop.step()
+            torch.cuda.synchronize()
+            trace, ops.TRACE = ops.TRACE, None
+            shapes, fam = {}, {}
+            for name, fl, e0, e1, tag in trace:
+                dt = e0.elapsed_time(e1) * 1e-3
+                for d, k in ((shapes, "%s %s" % (name, tag)), (fam, name)):
+                    a = d.setdefault(k, [0.0, 0.0, 0])
+                    a[0] += fl
+                    a[1] += dt
+                    a[2] += 1
+            for k, v in fam.items():
+                print("    %-64s launches %4d  %8.3f ms  %7.1f TF/s" % (k + " (all)", v[2], v[1] * 1e3, v[0] / v[1] / 1e12))
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:args.shapes]:
+                print("    %-64s launches %4d  %8.3f ms  %7.1f TF/s" % (k, v[2], v[1] * 1e3, v[0] / v[1] / 1e12))
+            del model, loop
+            torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--views-latent", type=int, default=32)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--small", action="store_true")
+    ap.add_argument("--no-trace", action="store_true", help="skip the instrumented extra step (profiling runs)")
     ap.add_argument("--shapes", action="store_true", help="per-shape table of the GEMM / attention launches of one step")
     ap.add_argument("--layout-cond", action="store_true", help="layout-conditioned training: the panorama ControlNet trains (all parameters)")
     args = ap.parse_args()
@@ -33,11 +34,11 @@ def main():
     if args.small:
         cfg.update(block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4), cross_attention_dim=128)
         lat, pano_hw = 16, (16, 32)
-    r = bench.training_step_leg(dev, dtype, cfg, args.precision, lat, pano_hw, args.steps, want_trace=True, layout_cond=args.layout_cond)
+    r = bench.training_step_leg(dev, dtype, cfg, args.precision, lat, pano_hw, args.steps, want_trace=not args.no_trace, layout_cond=args.layout_cond)
     print("training step (%s %s): %s: %.1f ms / step (forward alone %.1f ms), loss %.4f, %d / %d trainable tensors with gradients, "
           "peak memory %.1f GB" % (args.dtype, r["precision"], r["workload"], r["ms_per_step"], r["forward_only_ms"], r["loss"],
                                    r["with_gradient"], r["trainable_tensors"], r["peak_memory_gb"]))
-    for name, k in sorted(r["kernels"].items()):
+    for name, k in sorted(r.get("kernels", {}).items()):
         print("    %-18s launches %5d  %8.2f ms  %7.1f TF/s" % (name, k["launches"], k["ms"], k["tflops"]))
     if args.shapes:
         for name, k in sorted(r["shapes"].items(), key=lambda kv: -kv[1]["ms"]):
