@@ -20,6 +20,9 @@ _DT = {torch.bfloat16: PF_BF16, torch.float16: PF_F16, torch.float32: PF_F32}
 TRACE = None
 
 
+SPLITK_INKERNEL = os.environ.get("PF_SPLITK_INKERNEL") == "1"    # A/B switch, read once (as the library reads it)
+
+
 def _traced(name, flops, launch, tag=""):
     if TRACE is None:
         return launch()
@@ -439,7 +442,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     nbytes = _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
     ws = torch.empty(nbytes, device=a0.device, dtype=torch.uint8) if nbytes else None   # split-K slabs
     d.workspace, d.workspace_bytes = _p(ws), nbytes
-    if nbytes and os.environ.get("PF_SPLITK_INKERNEL") == "1":
+    if nbytes and SPLITK_INKERNEL:
         # a split-K plan, combined inside the launch by the last-arriving workgroup (off by default: it does not pay at these
         # tile sizes, DESIGN.md 11.4 -- and without it no counter ring has to exist before a graph capture)
         d.tickets, d.n_tickets = _ticket_slice(a0.device), _TICKET_SLICE

@@ -846,9 +846,9 @@ def test_split_k_combined_in_kernel_equals_the_reduce_kernel(dtype, case, monkey
     elif what == "res16":
         kw["residual"] = q16(rnd(M, cout, seed=114), dtype)[0]
     assert o.gemm_workspace_bytes(x, wt, cout, n_img=n, h_in=h, w_in=w, ksize=ks, pad=ks // 2) > 0, "not a split-K plan: %s" % (case,)
-    monkeypatch.setenv("PF_SPLITK_INKERNEL", "0")
+    monkeypatch.setattr(o, "SPLITK_INKERNEL", False)             # (ops reads PF_SPLITK_INKERNEL once, at import)
     ref = o.conv_gemm(x, wt, cout, **kw)
-    monkeypatch.setenv("PF_SPLITK_INKERNEL", "1")
+    monkeypatch.setattr(o, "SPLITK_INKERNEL", True)
     for _ in range(6):
         got = o.conv_gemm(x, wt, cout, **kw)
         assert torch.equal(got, ref)
@@ -860,9 +860,8 @@ def test_split_k_combined_in_kernel_equals_the_reduce_kernel(dtype, case, monkey
 def test_split_k_in_kernel_under_concurrent_streams():
     """Uneven load: split-K launches of two streams interleave on the chip (the panorama branch runs beside the view
     branch); every result must equal the serial one."""
-    import os
-    os.environ["PF_SPLITK_INKERNEL"] = "1"                     # (off by default: it does not pay; kept correct and tested)
     o = ops()
+    saved, o.SPLITK_INKERNEL = o.SPLITK_INKERNEL, True            # (off by default: it does not pay; kept correct and tested)
     dtype = torch.float16
     mk = lambda n, hh, ww, ci, co, seed: (q16(rnd(n, hh, ww, ci, seed=seed), dtype)[0],
                                            q16(rnd(co, 9 * ci, seed=seed + 1) / (9 * ci) ** 0.5, dtype)[0], n, hh, ww, co)
@@ -879,6 +878,6 @@ def test_split_k_in_kernel_under_concurrent_streams():
             bb = [run(probs[1]), run(probs[2])]
         outs.append((a, bb))
     torch.cuda.synchronize()
-    os.environ.pop("PF_SPLITK_INKERNEL", None)
+    o.SPLITK_INKERNEL = saved
     for a, bb in outs:
         assert torch.equal(a[0], want[0]) and torch.equal(a[1], want[3]) and torch.equal(bb[0], want[1]) and torch.equal(bb[1], want[2])
