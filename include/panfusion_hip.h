@@ -458,6 +458,18 @@ size_t pf_colsum_workspace_size(long rows, int N);
 pf_status pf_colsum(const void* x, int dtype, long rows, int N, long ld, float* out, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* Weighted column sums, the token-reducing half of the LoRA gradients (rank-4 LoRA of PanoGenerator.py:129-151 under autograd:
+ * d_up = dY^T (X down^T), d_down = (dY up)^T X):  out[r][c] = scale * sum_t w[r][t] * x[t][c]  for x [T][C] 16-bit row-major
+ * (row stride ld) and w fp32 [R][w_ld >= T], R = 4, 8, 12 or 16.  x is read once as the backward holds it (no transposed copy); partial
+ * sums per row slab are added in a fixed order.  scale = host_scale * (*dev_scale if given: the gradient-normalisation factor
+ * on the device).  blocks (host, n_blocks x 4 ints (row0, rows, col0, cols), n_blocks <= 4): when given, only these blocks of
+ * [R][C] are written, one after the other, block b TRANSPOSED as [cols_b][rows_b] (the [N_i][rank] layout of a LoRA up
+ * matrix); else out is [R][C].  workspace: pf_weighted_colsum_workspace_size(T, C, R) bytes. */
+size_t pf_weighted_colsum_workspace_size(long T, int C, int R);
+pf_status pf_weighted_colsum(const void* x, int dtype, long T, int C, long ld, const float* w, int R, long w_ld,
+                             const float* dev_scale, float host_scale, const int* blocks, int n_blocks, float* out,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* Gradient normalisation for 16-bit backward operands.  state: 4 floats on the device.
  *   pf_amax_f32: state[0] = max(state[0], max |x|) (reset = 1 clears it first);
  *   pf_pow2_scale: state[1] = 2^-e with amax * 2^-e in [1, 2) (1 when amax is 0 or not finite), state[2] = 2^e;

@@ -141,6 +141,9 @@ SIGNATURES = {
     "pf_im2col3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_lora_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p, c_long,
                              c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "pf_weighted_colsum_workspace_size": (c_size_t, [c_long, c_int, c_int]),
+    "pf_weighted_colsum": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_int, c_long, c_void_p, c_float, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
     "pf_zero_insert2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_sum2x2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_pad_width_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

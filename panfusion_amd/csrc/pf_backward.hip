@@ -1175,6 +1175,94 @@ __global__ void k_colsum_final(const float* __restrict__ part, int slabs, int N,
     out[col] = acc;
 }
 
+// ---- weighted column sums: out[r][c] = sum_t w[r][t] * x[t][c] -------------------------------------------------------------
+// The token-reducing half of the LoRA gradients (d_up = dY^T P, d_down = Q^T X with P = X down^T, Q = dY up: R <= 16 columns):
+// x is read ONCE, row-major as the backward holds it -- no transposed copy, no 64-row MFMA tile for a 4-row product.
+// Partial sums per (row slab, 4 row phases) in a fixed order, then a final pass that also applies the gradient-normalisation
+// factor and lays the result out per LoRA pair.
+struct WcsBlocks { int n; int row0[4], rows[4], col0[4], cols[4]; };
+
+template <typename T16, int RQ>                                     // R = 4 RQ weight rows (compile time: the row loop must not branch)
+__global__ __launch_bounds__(256) void k_wcolsum_partial(const unsigned short* __restrict__ x, long T, int C, long ld,
+                                                         const float* __restrict__ w, long w_ld, int slabs, float* __restrict__ part) {
+    constexpr int CH = 256, R = 4 * RQ;                            // rows per staged chunk of the weights
+    __shared__ __attribute__((aligned(16))) float sw[CH][R];       // w^T of the chunk: one ds_read_b128 per four weights, broadcast
+    __shared__ float red[3][R][128];
+    const int c2 = threadIdx.x & 63, ph = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = blockIdx.x * 128 + 2 * c2;
+    const long per = (T + slabs - 1) / slabs, r0 = blockIdx.y * per, r1 = min(T, r0 + per);
+    float a0[R], a1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a0[r] = a1[r] = 0.f;
+    for (long base = r0; base < r1; base += CH) {
+        const int nrow = static_cast<int>(min(static_cast<long>(CH), r1 - base));
+        __syncthreads();
+        for (int i = threadIdx.x; i < R * CH; i += 256) {
+            const int r = i / CH, j = i - r * CH;                  // (consecutive threads: consecutive rows of one weight row)
+            sw[j][r] = j < nrow ? w[r * w_ld + base + j] : 0.f;
+        }
+        __syncthreads();
+        if (col < C) {
+            const unsigned short* xp = x + base * ld + col;
+            // eight rows of x in flight per thread; rows past the chunk carry zero weights and are clamped to a valid address
+            for (int j0 = ph; j0 < nrow; j0 += 32) {
+                unsigned v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const unsigned*>(xp + static_cast<long>(min(j0 + 4 * u, nrow - 1)) * ld);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = min(j0 + 4 * u, CH - 1);
+                    const float x0 = to_f32<T16>(static_cast<unsigned short>(v[u] & 0xffffu)), x1 = to_f32<T16>(static_cast<unsigned short>(v[u] >> 16));
+#pragma unroll
+                    for (int q = 0; q < RQ; ++q) {
+                        const float4 wv = *reinterpret_cast<const float4*>(&sw[j][4 * q]);
+                        a0[4 * q] += wv.x * x0; a1[4 * q] += wv.x * x1;
+                        a0[4 * q + 1] += wv.y * x0; a1[4 * q + 1] += wv.y * x1;
+                        a0[4 * q + 2] += wv.z * x0; a1[4 * q + 2] += wv.z * x1;
+                        a0[4 * q + 3] += wv.w * x0; a1[4 * q + 3] += wv.w * x1;
+                    }
+                }
+            }
+        }
+    }
+    if (ph > 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { red[ph - 1][r][2 * c2] = a0[r]; red[ph - 1][r][2 * c2 + 1] = a1[r]; }
+    }
+    __syncthreads();
+    if (ph == 0 && col < C) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float* o = part + (static_cast<long>(blockIdx.y) * R + r) * C + col;
+            o[0] = ((a0[r] + red[0][r][2 * c2]) + red[1][r][2 * c2]) + red[2][r][2 * c2];
+            o[1] = ((a1[r] + red[0][r][2 * c2 + 1]) + red[1][r][2 * c2 + 1]) + red[2][r][2 * c2 + 1];
+        }
+    }
+}
+
+// out: blocks.n == 0 -> [R][C]; else the listed blocks one after the other, block b as [cols_b][rows_b] (transposed: the
+// [N_i][rank] layout of a LoRA up matrix), everything outside the blocks dropped.  scale: host factor * (optional) device scalar.
+__global__ void k_wcolsum_final(const float* __restrict__ part, int slabs, int R, int C, const float* __restrict__ dev_scale, float host_scale,
+                                WcsBlocks blocks, float* __restrict__ out) {
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    if (i >= static_cast<long>(R) * C) return;
+    const int r = static_cast<int>(i / C), c = static_cast<int>(i - static_cast<long>(r) * C);
+    long dst = i;
+    if (blocks.n > 0) {
+        dst = -1;
+        long off = 0;
+        for (int b = 0; b < blocks.n; ++b) {
+            if (r >= blocks.row0[b] && r < blocks.row0[b] + blocks.rows[b] && c >= blocks.col0[b] && c < blocks.col0[b] + blocks.cols[b])
+                dst = off + static_cast<long>(c - blocks.col0[b]) * blocks.rows[b] + (r - blocks.row0[b]);
+            off += static_cast<long>(blocks.rows[b]) * blocks.cols[b];
+        }
+        if (dst < 0) return;
+    }
+    float acc = 0.f;
+    for (int s = 0; s < slabs; ++s) acc += part[(static_cast<long>(s) * R + r) * C + c];
+    out[dst] = acc * host_scale * (dev_scale ? dev_scale[0] : 1.0f);
+}
+
 // ---- gradient normalisation ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_amax(const float* __restrict__ x, long n, unsigned* __restrict__ state) {
     __shared__ float red[4];
@@ -1382,6 +1470,42 @@ extern "C" pf_status pf_colsum(const void* x, int dtype, long rows, int N, long 
     else PF_REQUIRE(false, "pf_colsum: unsupported dtype %d", dtype);
     hipLaunchKernelGGL(k_colsum_final, dim3(cdiv(N, 256)), dim3(256), 0, st, part, slabs, N, out);
     PF_CHECK_LAUNCH("pf_colsum");
+    return PF_OK;
+}
+
+static int wcolsum_slabs(long T) { return static_cast<int>(std::max(1L, std::min<long>(64, T / 256))); }
+
+extern "C" size_t pf_weighted_colsum_workspace_size(long T, int C, int R) {
+    if (T <= 0 || C <= 0 || R <= 0) return 0;
+    return static_cast<size_t>(wcolsum_slabs(T)) * R * C * sizeof(float);
+}
+
+extern "C" pf_status pf_weighted_colsum(const void* x, int dtype, long n_tok, int C, long ld, const float* w, int R, long w_ld,
+                                        const float* dev_scale, float host_scale, const int* blocks, int n_blocks, float* out,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    PF_REQUIRE(x && w && out && workspace && n_tok > 0 && C > 0, "pf_weighted_colsum: bad arguments");
+    PF_REQUIRE(R > 0 && R <= 16 && R % 4 == 0 && w_ld >= n_tok, "pf_weighted_colsum: R = %d must be 4, 8, 12 or 16 and w_ld >= T", R);
+    PF_REQUIRE(C % 2 == 0 && ld % 2 == 0 && ld >= C && (reinterpret_cast<uintptr_t>(x) & 3) == 0, "pf_weighted_colsum: x needs an even width / row stride and 4-byte alignment");
+    PF_REQUIRE(n_blocks >= 0 && n_blocks <= 4 && (n_blocks == 0 || blocks), "pf_weighted_colsum: at most 4 output blocks");
+    PF_REQUIRE(workspace_bytes >= pf_weighted_colsum_workspace_size(n_tok, C, R), "pf_weighted_colsum: workspace too small");
+    WcsBlocks b;
+    b.n = n_blocks;
+    for (int i = 0; i < 4; ++i) {
+        b.row0[i] = i < n_blocks ? blocks[4 * i] : 0; b.rows[i] = i < n_blocks ? blocks[4 * i + 1] : 0;
+        b.col0[i] = i < n_blocks ? blocks[4 * i + 2] : 0; b.cols[i] = i < n_blocks ? blocks[4 * i + 3] : 0;
+        PF_REQUIRE(i >= n_blocks || (b.row0[i] >= 0 && b.rows[i] > 0 && b.row0[i] + b.rows[i] <= R && b.col0[i] >= 0 && b.cols[i] > 0 && b.col0[i] + b.cols[i] <= C),
+                   "pf_weighted_colsum: block %d outside [R][C]", i);
+    }
+    const int slabs = wcolsum_slabs(n_tok);
+    float* part = static_cast<float*>(workspace);
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(cdiv(C, 128), slabs), block(256);
+#define PF_WCS(RQ) hipLaunchKernelGGL((k_wcolsum_partial<T, RQ>), grid, block, 0, st, static_cast<const unsigned short*>(x), n_tok, C, ld, w, w_ld, slabs, part)
+    PF_DISPATCH_16(dtype, "pf_weighted_colsum",
+        if (R == 4) PF_WCS(1); else if (R == 8) PF_WCS(2); else if (R == 12) PF_WCS(3); else PF_WCS(4));
+#undef PF_WCS
+    hipLaunchKernelGGL(k_wcolsum_final, dim3(cdiv(static_cast<long>(R) * C, 256)), dim3(256), 0, st, part, slabs, R, C, dev_scale, host_scale, b, out);
+    PF_CHECK_LAUNCH("pf_weighted_colsum");
     return PF_OK;
 }
 

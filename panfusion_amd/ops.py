@@ -716,6 +716,26 @@ def lora_fold(w, up, down, scale, out, out_t=None, d_out=None, u_out=None):
     return out
 
 
+def weighted_colsum(x, w, dev_scale=None, host_scale=1.0, blocks=None):
+    """sum_t w[r, t] * x[t, c]: x [T, C] 16-bit (rows may be strided), w [R, T] fp32 (R <= 16) -> fp32 [R, C]; with blocks
+    = [(row0, rows, col0, cols), ...] (<= 4) a flat fp32 tensor holding only those blocks, each TRANSPOSED ([cols, rows]), one after
+    the other.  dev_scale: optional 1-element fp32 device tensor multiplied into the result together with host_scale."""
+    T, Cc = x.shape
+    R = w.shape[0]
+    assert w.dtype == torch.float32 and w.stride(1) == 1 and w.shape[1] >= T and x.stride(1) == 1
+    if blocks:
+        arr = (C.c_int * (4 * len(blocks)))(*[int(v) for b in blocks for v in b])
+        out = torch.empty(sum(b[1] * b[3] for b in blocks), device=x.device, dtype=torch.float32)
+    else:
+        arr = None
+        out = torch.empty(R, Cc, device=x.device, dtype=torch.float32)
+    nbytes = _lib.lib().pf_weighted_colsum_workspace_size(T, Cc, R)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    check(_lib.lib().pf_weighted_colsum(_p(x), dt(x), T, Cc, x.stride(0), _p(w), R, w.stride(0), _p(dev_scale), float(host_scale),
+                                        arr, len(blocks) if blocks else 0, _p(out), _p(ws), nbytes, _stream()), "pf_weighted_colsum")
+    return out
+
+
 def zero_insert2(x):
     """x NHWC 16-bit [n, h, w, C] -> [n, 2h, 2w, C] with x at the even positions (stride-2 conv data gradient)."""
     n, h, w, Cc = x.shape

@@ -161,12 +161,13 @@ def lora_of(attn, lin, name):
 class LoRAGroup:
     """The LoRA pairs of projections that read the SAME input x (q / k / v of a self-attention; k / v of the text
     cross-attention; a single projection) and whose output gradients sit side by side in one [T, sum N_i] tensor.
-    Their gradients come out of four thin GEMMs for the whole group:
-        P^T = D X^T          D = the down matrices stacked                      [R, K] x [T, K]^T -> [R, T]
+    Their gradients come out of two thin GEMMs and two weighted column sums for the whole group:
+        P^T = D X^T          D = the down matrices stacked                      [R, K] x [T, K]^T -> [R, T]   (MFMA GEMM, fp32 out)
         Q^T = U_bd dY^T      U_bd = the up^T matrices on a block diagonal      [R, N] x [T, N]^T -> [R, T]
-        d_up   = dY^T P      [N, T] x [R, T]^T -> [N, R]    (pair i: rows of block i, columns of block i)
-        d_down = Q^T X       [R, T] x [K, T]^T -> [R, K]    (pair i: rows of block i)
-    with R = sum of the ranks (rounded up to 4) and the reductions over tokens on token-contiguous operands.
+        d_up   = dY^T P      sum_t P^T[r, t] dY[t, n]    (pf_weighted_colsum: dY read once, row-major; pair i: block i of [R, N])
+        d_down = Q^T X       sum_t Q^T[r, t] X[t, k]     (pair i: rows of block i)
+    with R = sum of the ranks (rounded up to 4).  (Round 2 ran the two reductions as MFMA GEMMs on transposed copies of X and dY:
+    two transposes, two 4-row GEMMs with split-K reduces and four scaling / slicing passes per group -- ~160 groups per step.)
     D and U are allocated ONCE (zero outside the blocks); their blocks are (re)written by engine.fold_attention together with
     the folded weights -- `projs`: the packed attention's projection records, which get the views to write to."""
 
@@ -190,34 +191,23 @@ class LoRAGroup:
             self.slots.append((ref, row, rk, col, widths[i]))
             row += rk
 
-    def grads(self, x16, xt16, dy16, dyt16, sink):
-        """x16 [T, K] / xt16 [K, T], dy16 [T, N] / dyt16 [N, T] (16-bit, T a multiple of 64)."""
+    def grads(self, x16, dy16, sink):
+        """x16 [T, K] the projections' input, dy16 [T, N] the gradient of their outputs (16-bit, row-major as the backward holds
+        them; T a multiple of 4); sink: the block's ScaledSink (its normalisation factor is applied inside the reduction)."""
         if not self.live:
             return
         T = x16.shape[0]
-        pt = ops.conv_gemm(self.D, x16, T, w_in=self.R)                                        # [R, T]
-        qt = ops.conv_gemm(self.U, dy16, T, w_in=self.R)                                       # [R, T]
-        d_up = ops.conv_gemm(dyt16, pt, self.R, w_in=dyt16.shape[0], out_dtype=F32)            # [N, R]
-        d_down = ops.conv_gemm(qt, xt16, xt16.shape[0], w_in=self.R, out_dtype=F32)            # [R, K]
-        sink.scaled_pair(d_up, d_down, self.slots)
-
-
-def pad_tokens(x16):
-    """Token counts of the reduction GEMMs are multiples of 64 (pf_conv_gemm's channel rule): zero rows change nothing."""
-    T = x16.shape[0]
-    Tp = (T + 63) // 64 * 64
-    if Tp == T:
-        return x16
-    xp = torch.zeros(Tp, x16.shape[1], device=x16.device, dtype=x16.dtype)
-    xp[:T].copy_(x16)
-    return xp
-
-
-def with_transpose(x16):
-    """(x padded to a token count of 64 n, its token-contiguous transpose)."""
-    x16 = pad_tokens(x16)
-    T = x16.shape[0]
-    return x16, ops.transpose_tokens(x16.view(1, T, -1)).view(-1, T)
+        pt = ops.conv_gemm(self.D, x16, T, w_in=self.R, out_dtype=F32)                         # P^T [R, T]
+        qt = ops.conv_gemm(self.U, dy16, T, w_in=self.R, out_dtype=F32)                        # Q^T [R, T]
+        unscale = sink.state[2:3]                                                              # 2^e of the block's normalisation
+        blocks = [(row, rk, col, width) for _, row, rk, col, width in self.slots]
+        d_up = ops.weighted_colsum(dy16, pt, dev_scale=unscale, blocks=blocks)                 # per pair [N_i, rank], flat
+        d_down = ops.weighted_colsum(x16, qt, dev_scale=unscale)                               # [R, K]
+        off = 0
+        for ref, row, rk, col, width in self.slots:
+            sink.sink(ref.up, d_up[off:off + width * rk].view(width, rk), ref.scale)
+            sink.sink(ref.down, d_down[row:row + rk], ref.scale)
+            off += width * rk
 
 
 # ---------------------------------------------------------------------------------------------- per-layer training packs
@@ -478,7 +468,7 @@ def transformer_backward(t, x, text, dout, sink, wsink=None):
         put(blk.attn2.to_out[0].weight, wg(d16, a2.view(T, Cc)))
         put(blk.attn2.to_out[0].bias, ops.colsum(dtok2))
     if a2w.lora_out.live:
-        a2w.lora_out.grads(*with_transpose(a2.view(T, Cc)), *with_transpose(d16), lsink)
+        a2w.lora_out.grads(a2.view(T, Cc), d16, lsink)
     delta2 = ops.attention_delta(a2, da2, n, H, dh, hw)
     dq2 = torch.empty(n, hw, Cc, device=dev, dtype=dt16)
     dkv2 = torch.empty(n, TEXT_PAD, 2 * Cc, device=dev, dtype=dt16)
@@ -489,10 +479,10 @@ def transformer_backward(t, x, text, dout, sink, wsink=None):
                       dk_bs=TEXT_PAD * 2 * Cc, dv_bs=TEXT_PAD * 2 * Cc, bias=tbias, flags=tflags)
     dln2 = ops.linear(dq2.view(T, Cc), a2w.wq_t, out_dtype=F32)
     if a2w.lora_q.live:
-        a2w.lora_q.grads(*with_transpose(ln2), *with_transpose(dq2.view(T, Cc)), lsink)
+        a2w.lora_q.grads(ln2, dq2.view(T, Cc), lsink)
     if a2w.lora_kv.live:
         Tt = n * TEXT_PAD
-        a2w.lora_kv.grads(*with_transpose(textp.view(Tt, -1)), *with_transpose(dkv2.view(Tt, 2 * Cc)), lsink)
+        a2w.lora_kv.grads(textp.view(Tt, -1), dkv2.view(Tt, 2 * Cc), lsink)
     dtok1, g_ln2, b_ln2 = ops.layernorm_bwd(tok1, t.ln2.g, dln2, t.ln2.eps, dres=dtok2)
     if put is not None:
         put(blk.attn2.to_q.weight, wg(dq2.view(T, Cc), ln2))
@@ -509,7 +499,7 @@ def transformer_backward(t, x, text, dout, sink, wsink=None):
         put(blk.attn1.to_out[0].weight, wg(d16, a1.view(T, Cc)))
         put(blk.attn1.to_out[0].bias, ops.colsum(dtok1))
     if a1w.lora_out.live:
-        a1w.lora_out.grads(*with_transpose(a1.view(T, Cc)), *with_transpose(d16), lsink)
+        a1w.lora_out.grads(a1.view(T, Cc), d16, lsink)
     delta1 = ops.attention_delta(a1, da1, n, H, dh, hw)
     dqkv = torch.empty(n, hw, 3 * Cc, device=dev, dtype=dt16)
     ld = 3 * Cc
@@ -519,7 +509,7 @@ def transformer_backward(t, x, text, dout, sink, wsink=None):
                       q_bs=hw * ld, k_bs=hw * ld, v_bs=hw * ld, do_bs=hw * Cc, dq_bs=hw * ld, dk_bs=hw * ld, dv_bs=hw * ld)
     dln1 = ops.linear(dqkv.view(T, 3 * Cc), a1w.wqkv_t, out_dtype=F32)
     if a1w.lora_qkv.live:
-        a1w.lora_qkv.grads(*with_transpose(ln1), *with_transpose(dqkv.view(T, 3 * Cc)), lsink)
+        a1w.lora_qkv.grads(ln1, dqkv.view(T, 3 * Cc), lsink)
     dtok0, g_ln1, b_ln1 = ops.layernorm_bwd(tok0, t.ln1.g, dln1, t.ln1.eps, dres=dtok1)
     # proj_in and the GroupNorm in front of it; the block's own residual (out = proj_out(..) + x)
     dy = stream_linear(dtok0, tw.w_in_t, tw.w_in_t3, Cc, dt16)
@@ -540,18 +530,11 @@ def transformer_backward(t, x, text, dout, sink, wsink=None):
 
 
 class ScaledSink:
-    """Takes a LoRA group's stacked gradients in the block's normalised units, scales them back (two launches per
-    group) and hands the per-pair blocks to the parameter sink."""
+    """The parameter sink of one block's LoRA groups together with the block's gradient-normalisation state: the groups'
+    reductions (LoRAGroup.grads -> pf_weighted_colsum) scale their results back on the device by state[2] = 2^e."""
 
     def __init__(self, sink, state):
         self.sink, self.state = sink, state
-
-    def scaled_pair(self, d_up, d_down, slots):
-        _unscale(d_up, self.state)
-        _unscale(d_down, self.state)
-        for ref, row, rk, col, width in slots:
-            self.sink(ref.up, d_up[col:col + width, row:row + rk], ref.scale)
-            self.sink(ref.down, d_down[row:row + rk], ref.scale)
 
 
 def downsample_backward(d, dout, pano_pad, dev_dtype, wsink=None, x=None):

@@ -513,6 +513,14 @@ def lora_fold(w, up, down, scale, out, out_t=None, d_out=None, u_out=None):
     return out
 
 
+def weighted_colsum(x, w, dev_scale=None, host_scale=1.0, blocks=None):
+    T = x.shape[0]
+    full = (w[:, :T].float() @ x.float()) * host_scale * (float(dev_scale[0]) if dev_scale is not None else 1.0)
+    if not blocks:
+        return full
+    return torch.cat([full[r0:r0 + nr, c0:c0 + nc].t().reshape(-1) for r0, nr, c0, nc in blocks])
+
+
 def zero_insert2(x):
     n, h, w, C = x.shape
     y = torch.zeros(n, 2 * h, 2 * w, C, dtype=x.dtype)

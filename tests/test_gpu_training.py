@@ -350,6 +350,28 @@ def test_lora_fold_kernel(dtype, N, K, r):
         assert not D[:4].any() and not D[:, :8].any() and not Ubd[:4].any() and not Ubd[:, :16].any()
 
 
+@pytest.mark.parametrize("dtype", D16)
+@pytest.mark.parametrize("T,Cc,R,ld_extra", [(20480, 320, 4, 0), (1024, 960, 12, 0), (2560, 2048, 8, 64), (78, 130, 16, 2), (8192, 3840, 12, 0)])
+def test_weighted_column_sums(dtype, T, Cc, R, ld_extra):
+    """pf_weighted_colsum = w @ x in fp32 over token rows (the LoRA gradients' reductions), with the device / host scale, the
+    per-pair transposed block layout, strided rows, and run-to-run bit-identity."""
+    o = ops()
+    xfull = rnd(T, Cc + ld_extra, seed=1).to(dtype)
+    x = xfull[:, :Cc]
+    w = rnd(R, T, seed=2)
+    ref = (w.double() @ x.double()).float()
+    got = o.weighted_colsum(x, w)
+    assert got.shape == (R, Cc) and rel_l2(got.cpu(), ref.cpu()) < 2e-6
+    assert torch.equal(got, o.weighted_colsum(x, w))
+    state = torch.tensor([0.0, 0.25, 4.0, 0.0], device=DEV)
+    assert torch.allclose(o.weighted_colsum(x, w, dev_scale=state[2:3], host_scale=0.5), 2.0 * got, rtol=1e-6, atol=0)
+    if R >= 8 and Cc >= 128:
+        blocks = [(0, 4, 0, 64), (4, 4, 64, Cc - 64)]
+        flat = o.weighted_colsum(x, w, blocks=blocks)
+        want = torch.cat([got[0:4, 0:64].t().reshape(-1), got[4:8, 64:].t().reshape(-1)])
+        assert torch.equal(flat, want)
+
+
 # ------------------------------------------------------------------------------------ the trainable ControlNet
 @pytest.mark.parametrize("xdtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("n,hw,c0,c1,groups,act", [(3, 24 * 17, 64, 32, 32, 1), (2, 1024, 320, 0, 32, 1), (1, 64, 1280, 1280, 32, 0),
