@@ -127,6 +127,7 @@ class MultiViewBaseModel(nn.Module):
             for blk in [*self.cp_blocks_encoder, self.cp_blocks_mid, *self.cp_blocks_decoder]:
                 for t in blk.transformer.parameters():
                     add(t)
+        self._n_epa = len(out)
         for unet in (self.unet, self.pano_unet):
             if unet is None:
                 continue
@@ -171,8 +172,10 @@ class MultiViewBaseModel(nn.Module):
         return tuple(fp)
 
     def _lora_versions(self):
+        # the LoRA matrices only: the EPA blocks track their own parameters (WarpAttn.packed), the ControlNets theirs (packed()) --
+        # a layout-conditioned run (EPA + ControlNet train, LoRA frozen) must not re-fold 256 unchanged projections per step
         tensors = self.trainable_tensors()
-        return tuple((id(t), t._version) for t in tensors[:self._n_lora_epa])       # (not the ControlNets': packed())
+        return tuple((id(t), t._version) for t in tensors[self._n_epa:self._n_lora_epa])
 
     def forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras,
                 pers_layout_cond=None, pano_layout_cond=None):
