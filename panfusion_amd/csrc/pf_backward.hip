@@ -1006,13 +1006,20 @@ __global__ __launch_bounds__(256) void k_lora_fold(const float* __restrict__ w, 
     }
     __syncthreads();
     const int kl = t & 63;
-    for (int nl = t >> 6; nl < 64; nl += 4) {
-        const int n = n0 + nl, k = k0 + kl;
+    float wv[16];                                                  // the thread's 16 weights in flight before the first is used
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int n = n0 + (t >> 6) + 4 * i, k = k0 + kl;
+        wv[i] = (n < N && k < K) ? w[static_cast<long>(n) * K + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int nl = (t >> 6) + 4 * i, n = n0 + nl, k = k0 + kl;
         unsigned short v = 0;
         if (n < N && k < K) {
             float acc = 0.f;
             for (int j = 0; j < r; ++j) acc += s_up[nl][j] * s_down[j][kl];
-            v = from_f32<T>(w[static_cast<long>(n) * K + k] + scale * acc);
+            v = from_f32<T>(wv[i] + scale * acc);
             out[static_cast<long>(n) * out_ld + k] = v;
         }
         tile[nl][kl] = v;
