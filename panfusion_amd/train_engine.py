@@ -194,8 +194,8 @@ class LoRAGroup:
     def grads(self, x16, dy16, sink):
         """x16 [T, K] the projections' input, dy16 [T, N] the gradient of their outputs (16-bit, row-major as the backward holds
         them; T a multiple of 4); sink: the block's ScaledSink (its normalisation factor is applied inside the reduction)."""
-        if not self.live:
-            return
+        if not self.live or not any(ref.up.requires_grad or ref.down.requires_grad for _, ref in self.live):
+            return                                    # (frozen LoRA: the reference's layout-conditioned runs, PanoGenerator.py:173)
         T = x16.shape[0]
         pt = ops.conv_gemm(self.D, x16, T, w_in=self.R, out_dtype=F32)                         # P^T [R, T]
         qt = ops.conv_gemm(self.U, dy16, T, w_in=self.R, out_dtype=F32)                        # Q^T [R, T]
