@@ -194,7 +194,7 @@ class LoRAGroup:
     def grads(self, x16, dy16, sink):
         """x16 [T, K] the projections' input, dy16 [T, N] the gradient of their outputs (16-bit, row-major as the backward holds
         them; T a multiple of 4); sink: the block's ScaledSink (its normalisation factor is applied inside the reduction)."""
-        if not self.live or not any(ref.up.requires_grad or ref.down.requires_grad for _, ref in self.live):
+        if not self.live or not _trains(self.refs):
             return                                    # (frozen LoRA: the reference's layout-conditioned runs, PanoGenerator.py:173)
         T = x16.shape[0]
         pt = ops.conv_gemm(self.D, x16, T, w_in=self.R, out_dtype=F32)                         # P^T [R, T]
@@ -653,6 +653,27 @@ class ParamGrads:
         return None if hit is None else hit[1].to(device=param.device, dtype=param.dtype)      # (modules may live on the host)
 
 
+def _trains(refs):
+    return any(r is not None and (r.up.requires_grad or r.down.requires_grad) for r in refs)
+
+
+def _first_trainable_entry(tape):
+    """Index of the earliest tape entry whose backward feeds a parameter that requires a gradient: an EPA block, a ControlNet
+    marker, a transformer with a trainable LoRA pair.  None: nothing on the tape trains."""
+    for i, entry in enumerate(tape):
+        kind = entry[0]
+        if kind in ("cn_skips", "cn_mid"):
+            return i
+        if kind == "fuse" and any(p_.requires_grad for p_ in training.train_params(entry[3])):
+            return i
+        if kind == "attention":
+            tw = transformer_train(entry[2], entry[3].device)
+            groups = (tw.attn1.lora_qkv, tw.attn1.lora_out, tw.attn2.lora_q, tw.attn2.lora_kv, tw.attn2.lora_out)
+            if any(_trains(g.refs) for g in groups):
+                return i
+    return None
+
+
 def backward(tape, d_eps, sink, dh=None, dskips=None, wsink=None, dtemb=None):
     """Walk the tape backwards.  d_eps: {branch: fp32 NCHW gradient of that branch's predicted noise}.
     dh / dskips: gradients to start from (a ControlNet's tape starts at its mid output and its 12 skip tensors);
@@ -660,7 +681,13 @@ def backward(tape, d_eps, sink, dh=None, dskips=None, wsink=None, dtemb=None):
     appended to dtemb as (offset, [n, cout])."""
     dh = {} if dh is None else dh
     dskips = {} if dskips is None else dskips
-    for entry in reversed(tape):
+    # Nothing before the EARLIEST entry that has a trainable leaf behind it needs a gradient (autograd prunes the same way):
+    # with frozen LoRA matrices (layout-conditioned runs) the first encoder level of both branches is skipped.
+    first = 0 if wsink is not None else _first_trainable_entry(tape)
+    if first is None:
+        return dh, dskips
+    for index in range(len(tape) - 1, first - 1, -1):
+        entry = tape[index]
         kind, br = entry[0], entry[1]
         if kind == "cn_mid":                          # h += mid residual (MVGenModel.py:200-203): its gradient is dh as it stands
             entry[2].d_mid = dh[br]

@@ -226,7 +226,7 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
     s0, ps0 = hip(*args)
     ((s0 * w_s).sum() + (ps0 * w_p).sum()).backward()
     pack_before = hip.packed("unet", args[1].device)
-    res_before = pack_before.down[0].resnets[0].train
+    res_before = pack_before.down[0].resnets[1].train       # (resnets[0] sits before the first LoRA-carrying layer: never walked)
     opt.step()                                            # oracle shares the UNet modules: it steps with it
     for name in ("cp_blocks_encoder", "cp_blocks_mid", "cp_blocks_decoder"):
         getattr(oracle, name).load_state_dict(getattr(hip, name).state_dict())
@@ -235,7 +235,7 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
     s1, ps1 = hip(*args)
     assert rel_l2(want_s, s0.detach()) > 1e-3                      # the step moved the outputs
     assert rel_l2(s1.detach(), want_s) < 5e-5 and rel_l2(ps1.detach(), want_ps) < 5e-5
-    assert hip.packed("unet", args[1].device) is pack_before and pack_before.down[0].resnets[0].train is res_before
+    assert hip.packed("unet", args[1].device) is pack_before and pack_before.down[0].resnets[1].train is res_before
 
 
 def test_training_step_with_layout_condition_frozen_controlnet(fake_denoiser_backend):
@@ -345,6 +345,40 @@ def test_optimizer_step_on_the_controlnet_reaches_the_next_forward(fake_denoiser
     assert rel_l2(want_ps, ps0.detach()) > 1e-4                    # the step moved the panorama output
     assert rel_l2(s1, want_s) < 5e-5 and rel_l2(ps1, want_ps) < 5e-5
     assert hip.packed("pano_unet", args[1].device) is unet_pack
+
+
+def test_backward_stops_at_the_earliest_trainable_entry(fake_denoiser_backend, monkeypatch):
+    """Frozen LoRA matrices (the reference's layout-conditioned runs, PanoGenerator.py:173): only the EPA blocks train -- their
+    gradients are unchanged, no LoRA gradient is produced, and the backward does not walk the first encoder level of either
+    branch (nothing trainable lies before the first EPA block; torch autograd prunes the same way)."""
+    from panfusion_amd import train_engine
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    oracle, args, w_s, w_p = _denoiser_case()
+    for k, p in oracle.named_parameters():
+        if "lora" in k:
+            p.requires_grad_(False)
+    s, ps = oracle(*args)
+    ((s * w_s).sum() + (ps * w_p).sum()).backward()
+    want = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None and k.startswith("cp_blocks")}
+    assert len(want) == 7 * 13
+    for p in oracle.parameters():
+        p.grad = None
+    calls = []
+    real = train_engine.resnet_backward
+    monkeypatch.setattr(train_engine, "resnet_backward", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=torch.float32,
+                             precision="mixed", differentiable=True)
+    hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    s2, ps2 = hip(*args)
+    ((s2 * w_s).sum() + (ps2 * w_p).sum()).backward()
+    got = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert rel_l2(got[k], want[k]) < 1e-4, k
+    n_resnets = sum(len(b.resnets) for u in (oracle.unet, oracle.pano_unet) for b in [*u.down_blocks, u.mid_block, *u.up_blocks])
+    assert len(calls) == n_resnets - 2 * 2                          # the two resnets of encoder level 0, both branches
+    for p in oracle.parameters():
+        p.requires_grad_(True)
 
 
 def test_no_grad_forward_after_optimizer_step_sees_the_new_lora(fake_denoiser_backend):
