@@ -416,7 +416,7 @@ def pack_epa(block, dev, dtype, mixed=False):
 
 
 # ---------------------------------------------------------------------------- layer runners
-def run_resnet(r, x, skip, temb_all, groups_eps=None, wrap=0):
+def run_resnet(r, x, skip, temb_all, groups_eps=None, wrap=0, save=None):
     """x [n, h, w, C] (+ skip concatenated along channels) -> [n, h, w, cout], stream dtype in and out.
     GN -> SiLU -> conv3x3 (+bias +temb) -> GN -> SiLU -> conv3x3 (+bias) + shortcut(x).
     GroupNorm moments: conv1's epilogue leaves the moments of h1 behind for norm2 (ops.conv_gemm(gn_stats=True)); norm1 uses
@@ -425,11 +425,15 @@ def run_resnet(r, x, skip, temb_all, groups_eps=None, wrap=0):
     copies, bug-compatible with the reference: norm1's statistics count the wrapped columns twice, conv1 reads the
     normalised x through a virtual circular padding and produces the w + 2p columns the reference has (its zero padding
     contaminating the two outermost ones), norm2 normalises exactly that tensor, conv2 produces only the w columns that
-    survive the crop, and the 1x1 shortcut / identity acts on the un-padded x."""
+    survive the crop, and the 1x1 shortcut / identity acts on the un-padded x.
+    save (a namespace, training forward): keeps what the backward reads -- both norms' (scale, shift) and h1, which is then
+    produced in fp32 (the GroupNorm backward wants it at that precision) -- so that nothing is recomputed there."""
     n, h, w, _ = x.shape
     hw = h * w
     sc, sh = ops.groupnorm_scale_shift(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, r.norm1.b,
                                        wrap=(w, wrap) if wrap else None)
+    if save is not None:
+        save.sc1, save.sh1 = sc, sh
     pair = None
     if r.ws3 is not None and x.dtype == torch.float32 and RAW_PAIR_FUSED:
         # mixed scheme: the shortcut's split operand [hi | lo] of (x | skip) comes out of the same pass as norm1 + SiLU
@@ -439,9 +443,11 @@ def run_resnet(r, x, skip, temb_all, groups_eps=None, wrap=0):
     rowvec = temb_all[:, r.temb_off:] if temb_all is not None else None
     wp = w + 2 * wrap
     h1 = ops.conv_gemm(y, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec, gn_stats=True,
-                       wrap_pad=wrap)
+                       wrap_pad=wrap, out_dtype=torch.float32 if save is not None else None)
     h1 = ops.carry(h1.view(n, h * wp, r.cout), h1)
     sc, sh = ops.groupnorm_scale_shift(h1, None, n, h * wp, r.norm2.groups, r.norm2.eps, r.norm2.g, r.norm2.b)
+    if save is not None:
+        save.h1, save.sc2, save.sh2 = h1, sc, sh
     y2 = ops.scale_shift_act(h1, None, n, h * wp, sc, sh, 1, out_dtype=r.dtype)
     if r.ws3 is not None:         # mixed scheme: the shortcut maps the stream linearly -> split precision, fp32 out
         if pair is None:
@@ -556,15 +562,15 @@ class Branch:
     def _padded(self, t, p):
         return ops.pad_width(t, p) if (self.pad and t is not None) else t
 
-    def resnet(self, r, skip=False):
+    def resnet(self, r, skip=False, save=None):
         s = self.skips.pop() if skip else None
         if self.pad and VIRTUAL_PAD:
-            self.h = run_resnet(r, self.h, s, self.temb, wrap=2)
+            self.h = run_resnet(r, self.h, s, self.temb, wrap=2, save=save)
         elif self.pad:
-            out = run_resnet(r, self._padded(self.h, 2), self._padded(s, 2), self.temb)
+            out = run_resnet(r, self._padded(self.h, 2), self._padded(s, 2), self.temb, save=save)
             self.h = ops.crop_width(out, 2)
         else:
-            self.h = run_resnet(r, self.h, s, self.temb)
+            self.h = run_resnet(r, self.h, s, self.temb, save=save)
 
     def attention(self, t):
         if self.text_ready is not None:

@@ -35,6 +35,10 @@ F32 = torch.float32
 # transposes of the forward's stream-path GEMMs) run split-precision like their forward counterparts (engine.exact_gemm):
 # their operand roundings accumulate along the identity path of the residual network.  PF_TRAIN_EXACT=0: single pass (A/B).
 EXACT = os.environ.get("PF_TRAIN_EXACT", "1") != "0"
+# The training forward KEEPS what the backward reads (288 GB of HBM: the whole step peaks at 25-45 GB) instead of recomputing
+# every layer inside its backward as rounds 2 did (the reference checkpoints only the EPA blocks, transformer.py:77-127; the
+# UNets' activations stay alive under autograd there too).  PF_TRAIN_KEEP=0: recompute (A/B, and the lower-memory mode).
+KEEP = os.environ.get("PF_TRAIN_KEEP", "1") != "0"
 
 
 # ---------------------------------------------------------------------------------------------- weights of the backward GEMMs
@@ -320,20 +324,24 @@ def pad_text(text, dtype):
 
 
 # ---------------------------------------------------------------------------------------------- layer backward passes
-def resnet_backward(r, x, skip, rowvec, dout, wsink=None):
-    """x [n, h, w, cx] (+ skip [n, h, w, cs]) as the forward saw them, dout fp32 [n, h, w, cout] -> (dx, dskip) fp32.
+def resnet_backward(r, x, skip, rowvec, dout, wsink=None, saved=None):
+    """x [n, h, w, cx] (+ skip [n, h, w, cs]) as the forward saw them (the panorama branch: circularly padded by 2 columns, the
+    layout the kept activations have too), dout fp32 [n, h, w, cout] -> (dx, dskip) fp32.
     wsink (trainable resnet, the ControlNet's): also the gradients of norm1 / conv1 / norm2 / conv2 / conv_shortcut into
     wsink(param, grad), and a third result: the gradient [n, cout] of this resnet's slice of the time-embedding projection."""
     tw = resnet_train(r, x.device)
     n, h, w, cx = x.shape
     hw, M = h * w, n * h * w
     cin = cx + (skip.shape[-1] if skip is not None else 0)
-    # recompute: GN1 -> SiLU -> conv1 (+ bias + temb) -> GN2 statistics
-    sc1, sh1 = ops.groupnorm_scale_shift(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, r.norm1.b)
-    y1 = ops.scale_shift_act(x, skip, n, hw, sc1, sh1, 1, out_dtype=r.dtype)
-    h1 = ops.conv_gemm(y1, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec, out_dtype=F32)
-    h1 = h1.view(n, hw, r.cout)
-    sc2, sh2 = ops.groupnorm_scale_shift(h1, None, n, hw, r.norm2.groups, r.norm2.eps, r.norm2.g, r.norm2.b)
+    if saved is not None:                             # kept by the training forward (engine.run_resnet(save=...))
+        sc1, sh1, h1, sc2, sh2 = saved.sc1, saved.sh1, saved.h1.view(n, hw, r.cout), saved.sc2, saved.sh2
+        y1 = ops.scale_shift_act(x, skip, n, hw, sc1, sh1, 1, out_dtype=r.dtype) if wsink is not None else None
+    else:                                             # recompute: GN1 -> SiLU -> conv1 (+ bias + temb) -> GN2 statistics
+        sc1, sh1 = ops.groupnorm_scale_shift(x, skip, n, hw, r.norm1.groups, r.norm1.eps, r.norm1.g, r.norm1.b)
+        y1 = ops.scale_shift_act(x, skip, n, hw, sc1, sh1, 1, out_dtype=r.dtype)
+        h1 = ops.conv_gemm(y1, r.w1, r.cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=r.b1, rowvec=rowvec, out_dtype=F32)
+        h1 = h1.view(n, hw, r.cout)
+        sc2, sh2 = ops.groupnorm_scale_shift(h1, None, n, hw, r.norm2.groups, r.norm2.eps, r.norm2.g, r.norm2.b)
     # backward
     d, state = _normalise(dout.reshape(n, h, w, r.cout))
     dy2 = conv3_dgrad(d, tw.w2, r.cout, "s1", r.dtype)                                   # gradient of silu(gn2(h1))
@@ -399,9 +407,9 @@ def _self_attention(tw, ln, n, hw, dh):
     return qkv3, qkvt, a, lse
 
 
-def transformer_backward(t, x, text, dout, sink, wsink=None):
-    """x [n, h, w, C] as the forward saw it, text [n, L, Dt], dout fp32 [n, h, w, C] -> dx fp32; LoRA gradients into sink.
-    wsink (trainable transformer, the ControlNet's): the gradient of every parameter of the block into wsink(param, grad)."""
+def transformer_recompute(t, x, text):
+    """The block's forward up to the GEGLU input, keeping everything its backward reads.  Runs EITHER as the training forward
+    itself (KEEP: TrainBranch.attention -> transformer_forward_keep; nothing is recomputed later) or inside the backward."""
     dev = x.device
     tw = transformer_train(t, dev)
     a1w, a2w = tw.attn1, tw.attn2
@@ -411,7 +419,6 @@ def transformer_backward(t, x, text, dout, sink, wsink=None):
     dh = Cc // H
     L = text.shape[1]
     dt16 = t.dtype
-    # ---- recompute
     sc, sh = ops.groupnorm_scale_shift(x, None, n, hw, t.norm.groups, t.norm.eps, t.norm.g, t.norm.b)
     y = ops.scale_shift_act(x, None, n, hw, sc, sh, 0, out_dtype=dt16)
     if EXACT and t.w_in3 is not None:                 # as the mixed forward: proj_in carries the stream
@@ -435,6 +442,45 @@ def transformer_backward(t, x, text, dout, sink, wsink=None):
     tok2 = ops.linear(a2.view(T, Cc), a2w.wo, bias=a2w.bo, residual=tok1)
     ln3 = ops.layernorm(tok2, t.ln3.g, t.ln3.b, t.ln3.eps, out_dtype=dt16)
     u = ops.linear(ln3, tw.w1, bias=tw.b1)                                               # [T, 8C] = (value | gate)
+    return NS(sc=sc, sh=sh, y=y, tok0=tok0, ln1=ln1, qkv3=qkv3, qkvt=qkvt, a1=a1, lse1=lse1, tok1=tok1, ln2=ln2, q2=q2, q2t=q2t,
+              textp=textp, kv2=kv2, kv2t=kv2t, tbias=tbias, tflags=tflags, a2=a2, lse2=lse2, tok2=tok2, ln3=ln3, u=u)
+
+
+def transformer_forward_keep(t, x, text):
+    """The training forward of a transformer block that KEEPS its activations: transformer_recompute, then GEGLU, FF2 and
+    proj_out (+ the block's residual) exactly as engine.run_transformer ends.  -> (out [n, h, w, C] stream dtype, record).
+    Against the inference forward the only differences are roundings: the GEGLU input is materialised in 16 bit (the fused
+    epilogue gates the fp32 accumulators), the text keys are padded to 128 and masked."""
+    n, h, w, Cc = x.shape
+    T = n * h * w
+    rec = transformer_recompute(t, x, text)
+    tw = t.train
+    g = ops.geglu(rec.u)
+    if t.w_out3 is not None:          # mixed scheme: FF2's epilogue emits the [hi | lo] pair of the split-precision proj_out
+        pair = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=rec.tok2, split_out=True)
+        out = engine.exact_gemm(pair, t.w_out3, Cc, w_in=T, bias=t.b_out, residual=x.view(T, Cc), gn_stats=True)
+    else:
+        tok3 = ops.linear(g, t.w_ff2, bias=t.b_ff2, residual=rec.tok2)                   # (the kept token stream is fp32)
+        out = ops.linear(engine.to16(tok3, t.dtype), t.w_out, bias=t.b_out, residual=x.view(T, Cc), gn_stats=True)
+    return ops.carry(out.view(n, h, w, Cc), out), rec
+
+
+def transformer_backward(t, x, text, dout, sink, wsink=None, rec=None):
+    """x [n, h, w, C] as the forward saw it, text [n, L, Dt], dout fp32 [n, h, w, C] -> dx fp32; LoRA gradients into sink.
+    wsink (trainable transformer, the ControlNet's): the gradient of every parameter of the block into wsink(param, grad).
+    rec: the record the training forward kept (transformer_forward_keep); None: the block is recomputed here."""
+    dev = x.device
+    tw = transformer_train(t, dev)
+    a1w, a2w = tw.attn1, tw.attn2
+    n, h, w, Cc = x.shape
+    hw, T = h * w, n * h * w
+    H = a1w.heads
+    dh = Cc // H
+    dt16 = t.dtype
+    if rec is None:
+        rec = transformer_recompute(t, x, text)
+    sc, sh, y, tok0, ln1, qkv3, qkvt, a1, lse1, tok1, ln2 = rec.sc, rec.sh, rec.y, rec.tok0, rec.ln1, rec.qkv3, rec.qkvt, rec.a1, rec.lse1, rec.tok1, rec.ln2
+    q2, q2t, textp, kv2, kv2t, tbias, tflags, a2, lse2, tok2, ln3, u = rec.q2, rec.q2t, rec.textp, rec.kv2, rec.kv2t, rec.tbias, rec.tflags, rec.a2, rec.lse2, rec.tok2, rec.ln3, rec.u
 
     # ---- backward
     d, state = _normalise(dout.reshape(T, Cc))
@@ -603,13 +649,18 @@ class TrainBranch(engine.Branch):
 
     def resnet(self, r, skip=False):
         x, s = self.h, (self.skips[-1] if skip else None)
-        super().resnet(r, skip)
-        self.tape.append(("resnet", self, r, x, s))
+        saved = NS() if KEEP else None
+        super().resnet(r, skip, save=saved)
+        self.tape.append(("resnet", self, r, x, s, saved))
 
     def attention(self, t):
         x = self.h
-        super().attention(t)
-        self.tape.append(("attention", self, t, x))
+        rec = None
+        if KEEP:
+            self.h, rec = transformer_forward_keep(t, x, self.text)
+        else:
+            super().attention(t)
+        self.tape.append(("attention", self, t, x, rec))
 
     def push(self):
         super().push()
@@ -713,19 +764,19 @@ def backward(tape, d_eps, sink, dh=None, dskips=None, wsink=None, dtemb=None):
             g = dskips[br].pop()
             dh[br] = ops.add(dh[br], g) if dh.get(br) is not None else g
         elif kind == "attention":
-            dh[br] = transformer_backward(entry[2], entry[3], br.text, dh[br], sink, wsink)
+            dh[br] = transformer_backward(entry[2], entry[3], br.text, dh[br], sink, wsink, entry[4])
         elif kind == "resnet":
-            _, _, r, x, s = entry
+            _, _, r, x, s, saved = entry
             rowvec = br.temb[:, r.temb_off:]
             d = dh[br]
             if pad:                                   # pad 2 / resnet / crop 2 (MVGenModel.py:110-115)
                 d = ops.crop_width_bwd(d, 2)
                 x, s = ops.pad_width(x, 2), (ops.pad_width(s, 2) if s is not None else None)
             if wsink is not None:
-                dx, ds, dt = resnet_backward(r, x, s, rowvec, d, wsink)
+                dx, ds, dt = resnet_backward(r, x, s, rowvec, d, wsink, saved)
                 dtemb.append((r.temb_off, dt))
             else:
-                dx, ds = resnet_backward(r, x, s, rowvec, d)
+                dx, ds = resnet_backward(r, x, s, rowvec, d, saved=saved)
             if pad:
                 dx, ds = ops.pad_width_bwd(dx, 2), (ops.pad_width_bwd(ds, 2) if ds is not None else None)
             dh[br] = dx
