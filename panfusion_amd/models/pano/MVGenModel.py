@@ -332,8 +332,13 @@ class MultiViewBaseModel(nn.Module):
                 return
             join()
             keep.append(pano.h)
+            if tape is not None and train_engine.KEEP:      # training forward that keeps the block's activations
+                xp_in, xe_in = pers.h, pano.h
+                pers.h, pano.h, rec = block.forward_nhwc_keep(xp_in, xe_in, groups, m_total)
+                tape.append(("fuse", pers, pano, block, xp_in, xe_in, groups, m_total, rec))
+                return
             if tape is not None:
-                tape.append(("fuse", pers, pano, block, pers.h, pano.h, groups, m_total))
+                tape.append(("fuse", pers, pano, block, pers.h, pano.h, groups, m_total, None))
             epa_side = side if os.environ.get("PF_EPA_STREAMS", "2") != "1" else None
             pers.h, pano.h = block.forward_nhwc(pers.h, pano.h, groups, m_total, shard=shard, side=epa_side)
             keep.append(pano.h)

@@ -133,9 +133,9 @@ class WarpAttn(nn.Module):
         return dx_p, dx_e, [g.view(p_.shape).to(p_.dtype) for g, p_ in zip(grads, params)]
 
     @torch.no_grad()
-    def backward_nhwc(self, xp, xe, groups, m, d_p, d_e):
-        """The same on the denoiser's internal layout: xp [b*m, ph, pw, C], xe [b, eh, ew, C] (the inputs of forward_nhwc),
-        d_p / d_e fp32 NHWC gradients of its two outputs -> (dxp, dxe fp32 NHWC, parameter gradients)."""
+    def forward_nhwc_keep(self, xp, xe, groups, m):
+        """forward_nhwc for a training step that keeps its activations (train_engine.KEEP): the block through
+        training.epa_recompute (the record the backward reads) and the FF2 + residual tail.  -> (out_p, out_e, record)."""
         from ... import training
         dev = xp.device
         bm, ph, pw, Cc = xp.shape
@@ -143,6 +143,22 @@ class WarpAttn(nn.Module):
         tabs = self.tables_for(groups, ph, pw, eh, ew, dev)
         e = self.packed_train(dev)
         rec = training.epa_recompute(e, tabs, xe.reshape(-1, Cc), xp.reshape(-1, Cc), b, m)
+        out = ops.linear(rec.g, e.w2, bias=e.b2, residual=rec.y)
+        return out[rec.Te:].view(bm, ph, pw, Cc), out[:rec.Te].view(b, eh, ew, Cc), rec
+
+    @torch.no_grad()
+    def backward_nhwc(self, xp, xe, groups, m, d_p, d_e, rec=None):
+        """The same on the denoiser's internal layout: xp [b*m, ph, pw, C], xe [b, eh, ew, C] (the inputs of forward_nhwc),
+        d_p / d_e fp32 NHWC gradients of its two outputs -> (dxp, dxe fp32 NHWC, parameter gradients).
+        rec: the record forward_nhwc_keep left; None: the block is recomputed here."""
+        from ... import training
+        dev = xp.device
+        bm, ph, pw, Cc = xp.shape
+        b, eh, ew, _ = xe.shape
+        tabs = self.tables_for(groups, ph, pw, eh, ew, dev)
+        e = self.packed_train(dev)
+        if rec is None:
+            rec = training.epa_recompute(e, tabs, xe.reshape(-1, Cc), xp.reshape(-1, Cc), b, m)
         dx_e, dx_p, grads = training.epa_backward(e, tabs, rec, d_e.reshape(-1, Cc).float(), d_p.reshape(-1, Cc).float(), b, m)
         params = training.train_params(self)
         return dx_p.view(bm, ph, pw, Cc), dx_e.view(b, eh, ew, Cc), [g.view(p_.shape) for g, p_ in zip(grads, params)]

@@ -747,8 +747,8 @@ def backward(tape, d_eps, sink, dh=None, dskips=None, wsink=None, dtemb=None):
             controlnet_backward(entry[2], list(dskips[br]), entry[2].d_mid, sink)
             continue
         if kind == "fuse":
-            _, pers, pano, block, xp, xe, groups, m = entry
-            dp, de, grads = block.backward_nhwc(xp, xe, groups, m, dh[pers], dh[pano])
+            _, pers, pano, block, xp, xe, groups, m, rec = entry
+            dp, de, grads = block.backward_nhwc(xp, xe, groups, m, dh[pers], dh[pano], rec)
             dh[pers], dh[pano] = dp, de
             for p_, g_ in zip(training.train_params(block), grads):
                 sink(p_, g_)
