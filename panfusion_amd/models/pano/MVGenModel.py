@@ -225,6 +225,7 @@ class MultiViewBaseModel(nn.Module):
         branches = []
         cn_res = {}                                 # id(branch) -> (12 skip residuals, mid residual)
         shard = getattr(self, "shard", None)      # set by sharding.ShardedDenoiseLoop: latents hold only
+        from ... import train_engine
         if tape is not None:
             if shard is not None:
                 raise NotImplementedError("the training path covers the un-sharded denoiser")
@@ -270,7 +271,8 @@ class MultiViewBaseModel(nn.Module):
         view_only = two and shard is not None and not shard.has_pano
         main = torch.cuda.current_stream(dev) if pano_latent.is_cuda else None
         side = None
-        if two and self.two_streams and main is not None and not view_only and not pano_only and tape is None:
+        train_streams = tape is None or train_engine.TWO_STREAMS       # (a training step overlaps the two branches too)
+        if two and self.two_streams and main is not None and not view_only and not pano_only and train_streams:
             if self._side is None:
                 # PF_PANO_PRIORITY=1: the panorama branch's stream gets HIGH priority.  Its ~1400 small kernels are the
                 # critical path at the deep levels (the view stream idles 3-4 ms per step at the joins there,
@@ -294,19 +296,22 @@ class MultiViewBaseModel(nn.Module):
                 keep.clear()
 
         fork()
-        if side is not None:                        # the view branch's text K / V^T: 32 tiny GEMMs, off the critical path
+        keeps = tape is not None and train_engine.KEEP  # (such a forward projects the padded text inside every block)
+        if side is not None and not keeps:          # the view branch's text K / V^T: 32 tiny GEMMs, off the critical path
             with on_pano():                         # (computed once per prompt tensor, then served from the cache)
                 pers.precompute_text_kv()
                 pers.text_ready = torch.cuda.Event()
                 pers.text_ready.record(side)
-        elif pers is not None:
+        elif pers is not None and not keeps:
             pers.precompute_text_kv()
         pano = None
         if not view_only:
             with on_pano():
                 pano = make_branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
                                    self._prompt16(pano_prompt_embd), pano=True, pad=self.pano_pad)
-                pano.precompute_text_kv()
+                pano.on_side = side is not None     # (train_engine.backward walks its entries on the same stream)
+                if not keeps:
+                    pano.precompute_text_kv()
                 if pano_layout_cond is not None:    # reference :75-83: plain convolutions on the un-padded latent
                     controlnet("pano_cn", pano, pano_latent.flatten(0, 1), pano_t, pano_layout_cond.flatten(0, 1))
             branches.append(pano)
@@ -336,6 +341,7 @@ class MultiViewBaseModel(nn.Module):
                 xp_in, xe_in = pers.h, pano.h
                 pers.h, pano.h, rec = block.forward_nhwc_keep(xp_in, xe_in, groups, m_total)
                 tape.append(("fuse", pers, pano, block, xp_in, xe_in, groups, m_total, rec))
+                fork()
                 return
             if tape is not None:
                 tape.append(("fuse", pers, pano, block, pers.h, pano.h, groups, m_total, None))
@@ -409,5 +415,5 @@ class MultiViewBaseModel(nn.Module):
         else:
             sample = pers.head().to(out_dtype).unflatten(0, (b, m)) if two else None
         if tape is not None:
-            return sample, pano_sample, pers, pano
+            return sample, pano_sample, pers, pano, side
         return sample, pano_sample

@@ -39,6 +39,9 @@ EXACT = os.environ.get("PF_TRAIN_EXACT", "1") != "0"
 # every layer inside its backward as rounds 2 did (the reference checkpoints only the EPA blocks, transformer.py:77-127; the
 # UNets' activations stay alive under autograd there too).  PF_TRAIN_KEEP=0: recompute (A/B, and the lower-memory mode).
 KEEP = os.environ.get("PF_TRAIN_KEEP", "1") != "0"
+# Forward AND backward of a training step run the panorama branch on the model's side stream next to the view branch, joined at
+# the EPA blocks, as the inference step does (neither branch fills 256 CUs at the training resolution).  PF_TRAIN_STREAMS=0: one stream.
+TWO_STREAMS = os.environ.get("PF_TRAIN_STREAMS", "1") != "0"
 
 
 # ---------------------------------------------------------------------------------------------- weights of the backward GEMMs
@@ -725,13 +728,24 @@ def _first_trainable_entry(tape):
     return None
 
 
-def backward(tape, d_eps, sink, dh=None, dskips=None, wsink=None, dtemb=None):
+def backward(tape, d_eps, sink, dh=None, dskips=None, wsink=None, dtemb=None, side=None):
     """Walk the tape backwards.  d_eps: {branch: fp32 NCHW gradient of that branch's predicted noise}.
     dh / dskips: gradients to start from (a ControlNet's tape starts at its mid output and its 12 skip tensors);
     wsink: the taped network's own weights train -- parameter gradients into wsink, each resnet's time-embedding gradient
-    appended to dtemb as (offset, [n, cout])."""
+    appended to dtemb as (offset, [n, cout]).
+    side: the stream the forward ran the panorama branch on (entries of a branch with `on_side` are walked there, the EPA blocks
+    join the two streams as in the forward); tensors handed from one stream to the other stay referenced until the walk ends
+    (the caching allocator recycles per stream)."""
+    import contextlib
     dh = {} if dh is None else dh
     dskips = {} if dskips is None else dskips
+    main = torch.cuda.current_stream() if side is not None else None
+    crossing = []
+    if side is not None:
+        side.wait_stream(main)
+
+    def stream_of(br):
+        return torch.cuda.stream(side) if (side is not None and getattr(br, "on_side", False)) else contextlib.nullcontext()
     # Nothing before the EARLIEST entry that has a trainable leaf behind it needs a gradient (autograd prunes the same way):
     # with frozen LoRA matrices (layout-conditioned runs) the first encoder level of both branches is skipped.
     first = 0 if wsink is not None else _first_trainable_entry(tape)
@@ -744,45 +758,61 @@ def backward(tape, d_eps, sink, dh=None, dskips=None, wsink=None, dtemb=None):
             entry[2].d_mid = dh[br]
             continue
         if kind == "cn_skips":                        # skips += residuals (:154-170): every skip's gradient is known by now
-            controlnet_backward(entry[2], list(dskips[br]), entry[2].d_mid, sink)
+            with stream_of(br):
+                controlnet_backward(entry[2], list(dskips[br]), entry[2].d_mid, sink)
             continue
         if kind == "fuse":
             _, pers, pano, block, xp, xe, groups, m, rec = entry
+            if side is not None:
+                main.wait_stream(side)                # join: the panorama branch's gradient is complete
+                crossing.append(dh[pano])
             dp, de, grads = block.backward_nhwc(xp, xe, groups, m, dh[pers], dh[pano], rec)
             dh[pers], dh[pano] = dp, de
             for p_, g_ in zip(training.train_params(block), grads):
                 sink(p_, g_)
+            if side is not None:
+                crossing.append(de)
+                side.wait_stream(main)                # fork
             continue
-        pad = br.pad
-        if kind == "head":
-            dh[br] = head_backward(br.u, entry[2], d_eps[br], pad)
-        elif kind == "up":
-            dh[br] = upsample_backward(entry[2], dh[br], pad, br.u.dtype)
-        elif kind == "down":
-            dh[br] = downsample_backward(entry[2], dh[br], pad, br.u.dtype, wsink, entry[3] if wsink is not None else None)
-        elif kind == "push":
-            g = dskips[br].pop()
-            dh[br] = ops.add(dh[br], g) if dh.get(br) is not None else g
-        elif kind == "attention":
-            dh[br] = transformer_backward(entry[2], entry[3], br.text, dh[br], sink, wsink, entry[4])
-        elif kind == "resnet":
-            _, _, r, x, s, saved = entry
-            rowvec = br.temb[:, r.temb_off:]
-            d = dh[br]
-            if pad:                                   # pad 2 / resnet / crop 2 (MVGenModel.py:110-115)
-                d = ops.crop_width_bwd(d, 2)
-                x, s = ops.pad_width(x, 2), (ops.pad_width(s, 2) if s is not None else None)
-            if wsink is not None:
-                dx, ds, dt = resnet_backward(r, x, s, rowvec, d, wsink, saved)
-                dtemb.append((r.temb_off, dt))
-            else:
-                dx, ds = resnet_backward(r, x, s, rowvec, d, saved=saved)
-            if pad:
-                dx, ds = ops.pad_width_bwd(dx, 2), (ops.pad_width_bwd(ds, 2) if ds is not None else None)
-            dh[br] = dx
-            if s is not None:
-                dskips.setdefault(br, []).append(ds)
+        with stream_of(br):
+            _walk_entry(entry, kind, br, dh, dskips, d_eps, sink, wsink, dtemb)
+    if side is not None:
+        main.wait_stream(side)
+    del crossing
     return dh, dskips
+
+
+def _walk_entry(entry, kind, br, dh, dskips, d_eps, sink, wsink, dtemb):
+    """One UNet-layer entry of the tape (on the stream the caller selected)."""
+    pad = br.pad
+    if kind == "head":
+        dh[br] = head_backward(br.u, entry[2], d_eps[br], pad)
+    elif kind == "up":
+        dh[br] = upsample_backward(entry[2], dh[br], pad, br.u.dtype)
+    elif kind == "down":
+        dh[br] = downsample_backward(entry[2], dh[br], pad, br.u.dtype, wsink, entry[3] if wsink is not None else None)
+    elif kind == "push":
+        g = dskips[br].pop()
+        dh[br] = ops.add(dh[br], g) if dh.get(br) is not None else g
+    elif kind == "attention":
+        dh[br] = transformer_backward(entry[2], entry[3], br.text, dh[br], sink, wsink, entry[4])
+    elif kind == "resnet":
+        _, _, r, x, s, saved = entry
+        rowvec = br.temb[:, r.temb_off:]
+        d = dh[br]
+        if pad:                                   # pad 2 / resnet / crop 2 (MVGenModel.py:110-115)
+            d = ops.crop_width_bwd(d, 2)
+            x, s = ops.pad_width(x, 2), (ops.pad_width(s, 2) if s is not None else None)
+        if wsink is not None:
+            dx, ds, dt = resnet_backward(r, x, s, rowvec, d, wsink, saved)
+            dtemb.append((r.temb_off, dt))
+        else:
+            dx, ds = resnet_backward(r, x, s, rowvec, d, saved=saved)
+        if pad:
+            dx, ds = ops.pad_width_bwd(dx, 2), (ops.pad_width_bwd(ds, 2) if ds is not None else None)
+        dh[br] = dx
+        if s is not None:
+            dskips.setdefault(br, []).append(ds)
 
 
 # ---------------------------------------------------------------------------------------------- the trainable ControlNet
@@ -936,8 +966,8 @@ class DenoiserFunction(torch.autograd.Function):
     def forward(ctx, model, args, *params):
         tape = []
         model.refold_lora()
-        sample, pano_sample, pers, pano = model._forward(*args, tape=tape)
-        ctx.tape, ctx.pers, ctx.pano, ctx.params = tape, pers, pano, params
+        sample, pano_sample, pers, pano, side = model._forward(*args, tape=tape)
+        ctx.tape, ctx.pers, ctx.pano, ctx.params, ctx.side = tape, pers, pano, params, side
         ctx.has_sample = sample is not None
         ctx.sample_shape = None if sample is None else tuple(sample.shape)
         ctx.pano_shape = tuple(pano_sample.shape)
@@ -958,6 +988,6 @@ class DenoiserFunction(torch.autograd.Function):
                 d_pano = torch.zeros(ctx.pano_shape, device=d_sample.device, dtype=F32)
             d_eps[ctx.pano] = d_pano.flatten(0, 1).float().contiguous()
             sink = ParamGrads()
-            backward(ctx.tape, d_eps, sink)
+            backward(ctx.tape, d_eps, sink, side=ctx.side)
         ctx.tape = None
         return (None, None, *[sink.get(p_) for p_ in ctx.params])

@@ -57,7 +57,7 @@ def main():
     for _ in range(args.steps):
         tape = []
         with torch.no_grad():
-            a, b, pers, pano_br = model._forward(*args_, tape=tape)
+            a, b, pers, pano_br, side = model._forward(*args_, tape=tape)
             d = {pers: torch.randn_like(a).flatten(0, 1).contiguous(), pano_br: torch.randn_like(b).flatten(0, 1).contiguous()}
             torch.cuda.synchronize()
             pr.enable()
