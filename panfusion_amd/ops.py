@@ -20,6 +20,7 @@ _DT = {torch.bfloat16: PF_BF16, torch.float16: PF_F16, torch.float32: PF_F32}
 TRACE = None
 
 
+_PLANS = {}           # conv_gemm: problem shape -> [split-K scratch bytes, GroupNorm-moment rows] as the library plans it
 SPLITK_INKERNEL = os.environ.get("PF_SPLITK_INKERNEL") == "1"    # A/B switch, read once (as the library reads it)
 
 
@@ -439,7 +440,14 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     d.a_bstride, d.w_bstride, d.out_bstride, d.res_bstride = a_bstride, w_bstride, out_bstride, res_bstride
     d.epilogue = 1 if geglu else (2 if split_out else 0)
     d.wrap_pad, d.crop = wrap_pad, crop
-    nbytes = _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
+    # the library's plan for this problem (split-K scratch, GroupNorm-moment rows) depends on the shapes only: asked once per shape
+    pkey = (c0, c1, n_img, h_in, w_in, h_out, w_out, ksize, stride, pad, upsample, n_out, batch, d.epilogue, wrap_pad, crop,
+            d.dtype, d.out_dtype, residual is not None, d.res_dtype, d.res_ld, rowvec is not None, bias is not None, d.out_ld, d.a0_ld,
+            d.a1_ld, d.rowvec_ld)
+    plan = _PLANS.get(pkey)
+    if plan is None:
+        plan = _PLANS[pkey] = [_lib.lib().pf_conv_gemm_workspace_size(C.byref(d)), None]
+    nbytes = plan[0]
     ws = torch.empty(nbytes, device=a0.device, dtype=torch.uint8) if nbytes else None   # split-K slabs
     d.workspace, d.workspace_bytes = _p(ws), nbytes
     if nbytes and SPLITK_INKERNEL:
@@ -448,13 +456,18 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
         d.tickets, d.n_tickets = _ticket_slice(a0.device), _TICKET_SLICE
     gn = None
     if gn_stats and GN_FROM_EPILOGUE and batch == 1:
-        rows = _lib.lib().pf_conv_gemm_gn_rows(C.byref(d))
+        if plan[1] is None:
+            plan[1] = _lib.lib().pf_conv_gemm_gn_rows(C.byref(d))
+        rows = plan[1]
         if rows > 0:
             gn = (torch.empty(M // rows, 2, n_out // 2, device=a0.device, dtype=torch.float32), rows)
             d.gn_partial = _p(gn[0])
-    _traced("k_conv_gemm", 2.0 * M * n_out * (algo_k or ksize * ksize * (c0 + c1)) * batch,
-            lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"),
-            "M%d N%d K%d k%d s%d u%d b%d" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch))
+    if TRACE is None:
+        check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm")
+    else:
+        _traced("k_conv_gemm", 2.0 * M * n_out * (algo_k or ksize * ksize * (c0 + c1)) * batch,
+                lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"),
+                "M%d N%d K%d k%d s%d u%d b%d" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch))
     if gn is not None:
         out._pf_gn = gn
     return out
