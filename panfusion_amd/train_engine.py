@@ -3,10 +3,13 @@
 blocks and the rank-4 LoRA matrices on the attention projections of both UNets, PanoGenerator.py:129-160 -- the UNet
 weights themselves are frozen).
 
-The forward of a training step IS the inference forward (engine.Branch, same kernels, same precision scheme): a
-``TrainBranch`` only notes, per layer, which packed layer ran on which input tensors.  The backward walks that tape in
-reverse; every entry recomputes the activations its layer needs from the saved inputs (16-bit MFMA operands, fp32
-residual stream) and applies the layer's backward:
+The forward of a training step runs the inference engine (engine.Branch, same kernels, same precision scheme) through a
+``TrainBranch`` that notes, per layer, which packed layer ran on which input tensors AND keeps what the layer's backward reads
+(KEEP, round 3: the resnets' norms and h1, the transformers' and EPA blocks' whole records -- their training forward is the code
+that used to be the backward's recompute; PF_TRAIN_KEEP=0 recomputes from the inputs instead).  The backward walks that tape
+in reverse, the panorama branch on the side stream beside the view branch as in the forward (TWO_STREAMS), and stops at the
+earliest entry with a trainable leaf behind it; every entry applies its layer's backward (16-bit MFMA operands, fp32
+residual stream):
 
   resnet        GN+SiLU backward (pf_groupnorm_bwd), 3x3 data gradients = the forward GEMM kernel on flipped,
                 transposed weights, 1x1 shortcut on the transposed weight, the two-source concat splits into (dx, dskip)
