@@ -25,7 +25,6 @@ from dataclasses import dataclass
 import torch
 import torch.distributed as dist
 
-from . import ops
 from .pipeline import DenoiseLoop
 
 

@@ -2,7 +2,6 @@
 ``utils/pano.py:21-105``): camera samplers (host, radians) and the circular
 width padding."""
 import numpy as np
-import torch
 
 from .. import ops
 
