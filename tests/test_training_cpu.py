@@ -201,6 +201,29 @@ def test_denoiser_training_step_matches_autograd(fake_denoiser_backend, precisio
         assert rel_l2(got[k], want[k]) < 1e-4, (k, rel_l2(got[k], want[k]))
 
 
+def test_recompute_mode_gives_the_same_gradients(fake_denoiser_backend, monkeypatch):
+    """PF_TRAIN_KEEP=0 (the backward recomputes every layer from its input: the low-memory mode, and round 2's behaviour) against
+    the default (the training forward keeps its activations): same outputs up to the forward's fusion differences, same
+    gradients up to round-off -- with the panorama ControlNet trainable, so that every kind of tape entry is walked both ways."""
+    from panfusion_amd import train_engine
+    from panfusion_amd.models.pano import MultiViewBaseModel
+    oracle, cn, cns, args, kw, w_s, w_p = _with_controlnet("pano")
+    grads = {}
+    for keep in (True, False):
+        monkeypatch.setattr(train_engine, "KEEP", keep)
+        hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, *cns, oracle.pano_pad, compute_dtype=torch.float32,
+                                 precision="mixed", differentiable=True)
+        hip.load_state_dict({k: v for k, v in oracle.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+        for p in hip.parameters():
+            p.grad = None
+        s2, ps2 = hip(*args, **kw)
+        ((s2 * w_s).sum() + (ps2 * w_p).sum()).backward()
+        grads[keep] = {k: p.grad.clone() for k, p in hip.named_parameters() if p.grad is not None}
+    assert sorted(grads[True]) == sorted(grads[False]) and len(grads[True]) > 900
+    worst = max((rel_l2(grads[True][k], grads[False][k]), k) for k in grads[True])
+    assert worst[0] < 1e-4, worst
+
+
 def test_denoiser_inference_is_untouched_by_the_training_switch(fake_denoiser_backend):
     from panfusion_amd.models.pano import MultiViewBaseModel
     oracle, args, _, _ = _denoiser_case()
