@@ -19,10 +19,6 @@ def fake_backend(monkeypatch):
     import importlib
     for name in MODS:
         monkeypatch.setattr(importlib.import_module(name), "ops", fake_ops)
-    try:
-        monkeypatch.setattr(importlib.import_module("panfusion_amd.sharding"), "ops", fake_ops)
-    except ImportError:
-        pass
 
 
 def hip_model(oracle_model, precision="fast", dtype=torch.float32):
