@@ -422,31 +422,36 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     n_store = n_out // 2 if geglu else (2 * n_out if split_out else n_out)
     if out is None:
         out = torch.empty((batch, M, n_store) if batch > 1 else (M, n_store), device=a0.device, dtype=out_dtype)
-    d = ConvDesc()
-    d.a0, d.a1, d.c0, d.c1 = _p(a0), _p(a1), c0, c1
-    d.a0_ld = a0_ld if a0_ld is not None else _ld(a0)
-    d.a1_ld = (a1_ld if a1_ld is not None else _ld(a1)) if a1 is not None else 0
-    d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n_img, h_in, w_in, h_out, w_out
-    d.ksize, d.stride, d.pad, d.upsample = ksize, stride, pad, upsample
-    d.w, d.n_out = _p(w), n_out
-    d.bias = _p(bias)
-    d.rowvec, d.rowvec_ld = _p(rowvec), (_ld(rowvec) if rowvec is not None else 0)
-    d.residual = _p(residual)
-    d.res_ld = (res_ld if res_ld is not None else _ld(residual)) if residual is not None else 0
-    d.res_dtype = dt(residual) if residual is not None else dt(a0)
-    d.out, d.out_ld = _p(out), (out_ld if out_ld is not None else _ld(out))
-    d.out_dtype, d.dtype = dt(out_dtype), dt(a0)
-    d.batch = batch
-    d.a_bstride, d.w_bstride, d.out_bstride, d.res_bstride = a_bstride, w_bstride, out_bstride, res_bstride
-    d.epilogue = 1 if geglu else (2 if split_out else 0)
-    d.wrap_pad, d.crop = wrap_pad, crop
-    # the library's plan for this problem (split-K scratch, GroupNorm-moment rows) depends on the shapes only: asked once per shape
-    pkey = (c0, c1, n_img, h_in, w_in, h_out, w_out, ksize, stride, pad, upsample, n_out, batch, d.epilogue, wrap_pad, crop,
-            d.dtype, d.out_dtype, residual is not None, d.res_dtype, d.res_ld, rowvec is not None, bias is not None, d.out_ld, d.a0_ld,
-            d.a1_ld, d.rowvec_ld)
+    a0_ld = a0_ld if a0_ld is not None else _ld(a0)
+    a1_ld = (a1_ld if a1_ld is not None else _ld(a1)) if a1 is not None else 0
+    rowvec_ld = _ld(rowvec) if rowvec is not None else 0
+    res_ld = (res_ld if res_ld is not None else _ld(residual)) if residual is not None else 0
+    res_dtype = dt(residual) if residual is not None else dt(a0)
+    out_ld = out_ld if out_ld is not None else _ld(out)
+    epilogue = 1 if geglu else (2 if split_out else 0)
+    # One descriptor per problem SHAPE, filled once and reused (a launch-bound training step issues ~1500 of these per step:
+    # the ~35 scalar members cost more host time than the call); with it the library's plan for the shape (split-K scratch,
+    # GroupNorm-moment rows), asked once.  Per call only the pointers change.
+    pkey = (c0, c1, a0_ld, a1_ld, n_img, h_in, w_in, h_out, w_out, ksize, stride, pad, upsample, n_out, batch, epilogue, wrap_pad,
+            crop, dt(a0), dt(out_dtype), residual is not None, res_dtype, res_ld, rowvec is not None, rowvec_ld, bias is not None,
+            out_ld, a_bstride, w_bstride, out_bstride, res_bstride)
     plan = _PLANS.get(pkey)
     if plan is None:
-        plan = _PLANS[pkey] = [_lib.lib().pf_conv_gemm_workspace_size(C.byref(d)), None]
+        d = ConvDesc()
+        d.c0, d.c1, d.a0_ld, d.a1_ld = c0, c1, a0_ld, a1_ld
+        d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n_img, h_in, w_in, h_out, w_out
+        d.ksize, d.stride, d.pad, d.upsample = ksize, stride, pad, upsample
+        d.n_out, d.rowvec_ld, d.res_ld, d.res_dtype, d.out_ld = n_out, rowvec_ld, res_ld, res_dtype, out_ld
+        d.out_dtype, d.dtype = dt(out_dtype), dt(a0)
+        d.batch = batch
+        d.a_bstride, d.w_bstride, d.out_bstride, d.res_bstride = a_bstride, w_bstride, out_bstride, res_bstride
+        d.epilogue = epilogue
+        d.wrap_pad, d.crop = wrap_pad, crop
+        d.a0, d.a1, d.w, d.bias, d.rowvec, d.residual, d.out = _p(a0), _p(a1), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
+        plan = _PLANS[pkey] = [_lib.lib().pf_conv_gemm_workspace_size(C.byref(d)), None, d]
+    d = plan[2]
+    d.a0, d.a1, d.w, d.bias, d.rowvec, d.residual, d.out = _p(a0), _p(a1), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
+    d.gn_partial, d.tickets, d.n_tickets = None, None, 0
     nbytes = plan[0]
     ws = torch.empty(nbytes, device=a0.device, dtype=torch.uint8) if nbytes else None   # split-K slabs
     d.workspace, d.workspace_bytes = _p(ws), nbytes

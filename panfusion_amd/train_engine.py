@@ -992,5 +992,8 @@ class DenoiserFunction(torch.autograd.Function):
             d_eps[ctx.pano] = d_pano.flatten(0, 1).float().contiguous()
             sink = ParamGrads()
             backward(ctx.tape, d_eps, sink, side=ctx.side)
-        ctx.tape = None
+        # the tape (and with it every kept activation) must not outlive this call: the branches reference the same list, and the
+        # graph node stays alive for as long as the caller holds the step's loss -- typically into the next step's forward
+        ctx.tape.clear()
+        ctx.tape = ctx.pers = ctx.pano = None
         return (None, None, *[sink.get(p_) for p_ in ctx.params])
