@@ -302,6 +302,32 @@ int pf_conv_gemm_gn_rows(const pf_conv_desc* desc);
 pf_status pf_debug_gemm_profile(void* device_buffer, long capacity_blocks);
 pf_status pf_conv_gemm(const pf_conv_desc* desc, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Weight-stationary linear for the C = 320 token layers (K == 320, N a multiple of 320): the nn.Linear layers of the
+ * finest level's transformer blocks and of the C = 320 EPA block (models/modules/transformer.py:57-74 to_q / to_k / to_v /
+ * to_out, :8-38 GEGLU FeedForward; diffusers BasicTransformerBlock behind models/pano/MVGenModel.py:104-106).
+ * A workgroup keeps 320 output channels of the weights in registers and streams 64-token tiles of `a` through LDS.
+ *   PF_LWS_16:    out 16-bit [M][out_ld]      = a w^T + bias
+ *   PF_LWS_F32:   out fp32   [M][out_ld]      = a w^T + bias + residual (fp32 [M][res_ld] or NULL)
+ *   PF_LWS_GEGLU: out 16-bit [M][out_ld], N/2 columns: w / bias rows interleaved (value_j, gate_j), out = value * gelu(gate)
+ *   PF_LWS_QKV:   N == 960 = (q | k | v): out 16-bit [M][out_ld] receives the 640 columns (q | k); V leaves TRANSPOSED as
+ *                 out_vt[b][c][key] (b = m / rows_per_batch, key = m % rows_per_batch, row stride vt_ld, batch stride vt_bs):
+ *                 the layout pf_attention reads.  rows_per_batch a multiple of 64.
+ * a 16-bit [M][a_ld]; w 16-bit [N][320]; bias fp32 [N] or NULL.  pf_linear_ws_supported: 1 if (M, N, K, mode) is served. */
+typedef struct {
+    const void* a; int a_ld;
+    const void* w;
+    const float* bias;
+    const float* residual; int res_ld;
+    void* out; int out_ld;
+    void* out_vt; int vt_ld; int rows_per_batch; long vt_bs;
+    int M, N, K;
+    int dtype; int mode;
+} pf_linear_ws_desc;
+enum { PF_LWS_16 = 0, PF_LWS_F32 = 1, PF_LWS_GEGLU = 2, PF_LWS_QKV = 3 };
+int pf_linear_ws_supported(long M, int N, int K, int mode);
+pf_status pf_linear_ws(const pf_linear_ws_desc* desc, void* stream);
+
 /* 3x3 convolutions with 4 input or 4 output channels at the UNet boundary:
  * conv_in  (MVGenModel.py:86,89): x fp32 NCHW [n][cin][h][w] -> y NHWC [n][h][w][cout] (out_dtype 16-bit
  *          or PF_F32), weights fp32 [3][3][cin][cout];

@@ -49,6 +49,16 @@ class AttnDesc(C.Structure):
     ]
 
 
+class LinearWsDesc(C.Structure):
+    """pf_linear_ws_desc"""
+    _fields_ = [
+        ("a", c_void_p), ("a_ld", c_int), ("w", c_void_p), ("bias", c_void_p),
+        ("residual", c_void_p), ("res_ld", c_int), ("out", c_void_p), ("out_ld", c_int),
+        ("out_vt", c_void_p), ("vt_ld", c_int), ("rows_per_batch", c_int), ("vt_bs", c_long),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("mode", c_int),
+    ]
+
+
 class AttnBwdDesc(C.Structure):
     """pf_attn_bwd_desc"""
     _fields_ = [
@@ -120,6 +130,8 @@ SIGNATURES = {
     "pf_scale_shift_act_pair": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p]),
     "pf_debug_gemm_profile": (c_int, [c_void_p, c_long]),
+    "pf_linear_ws_supported": (c_int, [c_long, c_int, c_int, c_int]),
+    "pf_linear_ws": (c_int, [C.POINTER(LinearWsDesc), c_void_p]),
     "pf_conv_in": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                            c_void_p, c_void_p]),
     "pf_conv_out": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,

@@ -54,11 +54,20 @@ struct GemmParams {
     unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors of the 8-wave kernel (< 2 GiB)
     int adv_img, adv_y, adv_x;              // (image, row, column) advance of one DMA pass of output rows (8-wave kernel)
     unsigned long long* prof;      // diagnostics (pf_debug_gemm_profile): 4 s_memtime stamps per block, or NULL
+    int stagger;                   // 8-wave kernel: every second block (per XCD) starts this many shader clocks late, so that the CUs' epilogue /
+                                   // HBM phases do not all coincide (PF_GEMM_STAGGER: experiment)
     float* gn_partial;             // [M / gn_rows][2][N / 2] fp32 per-column-pair (sum, sum of squares) of the finished output over
     int gn_rows;                   // the gn_rows fragment rows of one wavefront (GroupNorm moments of the NEXT layer), or NULL
 };
 
 // phase stamp of wave 0 / lane 0 of a block: [block][4] = kernel entry, first tile landed, K loop done, exit
+#ifdef PF_GEMM_TIMELINE       /* debug build (make timeline): wave 0 of every block stamps the phases of ITS SECOND TILE (steady state of the
+                               * persistent loop) into slots 12..: tile begin, operands landed + barrier, stage 2 requested + first fragments,
+                               * after every K step (<= 8), after the epilogue -- tools/gemm_bench.py --timeline prints the differences */
+#define PF_TL(p, cond, slot) do { if ((cond) && (p).prof && threadIdx.x == 0) { const long b_ = blockIdx.x + static_cast<long>(gridDim.x) * (blockIdx.y + static_cast<long>(gridDim.y) * blockIdx.z); (p).prof[b_ * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define PF_TL(p, cond, slot) do { } while (0)
+#endif
 __device__ __forceinline__ void stamp(const GemmParams& p, int slot) {
     if (p.prof && threadIdx.x == 0) {
         const long b = blockIdx.x + static_cast<long>(gridDim.x) * (blockIdx.y + static_cast<long>(gridDim.y) * blockIdx.z);
@@ -1021,6 +1030,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     const std::true_type YES;
     const std::false_type NO;
     int cur = 0, nx1 = 1, nx2 = 2;
+#ifdef PF_GEMM_TIMELINE
+    int tl_tile = 0, tl_step = 0;
+#endif
     // One K step.  MORE: a next stage exists (wait for it, barrier, prefetch its first fragments);
     // DMA: a stage three ahead exists (issue its pieces between the MFMAs of the second half).  The flags
     // are compile-time so that the steady-state body is branch free and the compiler's s_waitcnt
@@ -1108,6 +1120,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
 #ifdef PF_GEMM_BDIRECT
         kw += 64;
 #endif
+#ifdef PF_GEMM_TIMELINE
+        PF_TL(p, tl_tile == 1 && tl_step < 8, 15 + tl_step);
+        ++tl_step;
+#endif
     };
 #ifndef PF_GEMM_FLEAD
 #define PF_GEMM_FLEAD 4
@@ -1121,11 +1137,16 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // both waves of a SIMD run the same MFMA-dense stream, there is no loader / computer pairing for a priority to help
     if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(PF_GEMM_SETPRIO);
 #endif
+    if (p.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < static_cast<unsigned long long>(p.stagger)) __builtin_amdgcn_s_sleep(16);
+    }
     int tile = blockIdx.x;
     set_tile(tile);
     issue_prologue();
     bool first = true;
     for (;;) {
+        PF_TL(p, tl_tile == 1, 12);
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
 #pragma unroll
@@ -1147,9 +1168,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         asm volatile("" ::: "memory");
         if (first) stamp(p, 1);
         first = false;
+        PF_TL(p, tl_tile == 1, 13);
         if (n_it > 2) dma_stage(2);                       // third stage in flight (slot 2 staged the previous tile's epilogue)
         load_frags(0, 0, fa0, fb0, 0);
         cur = 0; nx1 = 1; nx2 = 2;
+        PF_TL(p, tl_tile == 1, 14);
         // The slot of stage `it` is retired at the mid-step barrier of step `it` (its last fragments are
         // requested in the first half), and stage it+3 is requested into it right behind that barrier: with
         // three slots a stage has TWO K steps to arrive, the mid-step wait leaves the younger one in flight.
@@ -1192,9 +1215,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             asm volatile("" : "+v"(e_lane), "+v"(e_t));
             epilogue_tile<T, MREP, NREP, NT, BM, BN, 2, STATS>(p, bz, acc, smem + 2 * STAGE, em0, en0, wm * 16 * MREP, wn * 16 * NREP,
                                                         e_lane, e_t, [&]() { if (has_next) { set_tile(next); issue_prologue(); } });
+            PF_TL(p, tl_tile == 1, 23);
             if (!has_next) break;
         }
         tile = next;
+#ifdef PF_GEMM_TIMELINE
+        ++tl_tile; tl_step = 0;
+#endif
     }
     stamp(p, 3);
 }
@@ -1276,6 +1303,8 @@ static pf_status launch8w_s(const GemmParams& gp, int batch, hipStream_t st) {
     }
     const ProfState ps = prof_snapshot();
     p.prof = (ps.buf && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= ps.blocks) ? ps.buf : nullptr;
+    static const int stagger = tuning("PF_GEMM_STAGGER", 0), stagger_maxk = tuning("PF_GEMM_STAGGER_MAXK", 1 << 30);
+    p.stagger = (p.K <= stagger_maxk && p.mtiles * p.ntiles >= 512) ? stagger : 0;
     const size_t smem = static_cast<size_t>(3) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1436,6 +1465,7 @@ static void params_from_desc(const pf_conv_desc* d, GemmParams& p) {
     p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;
     p.mtiles = p.ntiles = 0;
     p.prof = nullptr;
+    p.stagger = 0;
     p.batch = d->batch;
     p.gn_partial = nullptr; p.gn_rows = 0;
     p.m_begin = 0; p.splits = 1; p.kb_per_split = 0; p.partial = nullptr; p.tickets = nullptr;

@@ -1,0 +1,399 @@
+// Weight-stationary linear layers for the C = 320 token stream of the finest UNet level (gfx950 / CDNA4).
+//
+//   out[m][n] = sum_k a[m][k] * w[n][k]  (+ bias[n]) (+ residual[m][n])        K = 320, N a multiple of 320
+//
+// Why a second GEMM structure: at K = 320 the tile kernel of pf_gemm.hip (256 x 160 tile, K loop of 5 steps) spends
+// 6.4 k clocks of a 32 k-clock tile in the matrix pipes (profiles/r4a_timeline.txt): 260 KB of operands per tile enter
+// through a pipeline that only ramps up, and the epilogue (11 - 16 k clocks) runs with the matrix pipes idle.  Here the roles
+// are turned round: a workgroup keeps a 320-channel slab of the WEIGHTS in registers for its whole life (8 wavefronts:
+// four hold 48 output channels, four hold 32, so that every SIMD serves 48 + 32 = 80 channels -- 120 / 80 registers per
+// lane) and streams 64-token tiles of the activation matrix through a 3-slot LDS ring (40 KB per slot, LDS-DMA with the
+// XOR-swizzled source offsets of pf_gemm.hip, one tile = the FULL K).  There is no K loop to pipeline, the only operand
+// traffic is the activation stream (12.5 B per clock and CU against ~24 for the tile kernel's two operands), and every
+// wavefront runs its own epilogue on 32-token slices between its MFMA bursts: the partner wavefront of the SIMD covers it.
+//
+// Grid: N / 320 channel blocks x S token ranges, block b on XCD b % 8; the channel blocks of one token range share an XCD
+// (one L2 fill of the activation tiles).  Epilogue modes: 16-bit out | fp32 out + fp32 residual (the residual stream of the
+// mixed scheme) | GEGLU pairing (transformer.py:8-21) | q | k | v in ONE launch with V written transposed [C][keys]
+// (what pf_attention reads).
+//
+// Replaces cuBLAS behind the nn.Linear layers of diffusers' BasicTransformerBlock / the reference's
+// models/modules/transformer.py:57-74 (to_q / to_k / to_v / to_out), :8-38 (GEGLU FeedForward) at C = 320.
+#include "pf_common.h"
+#include <stdlib.h>
+
+namespace pf {
+
+struct LwsParams {
+    const unsigned short* a; int a_ld;
+    const unsigned short* w;
+    const float* bias;
+    const float* residual; int res_ld;
+    void* out; int out_ld;
+    unsigned short* out_vt; int vt_ld; int rows_per_batch; long vt_bs;
+    int M, N;
+    int nblocks, splits_per_xcd, ntiles;
+    unsigned a_bytes;
+    int defer;                     // the 32-channel wavefronts run their epilogues half a tile late (PF_LWS_DEFER=0: A/B)
+};
+
+template <typename T> struct LwsMfma;
+template <> struct LwsMfma<Bf16> {
+    typedef __attribute__((ext_vector_type(8))) __bf16 frag;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct LwsMfma<F16> {
+    typedef __attribute__((ext_vector_type(8))) _Float16 frag;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+__device__ __forceinline__ float lws_erf(float x) {               // Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (as pf_gemm.hip)
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    float y = 1.061405429f;
+    y = y * t - 1.453152027f;
+    y = y * t + 1.421413741f;
+    y = y * t - 0.284496736f;
+    y = y * t + 0.254829592f;
+    y = 1.0f - y * t * __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
+    return copysignf(y, x);
+}
+
+// value * gelu(gate) with the same erf approximation, arranged as  g Phi(g) = relu(g) - |g| h,  h = 0.5 P(t) exp(-g^2 / 2),
+// t = 1 / (1 + p |g| / sqrt 2): 12 plain VALU operations + rcp + exp2 per output (the straightforward 0.5 g (1 + erf(g / sqrt 2))
+// with copysign costs 20): the GEGLU epilogue is VALU-bound (profiles/r4e_lws_pmc_kernel.txt: VALU busy 1.5 x MFMA busy).
+__device__ __forceinline__ float lws_geglu(float v, float g) {
+    const float ax = fabsf(g);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.23164189f, 1.0f));
+    float y = fmaf(t, 0.5307027145f, -0.7265760135f);
+    y = fmaf(y, t, 0.7107068705f);
+    y = fmaf(y, t, -0.142248368f);
+    y = fmaf(y, t, 0.127414796f);
+    y *= t;
+    const float h = y * __builtin_amdgcn_exp2f(-0.72134752044448170368f * (g * g));
+    return v * fmaf(-ax, h, fmaxf(g, 0.0f));
+}
+
+constexpr int LWS_K = 320, LWS_KS = LWS_K / 32, LWS_KB = LWS_K / 64, LWS_BM = 64, LWS_STAGES = 3;
+constexpr int LWS_STAGE_ELEMS = LWS_BM * LWS_K;                   // 16-bit elements per ring slot (40 KB)
+constexpr int LWS_STG_BYTES = 4096;                               // per-wave staging region (<= 48 channel rows x 80 B)
+enum { LWS_16 = 0, LWS_F32 = 1, LWS_GEGLU = 2, LWS_QKV = 3 };
+
+// The body of one wavefront: NB output-channel sub-blocks of 16 (cb = first channel inside the 320-block).
+// Vector-memory operations a wavefront issues in the epilogues of ONE tile (stores only: a lower bound is what the counted wait
+// needs -- the compiler may add its own waits for the residual loads, it never removes an operation).
+template <int MODE, int NB> constexpr int lws_epilogue_ops() {
+    return MODE == LWS_F32 ? 4 * NB : MODE == LWS_GEGLU ? 2 * ((32 * NB + 63) / 64) : 2 * NB;
+}
+constexpr int lws_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }   // gfx9 s_waitcnt immediate: vmcnt(n) only
+
+template <typename T, int MODE, int NB, bool COUNTED, bool DEFER>
+__device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* smem, unsigned char* stg, int nblk, int cb,
+                                         int t_lo, int t_hi, int wave, int lane) {
+    typedef typename LwsMfma<T>::frag frag;
+    const int frow = lane & 15, fchunk = lane >> 4, cq = 4 * fchunk;
+    const int n_base = nblk * 320 + cb;                           // first output channel of this wavefront
+
+    // ---- DMA addressing (every wave moves rows [8 wave, 8 wave + 8) of each of the 5 K-block images of a tile)
+    const int chunk = lane & 7, lrow = wave * 8 + (lane >> 3);
+    const unsigned src_lane = static_cast<unsigned>(lrow * p.a_ld + ((chunk ^ ((lrow >> 1) & 7)) << 3)) * 2u;   // bytes
+    auto uniform_ptr = [](const unsigned short* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+        const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+        return reinterpret_cast<unsigned short*>(static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32));
+    };
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.a), 0, __builtin_amdgcn_readfirstlane(p.a_bytes), 0x00020000);
+    auto dma_tile = [&](int tile, int slot) {                     // rows past M: an offset beyond num_records reads as zero
+        unsigned short* dst = smem + slot * LWS_STAGE_ELEMS + wave * 8 * 64;
+        const int soff0 = __builtin_amdgcn_readfirstlane(tile * LWS_BM * p.a_ld * 2);
+        const unsigned voff = tile * LWS_BM + lrow < p.M ? src_lane : 0x80000000u;
+#pragma unroll
+        for (int kb = 0; kb < LWS_KB; ++kb)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + kb * LWS_BM * 64), 16,
+                                                     voff, soff0 + kb * 128, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                        // (program order of the vector-memory operations is what the counted wait counts)
+    };
+    if (t_lo < t_hi) dma_tile(t_lo, 0);
+    if (t_lo + 1 < t_hi) dma_tile(t_lo + 1, 1);
+
+    // ---- the weight slab of this wavefront: NB x 10 MFMA "A" fragments, loaded once
+    frag wf[NB][LWS_KS];
+    {
+        const unsigned short* wp = p.w + static_cast<long>(n_base + frow) * LWS_K + fchunk * 8;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int ks = 0; ks < LWS_KS; ++ks)
+                wf[j][ks] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(wp + j * 16 * LWS_K + ks * 32));
+    }
+    float4 bias[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        bias[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n_base + j * 16 + cq) : float4{0.f, 0.f, 0.f, 0.f};
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // first tiles + weights (once)
+    // ---- epilogue of 32 tokens x NB*16 channels (rows m_half .. m_half + 31); the accumulators were initialised with the bias
+    auto epilogue = [&](f32x4 (&acc)[2][NB], int m_half) {
+#ifdef PF_LWS_ABL_NOEPI
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) asm volatile("" :: "v"(acc[pb][j]));
+        return;
+#endif
+        if constexpr (MODE == LWS_F32) {
+            const float* rp = p.residual;
+            float* op = static_cast<float*>(p.out);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int m = m_half + pb * 16 + frow;
+                const long mc = m < p.M ? m : p.M - 1;
+                float4 r[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    r[j] = rp ? *reinterpret_cast<const float4*>(rp + mc * p.res_ld + n_base + j * 16 + cq) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float4 v = float4{acc[pb][j][0] + r[j].x, acc[pb][j][1] + r[j].y, acc[pb][j][2] + r[j].z, acc[pb][j][3] + r[j].w};
+                    if (m < p.M) *reinterpret_cast<float4*>(op + static_cast<long>(m) * p.out_ld + n_base + j * 16 + cq) = v;
+                }
+            }
+        } else if constexpr (MODE == LWS_GEGLU) {
+            // columns interleaved (value, gate): 2 outputs per lane and sub-block -> staged rows of NB*8 outputs; 48-byte rows for both
+            // wave kinds (a 32-byte row stride puts rows r, r + 4, ... on the same banks)
+            constexpr int RS = 48;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const unsigned lo = from_f32<T>(lws_geglu(acc[pb][j][0], acc[pb][j][1]));
+                    const unsigned hi = from_f32<T>(lws_geglu(acc[pb][j][2], acc[pb][j][3]));
+                    *reinterpret_cast<unsigned*>(stg + (pb * 16 + frow) * RS + (j * 8 + (cq >> 1)) * 2) = lo | (hi << 16);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            unsigned short* op = static_cast<unsigned short*>(p.out);
+            const int ncol = (n_base >> 1);
+#pragma unroll
+            for (int i = 0; i < (32 * NB + 63) / 64; ++i) {
+                const int q = i * 64 + lane, row = q / NB, cc = q - row * NB;
+                if (q < 32 * NB) {
+                    const u16x8 x = *reinterpret_cast<const u16x8*>(stg + row * RS + cc * 16);
+                    const int m = m_half + row;
+                    if (m < p.M) *reinterpret_cast<u16x8*>(op + static_cast<long>(m) * p.out_ld + ncol + cc * 8) = x;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // staging region read out before the next slice overwrites it
+        } else if (MODE == LWS_QKV && nblk == 2) {
+            // V transposed: staged [channel][32 tokens] (64 B of tokens in 80-byte rows), leaves as 64-byte key runs of out_vt[b][channel][key]
+            constexpr int RS = 80;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        *reinterpret_cast<unsigned short*>(stg + (j * 16 + cq + e) * RS + (pb * 16 + frow) * 2) = from_f32<T>(acc[pb][j][e]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int bidx = m_half / p.rows_per_batch, key0 = m_half - bidx * p.rows_per_batch;
+            unsigned short* op = p.out_vt + bidx * p.vt_bs + static_cast<long>(cb) * p.vt_ld + key0;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {                         // NB*16 channel rows x 4 chunks = NB x 64 lanes
+                const int q = i * 64 + lane, ch = q >> 2, cc = q & 3;
+                const u16x8 x = *reinterpret_cast<const u16x8*>(stg + ch * RS + cc * 16);
+                if (m_half + cc * 8 < p.M) *reinterpret_cast<u16x8*>(op + static_cast<long>(ch) * p.vt_ld + cc * 8) = x;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            // 16-bit rows: staged [32 tokens][NB*16 channels] in rows padded by 16 bytes (an unpadded 96- / 64-byte stride puts the 16
+            // token rows of a ds_write_b64 on 4 / 2 distinct bank groups: 45 % of the LDS cycles of the first version were conflicts),
+            // leaves as 16-byte chunks
+            constexpr int RS = NB * 32 + 16;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    u16x4 w4;
+                    w4[0] = from_f32<T>(acc[pb][j][0]); w4[1] = from_f32<T>(acc[pb][j][1]);
+                    w4[2] = from_f32<T>(acc[pb][j][2]); w4[3] = from_f32<T>(acc[pb][j][3]);
+                    *reinterpret_cast<u16x4*>(stg + (pb * 16 + frow) * RS + (j * 16 + cq) * 2) = w4;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            unsigned short* op = static_cast<unsigned short*>(p.out);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {                         // 32 rows x 2 NB chunks = NB x 64 lanes
+                const int q = i * 64 + lane, row = q / (2 * NB), cc = q - row * 2 * NB;
+                const u16x8 x = *reinterpret_cast<const u16x8*>(stg + row * RS + cc * 16);
+                const int m = m_half + row;
+                if (m < p.M) *reinterpret_cast<u16x8*>(op + static_cast<long>(m) * p.out_ld + n_base + cc * 8) = x;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+
+    // DEFER (the 32-channel wavefronts): the epilogue of a tile's second half runs at the START of the next tile, so that between two
+    // barriers this wave goes  epilogue - MFMA - epilogue - MFMA  while its SIMD partner (a 48-channel wave) goes
+    // MFMA - epilogue - MFMA - epilogue: one of the two is in the matrix pipe while the other is in the vector ALU (the first
+    // version ran both in the same phase: MFMA busy 41 %, VALU busy 61 % in the GEGLU launch, their sum the whole time).
+    f32x4 acc[2][NB];
+    bool pending = false;
+    int pend_m = 0;
+    int slot = 0;
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        // The 5 DMA pieces of this tile were issued two tiles ago; younger than them are that tile's epilogue (E operations), the
+        // next tile's 5 pieces and the previous tile's epilogue: a COUNTED wait leaves those 5 + 2 E in flight (the first two tiles
+        // were drained before the loop).  COUNTED = false (PF_LWS_COUNTED=0): full drain, for A/B.
+        // (a DEFER wave has issued half a tile's epilogue less at its first tiles: 5 + 3 E / 2 is its safe count)
+        if constexpr (COUNTED) __builtin_amdgcn_s_waitcnt(lws_waitcnt_vm(LWS_KB + (DEFER ? 3 : 4) * lws_epilogue_ops<MODE, NB>() / 2));
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef PF_LWS_ABL_NOBAR   /* -DPF_LWS_ABL_*: timing-only ablation builds (wrong results), make -C panfusion_amd/csrc lws_ablate */
+        __builtin_amdgcn_s_barrier();                             // tile landed (all waves' pieces); slot (tile + 2) % 3 no longer read
+#endif
+        asm volatile("" ::: "memory");
+#ifndef PF_LWS_ABL_NODMA
+        if (tile + 2 < t_hi) dma_tile(tile + 2, slot >= 1 ? slot - 1 : 2);
+#endif
+        const unsigned short* As = smem + slot * LWS_STAGE_ELEMS;
+        const int m_tile = tile * LWS_BM;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (DEFER && half == 0 && pending) epilogue(acc, pend_m);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[pb][j] = f32x4{bias[j].x, bias[j].y, bias[j].z, bias[j].w};
+            // activation fragments: tokens half*32 + pb*16 + frow, K slab ks = (K block ks >> 1, 32-k half ks & 1)
+            auto afrag = [&](int pb, int ks) {
+                const int row = half * 32 + pb * 16 + frow;
+                const int c = (ks & 1) * 4 + fchunk;
+#ifdef PF_LWS_ABL_NOLDS
+                u16x8 z = {1, 2, 3, 4, 5, 6, 7, static_cast<unsigned short>(lane + ks)};
+                asm volatile("" : "+v"(z));
+                return __builtin_bit_cast(frag, z);
+#else
+                return __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(As + (ks >> 1) * LWS_BM * 64 + row * 64 + ((c ^ ((row >> 1) & 7)) << 3)));
+#endif
+            };
+            // software pipeline over steps of two K slabs: the 4 fragment reads of step s + 1 are issued BEFORE the 4 NB MFMAs
+            // of step s and pinned there (left alone, hipcc sinks every read to just ahead of its first use and waits for it:
+            // one exposed LDS round trip per K slab)
+            frag af[2][2][2];                                     // [buffer][slab of the step][token block]
+            auto load_step = [&](int st, int buf) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb) af[buf][h2][pb] = afrag(pb, 2 * st + h2);
+            };
+            load_step(0, 0);
+#pragma unroll
+            for (int st = 0; st < LWS_KS / 2; ++st) {
+                if (st + 1 < LWS_KS / 2) load_step(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int pb = 0; pb < 2; ++pb)
+                            acc[pb][j] = LwsMfma<T>::run(wf[j][2 * st + h2], af[st & 1][h2][pb], acc[pb][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int m_half = m_tile + half * 32;
+            if (!DEFER || half == 0) epilogue(acc, m_half);
+            else { pending = true; pend_m = m_half; }
+        }
+        slot = slot == LWS_STAGES - 1 ? 0 : slot + 1;
+    }
+    if (DEFER && pending) epilogue(acc, pend_m);
+}
+
+template <typename T, int MODE, bool COUNTED>
+__global__ __launch_bounds__(512, 1) void k_linear_ws(const LwsParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // block -> (token range, channel block): the channel blocks of one token range sit on one XCD (block b runs on XCD b % 8)
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int sl = idx / p.nblocks, nblk = idx - sl * p.nblocks;
+    if (sl >= p.splits_per_xcd) return;
+    const int s = xcd * p.splits_per_xcd + sl, S = 8 * p.splits_per_xcd;
+    const int t_lo = static_cast<int>(static_cast<long>(p.ntiles) * s / S), t_hi = static_cast<int>(static_cast<long>(p.ntiles) * (s + 1) / S);
+    unsigned char* stg = reinterpret_cast<unsigned char*>(smem + LWS_STAGES * LWS_STAGE_ELEMS) + wave * LWS_STG_BYTES;
+    // waves w and w + 4 share a SIMD: 48 + 32 channels each
+    if (wave < 4) lws_wave<T, MODE, 3, COUNTED, false>(p, smem, stg, nblk, wave * 48, t_lo, t_hi, wave, lane);
+    else if (p.defer) lws_wave<T, MODE, 2, COUNTED, true>(p, smem, stg, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
+    else lws_wave<T, MODE, 2, COUNTED, false>(p, smem, stg, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
+}
+
+template <typename T, int MODE, bool COUNTED>
+static pf_status lws_launch_c(const LwsParams& p, hipStream_t st) {
+    const size_t smem = static_cast<size_t>(LWS_STAGES) * LWS_STAGE_ELEMS * 2 + 8 * LWS_STG_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ws<T, MODE, COUNTED>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_linear_ws<T, MODE, COUNTED>), dim3(256), dim3(512), smem, st, p);
+    PF_CHECK_LAUNCH("pf_linear_ws");
+    return PF_OK;
+}
+template <typename T, int MODE>
+static pf_status lws_launch(const LwsParams& p, hipStream_t st) {
+    static const bool counted = !(getenv("PF_LWS_COUNTED") && atoi(getenv("PF_LWS_COUNTED")) == 0);
+    return counted ? lws_launch_c<T, MODE, true>(p, st) : lws_launch_c<T, MODE, false>(p, st);
+}
+
+}  // namespace pf
+
+extern "C" int pf_linear_ws_supported(long M, int N, int K, int mode) {
+    if (K != pf::LWS_K || N <= 0 || N % 320 != 0 || M < 64) return 0;
+    const int nb = N / 320;
+    if (nb > 32) return 0;
+    if (mode == PF_LWS_QKV && nb != 3) return 0;
+    return 1;
+}
+
+extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
+    using namespace pf;
+    PF_REQUIRE(d != nullptr, "pf_linear_ws: null descriptor");
+    PF_REQUIRE(d->a && d->w && d->out, "pf_linear_ws: null operand");
+    PF_REQUIRE(pf_linear_ws_supported(d->M, d->N, d->K, d->mode), "pf_linear_ws: needs K == 320, N a multiple of 320 (<= 32 blocks; q|k|v: N == 960), M >= 64 (got M %ld N %d K %d mode %d)",
+               static_cast<long>(d->M), d->N, d->K, d->mode);
+    PF_REQUIRE(d->mode >= PF_LWS_16 && d->mode <= PF_LWS_QKV, "pf_linear_ws: unknown mode %d", d->mode);
+    PF_REQUIRE(d->a_ld >= d->K && d->a_ld % 8 == 0 && aligned16(d->a) && aligned16(d->w) && aligned16(d->out), "pf_linear_ws: operands must be 16-byte aligned, a_ld a multiple of 8");
+    PF_REQUIRE(static_cast<long>(d->M) * d->a_ld * 2 < (2L << 30), "pf_linear_ws: activation matrix must be smaller than 2 GiB");
+    PF_REQUIRE(!d->bias || aligned16(d->bias), "pf_linear_ws: bias must be 16-byte aligned");
+    const int n_store = d->mode == PF_LWS_GEGLU ? d->N / 2 : d->mode == PF_LWS_QKV ? 640 : d->N;
+    PF_REQUIRE(d->out_ld >= n_store && d->out_ld % (d->mode == PF_LWS_F32 ? 4 : 8) == 0, "pf_linear_ws: out_ld %d does not hold %d columns in 16-byte chunks", d->out_ld, n_store);
+    if (d->mode == PF_LWS_F32)
+        PF_REQUIRE(!d->residual || (aligned16(d->residual) && d->res_ld >= d->N && d->res_ld % 4 == 0), "pf_linear_ws: residual must be 16-byte aligned fp32 rows");
+    else
+        PF_REQUIRE(!d->residual, "pf_linear_ws: a residual needs mode PF_LWS_F32");
+    if (d->mode == PF_LWS_QKV)
+        PF_REQUIRE(d->out_vt && aligned16(d->out_vt) && d->rows_per_batch > 0 && d->rows_per_batch % 64 == 0 && d->M % d->rows_per_batch == 0 &&
+                   d->vt_ld >= d->rows_per_batch && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0,
+                   "pf_linear_ws: q|k|v mode needs out_vt with 16-byte aligned key runs and batches of a multiple of 64 tokens");
+    LwsParams p;
+    p.a = static_cast<const unsigned short*>(d->a); p.a_ld = d->a_ld;
+    p.w = static_cast<const unsigned short*>(d->w);
+    p.bias = d->bias; p.residual = d->residual; p.res_ld = d->res_ld;
+    p.out = d->out; p.out_ld = d->out_ld;
+    p.out_vt = static_cast<unsigned short*>(d->out_vt); p.vt_ld = d->vt_ld; p.rows_per_batch = d->rows_per_batch; p.vt_bs = d->vt_bs;
+    p.M = d->M; p.N = d->N;
+    p.nblocks = d->N / 320;
+    p.splits_per_xcd = 32 / p.nblocks;
+    p.ntiles = static_cast<int>(cdiv(d->M, LWS_BM));
+    p.a_bytes = static_cast<unsigned>(static_cast<long>(d->M) * d->a_ld * 2);
+    static const int defer = getenv("PF_LWS_DEFER") ? atoi(getenv("PF_LWS_DEFER")) : 1;
+    p.defer = defer;
+    hipStream_t st = as_stream(stream);
+#define PF_LWS_MODE(MODE) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, MODE>(p, st)))
+    switch (d->mode) {
+        case PF_LWS_16: PF_LWS_MODE(LWS_16);
+        case PF_LWS_F32: PF_LWS_MODE(LWS_F32);
+        case PF_LWS_GEGLU: PF_LWS_MODE(LWS_GEGLU);
+        default: PF_LWS_MODE(LWS_QKV);
+    }
+#undef PF_LWS_MODE
+    return PF_OK;
+}

@@ -406,8 +406,8 @@ def pack_epa(block, dev, dtype, mixed=False):
     e.heads = e.dim // 32
     e.ln1, e.ln2 = _norm(tr.norm1, dev), _norm(tr.norm2, dev)
     a = tr.attn1
-    e.wqk = _w16(torch.cat([a.to_q.weight.detach().float(), a.to_k.weight.detach().float()], 0), dev, dtype)
-    e.wv = _w16(a.to_v.weight, dev, dtype)
+    e.wqkv = _w16(torch.cat([a.to_q.weight.detach().float(), a.to_k.weight.detach().float(), a.to_v.weight.detach().float()], 0), dev, dtype)
+    e.wqk, e.wv = e.wqkv[:2 * e.dim], e.wqkv[2 * e.dim:]
     e.wo, e.bo = _w16(a.to_out.weight, dev, dtype), _bias(a.to_out, dev)
     e.w_ff1, e.b_ff1 = ops.interleave_geglu(_w16(tr.ff.net[0].proj.weight, dev, dtype), _bias(tr.ff.net[0].proj, dev))
     e.w_ff2, e.b_ff2 = _w16(tr.ff.net[2].weight, dev, dtype), _bias(tr.ff.net[2], dev)
@@ -477,13 +477,21 @@ def all_transformers(u):
 def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv=None):
     """q_src [n*nq, C] already layer-normed; kv_tokens [n*nk, Ckv] (or kv = precomputed (k, vt))."""
     Cq = a.dim
+    vt = None
     if self_attn:
-        qk = ops.linear(q_src, a.wqk)                         # [rows, 2C]  (q | k)
+        fused = ops.linear_qkv(q_src, a.wqkv, n)              # q | k | v in one launch where the shape allows it (C = 320)
+        if fused is not None:
+            qk, vt = fused
+        else:
+            qk = ops.linear(q_src, a.wqk)                     # [rows, 2C]  (q | k)
         q, k, ld = qk, qk[:, Cq:], 2 * Cq
     else:
         q, ld = ops.linear(q_src, a.wq), Cq
         k = kv[0] if kv is not None else ops.linear(kv_tokens, a.wk)
-    vt = kv[1] if kv is not None else ops.linear_t(kv_tokens.view(n, nk, -1), a.wv)   # [n, C, ld_v] keys contiguous
+    if kv is not None:
+        vt = kv[1]
+    elif vt is None:
+        vt = ops.linear_t(kv_tokens.view(n, nk, -1), a.wv)    # [n, C, ld_v] keys contiguous
     o = ops.attention(q, k, vt, n, a.heads, head_dim, nq, nk,
                       q_ld=ld, k_ld=(ld if self_attn else Cq), vt_ld=vt.shape[-1],
                       q_bs=nq * ld, k_bs=nk * (ld if self_attn else Cq), vt_bs=vt.shape[1] * vt.shape[2])
@@ -765,9 +773,9 @@ def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None, side=None, pers_hw=N
         for i, t in enumerate(tables):
             ops.layernorm(tp[i * mP:(i + 1) * mP], e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_p, out=lnp[i * mP:(i + 1) * mP])
             ops.layernorm(te[i * E:(i + 1) * E], e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_e, out=lne[i * E:(i + 1) * E])
-    qk_p, qk_e = ops.linear(lnp, e.wqk), ops.linear(lne, e.wqk)           # [., 2C] = (q | k)
-    vt_p = ops.linear_t(lnp.view(b, mP, Cc), e.wv)                         # [b, C, mP]
-    vt_e = ops.linear_t(lne.view(b, E, Cc), e.wv)                          # [b, C, E]
+    fused_p, fused_e = ops.linear_qkv(lnp, e.wqkv, b), ops.linear_qkv(lne, e.wqkv, b)   # one launch for q | k | v where the shape allows
+    qk_p, vt_p = fused_p if fused_p is not None else (ops.linear(lnp, e.wqk), ops.linear_t(lnp.view(b, mP, Cc), e.wv))   # [., 2C] = (q | k), [b, C, mP]
+    qk_e, vt_e = fused_e if fused_e is not None else (ops.linear(lne, e.wqk), ops.linear_t(lne.view(b, E, Cc), e.wv))    # [b, C, E]
     ld = 2 * Cc
 
     def attend(q, k, vt, nq, nk, which):

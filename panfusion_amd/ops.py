@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import PF_BF16, PF_F16, PF_F32, AttnBwdDesc, AttnDesc, ConvDesc, check
+from ._lib import PF_BF16, PF_F16, PF_F32, AttnBwdDesc, AttnDesc, ConvDesc, LinearWsDesc, check
 
 _DT = {torch.bfloat16: PF_BF16, torch.float16: PF_F16, torch.float32: PF_F32}
 
@@ -492,11 +492,73 @@ def gemm_workspace_bytes(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, k
     return _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
 
 
+# ---- weight-stationary linear (pf_linear_ws): the C = 320 token layers
+LWS_16, LWS_F32, LWS_GEGLU, LWS_QKV = 0, 1, 2, 3
+LINEAR_WS = os.environ.get("PF_LINEAR_WS", "1") != "0"          # A/B: 0 = every linear on the tile kernel (pf_conv_gemm)
+LINEAR_WS_MIN_ROWS = int(os.environ.get("PF_LINEAR_WS_MIN_ROWS", "8192"))   # fewer 64-token tiles than workgroups: the tile kernel
+
+
+def linear_ws_ok(rows, N, K, mode, x=None):
+    """Does pf_linear_ws serve this problem (K == 320, N a multiple of 320, enough token tiles to stream)?"""
+    if not LINEAR_WS or rows < LINEAR_WS_MIN_ROWS or K != 320 or N % 320:
+        return False
+    if x is not None and (x.dtype not in (torch.float16, torch.bfloat16) or x.stride(-1) != 1 or x.stride(-2) % 8):
+        return False
+    return bool(_lib.lib().pf_linear_ws_supported(rows, N, K, mode))
+
+
+def linear_ws(x, w, mode, bias=None, residual=None, out=None, out_vt=None, rows_per_batch=0):
+    """pf_linear_ws: x [rows, 320] 16-bit, w [N, 320].  mode LWS_16 -> [rows, N] 16-bit; LWS_F32 -> fp32 [rows, N] (+ fp32 residual);
+    LWS_GEGLU -> [rows, N/2]; LWS_QKV (N = 960) -> ((q | k) [rows, 640], V^T [rows / rows_per_batch, 320, rows_per_batch])."""
+    rows, K = x.shape
+    N = w.shape[0]
+    d = LinearWsDesc()
+    if mode == LWS_QKV:
+        nb = rows // rows_per_batch
+        if out is None:
+            out = torch.empty(rows, 640, device=x.device, dtype=x.dtype)
+        if out_vt is None:
+            out_vt = torch.empty(nb, 320, rows_per_batch, device=x.device, dtype=x.dtype)
+        d.out_vt, d.vt_ld, d.rows_per_batch, d.vt_bs = _p(out_vt), out_vt.stride(1), rows_per_batch, out_vt.stride(0)
+    elif out is None:
+        out = torch.empty(rows, N // 2 if mode == LWS_GEGLU else N, device=x.device,
+                          dtype=torch.float32 if mode == LWS_F32 else x.dtype)
+    d.a, d.a_ld, d.w, d.bias = _p(x), _ld(x), _p(w), _p(bias)
+    d.residual, d.res_ld = _p(residual), (_ld(residual) if residual is not None else 0)
+    d.out, d.out_ld = _p(out), _ld(out)
+    d.M, d.N, d.K, d.dtype, d.mode = rows, N, K, dt(x), mode
+    if TRACE is None:
+        check(_lib.lib().pf_linear_ws(C.byref(d), _stream()), "pf_linear_ws")
+    else:
+        _traced("k_linear_ws", 2.0 * rows * N * K, lambda: check(_lib.lib().pf_linear_ws(C.byref(d), _stream()), "pf_linear_ws"),
+                "M%d N%d K%d mode%d" % (rows, N, K, mode))
+    return (out, out_vt) if mode == LWS_QKV else out
+
+
+def linear_qkv(x, wqkv, n_batch):
+    """Self-attention projections in one launch: x [n_batch * nk, 320] layer-normed tokens, wqkv [960, 320] = (q | k | v)
+    -> ((q | k) [rows, 640], V^T [n_batch, 320, nk]), or None when pf_linear_ws does not serve the shape."""
+    rows = x.shape[0]
+    nk = rows // n_batch
+    if wqkv.shape[0] != 960 or nk % 64 or not linear_ws_ok(rows, 960, x.shape[1], LWS_QKV, x):
+        return None
+    return linear_ws(x, wqkv, LWS_QKV, rows_per_batch=nk)
+
+
 def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False, split_out=False, gn_stats=False):
     """x [rows, K] 16-bit, w [N, K] 16-bit.  geglu: w / bias rows interleaved (value_j, gate_j),
     returns [rows, N/2] = value * gelu(gate).  gn_stats: see conv_gemm (the moment runs are runs of token rows; the
-    consumer's images must be whole runs, which groupnorm_scale_shift's entry point checks)."""
+    consumer's images must be whole runs, which groupnorm_scale_shift's entry point checks).
+    The C = 320 layers with enough tokens go to the weight-stationary kernel (pf_linear_ws)."""
     rows, K = x.shape
+    if not (split_out or gn_stats) and x.dim() == 2 and linear_ws_ok(rows, w.shape[0], K, LWS_16, x) and w.is_contiguous():
+        odt = out.dtype if out is not None else (out_dtype or (residual.dtype if residual is not None else x.dtype))
+        if geglu and residual is None and odt == x.dtype:
+            return linear_ws(x, w, LWS_GEGLU, bias=bias, out=out)
+        if not geglu and odt == torch.float32 and (residual is None or residual.dtype == torch.float32):
+            return linear_ws(x, w, LWS_F32, bias=bias, residual=residual, out=out)
+        if not geglu and residual is None and odt == x.dtype:
+            return linear_ws(x, w, LWS_16, bias=bias, out=out)
     return conv_gemm(x, w, w.shape[0], w_in=rows, bias=bias, residual=residual, out=out, out_dtype=out_dtype,
                      geglu=geglu, split_out=split_out, gn_stats=gn_stats)
 

@@ -330,6 +330,17 @@ def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False
                      geglu=geglu, split_out=split_out, gn_stats=gn_stats)
 
 
+def linear_qkv(x, wqkv, n_batch):
+    """Test double of ops.linear_qkv (one launch for q | k | v with V transposed): served whenever the batches are whole
+    64-token tiles, at any width -- the host logic that consumes the fused result runs on CPU at the tiny widths too."""
+    rows, K = x.shape
+    nk = rows // n_batch
+    if wqkv.shape[0] != 3 * K or nk % 64:
+        return None
+    y = (x.float() @ wqkv.float().T).to(x.dtype)
+    return y[:, :2 * K].contiguous(), y[:, 2 * K:].reshape(n_batch, nk, K).transpose(1, 2).contiguous()
+
+
 def interleave_geglu(w, b=None):
     inner = w.shape[0] // 2
     wi = torch.stack([w[:inner], w[inner:]], 1).reshape(w.shape).contiguous()

@@ -347,6 +347,57 @@ def test_linear_geglu_epilogue(dtype, mnk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [64 * 37 + 40, 64, 64 * 300])
+def test_linear_ws_modes_vs_fp32(dtype, M):
+    """pf_linear_ws (weight-stationary kernel of the C = 320 token layers) against fp32 torch: 16-bit out, fp32 out + fp32
+    residual, GEGLU pairing -- ragged last tile (M = 64 * 37 + 40), a single tile, more tiles than workgroups."""
+    o = ops()
+    K = 320
+    x, xf = q16(rnd(M, K, seed=60), dtype)
+    for N, seed in ((320, 61), (640, 62), (2560, 63)):
+        w, wf = q16(rnd(N, K, seed=seed) / K ** 0.5, dtype)
+        b = rnd(N, seed=seed + 10)
+        want = xf @ wf.T + b
+        got = o.linear_ws(x, w, o.LWS_16, bias=b.to(DEV))
+        check("linear_ws 16-bit N%d" % N, got, want, TOL[dtype])
+        if N == 320:
+            r = rnd(M, N, seed=70)
+            got = o.linear_ws(x, w, o.LWS_F32, bias=b.to(DEV), residual=r.to(DEV))
+            assert got.dtype == torch.float32
+            check("linear_ws fp32 + residual", got, want + r, 2e-5)
+            check("linear_ws fp32, no bias / residual", o.linear_ws(x, w, o.LWS_F32), xf @ wf.T, 2e-5)
+        if N == 2560:
+            wi, bi = o.interleave_geglu(w, b.to(DEV))
+            got = o.linear_ws(x, wi, o.LWS_GEGLU, bias=bi)
+            assert got.shape == (M, N // 2)
+            check("linear_ws geglu", got, want[:, :N // 2] * F.gelu(want[:, N // 2:]), TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n_batch,nk", [(3, 1024), (2, 64), (5, 4096)])
+def test_linear_ws_qkv_with_transposed_values(dtype, n_batch, nk):
+    """q | k | v in one launch: (q | k) rows + V^T [batch][C][keys] in the layout pf_attention reads; then through the
+    routed entry points (ops.linear_qkv / ops.linear) exactly as engine._attend calls them."""
+    o = ops()
+    K, M = 320, n_batch * nk
+    x, xf = q16(rnd(M, K, seed=80), dtype)
+    w, wf = q16(rnd(960, K, seed=81) / K ** 0.5, dtype)
+    want = xf @ wf.T
+    qk, vt = o.linear_ws(x, w, o.LWS_QKV, rows_per_batch=nk)
+    assert qk.shape == (M, 640) and vt.shape == (n_batch, 320, nk)
+    check("qkv: q | k", qk, want[:, :640], TOL[dtype])
+    check("qkv: V^T", vt, want[:, 640:].reshape(n_batch, nk, 320).transpose(1, 2), TOL[dtype])
+    routed = o.linear_qkv(x, w, n_batch)
+    if M >= o.LINEAR_WS_MIN_ROWS:
+        assert routed is not None and torch.equal(routed[0], qk) and torch.equal(routed[1], vt)
+        r = rnd(M, 320, seed=82).to(DEV)
+        a = o.linear(x, w[:320], residual=r)                      # fp32 residual stream in -> fp32 out (weight-stationary kernel)
+        check("routed linear + fp32 residual", a, want[:, :320] + r.cpu(), 2e-5)
+    else:
+        assert routed is None
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ["linear", "conv", "conv_cat_res"])
 def test_split_k(dtype, case):
     """Small output grids with a long K are split over K (fp32 slabs + ordered reduce)."""

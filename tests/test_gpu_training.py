@@ -300,7 +300,7 @@ def _tiny_denoiser(dtype, precision):
     return oracle, hip, args
 
 
-@pytest.mark.parametrize("dtype,precision,tol_out,tol_grad", [(torch.float16, "mixed", 1e-3, 3e-3), (torch.bfloat16, "fast", 2e-2, 4e-2)])
+@pytest.mark.parametrize("dtype,precision,tol_out,tol_grad", [(torch.float16, "mixed", 1e-3, 2e-3), (torch.bfloat16, "fast", 2e-2, 4e-2)])
 def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, tol_grad):
     """One training step of the dual-branch denoiser on the GPU (tiny widths, 4 views of 16^2, panorama 16x32, one sample) against
     torch autograd through the oracle denoiser on the CPU: the two outputs, and the gradient of an MSE-like loss with
@@ -477,7 +477,7 @@ def test_trainable_controlnet_training_step_vs_oracle_autograd():
     errs = sorted(((rel_l2(got[k].cpu().float(), want[k]), k) for k in cn_keys), reverse=True)
     print("\ntrainable ControlNet: outputs %.2e   %d ControlNet gradients as one vector %.2e   EPA + LoRA %.2e   worst tensors: %s"
           % (eo, len(cn_keys), e_cn, e_other, "  ".join("%.1e %s" % (e, k.replace("transformer_blocks.0.", "")) for e, k in errs[:4])))
-    assert eo < 1e-3 and e_cn < 3e-3 and e_other < 3e-3 and errs[0][0] < 3e-2, (eo, e_cn, e_other, errs[:4])
+    assert eo < 1e-3 and e_cn < 2e-3 and e_other < 2e-3 and errs[0][0] < 3e-2, (eo, e_cn, e_other, errs[:4])     # measured 1.18e-3 (tiny widths)
 
 
 @pytest.mark.parametrize("dtype", D16)
@@ -586,7 +586,7 @@ def test_full_width_trainable_controlnet_vs_oracle_autograd():
     errs = sorted(((rel_l2(got[k].cpu().float(), want[k]), k) for k in cn_keys), reverse=True)
     print("\nfull-width trainable ControlNet: outputs %.2e   340 ControlNet gradients as one vector %.2e   EPA %.2e   worst tensors: %s"
           % (eo, e_cn, e_epa, "  ".join("%.1e %s" % (e, k.replace("transformer_blocks.0.", "")) for e, k in errs[:4])))
-    assert eo < 1e-3 and e_cn < 3e-3 and e_epa < 3e-3 and errs[0][0] < 3e-2, (eo, e_cn, e_epa, errs[:4])
+    assert eo < 1e-3 and e_cn < 1.5e-3 and e_epa < 1.5e-3 and errs[0][0] < 3e-2, (eo, e_cn, e_epa, errs[:4])     # measured 7.3e-4 / 9.0e-4
 
 
 def test_whole_training_step_vs_oracle():

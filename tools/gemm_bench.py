@@ -38,6 +38,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--phases", action="store_true", help="per-block phase stamps (pf_debug_gemm_profile)")
+    ap.add_argument("--timeline", action="store_true", help="with PF_HIP_LIB=panfusion_amd/abl/lib_timeline.so (make -C panfusion_amd/csrc timeline): "
+                    "phases of every block's SECOND tile in the persistent 8-wave kernel, shader clocks")
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--gn", action="store_true", help="ask the epilogue for GroupNorm moments (pf_conv_desc.gn_partial)")
@@ -71,6 +73,24 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / args.reps
         fl = 2.0 * M * cout * ks * ks * cin
         byt = 2.0 * (M * cin + cout * ks * ks * cin + M * n_store * (2 if res is not None else 1))
+        if args.timeline:
+            from panfusion_amd import _lib
+            cap = 1 << 12
+            buf = torch.zeros(cap * 32, dtype=torch.int64, device=dev)
+            _lib.lib().pf_debug_gemm_profile(buf.data_ptr(), cap)
+            ops.conv_gemm(x, wt, cout, **kw)
+            torch.cuda.synchronize()
+            _lib.lib().pf_debug_gemm_profile(None, 0)
+            full = buf.view(cap, 32).cpu()
+            full = full[(full[:, 12] != 0) & (full[:, 23] != 0)].double()
+            if full.shape[0]:
+                d = lambda a, b: float((full[:, b] - full[:, a]).mean())
+                nst = int((full[0, 15:23] != 0).sum())
+                steps = [d(14, 15)] + [d(15 + i - 1, 15 + i) for i in range(1, nst)]
+                print("   timeline of tile #2 (%d blocks): wait+barrier %.0f | stage-2 DMA + first fragments %.0f | K steps %s | epilogue %.0f | tile total %.0f"
+                      % (full.shape[0], d(12, 13), d(13, 14), " ".join("%.0f" % v for v in steps), d(15 + nst - 1, 23), d(12, 23)))
+            else:
+                print("   timeline: no block ran a second tile of the 8-wave kernel (or the library is not the timeline build)")
         if args.phases:
             from panfusion_amd import _lib
             cap = 1 << 16

@@ -10,8 +10,10 @@ same seeded weights / inputs on the GPU box (oracle/fixtures.py) and compare the
                                            the 7 EPA blocks (the 20-view EPA softmax has K = 20 480 keys)
   cfg1  -> tests/golden/cfg1_ddim10.npz    configs[0]: m = 4, 256^2 views, 10 DDIM steps at full widths: latents after
                                            every step (drift per step)
-  cfg4  -> tests/golden/cfg4_eps.npz       128x256 panorama latent + 20 views, one CFG sample
-  cfg5  -> tests/golden/cfg5_eps.npz       cfg2's geometry + panorama ControlNet on a 512x1024 layout image, one CFG sample
+  cfg2b -> tests/golden/cfg2b_eps.npz      the same configuration at a LATE step of the loop: timestep t = 21, accumulated rotation 180
+                                           degrees (m = 20 x CFG pair; both epsilon outputs)
+  cfg4  -> tests/golden/cfg4_eps.npz       128x256 panorama latent + 20 views, the CFG pair (b = 2) as the loop calls it
+  cfg5  -> tests/golden/cfg5_eps.npz       cfg2's geometry + panorama ControlNet on a 512x1024 layout image, the CFG pair (b = 2)
 """
 import os
 import sys
@@ -67,6 +69,15 @@ def cfg2():
     np.savez_compressed(os.path.join(OUT, "cfg2_eps.npz"), sample=s.numpy(), pano_sample=ps.numpy(), **got)
 
 
+def cfg2b():
+    model = FX.build_full_width()
+    args = FX.first_step_call(FX.ico_cameras(), (64, 64), (64, 128), cfg_pair=True, t=21, rot=180.0)
+    t0 = time.time()
+    s, ps = call(model, args)
+    print("cfg2b oracle forward %.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(OUT, "cfg2b_eps.npz"), sample=s.numpy(), pano_sample=ps.numpy())
+
+
 def cfg1():
     model = FX.build_full_width()
     cams = FX.horizon4_cameras()
@@ -87,7 +98,7 @@ def cfg1():
 
 def cfg4():
     model = FX.build_full_width()
-    args = FX.first_step_call(FX.ico_cameras(), (64, 64), (128, 256), cfg_pair=False)
+    args = FX.first_step_call(FX.ico_cameras(), (64, 64), (128, 256), cfg_pair=True)
     t0 = time.time()
     s, ps = call(model, args)
     print("cfg4 oracle forward %.0f s" % (time.time() - t0), flush=True)
@@ -96,18 +107,17 @@ def cfg4():
 
 def cfg5():
     model = FX.build_full_width(controlnet=True)
-    args = FX.first_step_call(FX.ico_cameras(), (64, 64), (64, 128), cfg_pair=False)
+    args = FX.first_step_call(FX.ico_cameras(), (64, 64), (64, 128), cfg_pair=True)
     cond = torch.roll(FX.layout_image((64, 128)), 1024 // 4, dims=-1)       # rolled with the panorama (PanFusion.py:152-153)
+    cond = torch.cat([cond] * 2)                                            # gen_cls_free_guide_pair duplicates it (PanoGenerator.py:240-251)
     t0 = time.time()
     s, ps = call(model, args, pano_layout_cond=cond)
-    s0, ps0 = call(model, args)
-    print("cfg5 oracle forward x2 %.0f s; ControlNet moves pano eps by %.3e" % (
-        time.time() - t0, float((ps - ps0).norm() / ps0.norm())), flush=True)
+    print("cfg5 oracle forward %.0f s" % (time.time() - t0), flush=True)
     np.savez_compressed(os.path.join(OUT, "cfg5_eps.npz"), sample=s.numpy(), pano_sample=ps.numpy())
 
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("PF_THREADS", os.cpu_count() or 8)))
-    for name in (sys.argv[1:] or ["cfg2", "cfg1", "cfg4", "cfg5"]):
+    for name in (sys.argv[1:] or ["cfg2", "cfg2b", "cfg1", "cfg4", "cfg5"]):
         globals()[name]()
         print(name, "done", flush=True)
