@@ -243,6 +243,25 @@ def training_step_leg(dev, dtype, cfg, precision=None, views_latent=32, pano_hw=
     return out
 
 
+def launch_class(name, tag):
+    """The class of one MFMA launch of the instrumented step, from its trace tag (ops._traced): the table the roofline line breaks
+    the step into (`roofline.by_class`)."""
+    import re
+    f = {k: int(v) for k, v in re.findall(r"([A-Za-z]+)(\d+)", tag)}
+    if name == "k_attention":
+        if f.get("D") == 32:
+            return "attention EPA (D 32, sparse bias)"
+        return "attention text (<= 128 keys)" if f.get("nk", 0) <= 128 else "attention self (D 64)"
+    if name not in ("k_conv_gemm", "k_linear_ws"):
+        return name
+    M, K = f.get("M", 0) * max(f.get("b", 1), 1) if name == "k_conv_gemm" else f.get("M", 0), f.get("K", 0)
+    if name == "k_conv_gemm" and f.get("k") == 3:
+        return "conv 3x3, M >= 40960" if M >= 40960 else "conv 3x3, small M"
+    if M <= 4096:
+        return "linear / 1x1, small M (<= 4096)"
+    return "linear / 1x1, K <= 640" if K <= 640 else "linear / 1x1, K 641-2000" if K <= 2000 else "linear / 1x1, K > 2000"
+
+
 def usable_cores():
     """Host cores this process may actually use (affinity mask and cgroup CPU quota), capped at 64:
     the oracle's small-batch fp32 kernels do not scale past that."""
@@ -321,17 +340,17 @@ def main():
     th, ph = icosahedron_sample_camera()
     cams_deg = (np.degrees(th), np.degrees(ph))
 
+    layout = None
+    if args.cfg5:       # the layout condition image of the panorama ControlNet (rolled with the panorama every step, PanFusion.py:150-153)
+        layout = (torch.rand(1, 1, 3, pano_hw[0] * 8, pano_hw[1] * 8, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(dev)
     if world > 1:
         from panfusion_amd import sharding
         model, loop = sharding.build_sharded(build_model, build_inputs, dev, dtype, cfg, m, lat_hw, pano_hw,
                                              cams_deg, args.steps + args.warmup + 1, not args.no_graphs,
-                                             precision=args.precision)
+                                             precision=args.precision, layout_cond=args.cfg5, layout=layout)
     else:
         model = build_model(dev, dtype, cfg, layout_cond=args.cfg5, precision=args.precision)
         inputs = build_inputs(dev, m, lat_hw, pano_hw, cfg["cross_attention_dim"], cams_deg)
-        layout = None
-        if args.cfg5:
-            layout = (torch.rand(1, 1, 3, pano_hw[0] * 8, pano_hw[1] * 8, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(dev)
         loop = DenoiseLoop(model, *inputs, steps=args.steps + args.warmup + 1, use_graphs=not args.no_graphs,
                            pano_layout_cond=layout)
 
@@ -372,9 +391,11 @@ def main():
         model.two_streams = serial
     fam = {}
     shapes = {}
+    classes = {}
+    GEMM_FAMILY = ("k_conv_gemm", "k_linear_ws")      # the GEMM family: the tile kernels + the weight-stationary linear kernel
     for name, flops, e0, e1, tag in trace:
         sec = e0.elapsed_time(e1) * 1e-3
-        f = fam.setdefault(name, [0.0, 0.0, 0])
+        f = fam.setdefault("k_conv_gemm" if name in GEMM_FAMILY else name, [0.0, 0.0, 0])
         f[0] += flops
         f[1] += sec
         f[2] += 1
@@ -382,15 +403,24 @@ def main():
         g[0] += flops
         g[1] += sec
         g[2] += 1
+        c = classes.setdefault(launch_class(name, tag), [0.0, 0.0, 0, 0.0])
+        c[0] += flops
+        c[1] += sec
+        c[2] += 1
+        c[3] += sec if name == "k_linear_ws" else 0.0
     if args.trace_out and rank == 0:
         with open(args.trace_out, "w") as fh:
+            fh.write("classes of the instrumented (eager, single-stream) step: launches, ms, TF/s, fraction of the 2.5 PF dense peak\n")
+            for k, (fl, sec, n, _) in sorted(classes.items(), key=lambda kv: -kv[1][1]):
+                fh.write("  %-44s launches %3d  ms %8.3f  TF/s %7.1f  frac %.3f\n" % (k, n, sec * 1e3, fl / sec / 1e12, fl / sec / 1e12 / PEAK_BF16_DENSE_TFLOPS))
+            fh.write("\n")
             for k, (fl, sec, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 fh.write("%-60s launches %3d  ms %8.3f  TF/s %7.1f\n" % (k, n, sec * 1e3, fl / sec / 1e12))
     dom = max(fam, key=lambda k: fam[k][1]) if fam else None
     roofline = None
     traffic = None                                    # PMC-derived bytes per launch of the dominant kernel (profiles/)
     traffic_file = None
-    for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):   # newest committed PMC summary (r2 / r3: fp16 mixed; r1: bf16 all-16-bit)
+    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):   # newest committed PMC summary (r2 / r3: fp16 mixed; r1: bf16 all-16-bit)
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 traffic, traffic_file = json.load(fh), name
@@ -406,6 +436,10 @@ def main():
                                     "rocprofv3 PMC passes committed in profiles/%s (not re-measured in this run)" % traffic_file,
                     "launches_per_step": n, "avg_launch_us": sec / n * 1e6, "algorithmic_flop_per_launch": fl / n,
                     "share_of_step_time": sec / (elapsed / args.steps),
+                    "family": "k_conv_gemm (implicit-GEMM tile kernels) + k_linear_ws (weight-stationary linear, C = 320 layers)",
+                    "by_class": {k: {"launches": v[2], "ms": v[1] * 1e3, "tflops": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / 1e12 / PEAK_BF16_DENSE_TFLOPS,
+                                     **({"ms_in_k_linear_ws": v[3] * 1e3} if v[3] else {})}
+                                 for k, v in sorted(classes.items(), key=lambda kv: -kv[1][1])},
                     "other": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]}
                               for k, v in fam.items() if k != dom}}
 

@@ -69,20 +69,43 @@ class ShardInfo:
         return self.cfg * self.G + (self.pano_g or 0)
 
 
-# Cost of the panorama branch + its EPA side in units of one view, in TIME on one MI355X (tools/sim_rank.py:
-# a rank's step takes 7.5 ms + 0.88 ms per view + 6.9 ms for the panorama branch).  By FLOPs it is only 2.7
-# (1.918 / 0.804 TFLOP + EPA): the panorama branch runs 2 samples through layers too small to
-# fill 256 CUs.  An owner WITHOUT views is cheaper than that (12.0 ms instead of 14.4 + 0.88 per view: no second
-# chain of ~600 latency-bound kernels competing with the panorama branch's ~1400).
-PANO_VIEW_EQUIV = 7.8
-PANO_ONLY_EQUIV = 5.1
+# TIME model of one rank's step on one MI355X, per configuration (panorama latent, view latent): a view-only rank takes
+# base + per_view * views, the panorama owner WITH views base + per_view * views + pano, an owner WITHOUT views pano_only
+# (cheaper than base + pano: no second chain of latency-bound kernels competing with the panorama branch's).  Measured with
+# tools/sim_rank.py (the sharded loop of one rank in a single process, collectives replaced by local stand-ins; fp16 mixed;
+# profiles/r4_sim_ranks.txt).  By FLOPs the cfg-2 panorama branch is only 2.7 views (1.918 / 0.804 TFLOP + EPA);
+# in time it is ~8: two samples through layers too small to fill 256 CUs.  At cfg 4 (128 x 256 panorama latent) the
+# panorama branch IS the step: an owner without views is 3x slower than a 7-view rank, whatever the split.
+TIME_MODEL = {
+    # (pano_hw, lat_hw, layout_cond): milliseconds; `pano` / `pano_only` are what the panorama branch adds ABOVE `base` on an owner
+    # with / without views (round 4, profiles/r4_sim_ranks.txt: 7-view rank 14.44, 14-view rank 21.13, owner alone 11.78 / 28.50
+    # (cfg 4) / 16.54 (cfg 5), owner with 6 views 19.98 / 34.10 (cfg 4))
+    ((64, 128), (64, 64), False): dict(base=7.75, per_view=0.956, pano=6.5, pano_only=4.0),       # cfg 2 / 3
+    ((64, 128), (64, 64), True): dict(base=7.75, per_view=0.956, pano=11.3, pano_only=8.8),       # cfg 5: + the panorama ControlNet
+    ((128, 256), (64, 64), False): dict(base=7.75, per_view=0.956, pano=20.6, pano_only=20.75),   # cfg 4
+}
+_DEFAULT_KEY = ((64, 128), (64, 64), False)
 
 
-def owner_cost(m0):
-    return PANO_ONLY_EQUIV if m0 == 0 else m0 + PANO_VIEW_EQUIV
+def time_model(pano_hw=None, lat_hw=None, layout_cond=False):
+    """The constants for a configuration; an unmeasured one scales the cfg-2 panorama terms by the panorama token count (the
+    self-attention term grows faster: an underestimate, flagged by `measured=False`)."""
+    key = (tuple(pano_hw), tuple(lat_hw), bool(layout_cond)) if pano_hw is not None and lat_hw is not None else _DEFAULT_KEY
+    if key in TIME_MODEL:
+        return dict(TIME_MODEL[key], measured=True)
+    ref = TIME_MODEL[_DEFAULT_KEY]
+    r_p = (key[0][0] * key[0][1]) / (64.0 * 128.0)
+    r_v = (key[1][0] * key[1][1]) / (64.0 * 64.0)
+    return dict(base=ref["base"], per_view=ref["per_view"] * r_v, pano=ref["pano"] * r_p, pano_only=ref["pano_only"] * r_p, measured=False)
 
 
-def pano_rank_split(m, G):
+def owner_cost(m0, tm=None):
+    """Step time of the panorama owner holding m0 views, in view units (per_view = 1) above a view-only rank's base."""
+    tm = tm or time_model()
+    return (tm["pano_only"] if m0 == 0 else m0 * tm["per_view"] + tm["pano"]) / tm["per_view"]
+
+
+def pano_rank_split(m, G, tm=None):
     """Views per group when group 0 owns the panorama branch: (m0, ...rest spread as evenly as possible) for
     the m0 >= 0 that minimises the slowest group, max(owner_cost(m0), ceil((m - m0) / (G - 1))); m0 = 0 is a
     panorama-only owner.  None if G < 2 or the views do not give every other group at least one."""
@@ -91,25 +114,32 @@ def pano_rank_split(m, G):
     best, best_cost = None, None
     for m0 in range(0, m - (G - 1) + 1):
         rest = m - m0
-        cost = max(owner_cost(m0), -(-rest // (G - 1)))
+        cost = max(owner_cost(m0, tm), -(-rest // (G - 1)))
         if best_cost is None or cost < best_cost - 1e-9:
             best, best_cost = m0, cost
     rest, q, r = m - best, (m - best) // (G - 1), (m - best) % (G - 1)
     return (best,) + tuple(q + (1 if i < r else 0) for i in range(G - 1))
 
 
-def split_cost(split, pano_replicated):
+def split_cost(split, pano_replicated, tm=None):
     """Slowest group of a layout in view units (the model above)."""
+    tm = tm or time_model()
     if pano_replicated:
-        return max(split) + PANO_VIEW_EQUIV
-    return max(owner_cost(split[0]), max(split[1:]))
+        return max(split) + tm["pano"] / tm["per_view"]
+    return max(owner_cost(split[0], tm), max(split[1:]))
 
 
-def plan(world, rank, m, layout="auto", split=None):
+def step_time_ms(split, pano_replicated, tm=None):
+    """Predicted step time (ms) of the slowest rank of a layout: what tools/sim_rank.py measures."""
+    tm = tm or time_model()
+    return tm["base"] + split_cost(split, pano_replicated, tm) * tm["per_view"]
+
+
+def plan(world, rank, m, layout="auto", split=None, pano_hw=None, lat_hw=None, layout_cond=False):
     """Layout of `rank`: 2 CFG halves x G = world/2 view groups.
     layout "even": m/G views per group, the panorama branch replicated inside a CFG half.  layout "pano_rank"
     (chosen by "auto" whenever its slowest group is faster by the time model above, i.e. from G >= 2): group 0
-    of a half owns the panorama branch and fewer views (6 / 14 for m = 20, G = 2; none at all, 0 / 7 / 7 / 6, for G = 4); the
+    of a half owns the panorama branch and fewer views (7 / 13 for m = 20, G = 2; none at all, 0 / 7 / 7 / 6, for G = 4); the
     other groups run the view branch only and receive the layer-normed panorama tokens by a broadcast at every
     EPA block.  PF_SHARD_SPLIT=a,b,... overrides the split."""
     if world < 2 or world % 2:
@@ -123,15 +153,16 @@ def plan(world, rank, m, layout="auto", split=None):
             raise ValueError("split %r does not distribute %d views over %d groups" % (split, m, G))
         info.split, info.pano_g = tuple(split), 0
         return info
+    tm = time_model(pano_hw, lat_hw, layout_cond)         # per configuration: the panorama branch of cfg 4 costs 6x that of cfg 2
     if layout == "auto":                                  # whichever the time model says is faster
-        sp = pano_rank_split(m, G)
+        sp = pano_rank_split(m, G, tm)
         even_ok = m % G == 0
-        if sp is not None and (not even_ok or split_cost(sp, False) < split_cost((m // G,) * G, True)):
+        if sp is not None and (not even_ok or split_cost(sp, False, tm) < split_cost((m // G,) * G, True, tm)):
             layout = "pano_rank"
         else:
             layout = "even"
     if layout == "pano_rank":
-        sp = pano_rank_split(m, G)
+        sp = pano_rank_split(m, G, tm)
         if sp is None:
             raise ValueError("no panorama-rank split of %d views over %d groups" % (m, G))
         info.split, info.pano_g = sp, 0
@@ -141,14 +172,14 @@ def plan(world, rank, m, layout="auto", split=None):
     return info
 
 
-def make_shard(m, layout=None, split=None):
+def make_shard(m, layout=None, split=None, pano_hw=None, lat_hw=None, layout_cond=False):
     """Build this process' ShardInfo and the process group of its CFG half (collective call:
-    every rank creates every group, in the same order)."""
+    every rank creates every group, in the same order).  pano_hw / lat_hw select the time model of the configuration."""
     import os
     world, rank = dist.get_world_size(), dist.get_rank()
     if split is None and os.environ.get("PF_SHARD_SPLIT"):
         split = tuple(int(v) for v in os.environ["PF_SHARD_SPLIT"].split(","))
-    info = plan(world, rank, m, layout or os.environ.get("PF_SHARD_LAYOUT", "auto"), split)
+    info = plan(world, rank, m, layout or os.environ.get("PF_SHARD_LAYOUT", "auto"), split, pano_hw=pano_hw, lat_hw=lat_hw, layout_cond=layout_cond)
     if info.G > 1:
         groups = [dist.new_group(list(range(c * info.G, (c + 1) * info.G))) for c in range(2)]
         info.group = groups[info.cfg]
@@ -365,9 +396,14 @@ class ShardedDenoiseLoop(DenoiseLoop):
 
 
 def build_sharded(build_model, build_inputs, dev, dtype, cfg, m, lat_hw, pano_hw, cams_deg, steps, use_graphs,
-                  precision=None):
-    shard = make_shard(m)
-    model = build_model(dev, dtype, cfg, precision=precision)
+                  precision=None, layout_cond=False, layout=None):
+    """layout_cond / layout: BASELINE.json configs[4] -- the model carries the panorama ControlNet and the loop its condition
+    image (MVGenModel.py:75-83, PanFusion.py:150-153); the ranks that run the panorama branch run the ControlNet on their CFG
+    sample's copy of the image (ShardedDenoiseLoop._local)."""
+    if layout_cond and layout is None:
+        raise ValueError("a layout-conditioned model needs its condition image")
+    shard = make_shard(m, pano_hw=pano_hw, lat_hw=lat_hw, layout_cond=layout_cond)
+    model = build_model(dev, dtype, cfg, layout_cond=layout_cond, precision=precision)
     inputs = build_inputs(dev, m, lat_hw, pano_hw, cfg["cross_attention_dim"], cams_deg)
-    loop = ShardedDenoiseLoop(model, shard, *inputs, steps=steps, use_graphs=use_graphs)
+    loop = ShardedDenoiseLoop(model, shard, *inputs, steps=steps, use_graphs=use_graphs, pano_layout_cond=layout)
     return model, loop

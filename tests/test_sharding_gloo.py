@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_loop(sharded, steps=2, split=None, layout=None, precision="fast"):
+def _run_loop(sharded, steps=2, split=None, layout=None, precision="fast", controlnet=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import fake_ops
@@ -33,22 +33,35 @@ def _run_loop(sharded, steps=2, split=None, layout=None, precision="fast"):
     from panfusion_amd.pipeline import DenoiseLoop
     g = golden("mvgen_tiny.npz")
     t = lambda k: torch.from_numpy(g[k])
-    model = hip_model(build_tiny_oracle(), precision=precision)
+    om = build_tiny_oracle()
+    kw = {}
+    if controlnet:      # BASELINE.json configs[4]: a panorama ControlNet + its layout image, rolled with the panorama every step
+        from oracle import sd2_unet as U
+        from panfusion_amd.models.pano import MultiViewBaseModel
+        cn = U.ControlNetModel.from_unet(om.pano_unet)
+        U.init_synthetic(cn.controlnet_cond_embedding, 71)
+        U.init_synthetic(cn.controlnet_down_blocks, 72)
+        U.init_synthetic(cn.controlnet_mid_block, 73)
+        model = MultiViewBaseModel(om.unet, om.pano_unet, None, cn, True, compute_dtype=torch.float32, precision=precision)
+        model.load_state_dict({k: v for k, v in om.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+        kw["pano_layout_cond"] = torch.rand(1, 1, 3, 128, 256, generator=torch.Generator().manual_seed(7)) * 2 - 1
+    else:
+        model = hip_model(om, precision=precision)
     cam1 = {k: v[None] for k, v in cam4().items()}
     args = (t("latents")[:1], t("pano_latent")[:1], t("prompt_embd"), t("pano_prompt_embd"), cam1)
     if sharded:
-        loop = sharding.ShardedDenoiseLoop(model, sharding.make_shard(4, layout=layout, split=split), *args, steps=steps)
+        loop = sharding.ShardedDenoiseLoop(model, sharding.make_shard(4, layout=layout, split=split), *args, steps=steps, **kw)
     else:
-        loop = DenoiseLoop(model, *args, steps=steps)
+        loop = DenoiseLoop(model, *args, steps=steps, **kw)
     return loop.run()
 
 
-def _worker(rank, world, port, out, split=None, layout=None, precision="fast"):
+def _worker(rank, world, port, out, split=None, layout=None, precision="fast", controlnet=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        lat, pano = _run_loop(True, split=split, layout=layout, precision=precision)
+        lat, pano = _run_loop(True, split=split, layout=layout, precision=precision, controlnet=controlnet)
         torch.save((lat, pano), os.path.join(out, "r%d.pt" % rank))
     finally:
         dist.destroy_process_group()
@@ -67,8 +80,8 @@ def test_plan_layout():
     with pytest.raises(ValueError):
         sharding.plan(16, 0, 20, layout="even")          # 20 views do not split into 8 groups
     # panorama-rank layout: group 0 of a CFG half owns the panorama branch and fewer views; the split
-    # minimises the slowest group under the measured time model (panorama branch = 7.8 views)
-    assert sharding.pano_rank_split(20, 2) == (6, 14)
+    # minimises the slowest group under the measured time model (panorama branch = 6.8 views of time at cfg 2)
+    assert sharding.pano_rank_split(20, 2) == (7, 13)
     assert sharding.pano_rank_split(20, 4) == (0, 7, 7, 6)      # a panorama-only owner is cheaper than one with a view
     assert sharding.pano_rank_split(20, 1) is None
     s = sharding.plan(8, 5, 20)                           # "auto" picks it whenever it is faster than replicating
@@ -76,7 +89,7 @@ def test_plan_layout():
     s = sharding.plan(8, 4, 20)
     assert s.has_pano and s.views == (0, 0) and not s.has_views
     s = sharding.plan(4, 1, 20)
-    assert s.pano_g == 0 and s.views == (6, 20) and not s.has_pano
+    assert s.pano_g == 0 and s.views == (7, 20) and not s.has_pano
     assert sharding.plan(4, 1, 20, layout="even").pano_g is None and sharding.plan(8, 1, 20, layout="even").views == (5, 10)
     s = sharding.plan(8, 0, 20, split=(0, 7, 7, 6))      # explicit split only: a panorama-only owner
     assert s.has_pano and not s.has_views and s.views == (0, 0) and sharding.plan(8, 1, 20, split=(0, 7, 7, 6)).views == (0, 7)
@@ -84,6 +97,35 @@ def test_plan_layout():
         sharding.plan(8, 0, 20, split=(7, 0, 7, 6))      # only the owner may go without views
     s = sharding.plan(16, 3, 20)                          # 8 groups: 0 / 3 3 3 3 3 3 2
     assert sum(s.counts) == 20 and s.counts[0] == 0 and max(s.counts[1:]) - min(s.counts[1:]) <= 1
+
+
+def test_plan_uses_the_time_model_of_the_configuration():
+    """cfg 4 (128 x 256 panorama latent): the panorama branch costs six times that of cfg 2 -- the split follows the configuration."""
+    from panfusion_amd import sharding
+    tm2, tm4 = sharding.time_model((64, 128), (64, 64)), sharding.time_model((128, 256), (64, 64))
+    assert tm2["measured"] and tm4["measured"] and tm4["pano"] > 4 * tm2["pano"]
+    assert not sharding.time_model((32, 64), (32, 32))["measured"]
+    s2, s4 = sharding.plan(4, 0, 20, pano_hw=(64, 128), lat_hw=(64, 64)), sharding.plan(4, 0, 20, pano_hw=(128, 256), lat_hw=(64, 64))
+    assert s2.counts == (7, 13) and s4.counts == (0, 20)      # at cfg 4 the owner of 4 ranks keeps no views at all
+    assert sharding.time_model((64, 128), (64, 64), True)["pano_only"] > 2 * tm2["pano_only"]       # cfg 5: the ControlNet rides on the owner
+    assert sharding.plan(8, 0, 20, pano_hw=(128, 256), lat_hw=(64, 64)).counts == (0, 7, 7, 6)
+    assert sharding.step_time_ms((0, 7, 7, 6), False, tm4) > 3 * sharding.step_time_ms((0, 7, 7, 6), False, tm2)
+
+
+def test_sharded_loop_with_panorama_controlnet_equals_single_process():
+    """BASELINE.json configs[4] is an 8-GPU configuration: the sharded loop must run the panorama ControlNet on the ranks that own
+    the panorama branch, with the layout image rolled as the panorama is (MVGenModel.py:75-83, PanFusion.py:150-153)."""
+    base = _run_loop(False)
+    want = _run_loop(False, controlnet=True)
+    assert float((want[1] - base[1]).norm() / base[1].norm()) > 1e-3, "the ControlNet must change the result for the test to mean anything"
+    for world, split in ((4, None), (4, (1, 3))):
+        with tempfile.TemporaryDirectory() as out:
+            mp.spawn(_worker, args=(world, _free_port(), out, split, None, "fast", True), nprocs=world, join=True)
+            res = [torch.load(os.path.join(out, "r%d.pt" % r)) for r in range(world)]
+        rel = lambda a, b: float((a - b).norm() / b.norm())
+        for lat, pano in res:
+            assert rel(lat, want[0]) < 1e-4 and rel(pano, want[1]) < 1e-4, (world, split, rel(lat, want[0]), rel(pano, want[1]))
+        assert all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
 
 
 @pytest.mark.parametrize("world,split,layout,precision", [

@@ -56,21 +56,26 @@ def pmc(path, out):
                 fh.write("%-72s %-28s total %.6g  per-dispatch %.6g  dispatches %d\n" % (k, c, v, v / calls[(k, c)], calls[(k, c)]))
 
 
-def traffic(fetch_txt, write_txt, out, family="k_conv_gemm"):
-    """profiles/r<N>_traffic.json (read by bench.py for roofline.traffic) from the two PMC summaries."""
+def traffic(fetch_txt, write_txt, out, family=("k_conv_gemm", "k_linear_ws")):
+    """profiles/r<N>_traffic.json (read by bench.py for roofline.traffic) from the two PMC summaries: the GEMM family
+    (tile kernels + the weight-stationary linear kernel), and every kernel of the run together (`all_kernels`)."""
     import json
-    tot, n = {}, {}
+    tot, n, everything = {}, {}, {}
     for path in (fetch_txt, write_txt):
         for line in open(path):
             f = line.split()
-            if not line.startswith(family) or "total" not in f:
+            if "total" not in f:
                 continue
             c = f[f.index("total") - 1]
+            everything[c] = everything.get(c, 0.0) + float(f[f.index("total") + 1])
+            if not line.startswith(family):
+                continue
             tot[c] = tot.get(c, 0.0) + float(f[f.index("total") + 1])
             n[c] = n.get(c, 0) + int(f[f.index("dispatches") + 1])
     assert n["FETCH_SIZE"] == n["WRITE_SIZE"], n
     doc = {
-        "kernel": family + " (all tile variants)",
+        "kernel": "k_conv_gemm (all tile variants) + k_linear_ws",
+        "all_kernels_bytes_total": (2.0 * everything["FETCH_SIZE"] + everything["WRITE_SIZE"]) * 1024.0,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, PF_STREAMS=1 bench.py --steps 1 --warmup 0 --no-graphs",
         "launches": n["FETCH_SIZE"],
         "fetch_size_kb_total": tot["FETCH_SIZE"],

@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--precision", default=None, choices=["mixed", "fast"])
+    ap.add_argument("--cfg4", action="store_true", help="BASELINE.json configs[3]: 128 x 256 panorama latent")
+    ap.add_argument("--cfg5", action="store_true", help="BASELINE.json configs[4]: + panorama ControlNet on a layout image")
+    ap.add_argument("--split", default=None, help="views per group, e.g. 0,7,7,6 (default: sharding.plan's choice for the configuration)")
     ap.add_argument("--shapes", type=int, default=0, help="also print the N most expensive GEMM / attention shapes of one eager step of the rank")
     args = ap.parse_args()
     import bench
@@ -54,11 +57,16 @@ def main():
     th, ph = icosahedron_sample_camera()
     cams_deg = (np.degrees(th), np.degrees(ph))
     cfg = dict(SD2_BASE)
+    pano_hw = (128, 256) if args.cfg4 else (64, 128)
+    layout = (torch.rand(1, 1, 3, pano_hw[0] * 8, pano_hw[1] * 8, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(dev) if args.cfg5 else None
+    if args.split:
+        os.environ["PF_SHARD_SPLIT"] = args.split
+    build = lambda steps, graphs: sharding.build_sharded(bench.build_model, bench.build_inputs, dev, dtype, cfg, 20, (64, 64), pano_hw, cams_deg,
+                                                         steps, graphs, precision=args.precision, layout_cond=args.cfg5, layout=layout)
     for rank in [int(r) for r in args.ranks.split(",")]:
         fake_dist(args.world, rank)
         dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
-        model, loop = sharding.build_sharded(bench.build_model, bench.build_inputs, dev, dtype, cfg, 20, (64, 64), (64, 128),
-                                             cams_deg, args.steps + args.warmup + 1, True, precision=args.precision)
+        model, loop = build(args.steps + args.warmup + 1, True)
         loop.prepare()
         for _ in range(args.warmup):
             loop.step()
@@ -68,13 +76,13 @@ def main():
             loop.step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / args.steps
-        print("world %d rank %d  %-60s %7.2f ms/step  (graphs %s)" % (args.world, rank, "%s %s %s" % (loop.layout_desc, args.dtype, model.precision), ms, loop.use_graphs), flush=True)
+        print("world %d rank %d  %-8s %-60s %7.2f ms/step  (graphs %s)" % (args.world, rank, "cfg4" if args.cfg4 else "cfg5" if args.cfg5 else "cfg2",
+                                                                      "%s %s %s" % (loop.layout_desc, args.dtype, model.precision), ms, loop.use_graphs), flush=True)
         del model, loop
         torch.cuda.empty_cache()
         if args.shapes:
             from panfusion_amd import ops
-            model, loop = sharding.build_sharded(bench.build_model, bench.build_inputs, dev, dtype, cfg, 20, (64, 64), (64, 128),
-                                                 cams_deg, 4, False, precision=args.precision)
+            model, loop = build(4, False)
             loop.prepare()
             loop.step()
             torch.cuda.synchronize()
