@@ -100,16 +100,17 @@ def test_plan_layout():
 
 
 def test_plan_uses_the_time_model_of_the_configuration():
-    """cfg 4 (128 x 256 panorama latent): the panorama branch costs six times that of cfg 2 -- the split follows the configuration."""
+    """cfg 4 (128 x 256 panorama latent): the panorama branch costs three times that of cfg 2 in time (5 x for an owner without
+    views) -- the split follows the configuration."""
     from panfusion_amd import sharding
     tm2, tm4 = sharding.time_model((64, 128), (64, 64)), sharding.time_model((128, 256), (64, 64))
-    assert tm2["measured"] and tm4["measured"] and tm4["pano"] > 4 * tm2["pano"]
+    assert tm2["measured"] and tm4["measured"] and tm4["pano"] > 3 * tm2["pano"] and tm4["pano_only"] > 5 * tm2["pano_only"]
     assert not sharding.time_model((32, 64), (32, 32))["measured"]
     s2, s4 = sharding.plan(4, 0, 20, pano_hw=(64, 128), lat_hw=(64, 64)), sharding.plan(4, 0, 20, pano_hw=(128, 256), lat_hw=(64, 64))
     assert s2.counts == (7, 13) and s4.counts == (0, 20)      # at cfg 4 the owner of 4 ranks keeps no views at all
     assert sharding.time_model((64, 128), (64, 64), True)["pano_only"] > 2 * tm2["pano_only"]       # cfg 5: the ControlNet rides on the owner
     assert sharding.plan(8, 0, 20, pano_hw=(128, 256), lat_hw=(64, 64)).counts == (0, 7, 7, 6)
-    assert sharding.step_time_ms((0, 7, 7, 6), False, tm4) > 3 * sharding.step_time_ms((0, 7, 7, 6), False, tm2)
+    assert sharding.step_time_ms((0, 7, 7, 6), False, tm4) > 1.9 * sharding.step_time_ms((0, 7, 7, 6), False, tm2)
 
 
 def test_sharded_loop_with_panorama_controlnet_equals_single_process():
