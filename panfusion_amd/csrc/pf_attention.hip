@@ -302,7 +302,12 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
             f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+#ifdef PF_ATTN_ABL_NOLDS          /* timing-only ablation (make attn_ablate): fragments from registers instead of LDS */
+                u16x8 kf = {1, 2, 3, 4, 5, 6, 7, static_cast<unsigned short>(lane + ks)};
+                asm volatile("" : "+v"(kf));
+#else
                 const u16x8 kf = *reinterpret_cast<const u16x8*>(Ks + k_off(hh * 32 + ql, 2 * ks + hi));
+#endif
                 s = Mfma32<T>::run(__builtin_bit_cast(frag, kf), qf[ks], s);
             }
 #pragma unroll
@@ -371,7 +376,11 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const f32x2 x = f32x2{sv[hh][r], sv[hh][r + 1]} * c22 - mc2;
+#ifdef PF_ATTN_ABL_NOEXP          /* timing-only: what the 32 v_exp_f32 per key tile cost */
+                const f32x2 e = x * x;
+#else
                 const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+#endif
                 sv[hh][r] = e[0];
                 sv[hh][r + 1] = e[1];
                 ls2 += e;
@@ -388,10 +397,15 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
                 for (int e = 0; e < 8; ++e) pb[e] = from_f32<T>(sv[hh][8 * s2 + e]);
 #pragma unroll
                 for (int d = 0; d < DB; ++d) {
+#ifdef PF_ATTN_ABL_NOLDS
+                    u16x8 vf = {1, 2, 3, 4, 5, 6, 7, static_cast<unsigned short>(lane + d)};
+                    asm volatile("" : "+v"(vf));
+#else
                     const unsigned short* vrow = Vs + (d * 32 + ql) * VROW + hh * 32 + 16 * s2 + 4 * hi;
                     const u16x4 lo = *reinterpret_cast<const u16x4*>(vrow);
                     const u16x4 up = *reinterpret_cast<const u16x4*>(vrow + 8);
                     const u16x8 vf = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+#endif
                     o[d] = Mfma32<T>::run(__builtin_bit_cast(frag, vf), __builtin_bit_cast(frag, pb), o[d]);
                 }
             }

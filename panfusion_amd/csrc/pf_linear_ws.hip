@@ -34,7 +34,6 @@ struct LwsParams {
     int M, N;
     int nblocks, splits_per_xcd, ntiles;
     unsigned a_bytes;
-    int defer;                     // the 32-channel wavefronts run their epilogues half a tile late (PF_LWS_DEFER=0: A/B)
 };
 
 template <typename T> struct LwsMfma;
@@ -47,19 +46,7 @@ template <> struct LwsMfma<F16> {
     static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
-__device__ __forceinline__ float lws_erf(float x) {               // Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (as pf_gemm.hip)
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-    float y = 1.061405429f;
-    y = y * t - 1.453152027f;
-    y = y * t + 1.421413741f;
-    y = y * t - 0.284496736f;
-    y = y * t + 0.254829592f;
-    y = 1.0f - y * t * __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
-    return copysignf(y, x);
-}
-
-// value * gelu(gate) with the same erf approximation, arranged as  g Phi(g) = relu(g) - |g| h,  h = 0.5 P(t) exp(-g^2 / 2),
+// value * gelu(gate), erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, as pf_gemm.hip), arranged as  g Phi(g) = relu(g) - |g| h,  h = 0.5 P(t) exp(-g^2 / 2),
 // t = 1 / (1 + p |g| / sqrt 2): 12 plain VALU operations + rcp + exp2 per output (the straightforward 0.5 g (1 + erf(g / sqrt 2))
 // with copysign costs 20): the GEGLU epilogue is VALU-bound (profiles/r4e_lws_pmc_kernel.txt: VALU busy 1.5 x MFMA busy).
 __device__ __forceinline__ float lws_geglu(float v, float g) {
@@ -87,7 +74,7 @@ template <int MODE, int NB> constexpr int lws_epilogue_ops() {
 }
 constexpr int lws_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }   // gfx9 s_waitcnt immediate: vmcnt(n) only
 
-template <typename T, int MODE, int NB, bool COUNTED, bool DEFER>
+template <typename T, int MODE, int NB, bool COUNTED>
 __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* smem, unsigned char* stg, int nblk, int cb,
                                          int t_lo, int t_hi, int wave, int lane) {
     typedef typename LwsMfma<T>::frag frag;
@@ -231,20 +218,18 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
         }
     };
 
-    // DEFER (the 32-channel wavefronts): the epilogue of a tile's second half runs at the START of the next tile, so that between two
-    // barriers this wave goes  epilogue - MFMA - epilogue - MFMA  while its SIMD partner (a 48-channel wave) goes
-    // MFMA - epilogue - MFMA - epilogue: one of the two is in the matrix pipe while the other is in the vector ALU (the first
-    // version ran both in the same phase: MFMA busy 41 %, VALU busy 61 % in the GEGLU launch, their sum the whole time).
-    f32x4 acc[2][NB];
-    bool pending = false;
-    int pend_m = 0;
+    // Two ways of hiding the epilogue's vector-ALU work behind matrix work were built and measured on the GEGLU launch (the only one
+    // that is not HBM-bound: MFMA busy 41 %, VALU busy 52 %, their sum the whole time) -- both neutral, both removed again:
+    // (1) the 32-channel wave of a SIMD running its epilogues half a tile late, so that one wave of the SIMD is in the matrix pipe
+    // while the other is in the vector ALU (361 vs 348 us); (2) two accumulator sets with the epilogue of half h - 1 in the
+    // scheduling region of the MFMAs of half h, asked for as {1 MFMA, 4 VALU} groups (364 us).  profiles/r4_lws_notes.txt.
+    f32x4 acc[2][NB];                                             // [token block][channel sub-block]
     int slot = 0;
     for (int tile = t_lo; tile < t_hi; ++tile) {
         // The 5 DMA pieces of this tile were issued two tiles ago; younger than them are that tile's epilogue (E operations), the
         // next tile's 5 pieces and the previous tile's epilogue: a COUNTED wait leaves those 5 + 2 E in flight (the first two tiles
         // were drained before the loop).  COUNTED = false (PF_LWS_COUNTED=0): full drain, for A/B.
-        // (a DEFER wave has issued half a tile's epilogue less at its first tiles: 5 + 3 E / 2 is its safe count)
-        if constexpr (COUNTED) __builtin_amdgcn_s_waitcnt(lws_waitcnt_vm(LWS_KB + (DEFER ? 3 : 4) * lws_epilogue_ops<MODE, NB>() / 2));
+        if constexpr (COUNTED) __builtin_amdgcn_s_waitcnt(lws_waitcnt_vm(LWS_KB + 2 * lws_epilogue_ops<MODE, NB>()));
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef PF_LWS_ABL_NOBAR   /* -DPF_LWS_ABL_*: timing-only ablation builds (wrong results), make -C panfusion_amd/csrc lws_ablate */
         __builtin_amdgcn_s_barrier();                             // tile landed (all waves' pieces); slot (tile + 2) % 3 no longer read
@@ -257,7 +242,6 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
         const int m_tile = tile * LWS_BM;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            if (DEFER && half == 0 && pending) epilogue(acc, pend_m);
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
@@ -298,13 +282,10 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
                             acc[pb][j] = LwsMfma<T>::run(wf[j][2 * st + h2], af[st & 1][h2][pb], acc[pb][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const int m_half = m_tile + half * 32;
-            if (!DEFER || half == 0) epilogue(acc, m_half);
-            else { pending = true; pend_m = m_half; }
+            epilogue(acc, m_tile + half * 32);
         }
         slot = slot == LWS_STAGES - 1 ? 0 : slot + 1;
     }
-    if (DEFER && pending) epilogue(acc, pend_m);
 }
 
 template <typename T, int MODE, bool COUNTED>
@@ -320,9 +301,8 @@ __global__ __launch_bounds__(512, 1) void k_linear_ws(const LwsParams p) {
     const int t_lo = static_cast<int>(static_cast<long>(p.ntiles) * s / S), t_hi = static_cast<int>(static_cast<long>(p.ntiles) * (s + 1) / S);
     unsigned char* stg = reinterpret_cast<unsigned char*>(smem + LWS_STAGES * LWS_STAGE_ELEMS) + wave * LWS_STG_BYTES;
     // waves w and w + 4 share a SIMD: 48 + 32 channels each
-    if (wave < 4) lws_wave<T, MODE, 3, COUNTED, false>(p, smem, stg, nblk, wave * 48, t_lo, t_hi, wave, lane);
-    else if (p.defer) lws_wave<T, MODE, 2, COUNTED, true>(p, smem, stg, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
-    else lws_wave<T, MODE, 2, COUNTED, false>(p, smem, stg, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
+    if (wave < 4) lws_wave<T, MODE, 3, COUNTED>(p, smem, stg, nblk, wave * 48, t_lo, t_hi, wave, lane);
+    else lws_wave<T, MODE, 2, COUNTED>(p, smem, stg, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
 }
 
 template <typename T, int MODE, bool COUNTED>
@@ -384,8 +364,6 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     p.splits_per_xcd = 32 / p.nblocks;
     p.ntiles = static_cast<int>(cdiv(d->M, LWS_BM));
     p.a_bytes = static_cast<unsigned>(static_cast<long>(d->M) * d->a_ld * 2);
-    static const int defer = getenv("PF_LWS_DEFER") ? atoi(getenv("PF_LWS_DEFER")) : 1;
-    p.defer = defer;
     hipStream_t st = as_stream(stream);
 #define PF_LWS_MODE(MODE) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, MODE>(p, st)))
     switch (d->mode) {
