@@ -10,6 +10,7 @@
 // utils/pano.py:74-105; models/pano/PanoGenerator.py:253-269; DDIMScheduler.step
 // (models/pano/PanFusion.py:159-162).
 #include "pf_common.h"
+#include <stdlib.h>
 #include <math.h>
 #include <algorithm>
 
@@ -37,6 +38,8 @@ template <> struct In8<F32In> {
         f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
     }
 };
+template <typename TI> __device__ __forceinline__ float elem_to_f32(typename In8<TI>::elem v) { return to_f32<TI>(v); }
+template <> __device__ __forceinline__ float elem_to_f32<F32In>(float v) { return v; }
 __device__ __forceinline__ void store8_f32(float* ptr, const float (&f)[8]) {
     reinterpret_cast<float4*>(ptr)[0] = float4{f[0], f[1], f[2], f[3]};
     reinterpret_cast<float4*>(ptr)[1] = float4{f[4], f[5], f[6], f[7]};
@@ -171,6 +174,55 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ p
         const float sc = g_rstd[gg] * gamma[c];
         scale[static_cast<long>(img) * C + c] = sc;
         shift[static_cast<long>(img) * C + c] = beta[c] - g_mean[gg] * sc;
+    }
+}
+
+// Small tensors (the panorama branch's inner levels, the 8 x 8 / 16 x 16 view levels): statistics AND scale / shift in ONE launch,
+// one block per (image, group) walking its hw x C/groups elements directly -- the two-stage form costs such a tensor two launches
+// on a latency-bound chain (~75 of them per denoiser pass) for a few microseconds of work each.
+template <typename TI>
+__global__ __launch_bounds__(256) void k_gn_stats_direct(const typename In8<TI>::elem* __restrict__ x0, int c0,
+                                  const typename In8<TI>::elem* __restrict__ x1, int c1, int hw, int groups, int hw_counted, float eps,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale,
+                                  float* __restrict__ shift, int wimg, int wrap) {
+    typedef typename In8<TI>::elem elem;
+    __shared__ double red[2][4];
+    __shared__ float stat[2];
+    const int img = blockIdx.x, g = blockIdx.y, t = threadIdx.x;
+    const int C = c0 + c1, cpg = C / groups, cb = g * cpg;
+    const long total = static_cast<long>(hw) * cpg;
+    float s = 0.f, q = 0.f;
+    for (long e = t; e < total; e += 256) {
+        const int p = static_cast<int>(e / cpg), c = cb + static_cast<int>(e - static_cast<long>(p) * cpg);
+        float v;
+        if (c < c0) v = elem_to_f32<TI>(x0[(static_cast<long>(img) * hw + p) * c0 + c]);
+        else v = elem_to_f32<TI>(x1[(static_cast<long>(img) * hw + p) * c1 + (c - c0)]);
+        float wgt = 1.f;
+        if (wrap > 0) {
+            const int col = p % wimg;
+            wgt = (col < wrap || col >= wimg - wrap) ? 2.f : 1.f;
+        }
+        s += v * wgt;
+        q += v * v * wgt;
+    }
+    double ds = wave_sum(s), dq = wave_sum(q);                     // (fp32 inside a wave's 64 partial sums, fp64 across)
+    if ((t & 63) == 0) { red[0][t >> 6] = ds; red[1][t >> 6] = dq; }
+    __syncthreads();
+    if (t == 0) {
+        ds = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        dq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double cnt = static_cast<double>(hw_counted) * cpg;
+        const double mean = ds / cnt;
+        double var = dq / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[0] = static_cast<float>(mean);
+        stat[1] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    }
+    __syncthreads();
+    for (int c = cb + t; c < cb + cpg; c += 256) {
+        const float sc = stat[1] * gamma[c];
+        scale[static_cast<long>(img) * C + c] = sc;
+        shift[static_cast<long>(img) * C + c] = beta[c] - stat[0] * sc;
     }
 }
 
@@ -761,18 +813,27 @@ static pf_status groupnorm_stats_impl(const void* x0, int c0, const void* x1, in
     PF_REQUIRE(aligned16(x0) && (!x1 || aligned16(x1)), "pf_groupnorm_stats: inputs must be 16-byte aligned");
     PF_REQUIRE(dtype != PF_F32 || (c0 % 4 == 0 && c1 % 4 == 0), "pf_groupnorm_stats: fp32 sources need c0, c1 %% 4 == 0");
     PF_REQUIRE(ws_bytes >= pf_groupnorm_workspace_size(n_img, hw, C), "pf_groupnorm_stats: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int hw_counted = wrap > 0 ? hw / wimg * (wimg + 2 * wrap) : hw;         // pixels of the virtually padded tensor
+    static const long direct_max = getenv("PF_GN_DIRECT_MAX") ? atol(getenv("PF_GN_DIRECT_MAX")) : 32768;   // elements per (image, group); 0 = off (A/B)
+    if (static_cast<long>(hw) * (C / groups) <= direct_max && static_cast<long>(n_img) * hw * C <= (4L << 20)) {
+        PF_DISPATCH_IN(dtype, "pf_groupnorm_stats",
+            hipLaunchKernelGGL(k_gn_stats_direct<TI>, dim3(n_img, groups), dim3(256), 0, st,
+                               static_cast<const In8<TI>::elem*>(x0), c0, static_cast<const In8<TI>::elem*>(x1), c1,
+                               hw, groups, hw_counted, eps, gamma, beta, scale, shift, wimg, wrap));
+        PF_CHECK_LAUNCH("pf_groupnorm_stats (direct)");
+        return PF_OK;
+    }
     const int ppc = gn_pixels_per_chunk(n_img, hw);
     const int nchunks = static_cast<int>(cdiv(hw, ppc));
     const int OCT = C / 8, OCTB = OCT < 256 ? OCT : 256, pix_par = 256 / OCTB;
     const size_t smem = static_cast<size_t>(2) * pix_par * C * sizeof(float);
     PF_REQUIRE(smem <= 64 * 1024, "pf_groupnorm_stats: C=%d too large", C);
-    hipStream_t st = as_stream(stream);
     float* partial = static_cast<float*>(workspace);
     PF_DISPATCH_IN(dtype, "pf_groupnorm_stats",
         hipLaunchKernelGGL(k_gn_partial<TI>, dim3(nchunks, n_img), dim3(256), smem, st,
                            static_cast<const In8<TI>::elem*>(x0), c0, static_cast<const In8<TI>::elem*>(x1), c1,
                            hw, groups, ppc, partial, wimg, wrap));
-    const int hw_counted = wrap > 0 ? hw / wimg * (wimg + 2 * wrap) : hw;         // pixels of the virtually padded tensor
     hipLaunchKernelGGL(k_gn_finalize, dim3(n_img, cdiv(groups, GN_GPB)), dim3(256), 0, st, partial, nchunks, groups, C, hw_counted, eps,
                        gamma, beta, scale, shift);
     PF_CHECK_LAUNCH("pf_groupnorm_stats");
