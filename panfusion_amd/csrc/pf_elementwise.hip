@@ -705,6 +705,70 @@ __global__ void k_conv_in(const float* __restrict__ x, int n, int cin, int h, in
     else *reinterpret_cast<u16x8*>(static_cast<unsigned short*>(y) + pix * cout + oct * 8) = pack8<T>(acc);
 }
 
+// The same for the UNets' 4 latent channels: a thread owns one output-channel octet of FOUR horizontally adjacent pixels.  The
+// generic kernel above re-reads its 72 weight quads (9 taps x 4 channels x 32 B) for every pixel -- 73 KB per wavefront from
+// L1 / L2, 7.5 GB per launch for 210 MB of output; here they are read once per four pixels and the 72 input values of the
+// 3 x 6 patch are requested up front.  w % 4 == 0.
+template <typename T, bool OUT_F32>
+__global__ __launch_bounds__(256) void k_conv_in4(const float* __restrict__ x, int n, int h, int w,
+                                                const float* __restrict__ wgt, const float* __restrict__ bias, int cout,
+                                                int wrap, void* __restrict__ y) {
+    constexpr int CIN = 4, PX = 4;
+    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    const int OCT = cout / 8, wq = w / PX;
+    const long total = static_cast<long>(n) * h * wq * OCT;
+    if (i >= total) return;
+    const int oct = i % OCT;
+    const long pg = i / OCT;
+    const int x0 = (pg % wq) * PX, yy = (pg / wq) % h, b = pg / (static_cast<long>(wq) * h);
+    const long plane = static_cast<long>(h) * w;
+    const float* xb = x + static_cast<long>(b) * CIN * plane;
+    float v[3][PX + 2][CIN];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int j = 0; j < PX + 2; ++j) {
+            const int yi = yy + ky - 1;
+            int xi = x0 + j - 1;
+            bool ok = yi >= 0 && yi < h;
+            if (wrap) xi = xi < 0 ? xi + w : (xi >= w ? xi - w : xi);
+            else ok = ok && xi >= 0 && xi < w;
+            const long off = static_cast<long>(ok ? yi : yy) * w + (ok ? xi : x0);
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float t = xb[c * plane + off];
+                v[ky][j][c] = ok ? t : 0.f;
+            }
+        }
+    float acc[PX][8];
+#pragma unroll
+    for (int q = 0; q < PX; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[q][j] = bias ? bias[oct * 8 + j] : 0.f;
+    const float* wb = wgt + oct * 8;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float4* wp = reinterpret_cast<const float4*>(wb + static_cast<long>((ky * 3 + kx) * CIN + c) * cout);
+                const float4 w0 = wp[0], w1 = wp[1];
+#pragma unroll
+                for (int q = 0; q < PX; ++q) {
+                    const float t = v[ky][q + kx][c];
+                    acc[q][0] += t * w0.x; acc[q][1] += t * w0.y; acc[q][2] += t * w0.z; acc[q][3] += t * w0.w;
+                    acc[q][4] += t * w1.x; acc[q][5] += t * w1.y; acc[q][6] += t * w1.z; acc[q][7] += t * w1.w;
+                }
+            }
+    const long pix0 = (static_cast<long>(b) * h + yy) * w + x0;
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+        if (OUT_F32) store8_f32(static_cast<float*>(y) + (pix0 + q) * cout + oct * 8, acc[q]);
+        else *reinterpret_cast<u16x8*>(static_cast<unsigned short*>(y) + (pix0 + q) * cout + oct * 8) = pack8<T>(acc[q]);
+    }
+}
+
 // conv_out: x NHWC 16-bit [n][h][w][cin] -> y fp32 NCHW [n][cout<=8][h][w]; weights fp32
 // [cout][3][3][cin].  LPP lanes per output pixel (the smallest power of two >= cin / 8, lanes over the channel octets of
 // each tap), 64 / LPP pixels per wavefront: at the VAE's 128 channels a whole wavefront per pixel left 48 of 64 lanes idle
@@ -1148,6 +1212,18 @@ extern "C" pf_status pf_conv_in(const float* x, int n, int cin, int h, int w, co
     PF_REQUIRE(x && wgt && y && n > 0 && cin > 0 && h > 0 && w > 0, "pf_conv_in: bad arguments");
     PF_REQUIRE(cout % 8 == 0 && aligned16(wgt) && aligned16(y), "pf_conv_in: cout %% 8 and 16-byte alignment required");
     const long total = static_cast<long>(n) * h * w * (cout / 8);
+    if (cin == 4 && w % 4 == 0) {                                 // the UNets' latent input: four pixels per thread
+        const long total4 = total / 4;
+        if (out_dtype == PF_F32)
+            hipLaunchKernelGGL((k_conv_in4<Bf16, true>), dim3(cdiv(total4, 256)), dim3(256), 0, as_stream(stream), x, n, h, w,
+                               wgt, bias, cout, wrap, y);
+        else
+            PF_DISPATCH_16(out_dtype, "pf_conv_in",
+                hipLaunchKernelGGL((k_conv_in4<T, false>), dim3(cdiv(total4, 256)), dim3(256), 0, as_stream(stream), x, n, h, w,
+                                   wgt, bias, cout, wrap, y));
+        PF_CHECK_LAUNCH("pf_conv_in");
+        return PF_OK;
+    }
     if (out_dtype == PF_F32)
         hipLaunchKernelGGL((k_conv_in<Bf16, true>), dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), x, n, cin, h, w,
                            wgt, bias, cout, wrap, y);
@@ -1166,7 +1242,11 @@ extern "C" pf_status pf_conv_out(const void* x, int dtype, int n, int cin, int h
     PF_REQUIRE(aligned16(x) && aligned16(wgt), "pf_conv_out: 16-byte alignment required");
     const long npix = static_cast<long>(n) * h * w;
     const int oct = cin / 8;
-    const int lpp = oct <= 8 ? 8 : oct <= 16 ? 16 : oct <= 32 ? 32 : 64;     // lanes per output pixel
+    // lanes per output pixel: 8 (every lane walks cin / 64 octets of each tap; the 8 pixels of a wavefront read the SAME weight
+    // addresses in one instruction, and no lane idles: at the UNets' 320 channels the power-of-two rule gave 64 lanes, 40 of them
+    // busy, one pixel per wavefront, 0.5 ms per denoiser pass).  PF_CONV_OUT_LPP: A/B.
+    static const int lpp_env = getenv("PF_CONV_OUT_LPP") ? atoi(getenv("PF_CONV_OUT_LPP")) : 0;
+    const int lpp = lpp_env ? lpp_env : (oct <= 16 ? 8 : oct <= 64 ? 8 : 16);     // lanes per output pixel
 #define PF_CONV_OUT(L) hipLaunchKernelGGL((k_conv_out<TI, L>), dim3(cdiv(npix, 4 * (64 / L))), dim3(256), 0, as_stream(stream), \
                                           static_cast<const In8<TI>::elem*>(x), n, cin, h, w, wgt, bias, cout, wrap, y)
     PF_DISPATCH_IN(dtype, "pf_conv_out",
