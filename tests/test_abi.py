@@ -40,7 +40,8 @@ def test_struct_layouts_match_header(tmp_path):
     """The ctypes mirrors of pf_conv_desc / pf_attn_desc are pinned to the C header: a probe compiled by gcc
     against include/panfusion_hip.h prints sizeof and offsetof of every field; they must equal ctypes'."""
     import subprocess
-    structs = {"pf_conv_desc": _lib.ConvDesc, "pf_attn_desc": _lib.AttnDesc, "pf_attn_bwd_desc": _lib.AttnBwdDesc}
+    structs = {"pf_conv_desc": _lib.ConvDesc, "pf_attn_desc": _lib.AttnDesc, "pf_attn_bwd_desc": _lib.AttnBwdDesc,
+               "pf_linear_ws_desc": _lib.LinearWsDesc}
     lines = []
     for cname, cls in structs.items():
         lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -84,6 +85,27 @@ def _conv_desc(**kw):
     for k, v in kw.items():
         setattr(d, k, v)
     return d
+
+
+def test_linear_ws_rejects_bad_arguments_before_any_launch():
+    """pf_linear_ws validates shape, alignment and mode on the host (no GPU needed: every case fails before the launch)."""
+    lib = _lib.lib()
+    assert lib.pf_linear_ws_supported(163840, 960, 320, 3) == 1 and lib.pf_linear_ws_supported(163840, 640, 320, 3) == 0
+    assert lib.pf_linear_ws_supported(163840, 2560, 320, 2) == 1 and lib.pf_linear_ws_supported(163840, 320, 640, 0) == 0
+    assert lib.pf_linear_ws_supported(32, 320, 320, 0) == 0 and lib.pf_linear_ws_supported(4096, 300, 320, 0) == 0
+
+    def desc(**kw):
+        d = _lib.LinearWsDesc()
+        d.a, d.w, d.out, d.a_ld, d.out_ld = 0x10000, 0x20000, 0x30000, 320, 320
+        d.M, d.N, d.K, d.dtype, d.mode = 4096, 320, 320, _lib.PF_F16, 0
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    for bad in (dict(K=640), dict(N=300), dict(a=0), dict(a=0x10002), dict(a_ld=324), dict(out_ld=300), dict(mode=7),
+                dict(residual=0x40000), dict(mode=1, residual=0x40004, res_ld=320), dict(mode=3, N=960, out_ld=640),
+                dict(mode=3, N=960, out_ld=640, out_vt=0x50000, rows_per_batch=100, vt_ld=4096), dict(dtype=_lib.PF_F32)):
+        assert lib.pf_linear_ws(C.byref(desc(**bad)), None) != 0, bad
+        assert lib.pf_last_error_string()
 
 
 def test_conv_gemm_rejects_bad_arguments_before_any_launch():
