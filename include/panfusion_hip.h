@@ -313,6 +313,9 @@ pf_status pf_conv_gemm(const pf_conv_desc* desc, void* stream);
  *   PF_LWS_QKV:   N == 960 = (q | k | v): out 16-bit [M][out_ld] receives the 640 columns (q | k); V leaves TRANSPOSED as
  *                 out_vt[b][c][key] (b = m / rows_per_batch, key = m % rows_per_batch, row stride vt_ld, batch stride vt_bs):
  *                 the layout pf_attention reads.  rows_per_batch a multiple of 64.
+ *   PF_LWS_F32_LN: N == 320: PF_LWS_F32, and the LayerNorm of the result rides along (the norm2 / norm3 that follow the two
+ *                 attention output projections of a BasicTransformerBlock): ln_out 16-bit [M][ln_ld] =
+ *                 LayerNorm(out; ln_eps) * ln_gamma + ln_beta -- no separate pass over the stream tensor.
  * a 16-bit [M][a_ld]; w 16-bit [N][320]; bias fp32 [N] or NULL.  pf_linear_ws_supported: 1 if (M, N, K, mode) is served. */
 typedef struct {
     const void* a; int a_ld;
@@ -321,10 +324,11 @@ typedef struct {
     const float* residual; int res_ld;
     void* out; int out_ld;
     void* out_vt; int vt_ld; int rows_per_batch; long vt_bs;
+    const float* ln_gamma; const float* ln_beta; float ln_eps; void* ln_out; int ln_ld;
     int M, N, K;
     int dtype; int mode;
 } pf_linear_ws_desc;
-enum { PF_LWS_16 = 0, PF_LWS_F32 = 1, PF_LWS_GEGLU = 2, PF_LWS_QKV = 3 };
+enum { PF_LWS_16 = 0, PF_LWS_F32 = 1, PF_LWS_GEGLU = 2, PF_LWS_QKV = 3, PF_LWS_F32_LN = 4 };
 int pf_linear_ws_supported(long M, int N, int K, int mode);
 pf_status pf_linear_ws(const pf_linear_ws_desc* desc, void* stream);
 

@@ -55,6 +55,7 @@ class LinearWsDesc(C.Structure):
         ("a", c_void_p), ("a_ld", c_int), ("w", c_void_p), ("bias", c_void_p),
         ("residual", c_void_p), ("res_ld", c_int), ("out", c_void_p), ("out_ld", c_int),
         ("out_vt", c_void_p), ("vt_ld", c_int), ("rows_per_batch", c_int), ("vt_bs", c_long),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("ln_out", c_void_p), ("ln_ld", c_int),
         ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("mode", c_int),
     ]
 

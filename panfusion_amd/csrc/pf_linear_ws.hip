@@ -31,6 +31,7 @@ struct LwsParams {
     const float* residual; int res_ld;
     void* out; int out_ld;
     unsigned short* out_vt; int vt_ld; int rows_per_batch; long vt_bs;
+    const float* ln_gamma; const float* ln_beta; float ln_eps; unsigned short* ln_out; int ln_ld;   // mode LWS_F32_LN
     int M, N;
     int nblocks, splits_per_xcd, ntiles;
     unsigned a_bytes;
@@ -64,18 +65,19 @@ __device__ __forceinline__ float lws_geglu(float v, float g) {
 constexpr int LWS_K = 320, LWS_KS = LWS_K / 32, LWS_KB = LWS_K / 64, LWS_BM = 64, LWS_STAGES = 3;
 constexpr int LWS_STAGE_ELEMS = LWS_BM * LWS_K;                   // 16-bit elements per ring slot (40 KB)
 constexpr int LWS_STG_BYTES = 4096;                               // per-wave staging region (<= 48 channel rows x 80 B)
-enum { LWS_16 = 0, LWS_F32 = 1, LWS_GEGLU = 2, LWS_QKV = 3 };
+enum { LWS_16 = 0, LWS_F32 = 1, LWS_GEGLU = 2, LWS_QKV = 3, LWS_F32_LN = 4 };
+constexpr int LWS_LN_BYTES = 2 * 8 * 32 * 8;                       // LayerNorm exchange: [half parity][wave][token] (mean, M2) fp32
 
 // The body of one wavefront: NB output-channel sub-blocks of 16 (cb = first channel inside the 320-block).
 // Vector-memory operations a wavefront issues in the epilogues of ONE tile (stores only: a lower bound is what the counted wait
 // needs -- the compiler may add its own waits for the residual loads, it never removes an operation).
 template <int MODE, int NB> constexpr int lws_epilogue_ops() {
-    return MODE == LWS_F32 ? 4 * NB : MODE == LWS_GEGLU ? 2 * ((32 * NB + 63) / 64) : 2 * NB;
+    return MODE == LWS_F32 ? 4 * NB : MODE == LWS_F32_LN ? 6 * NB : MODE == LWS_GEGLU ? 2 * ((32 * NB + 63) / 64) : 2 * NB;
 }
 constexpr int lws_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }   // gfx9 s_waitcnt immediate: vmcnt(n) only
 
 template <typename T, int MODE, int NB, bool COUNTED>
-__device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* smem, unsigned char* stg, int nblk, int cb,
+__device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* smem, unsigned char* stg, float2* lnx, int nblk, int cb,
                                          int t_lo, int t_hi, int wave, int lane) {
     typedef typename LwsMfma<T>::frag frag;
     const int frow = lane & 15, fchunk = lane >> 4, cq = 4 * fchunk;
@@ -129,7 +131,87 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
             for (int j = 0; j < NB; ++j) asm volatile("" :: "v"(acc[pb][j]));
         return;
 #endif
-        if constexpr (MODE == LWS_F32) {
+        if constexpr (MODE == LWS_F32_LN) {
+            // out = a w^T + bias + residual (fp32 stream) AND ln_out = LayerNorm(out) gamma + beta in 16 bit: the row is complete inside
+            // the workgroup (N == 320), so the LayerNorm that follows every attention output projection of a transformer block costs
+            // no pass of its own (it read the 210 MB stream tensor back and wrote 105 MB).  Statistics: every wavefront forms the mean
+            // and the centred sum of squares of ITS channels of a token (two passes over registers, a 4-lane exchange each), the 8
+            // partial (mean, M2) pairs meet in LDS and are combined by Chan's formula -- no E[x^2] - mean^2 cancellation.
+            const float* rp = p.residual;
+            float* op = static_cast<float*>(p.out);
+            float mean[2], rstd[2];
+            float2* slot_x = lnx + ((m_half >> 5) & 1) * 8 * 32;      // [wave][token of the half]
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int m = m_half + pb * 16 + frow;
+                const long mc = m < p.M ? m : p.M - 1;
+                float4 r[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    r[j] = rp ? *reinterpret_cast<const float4*>(rp + mc * p.res_ld + n_base + j * 16 + cq) : float4{0.f, 0.f, 0.f, 0.f};
+                float s1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[pb][j][0] += r[j].x; acc[pb][j][1] += r[j].y; acc[pb][j][2] += r[j].z; acc[pb][j][3] += r[j].w;
+                    if (m < p.M) *reinterpret_cast<float4*>(op + static_cast<long>(m) * p.out_ld + n_base + j * 16 + cq) =
+                        float4{acc[pb][j][0], acc[pb][j][1], acc[pb][j][2], acc[pb][j][3]};
+                    s1 += (acc[pb][j][0] + acc[pb][j][1]) + (acc[pb][j][2] + acc[pb][j][3]);
+                }
+                s1 += __shfl_xor(s1, 16);
+                s1 += __shfl_xor(s1, 32);
+                const float mw = s1 * (1.0f / (NB * 16));
+                float m2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = acc[pb][j][e] - mw; m2 += d * d; }
+                m2 += __shfl_xor(m2, 16);
+                m2 += __shfl_xor(m2, 32);
+                if (fchunk == 0) slot_x[wave * 32 + pb * 16 + frow] = float2{mw, m2};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // (every wave runs the same halves: the barrier count is uniform)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                float2 px[8];
+#pragma unroll
+                for (int wv = 0; wv < 8; ++wv) px[wv] = slot_x[wv * 32 + pb * 16 + frow];
+                float mu = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 8; ++wv) mu += px[wv].x * (wv < 4 ? 48.0f : 32.0f);
+                mu *= (1.0f / 320.0f);
+                float M2 = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 8; ++wv) { const float d = px[wv].x - mu; M2 += px[wv].y + (wv < 4 ? 48.0f : 32.0f) * d * d; }
+                mean[pb] = mu;
+                rstd[pb] = __builtin_amdgcn_rsqf(M2 * (1.0f / 320.0f) + p.ln_eps);
+            }
+            constexpr int RS = NB * 32 + 16;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float4 g = *reinterpret_cast<const float4*>(p.ln_gamma + cb + j * 16 + cq);
+                const float4 bt = *reinterpret_cast<const float4*>(p.ln_beta + cb + j * 16 + cq);
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    u16x4 w4;
+                    w4[0] = from_f32<T>((acc[pb][j][0] - mean[pb]) * rstd[pb] * g.x + bt.x);
+                    w4[1] = from_f32<T>((acc[pb][j][1] - mean[pb]) * rstd[pb] * g.y + bt.y);
+                    w4[2] = from_f32<T>((acc[pb][j][2] - mean[pb]) * rstd[pb] * g.z + bt.z);
+                    w4[3] = from_f32<T>((acc[pb][j][3] - mean[pb]) * rstd[pb] * g.w + bt.w);
+                    *reinterpret_cast<u16x4*>(stg + (pb * 16 + frow) * RS + (j * 16 + cq) * 2) = w4;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int q = i * 64 + lane, row = q / (2 * NB), cc = q - row * 2 * NB;
+                const u16x8 x = *reinterpret_cast<const u16x8*>(stg + row * RS + cc * 16);
+                const int m = m_half + row;
+                if (m < p.M) *reinterpret_cast<u16x8*>(p.ln_out + static_cast<long>(m) * p.ln_ld + cb + cc * 8) = x;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if constexpr (MODE == LWS_F32) {
             const float* rp = p.residual;
             float* op = static_cast<float*>(p.out);
 #pragma unroll
@@ -300,14 +382,15 @@ __global__ __launch_bounds__(512, 1) void k_linear_ws(const LwsParams p) {
     const int s = xcd * p.splits_per_xcd + sl, S = 8 * p.splits_per_xcd;
     const int t_lo = static_cast<int>(static_cast<long>(p.ntiles) * s / S), t_hi = static_cast<int>(static_cast<long>(p.ntiles) * (s + 1) / S);
     unsigned char* stg = reinterpret_cast<unsigned char*>(smem + LWS_STAGES * LWS_STAGE_ELEMS) + wave * LWS_STG_BYTES;
+    float2* lnx = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(smem + LWS_STAGES * LWS_STAGE_ELEMS) + 8 * LWS_STG_BYTES);
     // waves w and w + 4 share a SIMD: 48 + 32 channels each
-    if (wave < 4) lws_wave<T, MODE, 3, COUNTED>(p, smem, stg, nblk, wave * 48, t_lo, t_hi, wave, lane);
-    else lws_wave<T, MODE, 2, COUNTED>(p, smem, stg, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
+    if (wave < 4) lws_wave<T, MODE, 3, COUNTED>(p, smem, stg, lnx, nblk, wave * 48, t_lo, t_hi, wave, lane);
+    else lws_wave<T, MODE, 2, COUNTED>(p, smem, stg, lnx, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
 }
 
 template <typename T, int MODE, bool COUNTED>
 static pf_status lws_launch_c(const LwsParams& p, hipStream_t st) {
-    const size_t smem = static_cast<size_t>(LWS_STAGES) * LWS_STAGE_ELEMS * 2 + 8 * LWS_STG_BYTES;
+    const size_t smem = static_cast<size_t>(LWS_STAGES) * LWS_STAGE_ELEMS * 2 + 8 * LWS_STG_BYTES + LWS_LN_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ws<T, MODE, COUNTED>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
@@ -330,6 +413,7 @@ extern "C" int pf_linear_ws_supported(long M, int N, int K, int mode) {
     const int nb = N / 320;
     if (nb > 32) return 0;
     if (mode == PF_LWS_QKV && nb != 3) return 0;
+    if (mode == PF_LWS_F32_LN && nb != 1) return 0;
     return 1;
 }
 
@@ -339,16 +423,21 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     PF_REQUIRE(d->a && d->w && d->out, "pf_linear_ws: null operand");
     PF_REQUIRE(pf_linear_ws_supported(d->M, d->N, d->K, d->mode), "pf_linear_ws: needs K == 320, N a multiple of 320 (<= 32 blocks; q|k|v: N == 960), M >= 64 (got M %ld N %d K %d mode %d)",
                static_cast<long>(d->M), d->N, d->K, d->mode);
-    PF_REQUIRE(d->mode >= PF_LWS_16 && d->mode <= PF_LWS_QKV, "pf_linear_ws: unknown mode %d", d->mode);
+    PF_REQUIRE(d->mode >= PF_LWS_16 && d->mode <= PF_LWS_F32_LN, "pf_linear_ws: unknown mode %d", d->mode);
     PF_REQUIRE(d->a_ld >= d->K && d->a_ld % 8 == 0 && aligned16(d->a) && aligned16(d->w) && aligned16(d->out), "pf_linear_ws: operands must be 16-byte aligned, a_ld a multiple of 8");
     PF_REQUIRE(static_cast<long>(d->M) * d->a_ld * 2 < (2L << 30), "pf_linear_ws: activation matrix must be smaller than 2 GiB");
     PF_REQUIRE(!d->bias || aligned16(d->bias), "pf_linear_ws: bias must be 16-byte aligned");
     const int n_store = d->mode == PF_LWS_GEGLU ? d->N / 2 : d->mode == PF_LWS_QKV ? 640 : d->N;
-    PF_REQUIRE(d->out_ld >= n_store && d->out_ld % (d->mode == PF_LWS_F32 ? 4 : 8) == 0, "pf_linear_ws: out_ld %d does not hold %d columns in 16-byte chunks", d->out_ld, n_store);
-    if (d->mode == PF_LWS_F32)
+    const bool f32out = d->mode == PF_LWS_F32 || d->mode == PF_LWS_F32_LN;
+    PF_REQUIRE(d->out_ld >= n_store && d->out_ld % (f32out ? 4 : 8) == 0, "pf_linear_ws: out_ld %d does not hold %d columns in 16-byte chunks", d->out_ld, n_store);
+    if (f32out)
         PF_REQUIRE(!d->residual || (aligned16(d->residual) && d->res_ld >= d->N && d->res_ld % 4 == 0), "pf_linear_ws: residual must be 16-byte aligned fp32 rows");
     else
         PF_REQUIRE(!d->residual, "pf_linear_ws: a residual needs mode PF_LWS_F32");
+    if (d->mode == PF_LWS_F32_LN)
+        PF_REQUIRE(d->N == 320 && d->ln_gamma && d->ln_beta && d->ln_out && aligned16(d->ln_gamma) && aligned16(d->ln_beta) && aligned16(d->ln_out) &&
+                   d->ln_ld >= 320 && d->ln_ld % 8 == 0 && d->ln_eps > 0.f,
+                   "pf_linear_ws: the LayerNorm mode needs N == 320 (a whole row per workgroup), gamma / beta / ln_out 16-byte aligned");
     if (d->mode == PF_LWS_QKV)
         PF_REQUIRE(d->out_vt && aligned16(d->out_vt) && d->rows_per_batch > 0 && d->rows_per_batch % 64 == 0 && d->M % d->rows_per_batch == 0 &&
                    d->vt_ld >= d->rows_per_batch && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0,
@@ -359,6 +448,7 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     p.bias = d->bias; p.residual = d->residual; p.res_ld = d->res_ld;
     p.out = d->out; p.out_ld = d->out_ld;
     p.out_vt = static_cast<unsigned short*>(d->out_vt); p.vt_ld = d->vt_ld; p.rows_per_batch = d->rows_per_batch; p.vt_bs = d->vt_bs;
+    p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps; p.ln_out = static_cast<unsigned short*>(d->ln_out); p.ln_ld = d->ln_ld;
     p.M = d->M; p.N = d->N;
     p.nblocks = d->N / 320;
     p.splits_per_xcd = 32 / p.nblocks;
@@ -370,6 +460,7 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
         case PF_LWS_16: PF_LWS_MODE(LWS_16);
         case PF_LWS_F32: PF_LWS_MODE(LWS_F32);
         case PF_LWS_GEGLU: PF_LWS_MODE(LWS_GEGLU);
+        case PF_LWS_F32_LN: PF_LWS_MODE(LWS_F32_LN);
         default: PF_LWS_MODE(LWS_QKV);
     }
 #undef PF_LWS_MODE

@@ -474,8 +474,10 @@ def all_transformers(u):
             yield t
 
 
-def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv=None):
-    """q_src [n*nq, C] already layer-normed; kv_tokens [n*nk, Ckv] (or kv = precomputed (k, vt))."""
+def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv=None, next_ln=None):
+    """q_src [n*nq, C] already layer-normed; kv_tokens [n*nk, Ckv] (or kv = precomputed (k, vt)).
+    next_ln: the LayerNorm that follows the output projection -> (tokens, its output or None): where the output projection runs on
+    the weight-stationary kernel the norm rides in its epilogue (ops.linear_ln)."""
     Cq = a.dim
     vt = None
     if self_attn:
@@ -495,6 +497,8 @@ def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv
     o = ops.attention(q, k, vt, n, a.heads, head_dim, nq, nk,
                       q_ld=ld, k_ld=(ld if self_attn else Cq), vt_ld=vt.shape[-1],
                       q_bs=nq * ld, k_bs=nk * (ld if self_attn else Cq), vt_bs=vt.shape[1] * vt.shape[2])
+    if next_ln is not None:
+        return ops.linear_ln(o.view(n * nq, Cq), a.wo, a.bo, residual, next_ln.g, next_ln.b, next_ln.eps)
     return ops.linear(o.view(n * nq, Cq), a.wo, bias=a.bo, residual=residual)
 
 
@@ -512,11 +516,13 @@ def run_transformer(t, x, text, kv=None):
         tok = ops.linear(y.view(n * hw, Cc), t.w_in, bias=t.b_in)
     dh = t.attn1.dim // t.attn1.heads
     ln = ops.layernorm(tok, t.ln1.g, t.ln1.b, t.ln1.eps, out_dtype=t.dtype)
-    tok = _attend(t.attn1, ln, ln, n, hw, hw, dh, self_attn=True, residual=tok)
-    ln = ops.layernorm(tok, t.ln2.g, t.ln2.b, t.ln2.eps, out_dtype=t.dtype)
+    tok, ln = _attend(t.attn1, ln, ln, n, hw, hw, dh, self_attn=True, residual=tok, next_ln=t.ln2)
+    if ln is None:
+        ln = ops.layernorm(tok, t.ln2.g, t.ln2.b, t.ln2.eps, out_dtype=t.dtype)
     L = text.shape[1]
-    tok = _attend(t.attn2, ln, text.reshape(n * L, -1), n, hw, L, dh, self_attn=False, residual=tok, kv=kv)
-    ln = ops.layernorm(tok, t.ln3.g, t.ln3.b, t.ln3.eps, out_dtype=t.dtype)
+    tok, ln = _attend(t.attn2, ln, text.reshape(n * L, -1), n, hw, L, dh, self_attn=False, residual=tok, kv=kv, next_ln=t.ln3)
+    if ln is None:
+        ln = ops.layernorm(tok, t.ln3.g, t.ln3.b, t.ln3.eps, out_dtype=t.dtype)
     g = ops.linear(ln, t.w_ff1, bias=t.b_ff1, geglu=True)
     if t.w_out3 is not None and os.environ.get("PF_FF2_PAIR", "1") != "0":
         # the token stream's last value feeds proj_out only: FF2's epilogue emits it directly as the [hi | lo]
@@ -671,8 +677,9 @@ class EPATables:
 
 def _epa_tail(e, attn_out, x, Cc):
     """to_out + residual, then LN2 -> GEGLU FF -> + residual (transformer.py:159-161)."""
-    y = ops.linear(attn_out.view(-1, Cc), e.wo, bias=e.bo, residual=x)
-    ln2 = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps, out_dtype=e.cdtype)
+    y, ln2 = ops.linear_ln(attn_out.view(-1, Cc), e.wo, e.bo, x, e.ln2.g, e.ln2.b, e.ln2.eps)
+    if ln2 is None:
+        ln2 = ops.layernorm(y, e.ln2.g, e.ln2.b, e.ln2.eps, out_dtype=e.cdtype)
     g = ops.linear(ln2, e.w_ff1, bias=e.b_ff1, geglu=True)
     return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y, gn_stats=True)
 

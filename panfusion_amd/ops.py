@@ -493,7 +493,7 @@ def gemm_workspace_bytes(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, k
 
 
 # ---- weight-stationary linear (pf_linear_ws): the C = 320 token layers
-LWS_16, LWS_F32, LWS_GEGLU, LWS_QKV = 0, 1, 2, 3
+LWS_16, LWS_F32, LWS_GEGLU, LWS_QKV, LWS_F32_LN = 0, 1, 2, 3, 4
 LINEAR_WS = os.environ.get("PF_LINEAR_WS", "1") != "0"          # A/B: 0 = every linear on the tile kernel (pf_conv_gemm)
 LINEAR_WS_MIN_ROWS = int(os.environ.get("PF_LINEAR_WS_MIN_ROWS", "8192"))   # fewer 64-token tiles than workgroups: the tile kernel
 
@@ -507,12 +507,17 @@ def linear_ws_ok(rows, N, K, mode, x=None):
     return bool(_lib.lib().pf_linear_ws_supported(rows, N, K, mode))
 
 
-def linear_ws(x, w, mode, bias=None, residual=None, out=None, out_vt=None, rows_per_batch=0):
+def linear_ws(x, w, mode, bias=None, residual=None, out=None, out_vt=None, rows_per_batch=0, ln=None):
     """pf_linear_ws: x [rows, 320] 16-bit, w [N, 320].  mode LWS_16 -> [rows, N] 16-bit; LWS_F32 -> fp32 [rows, N] (+ fp32 residual);
-    LWS_GEGLU -> [rows, N/2]; LWS_QKV (N = 960) -> ((q | k) [rows, 640], V^T [rows / rows_per_batch, 320, rows_per_batch])."""
+    LWS_GEGLU -> [rows, N/2]; LWS_QKV (N = 960) -> ((q | k) [rows, 640], V^T [rows / rows_per_batch, 320, rows_per_batch]);
+    LWS_F32_LN (N = 320, ln = (gamma, beta, eps)) -> (fp32 [rows, 320], LayerNorm of it in 16 bit [rows, 320])."""
     rows, K = x.shape
     N = w.shape[0]
     d = LinearWsDesc()
+    ln_out = None
+    if mode == LWS_F32_LN:
+        ln_out = torch.empty(rows, N, device=x.device, dtype=x.dtype)
+        d.ln_gamma, d.ln_beta, d.ln_eps, d.ln_out, d.ln_ld = _p(ln[0]), _p(ln[1]), float(ln[2]), _p(ln_out), N
     if mode == LWS_QKV:
         nb = rows // rows_per_batch
         if out is None:
@@ -522,7 +527,7 @@ def linear_ws(x, w, mode, bias=None, residual=None, out=None, out_vt=None, rows_
         d.out_vt, d.vt_ld, d.rows_per_batch, d.vt_bs = _p(out_vt), out_vt.stride(1), rows_per_batch, out_vt.stride(0)
     elif out is None:
         out = torch.empty(rows, N // 2 if mode == LWS_GEGLU else N, device=x.device,
-                          dtype=torch.float32 if mode == LWS_F32 else x.dtype)
+                          dtype=torch.float32 if mode in (LWS_F32, LWS_F32_LN) else x.dtype)
     d.a, d.a_ld, d.w, d.bias = _p(x), _ld(x), _p(w), _p(bias)
     d.residual, d.res_ld = _p(residual), (_ld(residual) if residual is not None else 0)
     d.out, d.out_ld = _p(out), _ld(out)
@@ -532,7 +537,18 @@ def linear_ws(x, w, mode, bias=None, residual=None, out=None, out_vt=None, rows_
     else:
         _traced("k_linear_ws", 2.0 * rows * N * K, lambda: check(_lib.lib().pf_linear_ws(C.byref(d), _stream()), "pf_linear_ws"),
                 "M%d N%d K%d mode%d" % (rows, N, K, mode))
-    return (out, out_vt) if mode == LWS_QKV else out
+    return (out, out_vt) if mode == LWS_QKV else (out, ln_out) if mode == LWS_F32_LN else out
+
+
+def linear_ln(x, w, bias, residual, gamma, beta, eps):
+    """out = x w^T + bias + residual (fp32 stream) together with LayerNorm(out) in 16 bit, in ONE launch where pf_linear_ws serves
+    the shape (C = 320: the row is complete inside a workgroup) -> (out, ln_out); (out, None) otherwise -- the caller then runs
+    ops.layernorm itself."""
+    rows, K = x.shape
+    if (w.shape[0] == 320 and x.dim() == 2 and w.is_contiguous() and residual is not None and residual.dtype == torch.float32
+            and linear_ws_ok(rows, 320, K, LWS_F32_LN, x) and os.environ.get("PF_LINEAR_LN", "1") != "0"):
+        return linear_ws(x, w, LWS_F32_LN, bias=bias, residual=residual, ln=(gamma, beta, eps))
+    return linear(x, w, bias=bias, residual=residual), None
 
 
 def linear_qkv(x, wqkv, n_batch):

@@ -330,6 +330,14 @@ def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False
                      geglu=geglu, split_out=split_out, gn_stats=gn_stats)
 
 
+def linear_ln(x, w, bias, residual, gamma, beta, eps):
+    """Test double of ops.linear_ln: the fused form whenever the projection is square (any width: host logic runs on CPU)."""
+    out = linear(x, w, bias=bias, residual=residual)
+    if w.shape[0] != w.shape[1] or residual is None:
+        return out, None
+    return out, torch.nn.functional.layer_norm(out.float(), (out.shape[-1],), gamma, beta, eps).to(x.dtype)
+
+
 def linear_qkv(x, wqkv, n_batch):
     """Test double of ops.linear_qkv (one launch for q | k | v with V transposed): served whenever the batches are whole
     64-token tiles, at any width -- the host logic that consumes the fused result runs on CPU at the tiny widths too."""

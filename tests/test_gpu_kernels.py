@@ -374,6 +374,28 @@ def test_linear_ws_modes_vs_fp32(dtype, M):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [64 * 37 + 40, 64 * 200])
+def test_linear_ws_with_layernorm_epilogue(dtype, M):
+    """PF_LWS_F32_LN: output projection + fp32 residual, and the LayerNorm of the result from the same launch (a row of 320
+    channels is spread over 8 wavefronts: per-wave (mean, M2) partials combined through LDS) -- against fp32 torch, with a
+    non-trivial affine and a row offset that makes E[x^2] - mean^2 lose digits (mean 30, spread 1)."""
+    o = ops()
+    K = N = 320
+    x, xf = q16(rnd(M, K, seed=90), dtype)
+    w, wf = q16(rnd(N, K, seed=91) / K ** 0.5, dtype)
+    b, r = rnd(N, seed=92), rnd(M, N, seed=93) + 30.0
+    g, bt = 1.0 + 0.3 * rnd(N, seed=94), 0.2 * rnd(N, seed=95)
+    want = xf @ wf.T + b + r
+    out, ln = o.linear_ws(x, w, o.LWS_F32_LN, bias=b.to(DEV), residual=r.to(DEV), ln=(g.to(DEV), bt.to(DEV), 1e-5))
+    assert out.dtype == torch.float32 and ln.dtype == dtype and ln.shape == (M, N)
+    check("linear_ws fp32 + residual (LN mode)", out, want, 2e-5)
+    check("linear_ws LayerNorm epilogue", ln, F.layer_norm(want, (N,), g, bt, 1e-5), TOL[dtype])
+    if M >= o.LINEAR_WS_MIN_ROWS:
+        out2, ln2 = o.linear_ln(x, w, b.to(DEV), r.to(DEV), g.to(DEV), bt.to(DEV), 1e-5)      # the routed entry point of engine._attend
+        assert ln2 is not None and torch.equal(out2, out) and torch.equal(ln2, ln)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n_batch,nk", [(3, 1024), (2, 64), (5, 4096)])
 def test_linear_ws_qkv_with_transposed_values(dtype, n_batch, nk):
     """q | k | v in one launch: (q | k) rows + V^T [batch][C][keys] in the layout pf_attention reads; then through the
