@@ -502,6 +502,8 @@ def linear_ws_ok(rows, N, K, mode, x=None):
     """Does pf_linear_ws serve this problem (K == 320, N a multiple of 320, enough token tiles to stream)?"""
     if not LINEAR_WS or rows < LINEAR_WS_MIN_ROWS or K != 320 or N % 320:
         return False
+    if N == 320 and rows < 4 * LINEAR_WS_MIN_ROWS:       # one channel block: 256 token ranges -- under 2 tiles each the tile kernel wins
+        return False                                      # (M = 16384: 0.88 - 0.94 x; q | k | v and FF1 win from 8192 rows, profiles/r4_lws_notes.txt)
     if x is not None and (x.dtype not in (torch.float16, torch.bfloat16) or x.stride(-1) != 1 or x.stride(-2) % 8):
         return False
     return bool(_lib.lib().pf_linear_ws_supported(rows, N, K, mode))
