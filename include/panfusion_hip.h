@@ -137,14 +137,15 @@ pf_status pf_groupnorm_from_partials(const float* part0, int c0, int rows0, cons
 /* y = act(x*scale + shift), act 0 = identity, 1 = SiLU (scale = shift = NULL: y = act(x)).  Same concat
  * convention.  dtype = type of the sources (16-bit or PF_F32).  Output:
  *   out_dtype 16-bit, out_split 0:  y [n_img][hw][C]
- *   out_dtype 16-bit, out_split 1:  y [n_img][hw][2C] = [hi | lo], hi = round16(v), lo = round16(v - hi):
- *                                   the A operand of a split-precision GEMM (3 MFMA passes reproduce the
- *                                   fp32 product to ~2^-22: A_hi W_hi + A_lo W_hi + A_hi W_lo)
+ *   out_dtype 16-bit, out_split 1:  y [n_img][hw][2C]: per block of 32 channels [hi(32) | lo(32)], hi = round16(v),
+ *                                   lo = round16(v - hi) (C %% 32 == 0): the A operand of a split-precision GEMM
+ *                                   (pf_conv_desc.split3: A_hi W_hi + A_lo W_hi + A_hi W_lo reproduce the fp32
+ *                                   product to ~2^-22)
  *   out_dtype PF_F32:               y [n_img][hw][C] fp32. */
 pf_status pf_scale_shift_act(const void* x0, int c0, const void* x1, int c1, int dtype,
                              int n_img, int hw, const float* scale, const float* shift, int act,
                              int out_dtype, int out_split, void* y, void* stream);
-/* fp32 sources, 16-bit y as above, PLUS the un-normalised input as the split pair raw_pair [n_img][hw][hi(C) | lo(C)]
+/* fp32 sources, 16-bit y as above, PLUS the un-normalised input as the split pair raw_pair [n_img][hw][2C] (same layout)
  * in the same pass (the A operand of a ResnetBlock2D's split-precision conv_shortcut next to norm1 + SiLU of the same
  * tensor: one read of the fp32 stream instead of two). */
 pf_status pf_scale_shift_act_pair(const void* x0, int c0, const void* x1, int c1, int n_img, int hw,
@@ -259,9 +260,9 @@ typedef struct {
     long a_bstride, w_bstride, out_bstride, res_bstride;
     int epilogue;        /* PF_EPILOGUE_NONE; PF_EPILOGUE_GEGLU: W rows interleaved (value_j, gate_j),
                           * out [M][n_out/2] = value * gelu(gate) (transformer.py:8-21, erf GELU);
-                          * PF_EPILOGUE_SPLIT: out is the 16-bit pair [M][hi(n_out) | lo(n_out)] of the fp32
-                          * result (hi = round16(v), lo = round16(v - hi)), out_ld >= 2 n_out: the A operand
-                          * of a following split-precision GEMM without a separate split pass            */
+                          * PF_EPILOGUE_SPLIT: out is the 16-bit pair [M][2 n_out] of the fp32 result, per block of 32
+                          * columns [hi(32) | lo(32)] (hi = round16(v), lo = round16(v - hi)), out_ld >= 2 n_out,
+                          * n_out %% 32 == 0: the A operand of a following split3 GEMM without a separate split pass */
     void* workspace;     /* split-K scratch (may be NULL: no split) of pf_conv_gemm_workspace_size   */
     size_t workspace_bytes;
     float* gn_partial;   /* optional by-product (NULL: none): GroupNorm moments of the OUTPUT for the next layer's
@@ -284,6 +285,10 @@ typedef struct {
                           * (same sums in split order as the second kernel: bit-identical).  n_tickets >= tiles x batch of the
                           * split launch (<= 1024 for every plan this library makes).                                  */
     int n_tickets;
+    int split3;          /* split-precision walk: a0 is a PAIR tensor -- per block of 32 channels [hi(32) | lo(32)], c0 = 2 x channels (what
+                          * pf_scale_shift_act(out_split) / PF_EPILOGUE_SPLIT write) -- and w holds per tap and block of 32 channels
+                          * [W_hi(32) | W_lo(32)]; every 64-element K block is multiplied as W_hi A_hi + W_hi A_lo + W_lo A_hi (2^-22
+                          * relative: an fp32-grade product from 16-bit MFMA operands).  a1 must be NULL.                       */
 } pf_conv_desc;
 
 enum { PF_EPILOGUE_NONE = 0, PF_EPILOGUE_GEGLU = 1, PF_EPILOGUE_SPLIT = 2 };

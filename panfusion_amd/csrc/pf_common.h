@@ -76,6 +76,10 @@ template <typename T> __device__ __forceinline__ u16x8 pack8(const float (&f)[8]
     return v;
 }
 
+// Element offset of channel c inside a split-precision pair row: per block of 32 channels [hi(32) | lo(32)] (lo = + 32).  A 64-element
+// K block of the GEMM kernels then holds hi and lo of the SAME 32 channels (pf_conv_desc.split3).
+__host__ __device__ __forceinline__ int pair_off(int c) { return ((c >> 5) << 6) | (c & 31); }
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // Element access by storage tag (fp32 / bf16 / fp16) for the kernels that take any of the three.

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_gn_finalize_cols(const float* __restric
 }
 
 // y = act(x * scale + shift) (scale == nullptr: identity), x = channel concat of two sources, 16-bit or fp32.
-// OUT 0: 16-bit T [pix][C];  OUT 1: split pair [pix][hi(C) | lo(C)] with hi = round16(v), lo = round16(v - hi)
+// OUT 0: 16-bit T [pix][C];  OUT 1: split pair [pix][per 32 channels: hi(32) | lo(32)] with hi = round16(v), lo = round16(v - hi)
 // (the A operand of a split-precision GEMM, engine.py);  OUT 2: fp32 [pix][C].
 template <typename TI, typename T, int OUT>
 __global__ __launch_bounds__(256) void k_scale_shift_act(const typename In8<TI>::elem* __restrict__ x0, int c0,
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const typename In8<TI>:
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   int act, void* __restrict__ yv, unsigned short* __restrict__ raw_pair) {
     typedef typename In8<TI>::elem elem;
-    // raw_pair (optional): the UN-normalised input as the split pair [pix][hi(C) | lo(C)] -- the A operand of the resnet's
+    // raw_pair (optional): the UN-normalised input as the split pair (same layout) -- the A operand of the resnet's
     // split-precision shortcut GEMM, written from the registers that already hold the fp32 input (its own pass re-read 629 MB
     // per 960-channel decoder resnet at 64 x 64)
     // grid (octet pairs of one image, image): 32-bit index arithmetic only, two octet loads in flight per thread
@@ -340,13 +340,13 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const typename In8<TI>:
     for (int u = 0; u < 2; ++u) {
         if (j0 + u >= per_img) break;
         if (raw_pair) {
-            unsigned short* y = raw_pair + pix[u] * (2 * C) + cc[u];
+            unsigned short* y = raw_pair + pix[u] * (2 * C) + pair_off(cc[u]);
             const u16x8 hi = pack8<T>(v[u]);
             float lo[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) lo[j] = v[u][j] - to_f32<T>(hi[j]);
             *reinterpret_cast<u16x8*>(y) = hi;
-            *reinterpret_cast<u16x8*>(y + C) = pack8<T>(lo);
+            *reinterpret_cast<u16x8*>(y + 32) = pack8<T>(lo);
         }
         float f[8];
         if (scale) {
@@ -369,13 +369,13 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const typename In8<TI>:
         if (OUT == 0) {
             *reinterpret_cast<u16x8*>(static_cast<unsigned short*>(yv) + pix[u] * C + cc[u]) = pack8<T>(f);
         } else if (OUT == 1) {
-            unsigned short* y = static_cast<unsigned short*>(yv) + pix[u] * (2 * C) + cc[u];
+            unsigned short* y = static_cast<unsigned short*>(yv) + pix[u] * (2 * C) + pair_off(cc[u]);
             const u16x8 hi = pack8<T>(f);
             float lo[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) lo[j] = f[j] - to_f32<T>(hi[j]);
             *reinterpret_cast<u16x8*>(y) = hi;
-            *reinterpret_cast<u16x8*>(y + C) = pack8<T>(lo);
+            *reinterpret_cast<u16x8*>(y + 32) = pack8<T>(lo);
         } else {
             store8_f32(static_cast<float*>(yv) + pix[u] * C + cc[u], f);
         }
@@ -953,6 +953,7 @@ static pf_status scale_shift_act_impl(const void* x0, int c0, const void* x1, in
                "pf_scale_shift_act: out_dtype must be 16-bit (optionally split) or PF_F32");
     PF_REQUIRE(dtype == PF_F32 || out_dtype == PF_F32 || dtype == out_dtype, "pf_scale_shift_act: 16-bit input and output types must agree");
     PF_REQUIRE(!raw_pair || (dtype == PF_F32 && out_dtype != PF_F32 && !out_split), "pf_scale_shift_act_pair: fp32 sources, plain 16-bit output");
+    PF_REQUIRE(!(raw_pair || out_split) || C % 32 == 0, "pf_scale_shift_act: a split pair interleaves hi / lo per 32 channels: C=%d must be a multiple of 32", C);
     const long per_img = static_cast<long>(hw) * (C / 8);
     PF_REQUIRE(per_img < (1L << 31) && n_img <= 65535, "pf_scale_shift_act: image too large / too many images");
     const dim3 grid(cdiv(per_img, 512), n_img), block(256);

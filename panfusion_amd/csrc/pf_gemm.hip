@@ -54,8 +54,8 @@ struct GemmParams {
     unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors of the 8-wave kernel (< 2 GiB)
     int adv_img, adv_y, adv_x;              // (image, row, column) advance of one DMA pass of output rows (8-wave kernel)
     unsigned long long* prof;      // diagnostics (pf_debug_gemm_profile): 4 s_memtime stamps per block, or NULL
-    int stagger;                   // 8-wave kernel: every second block (per XCD) starts this many shader clocks late, so that the CUs' epilogue /
-                                   // HBM phases do not all coincide (PF_GEMM_STAGGER: experiment)
+    int s3;                        // split-precision walk (pf_conv_desc.split3): every 64-element K block of A holds [hi(32) | lo(32)] of 32
+                                   // channels, of W [W_hi(32) | W_lo(32)]: a K step multiplies W_hi A_hi + W_hi A_lo + W_lo A_hi
     float* gn_partial;             // [M / gn_rows][2][N / 2] fp32 per-column-pair (sum, sum of squares) of the finished output over
     int gn_rows;                   // the gn_rows fragment rows of one wavefront (GroupNorm moments of the NEXT layer), or NULL
 };
@@ -155,8 +155,8 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
             hi[e] = from_f32<T>(v[e]);
             lo[e] = from_f32<T>(v[e] - to_f32<T>(hi[e]));
         }
-        *reinterpret_cast<u16x4*>(o) = hi;
-        *reinterpret_cast<u16x4*>(o + p.N) = lo;
+        *reinterpret_cast<u16x4*>(o + (pair_off(n4) - n4)) = hi;
+        *reinterpret_cast<u16x4*>(o + (pair_off(n4) - n4) + 32) = lo;
     } else if (p.out_f32) {
         float* o = static_cast<float*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
         *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
@@ -435,7 +435,7 @@ __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4
     }
     const float* resp = RES ? static_cast<const float*>(p.residual) + bz * p.res_bs : nullptr;
     float* outp = static_cast<float*>(p.out) + bz * p.out_bs;
-    unsigned short* outp16 = static_cast<unsigned short*>(p.out) + bz * p.out_bs;    // PAIR: [M][hi(N) | lo(N)] 16-bit
+    unsigned short* outp16 = static_cast<unsigned short*>(p.out) + bz * p.out_bs;    // PAIR: [M][per 32 columns: hi(32) | lo(32)] 16-bit
     float4 res[2][G][NREP];
     auto request = [&](int g, int bf) {
         if (!RES) return;
@@ -465,7 +465,7 @@ __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4
                 }
                 if (PAIR) {
                     if (m < p.M && nok[j]) {
-                        unsigned short* o16 = outp16 + static_cast<long>(m) * p.out_ld + ncl[j];
+                        unsigned short* o16 = outp16 + static_cast<long>(m) * p.out_ld + pair_off(ncl[j]);
                         const float f[4] = {v.x, v.y, v.z, v.w};
                         u16x4 hi, lo;
 #pragma unroll
@@ -474,7 +474,7 @@ __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4
                             lo[e] = from_f32<T>(f[e] - to_f32<T>(hi[e]));
                         }
                         *reinterpret_cast<u16x4*>(o16) = hi;
-                        *reinterpret_cast<u16x4*>(o16 + p.N) = lo;
+                        *reinterpret_cast<u16x4*>(o16 + 32) = lo;
                     }
                 } else if (m < p.M && nok[j]) *reinterpret_cast<float4*>(op + ncl[j]) = v;
             }
@@ -596,7 +596,7 @@ __device__ __forceinline__ void splitk_finish(const GemmParams& p, long bz, int 
     if (t == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T, int MREP, int NREP, bool STATS = false>
+template <typename T, int MREP, int NREP, bool STATS = false, bool S3 = false>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -720,6 +720,28 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     typedef typename Mfma<T>::frag frag;
     const int frow = lane & 15, fchunk = lane >> 4;
     auto compute = [&](int buf) {
+        if constexpr (S3) {
+            // split-precision K block: slab 0 = (W_hi, A_hi), slab 1 = (W_lo, A_lo) of the same 32 channels
+            frag af[2][MREP], bf[2][NREP];
+#pragma unroll
+            for (int slab = 0; slab < 2; ++slab) {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+                    af[slab][i] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(As + buf * BM * 64 + lds_off(wm * 16 * MREP + i * 16 + frow, slab * 4 + fchunk)));
+#pragma unroll
+                for (int j = 0; j < NREP; ++j)
+                    bf[slab][j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Bs + buf * BN * 64 + lds_off(wn * 16 * NREP + j * 16 + frow, slab * 4 + fchunk)));
+            }
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) {
+                    acc[i][j] = Mfma<T>::run(bf[0][j], af[0][i], acc[i][j]);
+                    acc[i][j] = Mfma<T>::run(bf[0][j], af[1][i], acc[i][j]);
+                    acc[i][j] = Mfma<T>::run(bf[1][j], af[0][i], acc[i][j]);
+                }
+            return;
+        }
 #pragma unroll
         for (int slab = 0; slab < 2; ++slab) {
             frag af[MREP], bf[NREP];
@@ -786,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
 // by the lower 32 lanes of all 8 waves), so one immediate serves all.
 // Tile boundary: right after the barrier that retires the ring the block decodes its next tile and requests
 // that tile's first two stages into slots 0 / 1; the epilogue runs meanwhile in two row slices through slot 2.
-template <typename T, int NREP, int NW, bool STATS = false>
+template <typename T, int NREP, int NW, bool STATS = false, bool S3 = false>
 __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // NW = 8: 4 x 2 waves, 64x80 per wave, two waves per SIMD.  NW = 4: 2 x 2 waves, 128x80 per wave, ONE wave
     // per SIMD with the whole register file (160 accumulator + 104 fragment registers): twice the MFMAs per
@@ -1047,8 +1069,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         // (the compiler drains to 0, it does not count), and they were issued >= NM - LEAD MFMAs earlier.
 #pragma unroll
         for (int idx = 0; idx < NM; ++idx) {
-            if constexpr (NW == 4) Mfma<T>::acc_agpr(fb0[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
-            else acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb0[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
+            // (S3: weight-fragment-major order -- the fragment fb0[j] of THIS step was requested j-th during the previous step's last
+            // group, so the later ones have time to arrive)
+            const int fi = S3 ? idx % MREP : idx / NREP, fj = S3 ? idx / MREP : idx % NREP;
+            if constexpr (NW == 4) Mfma<T>::acc_agpr(fb0[fj], fa0[fi], acc[fi][fj]);
+            else acc[fi][fj] = Mfma<T>::run(fb0[fj], fa0[fi], acc[fi][fj]);
 #ifdef PF_GEMM_FLEAD2          /* two bursts: A fragments after FLEAD MFMAs, B fragments after FLEAD2 (A/B build) */
             if (idx == FLEAD - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_a(cur, 1, fa1); __builtin_amdgcn_sched_barrier(0); }
             if (idx == PF_GEMM_FLEAD2 - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_b(cur, 1, fb1, 0); __builtin_amdgcn_sched_barrier(0); }
@@ -1082,6 +1107,37 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         }
         __amdgpu_buffer_rsrc_t rs_a = rs_w;
         if constexpr (DMA) rs_a = stage_begin();
+        if constexpr (S3) {
+            // Split-precision step: the stage holds [hi(32) | lo(32)] of 32 channels for both operands, f0 = (W_hi, A_hi),
+            // f1 = (W_lo, A_lo).  The first half multiplied W_hi A_hi; here W_lo A_hi (group X, fa0's last use -> the next stage's fa0
+            // is requested behind it) and W_hi A_lo (group Y, weight-fragment-major: fb0[j] is re-requested as soon as its four
+            // MFMAs are issued).  W_lo A_lo (2^-22) is not formed.  60 MFMAs per 52 KB stage instead of 40: the K' = 3 K walk of
+            // rounds 2-3 moved [hi] twice and ran 3 stages per 64 channels, this one 2.
+#pragma unroll
+            for (int idx = 0; idx < NM; ++idx) {
+                acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb1[idx % NREP], fa0[idx / NREP], acc[idx / NREP][idx % NREP]);
+                if constexpr (DMA) {
+                    const int k = idx - LEAD;
+                    if (k >= 0 && (k & 1) == 0 && (k >> 1) < NPIECE) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma_piece(rs_a, cur, k >> 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (MORE) { __builtin_amdgcn_sched_barrier(0); load_frags_a(nx1, 0, fa0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) acc[i][j] = Mfma<T>::run(fb0[j], fa1[i], acc[i][j]);
+                if (MORE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned short* Bn = smem + nx1 * STAGE + BM * 64;
+                    fb0[j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Bn + lds_off(wn * 16 * NREP + j * 16 + frow, fchunk)));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int idx = 0; idx < NM; ++idx) {
             if constexpr (NW == 4) Mfma<T>::acc_agpr(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
@@ -1112,6 +1168,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
                 }
             }
         }
+        }
         static_assert(LEAD + 2 * (NPIECE - 1) < NM, "DMA pieces must fit behind the MFMAs of the second half");
         if constexpr (DMA) stage_end();
         cur = cur == STAGES - 1 ? 0 : cur + 1;
@@ -1137,10 +1194,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // both waves of a SIMD run the same MFMA-dense stream, there is no loader / computer pairing for a priority to help
     if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(PF_GEMM_SETPRIO);
 #endif
-    if (p.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < static_cast<unsigned long long>(p.stagger)) __builtin_amdgcn_s_sleep(16);
-    }
     int tile = blockIdx.x;
     set_tile(tile);
     issue_prologue();
@@ -1258,7 +1311,7 @@ static inline ProfState prof_snapshot() {
 }
 
 
-template <typename T, int MREP, int NREP, bool STATS = false>
+template <typename T, int MREP, int NREP, bool STATS = false, bool S3 = false>
 static pf_status launch_s(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     GemmParams p = gp;
@@ -1269,11 +1322,11 @@ static pf_status launch_s(const GemmParams& gp, int batch, hipStream_t st) {
     const size_t smem = static_cast<size_t>(2) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP, STATS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP, STATS, S3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP, STATS>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP, STATS, S3>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(256), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm");
     if (p.splits > 1 && !p.tickets) {
         const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
@@ -1285,11 +1338,12 @@ static pf_status launch_s(const GemmParams& gp, int batch, hipStream_t st) {
 
 template <typename T, int MREP, int NREP>
 static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
+    if (gp.s3) return gp.gn_partial ? launch_s<T, MREP, NREP, true, true>(gp, batch, st) : launch_s<T, MREP, NREP, false, true>(gp, batch, st);
     return gp.gn_partial ? launch_s<T, MREP, NREP, true>(gp, batch, st) : launch_s<T, MREP, NREP, false>(gp, batch, st);
 }
 
 static int tuning(const char* name, int dflt);
-template <typename T, int NREP, int NW, bool STATS = false>
+template <typename T, int NREP, int NW, bool STATS = false, bool S3 = false>
 static pf_status launch8w_s(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 256, BN = 32 * NREP;
     GemmParams p = gp;
@@ -1303,12 +1357,10 @@ static pf_status launch8w_s(const GemmParams& gp, int batch, hipStream_t st) {
     }
     const ProfState ps = prof_snapshot();
     p.prof = (ps.buf && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= ps.blocks) ? ps.buf : nullptr;
-    static const int stagger = tuning("PF_GEMM_STAGGER", 0), stagger_maxk = tuning("PF_GEMM_STAGGER_MAXK", 1 << 30);
-    p.stagger = (p.K <= stagger_maxk && p.mtiles * p.ntiles >= 512) ? stagger : 0;
     const size_t smem = static_cast<size_t>(3) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm8<T, NREP, NW, STATS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm8<T, NREP, NW, STATS, S3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
@@ -1321,7 +1373,7 @@ static pf_status launch8w_s(const GemmParams& gp, int batch, hipStream_t st) {
         if (gx >= 8) gx = gx / 8 * 8;
         grid = std::min(grid, gx);
     }
-    hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW, STATS>), dim3(grid, p.splits, batch), dim3(64 * NW), smem, st, p);
+    hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW, STATS, S3>), dim3(grid, p.splits, batch), dim3(64 * NW), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm (8-wave)");
     if (p.splits > 1 && !p.tickets) {
         const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
@@ -1333,7 +1385,10 @@ static pf_status launch8w_s(const GemmParams& gp, int batch, hipStream_t st) {
 
 template <typename T, int NREP, int NW>
 static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
-    if constexpr (NW == 8) { if (gp.gn_partial) return launch8w_s<T, NREP, NW, true>(gp, batch, st); }
+    if constexpr (NW == 8) {
+        if (gp.s3) return gp.gn_partial ? launch8w_s<T, NREP, NW, true, true>(gp, batch, st) : launch8w_s<T, NREP, NW, false, true>(gp, batch, st);
+        if (gp.gn_partial) return launch8w_s<T, NREP, NW, true>(gp, batch, st);
+    }
     return launch8w_s<T, NREP, NW, false>(gp, batch, st);
 }
 
@@ -1344,7 +1399,7 @@ static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
     // (K step 2520 vs 2222 clocks, epilogue 2x): a lone in-order wave exposes every lgkmcnt / vmcnt / barrier wait.
     // PF_GEMM8_WAVES=4 selects it (A/B: it moves 28 % fewer fragment bytes through the LDS).
     static const int nw = tuning("PF_GEMM8_WAVES", 8);
-    if (nw == 4) return launch8w<T, NREP, 4>(gp, batch, st);
+    if (nw == 4 && !gp.s3) return launch8w<T, NREP, 4>(gp, batch, st);       // (the A/B instantiation has no split-precision variant)
     return launch8w<T, NREP, 8>(gp, batch, st);
 }
 
@@ -1465,7 +1520,7 @@ static void params_from_desc(const pf_conv_desc* d, GemmParams& p) {
     p.a_bs = d->a_bstride; p.w_bs = d->w_bstride; p.out_bs = d->out_bstride; p.res_bs = d->res_bstride;
     p.mtiles = p.ntiles = 0;
     p.prof = nullptr;
-    p.stagger = 0;
+    p.s3 = d->split3 != 0;
     p.batch = d->batch;
     p.gn_partial = nullptr; p.gn_rows = 0;
     p.m_begin = 0; p.splits = 1; p.kb_per_split = 0; p.partial = nullptr; p.tickets = nullptr;
@@ -1529,8 +1584,10 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     PF_REQUIRE(d->epilogue == PF_EPILOGUE_NONE || d->epilogue == PF_EPILOGUE_GEGLU || d->epilogue == PF_EPILOGUE_SPLIT,
                "pf_conv_gemm: unknown epilogue %d", d->epilogue);
     if (d->epilogue == PF_EPILOGUE_SPLIT)
-        PF_REQUIRE(d->n_out % 4 == 0 && d->out_dtype == d->dtype && d->out_ld >= 2 * d->n_out && !d->rowvec,
-                   "pf_conv_gemm: SPLIT epilogue needs n_out %% 4 == 0, a 16-bit output with out_ld >= 2 n_out, no row vector");
+        PF_REQUIRE(d->n_out % 32 == 0 && d->out_dtype == d->dtype && d->out_ld >= 2 * d->n_out && !d->rowvec,
+                   "pf_conv_gemm: SPLIT epilogue needs n_out %% 32 == 0 (hi / lo interleave per 32 columns), a 16-bit output with out_ld >= 2 n_out, no row vector");
+    if (d->split3)
+        PF_REQUIRE(!d->a1 && d->c0 % 64 == 0, "pf_conv_gemm: a split-precision walk (split3) takes ONE source of 2 x channels = c0 (hi / lo interleaved per 32)");
     if (d->epilogue == PF_EPILOGUE_GEGLU)
         PF_REQUIRE(d->n_out % 4 == 0 && d->out_dtype == d->dtype && !d->residual && d->out_ld >= d->n_out / 2 && d->out_ld % 2 == 0,
                    "pf_conv_gemm: GEGLU epilogue needs n_out %% 4 == 0, 16-bit output, no residual, out_ld >= n_out/2");

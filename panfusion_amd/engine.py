@@ -15,9 +15,9 @@ Two storage schemes (``precision``):
     streams (block outputs, the token stream inside a transformer block, the shortcut) are fp32; and the few
     GEMMs that map the stream linearly onto itself -- resnet shortcut 1x1, proj_in, proj_out, the
     downsampling conv -- run as SPLIT-PRECISION GEMMs: A = A_hi + A_lo, W = W_hi + W_lo (16-bit each),
-    A_hi W_hi + A_lo W_hi + A_hi W_lo in one launch of the same kernel with K' = 3K (the operand is stored
-    as [hi | lo], the kernel's two-source channel concat reads it as [hi | lo] + [hi], the weights are
-    packed [W_hi | W_hi | W_lo] per tap): ~2^-22 relative, 8 % of the step's FLOPs.
+    A_hi W_hi + A_lo W_hi + A_hi W_lo inside one K step of the same kernels (operand and weights interleave
+    hi / lo per 32 channels, a 64-element K block holds both of the same channels): ~2^-22 relative, 8 % of
+    the step's FLOPs run three MFMAs per operand pair.
 """
 import os
 from types import SimpleNamespace as NS
@@ -68,12 +68,12 @@ def _conv3_weight(conv, dev, dtype):
 
 
 def _split_weight(w, taps, dev, dtype):
-    """Split-precision packing of an fp32 weight [N, taps * C] (tap-major): per tap [W_hi | W_hi | W_lo],
-    the partner of the A operand [hi | lo] + [hi] (see exact_gemm)."""
-    w = w.detach().to(device=dev, dtype=torch.float32).reshape(w.shape[0], taps, -1)
+    """Split-precision packing of an fp32 weight [N, taps * C] (tap-major): per tap and per block of 32 channels
+    [W_hi(32) | W_lo(32)], the partner of the pair operand of exact_gemm (same interleave)."""
+    w = w.detach().to(device=dev, dtype=torch.float32).reshape(w.shape[0], taps, -1, 32)
     hi = w.to(dtype)
     lo = (w - hi.float()).to(dtype)
-    return torch.cat([hi, hi, lo], -1).reshape(w.shape[0], -1).contiguous()
+    return torch.stack([hi, lo], 3).reshape(w.shape[0], -1).contiguous()
 
 
 def split_operand(x0, x1=None, scale=None, shift=None, act=0, dtype=None):
@@ -86,13 +86,13 @@ def split_operand(x0, x1=None, scale=None, shift=None, act=0, dtype=None):
 
 
 def exact_gemm(a_split, w3, n_out, **kw):
-    """Split-precision GEMM / conv: a_split [.., 2C] = [A_hi | A_lo], w3 per tap [W_hi | W_hi | W_lo].
-    The kernel's channel concat takes source 0 = the whole pair (2C channels) and source 1 = its hi half
-    again (C channels, same row stride): sum_k A_hi W_hi + A_lo W_hi + A_hi W_lo."""
+    """Split-precision GEMM / conv: a_split [.., 2C] and w3 (per tap) hold, per block of 32 channels, [hi(32) | lo(32)]; every
+    64-element K block is multiplied as W_hi A_hi + W_hi A_lo + W_lo A_hi in ONE stage of the kernels (pf_conv_desc.split3:
+    60 MFMAs on the 52 KB a plain stage moves for 40).  Rounds 2-3 walked K' = 3 K over [hi | lo] + [hi] against
+    [W_hi | W_hi | W_lo]: the same three products, half again as many stages."""
     C2 = a_split.shape[-1]
-    C = C2 // 2
     k = kw.get("ksize", 1)
-    return ops.conv_gemm(a_split, w3, n_out, a1=a_split, c0=C2, c1=C, a0_ld=C2, a1_ld=C2, algo_k=k * k * C, **kw)
+    return ops.conv_gemm(a_split, w3, n_out, c0=C2, a0_ld=C2, algo_k=k * k * (C2 // 2), split3=True, **kw)
 
 
 def to16(x, dtype):

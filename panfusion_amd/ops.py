@@ -395,12 +395,13 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,
               a_bstride=0, w_bstride=0, out_bstride=0, res_bstride=0, a0_ld=None, a1_ld=None, c0=None, c1=None,
               out_ld=None, res_ld=None, geglu=False, algo_k=None, split_out=False, pad_hi=0, gn_stats=False,
-              wrap_pad=0, crop=0):
+              wrap_pad=0, crop=0, split3=False):
     """out[m, n] = sum_k A[m, k] W[n, k] (+bias +rowvec[img] +residual).  a0/a1 NHWC, the last
     dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out).  The output takes the
     residual's dtype unless out_dtype says otherwise (fp32 residual stream in, fp32 out).
     algo_k: K of the layer for the FLOP count when the launched K carries split-precision passes.
-    split_out: the result leaves as the 16-bit pair [M, hi(n_out) | lo(n_out)] (operand of engine.exact_gemm).
+    split_out: the result leaves as the 16-bit pair [M, 2 n_out] (per 32 columns [hi | lo]: operand of engine.exact_gemm).
+    split3: a0 IS such a pair (c0 = 2 x channels) and w the matching [W_hi | W_lo] packing: three products per K block.
     pad_hi = 1: one more zero row / column at the bottom / right (F.pad(x, (0, 1, 0, 1)) of the VAE encoder's down-convs).
     gn_stats: the result feeds a GroupNorm -- where the kernel serving this problem can, its epilogue leaves the per-column
     moments of the output behind (attribute `_pf_gn` of the returned tensor, read by groupnorm_scale_shift).
@@ -434,7 +435,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     # GroupNorm-moment rows), asked once.  Per call only the pointers change.
     pkey = (c0, c1, a0_ld, a1_ld, n_img, h_in, w_in, h_out, w_out, ksize, stride, pad, upsample, n_out, batch, epilogue, wrap_pad,
             crop, dt(a0), dt(out_dtype), residual is not None, res_dtype, res_ld, rowvec is not None, rowvec_ld, bias is not None,
-            out_ld, a_bstride, w_bstride, out_bstride, res_bstride)
+            out_ld, a_bstride, w_bstride, out_bstride, res_bstride, bool(split3))
     plan = _PLANS.get(pkey)
     if plan is None:
         d = ConvDesc()
@@ -447,6 +448,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
         d.a_bstride, d.w_bstride, d.out_bstride, d.res_bstride = a_bstride, w_bstride, out_bstride, res_bstride
         d.epilogue = epilogue
         d.wrap_pad, d.crop = wrap_pad, crop
+        d.split3 = int(bool(split3))
         d.a0, d.a1, d.w, d.bias, d.rowvec, d.residual, d.out = _p(a0), _p(a1), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
         plan = _PLANS[pkey] = [_lib.lib().pf_conv_gemm_workspace_size(C.byref(d)), None, d]
     d = plan[2]

@@ -77,3 +77,10 @@ def build_tiny_oracle(seed=11):
 def cam4():
     return {"FoV": torch.full((4,), 90), "theta": torch.tensor([0., 90, 180, 270], dtype=torch.float64),
             "phi": torch.tensor([0., 10, -20, 45], dtype=torch.float64)}
+
+
+def unpair(p):
+    """Split-precision pair [.., 2C] of the kernels (per block of 32 channels [hi(32) | lo(32)]) -> (hi, lo) [.., C]."""
+    C2 = p.shape[-1]
+    q = p.reshape(*p.shape[:-1], C2 // 64, 2, 32)
+    return q[..., 0, :].reshape(*p.shape[:-1], C2 // 2), q[..., 1, :].reshape(*p.shape[:-1], C2 // 2)

@@ -138,17 +138,30 @@ def groupnorm_scale_shift(x0, x1, n_img, hw, groups, eps, gamma, beta, ws=None, 
     return scale, shift
 
 
+def _pair(v, dtype):
+    """fp32 [.., C] -> the split-precision pair [.., 2C] of the kernels: per block of 32 channels [hi(32) | lo(32)]."""
+    hi = v.to(dtype)
+    lo = (v - hi.float()).to(dtype)
+    C = v.shape[-1]
+    return torch.stack([hi.reshape(*v.shape[:-1], C // 32, 32), lo.reshape(*v.shape[:-1], C // 32, 32)], -2).reshape(*v.shape[:-1], 2 * C)
+
+
+def _unpair(p):
+    """pair [.., 2C] -> (hi, lo) [.., C] fp32."""
+    C2 = p.shape[-1]
+    q = p.float().reshape(*p.shape[:-1], C2 // 64, 2, 32)
+    return q[..., 0, :].reshape(*p.shape[:-1], C2 // 2), q[..., 1, :].reshape(*p.shape[:-1], C2 // 2)
+
+
 def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None, out_dtype=None, split=False, raw_pair=False):
     x = _cat(x0, x1).float().reshape(n_img, hw, -1)
     y = x if scale is None else x * scale[:, None] + shift[:, None]
     y = F.silu(y) if act else y
     out_dtype = out_dtype or x0.dtype
     if raw_pair:
-        hi = x.to(out_dtype)
-        return y.to(out_dtype), torch.cat([hi, (x - hi.float()).to(out_dtype)], -1)
+        return y.to(out_dtype), _pair(x, out_dtype)
     if split:
-        hi = y.to(out_dtype)
-        return torch.cat([hi, (y - hi.float()).to(out_dtype)], -1)
+        return _pair(y, out_dtype)
     return y.to(out_dtype)
 
 
@@ -261,7 +274,23 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, c1=None,
               a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, split_out=False, pad_hi=0,
-              gn_stats=False, wrap_pad=0, crop=0, **kw):
+              gn_stats=False, wrap_pad=0, crop=0, split3=False, **kw):
+    if split3:
+        # split-precision walk (pf_conv_desc.split3): a0 is a pair tensor, w holds per tap and 32-channel block [W_hi | W_lo];
+        # W_hi A_hi + W_hi A_lo + W_lo A_hi  (W_lo A_lo is not formed)
+        assert a1 is None and batch == 1
+        C2 = c0 or a0.shape[-1]
+        a_hi, a_lo = _unpair(a0.reshape(-1, a0_ld or a0.shape[-1])[:, :C2])
+        w_hi, w_lo = _unpair(w.reshape(n_out, ksize * ksize, C2))
+        common = dict(n_img=n_img, h_in=h_in, w_in=w_in, ksize=ksize, stride=stride, pad=pad, upsample=upsample, pad_hi=pad_hi,
+                      wrap_pad=wrap_pad, crop=crop, out_dtype=torch.float32)
+        part = conv_gemm(a_hi, w_lo.reshape(n_out, -1), n_out, **common)
+        if w_in is None:
+            w_in = a_hi.shape[0]
+        return conv_gemm(a_hi + a_lo, w_hi.reshape(n_out, -1), n_out, bias=bias, rowvec=rowvec,
+                         residual=part if residual is None else part + residual.float().reshape(part.shape[0], -1)[:, :n_out],
+                         out=out, out_dtype=out_dtype or (residual.dtype if residual is not None else a0.dtype), geglu=geglu,
+                         split_out=split_out, gn_stats=gn_stats, **{k: v for k, v in common.items() if k != "out_dtype"})
     if batch > 1:          # independent problems (attention scores / P.V of the VAE): plain linears only
         assert ksize == 1 and a1 is None and bias is None and residual is None and rowvec is None and not geglu
         K = c0 or a0.shape[-1]
@@ -310,8 +339,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     if geglu:                                     # rows interleaved (value_j, gate_j)
         y = y[:, 0::2] * F.gelu(y[:, 1::2])
     if split_out:
-        hi = y.to(a0.dtype)
-        y = torch.cat([hi, (y - hi.float()).to(a0.dtype)], -1)
+        y = _pair(y, a0.dtype)
     else:
         y = y.to(out_dtype or (residual.dtype if residual is not None else a0.dtype))
     if out is not None:

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import cam4, golden, rel_l2
+from conftest import cam4, golden, rel_l2, unpair
 from oracle import ddim as oddim
 from oracle import geometry as G
 from oracle import sd2_unet as U
@@ -822,8 +822,8 @@ def test_scale_shift_act_with_raw_pair(dtype):
     p_ref = o.scale_shift_act(x0, x1, n, hw, None, None, 0, out_dtype=dtype, split=True)
     y, pair = o.scale_shift_act(x0, x1, n, hw, sc, sh, 1, out_dtype=dtype, raw_pair=True)
     assert torch.equal(y, y_ref) and torch.equal(pair, p_ref)
-    C = c0 + c1
-    rec = pair[..., :C].float() + pair[..., C:].float()
+    hi, lo = unpair(pair)
+    rec = hi.float() + lo.float()
     check("pair reconstructs the input", rec, torch.cat([x0, x1], -1), 2e-6 if dtype == torch.float16 else 4e-5)
 
 

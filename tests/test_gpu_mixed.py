@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l2
+from conftest import rel_l2, unpair
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -41,16 +41,16 @@ def test_groupnorm_and_apply_on_fp32_stream(dtype):
     pair = o.scale_shift_act(x0, x1, n, hw, sc, sh, 1, out_dtype=dtype, split=True)
     C = c0 + c1
     assert pair.shape == (n, hw, 2 * C)
-    hi, lo = pair[..., :C], pair[..., C:]
+    hi, lo = unpair(pair)
     assert torch.equal(hi, y32.to(dtype))                                   # hi is the plain rounding ...
     assert torch.equal(lo, (y32 - hi.float()).to(dtype))                    # ... lo the rounded remainder
     # identity (no statistics): the raw stream as a split operand
     raw = o.scale_shift_act(x0, None, 1, n * hw, None, None, 0, out_dtype=dtype, split=True)
-    assert torch.equal(raw[..., :c0].reshape(n, hw, c0), x0.to(dtype))
+    assert torch.equal(unpair(raw)[0].reshape(n, hw, c0), x0.to(dtype))
     # 16-bit source, split output
     x16 = x0.to(dtype)
     p16 = o.scale_shift_act(x16, None, 1, n * hw, None, None, 0, split=True)
-    assert torch.equal(p16[..., :c0].reshape(n, hw, c0), x16) and float(p16[..., c0:].float().abs().max()) == 0.0
+    assert torch.equal(unpair(p16)[0].reshape(n, hw, c0), x16) and float(unpair(p16)[1].float().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dtype", D16)
@@ -113,10 +113,10 @@ def test_gemm_fp32_residual_and_output(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", D16)
-@pytest.mark.parametrize("M,N,K", [(40 * 1024, 640, 2560), (4096, 320, 1280), (1000, 320, 5120), (333, 132, 64)])
+@pytest.mark.parametrize("M,N,K", [(40 * 1024, 640, 2560), (4096, 320, 1280), (1000, 320, 5120), (333, 128, 64)])
 def test_gemm_split_pair_epilogue(dtype, M, N, K):
-    """PF_EPILOGUE_SPLIT: bias (+ fp32 residual) -> the 16-bit pair [hi | lo] of the fp32 result (FF2 feeding the
-    split-precision proj_out); hi is the 16-bit rounding of the fp32 epilogue output, lo the rounded remainder."""
+    """PF_EPILOGUE_SPLIT: bias (+ fp32 residual) -> the 16-bit pair of the fp32 result, per block of 32 columns [hi | lo] (FF2
+    feeding the split-precision proj_out); hi is the 16-bit rounding of the fp32 epilogue output, lo the rounded remainder."""
     o = ops()
     x = rnd(M, K, seed=40).to(dtype)
     w = (rnd(N, K, seed=41) / K ** 0.5).to(dtype)
@@ -125,14 +125,14 @@ def test_gemm_split_pair_epilogue(dtype, M, N, K):
         want = o.linear(x, w, bias=b, residual=r, out_dtype=torch.float32)
         pair = o.linear(x, w, bias=b, residual=r, split_out=True)
         assert pair.dtype == dtype and pair.shape == (M, 2 * N)
-        hi, lo = pair[:, :N], pair[:, N:]
+        hi, lo = unpair(pair)
         assert torch.equal(hi, want.to(dtype))
         assert torch.equal(lo, (want - hi.float()).to(dtype))
 
 
 @pytest.mark.parametrize("dtype", D16)
 def test_split_precision_gemm_reproduces_fp32(dtype):
-    """exact_gemm: [A_hi | A_lo] x [W_hi | W_hi | W_lo] in one launch == the fp32 product to ~2^-2p."""
+    """exact_gemm: pair operand x [W_hi | W_lo] weights, three products per K block in one launch == the fp32 product to ~2^-2p."""
     from panfusion_amd import engine
     o = ops()
     # 1x1: resnet shortcut over a channel concat of two fp32 stream tensors
