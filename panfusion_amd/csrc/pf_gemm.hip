@@ -1087,6 +1087,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             }
 #endif
         }
+        // (S3: hipcc sank 15 of the first group's 20 MFMAs below the wait -- register-only instructions move across an inline-asm
+        // s_waitcnt -- so the wait found the nine f1 reads it had just issued: pinned)
+        if constexpr (S3) __builtin_amdgcn_sched_barrier(0);
         if constexpr (MORE) {
             // my pieces of the next stage have landed (the stage after it may still be in flight: WAIT), and my
             // reads of the current slot have returned -- it is refilled right after the barrier
