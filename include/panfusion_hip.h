@@ -460,7 +460,7 @@ pf_status pf_im2col3(const void* x, int dtype, int n, int h, int w, int C, int s
 
 /* LoRA fold, once per projection and optimizer step of a training run (the rank-4 LoRA of models/pano/PanoGenerator.py:129-151
  * on q / k / v / out of every attention; diffusers LoRALinearLayer: y = W x + scale * up(down(x))):
- *   out [N][out_ld] (16-bit `dtype`) = W + scale * up @ down,   W fp32 [N][K], up fp32 [N][r], down fp32 [r][K], r <= 16
+ *   out [N][out_ld] (16-bit `dtype`) = W + scale * up @ down,   W fp32 [N][K], up fp32 [N][r], down fp32 [r][K], r <= 64
  * (r = 0: a plain fp32 -> 16-bit conversion).  Optional by-products for the backward, NULL to skip: out_t [K][out_t_ld] the
  * transpose of the folded weight; d_out [r][d_ld] = down and u_out [r][u_ld] = up^T in 16 bit (rows / a block of the
  * stacked matrices the LoRA gradient GEMMs read).  `out` may be a row slice of a larger packed weight. */
@@ -495,7 +495,8 @@ pf_status pf_colsum(const void* x, int dtype, long rows, int N, long ld, float* 
 
 /* Weighted column sums, the token-reducing half of the LoRA gradients (rank-4 LoRA of PanoGenerator.py:129-151 under autograd:
  * d_up = dY^T (X down^T), d_down = (dY up)^T X):  out[r][c] = scale * sum_t w[r][t] * x[t][c]  for x [T][C] 16-bit row-major
- * (row stride ld) and w fp32 [R][w_ld >= T], R = 4, 8, 12 or 16.  x is read once as the backward holds it (no transposed copy); partial
+ * (row stride ld) and w fp32 [R][w_ld >= T], R a multiple of 4 (the stacked ranks of a
+ * projection group: 12 for q / k / v at rank 4, 24 at rank 8).  x is read once per 16 rows of w, as the backward holds it (no transposed copy); partial
  * sums per row slab are added in a fixed order.  scale = host_scale * (*dev_scale if given: the gradient-normalisation factor
  * on the device).  blocks (host, n_blocks x 4 ints (row0, rows, col0, cols), n_blocks <= 4): when given, only these blocks of
  * [R][C] are written, one after the other, block b TRANSPOSED as [cols_b][rows_b] (the [N_i][rank] layout of a LoRA up

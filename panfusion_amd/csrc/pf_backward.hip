@@ -990,13 +990,14 @@ __global__ void k_im2col3(const u16x8* __restrict__ x, int n, int h, int w, int 
 //   d_out [r][d_ld]      the down matrix in 16 bit (rows of the group's stacked D), optional,
 //   u_out [r][u_ld]      the up matrix transposed in 16 bit (a block of the group's block-diagonal U), optional.
 // 64 x 64 tiles; the transpose goes through LDS so that both outputs are written in whole rows.
+constexpr int LORA_MAX_RANK = 64;                                  // (lora_rank is a hyperparameter of the reference: PanoGenerator.py:73)
 template <typename T>
 __global__ __launch_bounds__(256) void k_lora_fold(const float* __restrict__ w, const float* __restrict__ up, const float* __restrict__ down,
                                                    int N, int K, int r, float scale, unsigned short* __restrict__ out, long out_ld,
                                                    unsigned short* __restrict__ out_t, long out_t_ld, unsigned short* __restrict__ d_out,
                                                    long d_ld, unsigned short* __restrict__ u_out, long u_ld) {
     __shared__ unsigned short tile[64][66];
-    __shared__ float s_up[64][16], s_down[16][64];
+    __shared__ float s_up[64][LORA_MAX_RANK], s_down[LORA_MAX_RANK][64];
     const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64, t = threadIdx.x;
     for (int i = t; i < 64 * r; i += 256) {
         const int a = i / r, j = i - a * r;                         // up [N][r]: row n0 + a
@@ -1183,7 +1184,7 @@ __global__ void k_colsum_final(const float* __restrict__ part, int slabs, int N,
 }
 
 // ---- weighted column sums: out[r][c] = sum_t w[r][t] * x[t][c] -------------------------------------------------------------
-// The token-reducing half of the LoRA gradients (d_up = dY^T P, d_down = Q^T X with P = X down^T, Q = dY up: R <= 16 columns):
+// The token-reducing half of the LoRA gradients (d_up = dY^T P, d_down = Q^T X with P = X down^T, Q = dY up: R columns, <= 16 per launch):
 // x is read ONCE, row-major as the backward holds it -- no transposed copy, no 64-row MFMA tile for a 4-row product.
 // Partial sums per (row slab, 4 row phases) in a fixed order, then a final pass that also applies the gradient-normalisation
 // factor and lays the result out per LoRA pair.
@@ -1265,8 +1266,11 @@ __global__ void k_wcolsum_final(const float* __restrict__ part, int slabs, int R
         }
         if (dst < 0) return;
     }
+    // partial sums: one region per chunk of <= 16 weight rows, [slab][rows of the chunk][C] each
+    const int chunk = r >> 4, rc = r & 15, Rc = min(16, R - 16 * chunk);
+    const float* pc = part + static_cast<long>(slabs) * 16 * chunk * C;
     float acc = 0.f;
-    for (int s = 0; s < slabs; ++s) acc += part[(static_cast<long>(s) * R + r) * C + c];
+    for (int s = 0; s < slabs; ++s) acc += pc[(static_cast<long>(s) * Rc + rc) * C + c];
     out[dst] = acc * host_scale * (dev_scale ? dev_scale[0] : 1.0f);
 }
 
@@ -1491,7 +1495,7 @@ extern "C" pf_status pf_weighted_colsum(const void* x, int dtype, long n_tok, in
                                         const float* dev_scale, float host_scale, const int* blocks, int n_blocks, float* out,
                                         void* workspace, size_t workspace_bytes, void* stream) {
     PF_REQUIRE(x && w && out && workspace && n_tok > 0 && C > 0, "pf_weighted_colsum: bad arguments");
-    PF_REQUIRE(R > 0 && R <= 16 && R % 4 == 0 && w_ld >= n_tok, "pf_weighted_colsum: R = %d must be 4, 8, 12 or 16 and w_ld >= T", R);
+    PF_REQUIRE(R > 0 && R % 4 == 0 && w_ld >= n_tok, "pf_weighted_colsum: R = %d must be a positive multiple of 4 and w_ld >= T", R);
     PF_REQUIRE(C % 2 == 0 && ld % 2 == 0 && ld >= C && (reinterpret_cast<uintptr_t>(x) & 3) == 0, "pf_weighted_colsum: x needs an even width / row stride and 4-byte alignment");
     PF_REQUIRE(n_blocks >= 0 && n_blocks <= 4 && (n_blocks == 0 || blocks), "pf_weighted_colsum: at most 4 output blocks");
     PF_REQUIRE(workspace_bytes >= pf_weighted_colsum_workspace_size(n_tok, C, R), "pf_weighted_colsum: workspace too small");
@@ -1507,9 +1511,14 @@ extern "C" pf_status pf_weighted_colsum(const void* x, int dtype, long n_tok, in
     float* part = static_cast<float*>(workspace);
     hipStream_t st = as_stream(stream);
     const dim3 grid(cdiv(C, 128), slabs), block(256);
-#define PF_WCS(RQ) hipLaunchKernelGGL((k_wcolsum_partial<T, RQ>), grid, block, 0, st, static_cast<const unsigned short*>(x), n_tok, C, ld, w, w_ld, slabs, part)
-    PF_DISPATCH_16(dtype, "pf_weighted_colsum",
-        if (R == 4) PF_WCS(1); else if (R == 8) PF_WCS(2); else if (R == 12) PF_WCS(3); else PF_WCS(4));
+    // weight rows in chunks of <= 16 (the kernel keeps 2 accumulators per row in registers): x is re-read once per chunk
+#define PF_WCS(RQ) hipLaunchKernelGGL((k_wcolsum_partial<T, RQ>), grid, block, 0, st, static_cast<const unsigned short*>(x), n_tok, C, ld, \
+                                      w + static_cast<long>(r0) * w_ld, w_ld, slabs, part + static_cast<long>(slabs) * r0 * C)
+    for (int r0 = 0; r0 < R; r0 += 16) {
+        const int Rc = std::min(16, R - r0);
+        PF_DISPATCH_16(dtype, "pf_weighted_colsum",
+            if (Rc == 4) PF_WCS(1); else if (Rc == 8) PF_WCS(2); else if (Rc == 12) PF_WCS(3); else PF_WCS(4));
+    }
 #undef PF_WCS
     hipLaunchKernelGGL(k_wcolsum_final, dim3(cdiv(static_cast<long>(R) * C, 256)), dim3(256), 0, st, part, slabs, R, C, dev_scale, host_scale, b, out);
     PF_CHECK_LAUNCH("pf_weighted_colsum");
@@ -1671,7 +1680,7 @@ extern "C" pf_status pf_lora_fold(const float* w, const float* up, const float* 
                                   void* out, long out_ld, void* out_t, long out_t_ld, void* d_out, long d_ld, void* u_out, long u_ld,
                                   void* stream) {
     PF_REQUIRE(w && out && N > 0 && K > 0, "pf_lora_fold: bad arguments");
-    PF_REQUIRE(r >= 0 && r <= 16 && (r == 0 || (up && down)), "pf_lora_fold: rank %d unsupported (0..16, with both matrices)", r);
+    PF_REQUIRE(r >= 0 && r <= LORA_MAX_RANK && (r == 0 || (up && down)), "pf_lora_fold: rank %d unsupported (0..%d, with both matrices)", r, LORA_MAX_RANK);
     PF_REQUIRE(out_ld >= K && (!out_t || out_t_ld >= N) && (!d_out || d_ld >= K) && (!u_out || u_ld >= N), "pf_lora_fold: leading dimensions too small");
     PF_REQUIRE(cdiv(N, 64) <= 65535, "pf_lora_fold: too many rows");
     const dim3 grid(cdiv(K, 64), cdiv(N, 64)), block(256);

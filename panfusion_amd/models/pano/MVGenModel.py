@@ -207,7 +207,14 @@ class MultiViewBaseModel(nn.Module):
             for t in engine.all_transformers(u):
                 engine.fold_attention(t.attn1)          # in place: one launch per LoRA-carrying projection
                 engine.fold_attention(t.attn2)
-            u.__dict__.pop("text_kv_cache", None)          # K / V^T of the prompt depend on to_k / to_v
+            # K / V^T of the cached prompts depend on to_k / to_v: recomputed INTO the cached buffers -- a DenoiseLoop graph
+            # captured before the optimizer step reads them (like the folded weights) by address, and a replay must not mix
+            # the new to_q / to_out with K / V^T of the old to_k / to_v
+            for hit in getattr(u, "text_kv_cache", {}).values():
+                for t in engine.all_transformers(u):
+                    k, vt = engine.text_kv(t.attn2, hit["text"])
+                    hit[id(t)][0].copy_(k)
+                    hit[id(t)][1].copy_(vt)
             u.lora_key = key
 
     @torch.no_grad()

@@ -20,7 +20,17 @@ _DT = {torch.bfloat16: PF_BF16, torch.float16: PF_F16, torch.float32: PF_F32}
 TRACE = None
 
 
-_PLANS = {}           # conv_gemm: problem shape -> [split-K scratch bytes, GroupNorm-moment rows] as the library plans it
+class _PlanCache(__import__("threading").local):
+    """conv_gemm: problem shape -> [split-K scratch bytes, GroupNorm-moment rows, descriptor] as the library plans it.  Per host
+    THREAD (the cached descriptor's pointer members are rewritten on every call: two threads issuing the same shape must not
+    share one) and bounded (variable batch sizes / resolutions: the oldest shape goes first)."""
+    LIMIT = 4096
+
+    def __init__(self):
+        self.plans = {}
+
+
+_PLANS = _PlanCache()
 SPLITK_INKERNEL = os.environ.get("PF_SPLITK_INKERNEL") == "1"    # A/B switch, read once (as the library reads it)
 
 
@@ -219,6 +229,8 @@ def scale_shift_act(x0, x1, n_img, hw, scale, shift, act, out=None, out_dtype=No
     out_dtype = out_dtype or x0.dtype
     if out is None:
         out = torch.empty(n_img, hw, (c0 + c1) * (2 if split else 1), device=x0.device, dtype=out_dtype)
+    else:
+        _written(out)
     if raw_pair:
         assert x0.dtype == torch.float32 and not split and out_dtype != torch.float32
         pair = torch.empty(n_img, hw, 2 * (c0 + c1), device=x0.device, dtype=out_dtype)
@@ -236,6 +248,8 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, out=None, out_dtype=None):
     rows, Cc = x.shape
     if out is None:
         out = torch.empty(rows, Cc, device=x.device, dtype=out_dtype or x.dtype)
+    else:
+        _written(out)
     check(_lib.lib().pf_layernorm(_p(x), _p(pe), 0 if pe is None else pe.shape[0], dt(x), rows, Cc,
                                   _p(gamma), _p(beta), eps, dt(out), _p(out), _stream()), "pf_layernorm")
     return out
@@ -246,6 +260,8 @@ def geglu(x, out=None):
     inner = two_inner // 2
     if out is None:
         out = torch.empty(rows, inner, device=x.device, dtype=x.dtype)
+    else:
+        _written(out)
     check(_lib.lib().pf_geglu(_p(x), dt(x), rows, inner, _p(out), _stream()), "pf_geglu")
     return out
 
@@ -258,9 +274,19 @@ def timestep_features(t, dim, dtype):
     return out
 
 
+def _written(out):
+    """An op wrote into a caller's `out=` buffer: GroupNorm moments it carried (`_pf_gn`, attached by a GEMM epilogue) described
+    its previous contents."""
+    if hasattr(out, "_pf_gn"):
+        del out._pf_gn
+    return out
+
+
 def silu(x, out=None):
     if out is None:
         out = torch.empty_like(x)
+    else:
+        _written(out)
     check(_lib.lib().pf_silu(_p(x), dt(x), x.numel(), _p(out), _stream()), "pf_silu")
     return out
 
@@ -269,6 +295,8 @@ def add(a, b, out=None):
     """a + b in a's dtype (b may have another one: fp32 stream + 16-bit ControlNet residual)."""
     if out is None:
         out = torch.empty_like(a)
+    else:
+        _written(out)
     check(_lib.lib().pf_add(_p(a), dt(a), _p(b), dt(b), a.numel(), _p(out), _stream()), "pf_add")
     return out
 
@@ -278,6 +306,8 @@ def pad_width(x, pad, out=None):
     n, h, w, Cc = x.shape
     if out is None:
         out = torch.empty(n, h, w + 2 * pad, Cc, device=x.device, dtype=x.dtype)
+    else:
+        _written(out)
     check(_lib.lib().pf_pad_width(_p(x), dt(x), n, h, w, Cc, pad, _p(out), _stream()), "pf_pad_width")
     return out
 
@@ -286,6 +316,8 @@ def crop_width(x, crop, out=None):
     n, h, w, Cc = x.shape
     if out is None:
         out = torch.empty(n, h, w - 2 * crop, Cc, device=x.device, dtype=x.dtype)
+    else:
+        _written(out)
     check(_lib.lib().pf_crop_width(_p(x), dt(x), n, h, w, Cc, crop, _p(out), _stream()), "pf_crop_width")
     return out
 
@@ -307,6 +339,8 @@ def roll_width(x, shift, out=None):
     w = x.shape[-1]
     if out is None:
         out = torch.empty_like(x)
+    else:
+        _written(out)
     check(_lib.lib().pf_roll_width_rows(_p(x), x.element_size(), x.numel() // w, w, int(shift), _p(out), _stream()),
           "pf_roll_width_rows")
     return out
@@ -317,6 +351,8 @@ def nchw_to_nhwc(x, dtype, out=None):
     n, Cc, h, w = x.shape
     if out is None:
         out = torch.empty(n, h, w, Cc, device=x.device, dtype=dtype)
+    else:
+        _written(out)
     check(_lib.lib().pf_nchw_to_nhwc(_p(x), dt(x), n, Cc, h, w, dt(dtype), _p(out), _stream()), "pf_nchw_to_nhwc")
     return out
 
@@ -325,6 +361,8 @@ def nhwc_to_nchw(x, dtype, out=None):
     n, h, w, Cc = x.shape
     if out is None:
         out = torch.empty(n, Cc, h, w, device=x.device, dtype=dtype)
+    else:
+        _written(out)
     check(_lib.lib().pf_nhwc_to_nchw(_p(x), dt(x), n, Cc, h, w, dt(dtype), _p(out), _stream()), "pf_nhwc_to_nchw")
     return out
 
@@ -436,7 +474,8 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     pkey = (c0, c1, a0_ld, a1_ld, n_img, h_in, w_in, h_out, w_out, ksize, stride, pad, upsample, n_out, batch, epilogue, wrap_pad,
             crop, dt(a0), dt(out_dtype), residual is not None, res_dtype, res_ld, rowvec is not None, rowvec_ld, bias is not None,
             out_ld, a_bstride, w_bstride, out_bstride, res_bstride, bool(split3))
-    plan = _PLANS.get(pkey)
+    plans = _PLANS.plans
+    plan = plans.get(pkey)
     if plan is None:
         d = ConvDesc()
         d.c0, d.c1, d.a0_ld, d.a1_ld = c0, c1, a0_ld, a1_ld
@@ -450,7 +489,9 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
         d.wrap_pad, d.crop = wrap_pad, crop
         d.split3 = int(bool(split3))
         d.a0, d.a1, d.w, d.bias, d.rowvec, d.residual, d.out = _p(a0), _p(a1), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
-        plan = _PLANS[pkey] = [_lib.lib().pf_conv_gemm_workspace_size(C.byref(d)), None, d]
+        if len(plans) >= _PLANS.LIMIT:
+            plans.pop(next(iter(plans)))
+        plan = plans[pkey] = [_lib.lib().pf_conv_gemm_workspace_size(C.byref(d)), None, d]
     d = plan[2]
     d.a0, d.a1, d.w, d.bias, d.rowvec, d.residual, d.out = _p(a0), _p(a1), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
     d.gn_partial, d.tickets, d.n_tickets = None, None, 0
@@ -476,7 +517,9 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
                 lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"),
                 "M%d N%d K%d k%d s%d u%d b%d" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch))
     if gn is not None:
-        out._pf_gn = gn
+        out._pf_gn = gn                      # (a tensor that carries moments must not be written in place afterwards)
+    elif hasattr(out, "_pf_gn"):
+        del out._pf_gn                       # a reused out= buffer: moments of what it held before are stale now
     return out
 
 
@@ -749,6 +792,8 @@ def scale_by_state(x, state, index, out_dtype=torch.float32, out=None):
     """y = x * state[index] (x fp32 contiguous); out may alias x when fp32."""
     if out is None:
         out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    else:
+        _written(out)
     check(_lib.lib().pf_scale_f32(_p(x), x.numel(), _p(state), index, dt(out), _p(out), _stream()), "pf_scale_f32")
     return out
 
@@ -817,7 +862,7 @@ def lora_fold(w, up, down, scale, out, out_t=None, d_out=None, u_out=None):
 
 
 def weighted_colsum(x, w, dev_scale=None, host_scale=1.0, blocks=None):
-    """sum_t w[r, t] * x[t, c]: x [T, C] 16-bit (rows may be strided), w [R, T] fp32 (R <= 16) -> fp32 [R, C]; with blocks
+    """sum_t w[r, t] * x[t, c]: x [T, C] 16-bit (rows may be strided), w [R, T] fp32 (R a multiple of 4; rows go through the kernel in chunks of 16) -> fp32 [R, C]; with blocks
     = [(row0, rows, col0, cols), ...] (<= 4) a flat fp32 tensor holding only those blocks, each TRANSPOSED ([cols, rows]), one after
     the other.  dev_scale: optional 1-element fp32 device tensor multiplied into the result together with host_scale."""
     T, Cc = x.shape

@@ -56,14 +56,14 @@ def rel_l2(a, b):
 TINY = dict(width=64, cross_attention_dim=128, heads=(1, 2, 4, 4), groups=32)
 
 
-def build_tiny_oracle(seed=11):
+def build_tiny_oracle(seed=11, lora_rank=4):
     """Same construction as tools/make_golden.py:build_tiny_models, on the oracle classes."""
     from oracle import mvgen as MV
     from oracle import sd2_unet as U
     cfg = U.tiny_config(**TINY)
     unet, pano_unet = U.UNet2DConditionModel(**cfg), U.UNet2DConditionModel(**cfg)
-    unet.add_lora(4)
-    pano_unet.add_lora(4)
+    unet.add_lora(lora_rank)                    # (a hyperparameter of the reference: PanoGenerator.py:73)
+    pano_unet.add_lora(lora_rank)
     U.init_synthetic(unet, seed)
     U.init_synthetic(pano_unet, seed + 1)
     model = MV.DualBranchDenoiser(unet, pano_unet, None, None, True)

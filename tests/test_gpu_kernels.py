@@ -745,7 +745,7 @@ def test_conv_gemm_leaves_groupnorm_moments(dtype, case, monkeypatch):
     that the residual variants of the moment phase stay covered.)"""
     monkeypatch.setenv("PF_GN_EPILOGUE_RES", "1")
     o = ops()
-    monkeypatch.setattr(o, "_PLANS", {})          # (ops caches the library's per-shape plan; this switch changes it)
+    monkeypatch.setattr(o._PLANS, "plans", {})          # (ops caches the library's per-shape plan; this switch changes it)
     n, h, w, cin, cout, ks, what = case
     x, xf = q16(rnd(n, h, w, cin, seed=60), dtype)
     wt, wf = q16(rnd(cout, ks * ks * cin, seed=61) / (ks * ks * cin) ** 0.5, dtype)

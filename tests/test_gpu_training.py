@@ -285,12 +285,12 @@ def test_conv_data_gradients_through_the_forward_kernel(dtype):
         assert rel_l2(got.permute(0, 3, 1, 2).cpu(), xr.grad.cpu()) < 1e-5
 
 
-def _tiny_denoiser(dtype, precision):
+def _tiny_denoiser(dtype, precision, lora_rank=4):
     from conftest import build_tiny_oracle, golden
     from panfusion_amd.models.pano import MultiViewBaseModel
     g = golden("mvgen_tiny.npz")
     t = lambda k: torch.from_numpy(g[k])
-    oracle = build_tiny_oracle()
+    oracle = build_tiny_oracle(lora_rank=lora_rank)
     cams = {k: v[None] for k, v in cam4().items()}
     cams["theta"], cams["phi"] = cams["theta"] + 7.3, cams["phi"] + 3.1     # generic angles (see the C = 320 note above: PE up to 2^63 here)
     args = (t("latents")[:1], t("pano_latent")[:1], torch.full((1, 4), 981), t("prompt_embd")[:1], t("pano_prompt_embd")[:1], cams)
@@ -300,12 +300,14 @@ def _tiny_denoiser(dtype, precision):
     return oracle, hip, args
 
 
-@pytest.mark.parametrize("dtype,precision,tol_out,tol_grad", [(torch.float16, "mixed", 1e-3, 2e-3), (torch.bfloat16, "fast", 2e-2, 4e-2)])
-def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, tol_grad):
+@pytest.mark.parametrize("dtype,precision,tol_out,tol_grad,lora_rank", [(torch.float16, "mixed", 1e-3, 2e-3, 4), (torch.bfloat16, "fast", 2e-2, 4e-2, 4),
+                                                                        (torch.float16, "mixed", 1e-3, 2e-3, 8)])
+def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, tol_grad, lora_rank):
     """One training step of the dual-branch denoiser on the GPU (tiny widths, 4 views of 16^2, panorama 16x32, one sample) against
     torch autograd through the oracle denoiser on the CPU: the two outputs, and the gradient of an MSE-like loss with
-    respect to every EPA tensor and every LoRA matrix (603 tensors).  Gradients are compared per tensor and as one vector."""
-    oracle, hip, args = _tiny_denoiser(dtype, precision)
+    respect to every EPA tensor and every LoRA matrix (603 tensors).  Gradients are compared per tensor and as one vector.
+    lora_rank 8 (PanoGenerator.py:73 exposes the rank): a q / k / v group then stacks R = 24 rows, two chunks of pf_weighted_colsum."""
+    oracle, hip, args = _tiny_denoiser(dtype, precision, lora_rank)
     gen = torch.Generator().manual_seed(5)
     w_s, w_p = torch.randn(args[0].shape, generator=gen) * 1e-4, torch.randn(args[1].shape, generator=gen) * 1e-4
     s, ps = oracle(*args)
@@ -328,7 +330,7 @@ def test_denoiser_training_step_vs_oracle_autograd(dtype, precision, tol_out, to
 
 
 @pytest.mark.parametrize("dtype", D16)
-@pytest.mark.parametrize("N,K,r", [(320, 320, 4), (1280, 1024, 4), (640, 640, 16), (96, 200, 3), (320, 320, 0)])
+@pytest.mark.parametrize("N,K,r", [(320, 320, 4), (1280, 1024, 4), (640, 640, 16), (96, 200, 3), (320, 320, 0), (320, 1024, 8), (640, 640, 64)])
 def test_lora_fold_kernel(dtype, N, K, r):
     """pf_lora_fold: W + scale * up @ down in the operand type (bit-identical to torch's fp32 sum rounded once), written into a
     row slice of a packed weight, with its transpose and the 16-bit copies of down / up^T as by-products."""
@@ -351,7 +353,8 @@ def test_lora_fold_kernel(dtype, N, K, r):
 
 
 @pytest.mark.parametrize("dtype", D16)
-@pytest.mark.parametrize("T,Cc,R,ld_extra", [(20480, 320, 4, 0), (1024, 960, 12, 0), (2560, 2048, 8, 64), (78, 130, 16, 2), (8192, 3840, 12, 0)])
+@pytest.mark.parametrize("T,Cc,R,ld_extra", [(20480, 320, 4, 0), (1024, 960, 12, 0), (2560, 2048, 8, 64), (78, 130, 16, 2), (8192, 3840, 12, 0), (4096, 960, 24, 0),
+                                              (1000, 322, 36, 6)])
 def test_weighted_column_sums(dtype, T, Cc, R, ld_extra):
     """pf_weighted_colsum = w @ x in fp32 over token rows (the LoRA gradients' reductions), with the device / host scale, the
     per-pair transposed block layout, strided rows, and run-to-run bit-identity."""
@@ -370,6 +373,10 @@ def test_weighted_column_sums(dtype, T, Cc, R, ld_extra):
         flat = o.weighted_colsum(x, w, blocks=blocks)
         want = torch.cat([got[0:4, 0:64].t().reshape(-1), got[4:8, 64:].t().reshape(-1)])
         assert torch.equal(flat, want)
+    if R >= 24:                                                      # a block across the 16-row chunk boundary (rank 8: rows 8..16, 16..24)
+        blocks = [(8, 8, 0, 64), (16, 8, 64, Cc - 64)]
+        flat = o.weighted_colsum(x, w, blocks=blocks)
+        assert torch.equal(flat, torch.cat([got[8:16, 0:64].t().reshape(-1), got[16:24, 64:].t().reshape(-1)]))
 
 
 # ------------------------------------------------------------------------------------ the trainable ControlNet

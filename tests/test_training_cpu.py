@@ -158,11 +158,11 @@ def fake_denoiser_backend(monkeypatch):
         monkeypatch.setattr(importlib.import_module(name), "ops", fake_ops)
 
 
-def _denoiser_case(seed=0):
+def _denoiser_case(seed=0, lora_rank=4):
     from conftest import build_tiny_oracle, golden
     g = golden("mvgen_tiny.npz")
     t = lambda k: torch.from_numpy(g[k])
-    oracle = build_tiny_oracle()
+    oracle = build_tiny_oracle(lora_rank=lora_rank)
     cams = {k: v[None] for k, v in cam4().items()}
     args = (t("latents")[:1], t("pano_latent")[:1], torch.full((1, 4), 981), t("prompt_embd")[:1], t("pano_prompt_embd")[:1], cams)
     gen = torch.Generator().manual_seed(seed)
@@ -170,13 +170,14 @@ def _denoiser_case(seed=0):
     return oracle, args, w_s, w_p
 
 
-@pytest.mark.parametrize("precision", ["fast", "mixed"])
-def test_denoiser_training_step_matches_autograd(fake_denoiser_backend, precision):
+@pytest.mark.parametrize("precision,lora_rank", [("fast", 4), ("mixed", 4), ("mixed", 8)])
+def test_denoiser_training_step_matches_autograd(fake_denoiser_backend, precision, lora_rank):
     """One training step of the dual-branch denoiser (forward on the engine, backward on train_engine's tape) against torch
     autograd through the oracle denoiser (reference MultiViewBaseModel + EPA on the restated UNets with UNFUSED LoRA):
-    gradients of every EPA parameter and every LoRA matrix of both UNets.  fp32 test double: agreement at round-off."""
+    gradients of every EPA parameter and every LoRA matrix of both UNets.  fp32 test double: agreement at round-off.  lora_rank 8:
+    the stacked rank of a q / k / v group is 24 (more than one 16-row chunk of the column-sum kernel)."""
     from panfusion_amd.models.pano import MultiViewBaseModel
-    oracle, args, w_s, w_p = _denoiser_case()
+    oracle, args, w_s, w_p = _denoiser_case(lora_rank=lora_rank)
     s, ps = oracle(*args)
     ((s * w_s).sum() + (ps * w_p).sum()).backward()
     want = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None}
@@ -239,7 +240,8 @@ def test_denoiser_inference_is_untouched_by_the_training_switch(fake_denoiser_ba
 
 def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_backend):
     """After an optimizer step on the LoRA matrices the next forward must see W + up' @ down' (re-folded attention
-    projections, text K / V cache dropped) -- and nothing else is re-packed."""
+    projections; the cached text K / V^T recomputed INTO their buffers, which graphs captured earlier read by address) -- and nothing
+    else is re-packed."""
     from panfusion_amd.models.pano import MultiViewBaseModel
     oracle, args, w_s, w_p = _denoiser_case()
     hip = MultiViewBaseModel(oracle.unet, oracle.pano_unet, None, None, oracle.pano_pad, compute_dtype=torch.float32,
@@ -250,6 +252,10 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
     ((s0 * w_s).sum() + (ps0 * w_p).sum()).backward()
     pack_before = hip.packed("unet", args[1].device)
     res_before = pack_before.down[0].resnets[1].train       # (resnets[0] sits before the first LoRA-carrying layer: never walked)
+    with torch.no_grad():
+        hip(*args)                                        # an inference forward (validation, DenoiseLoop): caches the prompts' K / V^T
+    kv_before = {k: (hit, {i: (v[0].data_ptr(), v[0].clone()) for i, v in hit.items() if i != "text"})
+                 for k, hit in getattr(pack_before, "text_kv_cache", {}).items()}
     opt.step()                                            # oracle shares the UNet modules: it steps with it
     for name in ("cp_blocks_encoder", "cp_blocks_mid", "cp_blocks_decoder"):
         getattr(oracle, name).load_state_dict(getattr(hip, name).state_dict())
@@ -259,6 +265,14 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
     assert rel_l2(want_s, s0.detach()) > 1e-3                      # the step moved the outputs
     assert rel_l2(s1.detach(), want_s) < 5e-5 and rel_l2(ps1.detach(), want_ps) < 5e-5
     assert hip.packed("unet", args[1].device) is pack_before and pack_before.down[0].resnets[1].train is res_before
+    with torch.no_grad():
+        s2, ps2 = hip(*args)                              # served from the cache
+    assert rel_l2(s2, want_s) < 5e-5 and rel_l2(ps2, want_ps) < 5e-5
+    assert kv_before
+    for k, (hit, olds) in kv_before.items():                 # same entries, same storage, new contents
+        assert pack_before.text_kv_cache[k] is hit
+        for i, (ptr, old) in olds.items():
+            assert hit[i][0].data_ptr() == ptr and not torch.equal(hit[i][0], old)
 
 
 def test_training_step_with_layout_condition_frozen_controlnet(fake_denoiser_backend):
