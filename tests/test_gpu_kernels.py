@@ -581,7 +581,10 @@ def attn_ref(q, k, v, H, scale, bias=None):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 3, 64, 256, 256), (2, 2, 64, 200, 77), (1, 5, 64, 1024, 1024), (2, 4, 32, 128, 320), (1, 2, 32, 96, 50)])
+@pytest.mark.parametrize("cfg", [(2, 3, 64, 256, 256), (2, 2, 64, 200, 77), (1, 5, 64, 1024, 1024), (2, 4, 32, 128, 320), (1, 2, 32, 96, 50),
+                                 # the text cross-attention's shapes (77 keys: two key tiles, 51 masked keys) and other short key ranges
+                                 (3, 5, 64, 4096, 77), (1, 10, 64, 1024, 77), (2, 20, 64, 64, 77), (1, 2, 64, 40, 96), (1, 2, 64, 33, 1),
+                                 (1, 2, 64, 2080, 65), (1, 2, 64, 256, 97)])
 def test_attention(dtype, cfg):
     B, H, D, nq, nk = cfg
     Cq = H * D

@@ -14,6 +14,9 @@ SHAPES = {  # name: (B, H, D, nq, nk)
     "self16": (40, 20, 64, 256, 256),
     "pano64": (2, 5, 64, 8192, 8192),
     "text64": (40, 5, 64, 4096, 77),
+    "text32": (40, 10, 64, 1024, 77),
+    "text16": (40, 20, 64, 256, 77),
+    "textpano": (2, 5, 64, 8192, 77),
     "epa_e": (2, 20, 32, 2048, 20480),
     "epa_p": (2, 20, 32, 20480, 2048),
 }
@@ -47,7 +50,8 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / args.reps
         fl = 4.0 * B * H * nq * nk * D
-        print("%-8s B%-3d H%-3d D%-3d nq%-6d nk%-6d %9.1f us  %7.1f TF/s" % (name, B, H, D, nq, nk, us, fl / us / 1e6), flush=True)
+        gb = 2.0 * (2 * B * nq * C + B * nk * C + B * C * ld)          # q + out, k + vt: the bytes that must move once
+        print("%-8s B%-3d H%-3d D%-3d nq%-6d nk%-6d %9.1f us  %7.1f TF/s  %5.2f TB/s algorithmic" % (name, B, H, D, nq, nk, us, fl / us / 1e6, gb / us / 1e6), flush=True)
 
 
 if __name__ == "__main__":

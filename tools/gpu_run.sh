@@ -18,6 +18,7 @@
 #   gemm[:<shapes>] attn elem vae   kernel microbenchmarks (gemm: + --phases stamps with gemmphases[:shapes])
 #   train                      training-step benches (LoRA + EPA; layout-conditioned)
 #   sim[:"VAR=v"]              per-rank compute time of the sharded layouts on one GPU (tools/sim_rank.py)
+#   simprof[:"--world 8 --ranks 1"]  rocprofv3 per-kernel table of one simulated rank      -> <tag>_simprof_*.txt
 #   dist[:"2 4 8"]             functional dry run of the sharded path over gloo on one GPU (tools/gpu_dist_dry.sh)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -99,6 +100,11 @@ for SEC in "$@"; do
       timeout 400 python tools/train_bench.py --layout-cond --steps 3 2>&1 | q | tail -n 6 > gpurun_out/${TAG}_train_layout_cond.txt; head -n 1 gpurun_out/${TAG}_train_layout_cond.txt | cut -c1-300 ;;
     sim)
       { for W in "2 0" "4 0,1" "8 0,1"; do read SW SR <<< "$W"; env $ARG python tools/sim_rank.py --world $SW --ranks $SR $SIM_ARGS 2>&1 | grep "^world"; done; } | tee -a gpurun_out/${TAG}_sim_ranks.txt ;;
+    simprof)     # per-kernel table of ONE rank of a sharded layout (eager; 4 table-building + 1 warm-up + 3 timed passes)
+      cd /tmp
+      timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pf_sp -o t -- python $R/tools/sim_rank.py ${ARG:---world 8 --ranks 1} --steps 3 --warmup 1 --no-graphs > $R/gpurun_out/${TAG}_simprof.log 2>&1
+      python $R/tools/prof_summary.py trace $(find /tmp/pf_sp -name '*kernel_trace.csv' | head -1) $R/gpurun_out/${TAG}_simprof_$(slug "$ARG").txt 8
+      rm -rf /tmp/pf_sp; head -n 24 $R/gpurun_out/${TAG}_simprof_$(slug "$ARG").txt ;;
     dist)
       NS="${ARG:-2 4 8}" bash tools/gpu_dist_dry.sh 2>&1 | tee gpurun_out/${TAG}_dist_dry.txt ;;
     *) echo "unknown section $NAME" ;;

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--cfg4", action="store_true", help="BASELINE.json configs[3]: 128 x 256 panorama latent")
     ap.add_argument("--cfg5", action="store_true", help="BASELINE.json configs[4]: + panorama ControlNet on a layout image")
     ap.add_argument("--split", default=None, help="views per group, e.g. 0,7,7,6 (default: sharding.plan's choice for the configuration)")
+    ap.add_argument("--no-graphs", action="store_true", help="eager (for a rocprofv3 kernel trace: 4 + warmup + steps passes per rank)")
     ap.add_argument("--shapes", type=int, default=0, help="also print the N most expensive GEMM / attention shapes of one eager step of the rank")
     args = ap.parse_args()
     import bench
@@ -66,7 +67,7 @@ def main():
     for rank in [int(r) for r in args.ranks.split(",")]:
         fake_dist(args.world, rank)
         dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
-        model, loop = build(args.steps + args.warmup + 1, True)
+        model, loop = build(args.steps + args.warmup + 1, not args.no_graphs)
         loop.prepare()
         for _ in range(args.warmup):
             loop.step()
