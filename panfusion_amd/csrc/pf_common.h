@@ -109,6 +109,22 @@ template <> struct Mfma32<F16> {
     }
 };
 
+// value * gelu(gate), erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), arranged as  g Phi(g) = relu(g) - |g| h,  h = 0.5 P(t) exp(-g^2 / 2),
+// t = 1 / (1 + p |g| / sqrt 2): 12 plain VALU operations + rcp + exp2 per output (the straightforward 0.5 g (1 + erf(g / sqrt 2))
+// with copysign costs 20): the GEGLU epilogues are VALU-bound
+// (profiles/r4e_lws_pmc_kernel.txt: VALU busy 1.5 x MFMA busy).  Used by both GEMM kernels (pf_gemm.hip, pf_linear_ws.hip): transformer.py:8-21.
+__device__ __forceinline__ float geglu_value(float v, float g) {
+    const float ax = fabsf(g);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.23164189f, 1.0f));
+    float y = fmaf(t, 0.5307027145f, -0.7265760135f);
+    y = fmaf(y, t, 0.7107068705f);
+    y = fmaf(y, t, -0.142248368f);
+    y = fmaf(y, t, 0.127414796f);
+    y *= t;
+    const float h = y * __builtin_amdgcn_exp2f(-0.72134752044448170368f * (g * g));
+    return v * fmaf(-ax, h, fmaxf(g, 0.0f));
+}
+
 // Dispatch a 16-bit dtype id to a tag type.
 #define PF_DISPATCH_16(dtype, name, ...)                                         \
     do {                                                                         \

@@ -101,20 +101,6 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // in 16-bit elem
     return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one rcp, one exp2, five fma -- the
-// epilogue of the GEGLU projection evaluates it for every second accumulator.
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-    float y = 1.061405429f;
-    y = y * t - 1.453152027f;
-    y = y * t + 1.421413741f;
-    y = y * t - 0.284496736f;
-    y = y * t + 0.254829592f;
-    y = 1.0f - y * t * __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
-    return copysignf(y, x);
-}
-
 // Epilogue of one output row m, 4 consecutive columns n4..n4+3 (fp32 accumulators v): bias, per-image
 // row vector, residual, then either a plain 16-bit / fp32 store or the GEGLU pairing
 // (columns interleaved (value, gate): out[m][n4/2 + {0,1}] = value * gelu(gate), transformer.py:8-21).
@@ -144,7 +130,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const float g = v[2 * e + 1];
-            w2[e] = from_f32<T>(v[2 * e] * (0.5f * g * (1.0f + erf_as(g * 0.70710678118654752440f))));
+            w2[e] = from_f32<T>(geglu_value(v[2 * e], g));
         }
         *reinterpret_cast<u16x2*>(o) = w2;
     } else if (p.split_out) {
@@ -360,7 +346,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const float gt = v[2 * e + 1];
-                        w2[e] = from_f32<T>(v[2 * e] * (0.5f * gt * (1.0f + erf_as(gt * 0.70710678118654752440f))));
+                        w2[e] = from_f32<T>(geglu_value(v[2 * e], gt));
                     }
                     *reinterpret_cast<u16x2*>(smem16 + r * SLD + (c >> 1)) = w2;
                 } else {

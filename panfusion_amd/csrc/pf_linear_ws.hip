@@ -47,20 +47,6 @@ template <> struct LwsMfma<F16> {
     static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
-// value * gelu(gate), erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, as pf_gemm.hip), arranged as  g Phi(g) = relu(g) - |g| h,  h = 0.5 P(t) exp(-g^2 / 2),
-// t = 1 / (1 + p |g| / sqrt 2): 12 plain VALU operations + rcp + exp2 per output (the straightforward 0.5 g (1 + erf(g / sqrt 2))
-// with copysign costs 20): the GEGLU epilogue is VALU-bound (profiles/r4e_lws_pmc_kernel.txt: VALU busy 1.5 x MFMA busy).
-__device__ __forceinline__ float lws_geglu(float v, float g) {
-    const float ax = fabsf(g);
-    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.23164189f, 1.0f));
-    float y = fmaf(t, 0.5307027145f, -0.7265760135f);
-    y = fmaf(y, t, 0.7107068705f);
-    y = fmaf(y, t, -0.142248368f);
-    y = fmaf(y, t, 0.127414796f);
-    y *= t;
-    const float h = y * __builtin_amdgcn_exp2f(-0.72134752044448170368f * (g * g));
-    return v * fmaf(-ax, h, fmaxf(g, 0.0f));
-}
 
 constexpr int LWS_K = 320, LWS_KS = LWS_K / 32, LWS_KB = LWS_K / 64, LWS_BM = 64, LWS_STAGES = 3;
 constexpr int LWS_STAGE_ELEMS = LWS_BM * LWS_K;                   // 16-bit elements per ring slot (40 KB)
@@ -236,8 +222,8 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const unsigned lo = from_f32<T>(lws_geglu(acc[pb][j][0], acc[pb][j][1]));
-                    const unsigned hi = from_f32<T>(lws_geglu(acc[pb][j][2], acc[pb][j][3]));
+                    const unsigned lo = from_f32<T>(geglu_value(acc[pb][j][0], acc[pb][j][1]));
+                    const unsigned hi = from_f32<T>(geglu_value(acc[pb][j][2], acc[pb][j][3]));
                     *reinterpret_cast<unsigned*>(stg + (pb * 16 + frow) * RS + (j * 8 + (cq >> 1)) * 2) = lo | (hi << 16);
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
