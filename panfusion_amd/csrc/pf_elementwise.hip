@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void k_conv_in4(const float* __restrict__ x, i
 // conv_out: x NHWC 16-bit [n][h][w][cin] -> y fp32 NCHW [n][cout<=8][h][w]; weights fp32
 // [cout][3][3][cin].  LPP lanes per output pixel (the smallest power of two >= cin / 8, lanes over the channel octets of
 // each tap), 64 / LPP pixels per wavefront: at the VAE's 128 channels a whole wavefront per pixel left 48 of 64 lanes idle
-// (12.8 ms of a 107 ms decode in three launches, profiles/r3h_vae_kernels.txt).
+// (12.8 ms of a 107 ms decode in three launches, profiles/archive/r3h_vae_kernels.txt).
 template <typename TI, int LPP>
 __global__ void k_conv_out(const typename In8<TI>::elem* __restrict__ x, int n, int cin, int h, int w,
                            const float* __restrict__ wgt, const float* __restrict__ bias, int cout,

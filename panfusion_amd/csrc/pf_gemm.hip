@@ -174,7 +174,7 @@ __device__ __forceinline__ float row16_allreduce(float v) {
 // and pairs never straddle a group.  They are computed in a phase of their own BEFORE the block epilogue, column block by
 // column block, while nothing but the accumulators is live -- folded into the epilogue's own loops the 20 + 20 running sums
 // pushed the 8-wave kernel from 244 registers into scratch, and every reload drained the DMA queue of the next tile
-// (K loop + 15 %, epilogue x 1.8: profiles/r3c_gemm_gn.txt).  The phase re-reads the tile's residual (the epilogue proper
+// (K loop + 15 %, epilogue x 1.8: profiles/archive/r3c_gemm_gn.txt).  The phase re-reads the tile's residual (the epilogue proper
 // reads it again, from L2); bias and the image's time-embedding row are one float4 each per column block -- an image is
 // whole runs of gn_rows rows (gn_rows_for), so a wavefront's rows belong to ONE image.
 template <typename T, int MREP, int NREP, int RES>            // RES: 0 none, 1 fp32 residual, 2 16-bit residual
@@ -536,7 +536,7 @@ generic:
 // fp32 slab store of a split-K partial: WRITE-THROUGH (sc1) when the slabs are combined inside the launch -- the bytes leave
 // the XCD's L2 with the store itself, so publishing needs no agent-scope release fence (buffer_wbl2 writes back EVERY dirty
 // line of the L2, the concurrently running branch's outputs included: with one fence per K-slice workgroup the step lost
-// 4.4 ms, profiles/r3k_ab_splitk.txt).
+// 4.4 ms, profiles/archive/r3k_ab_splitk.txt).
 __device__ __forceinline__ void slab_store(const GemmParams& p, long elem, const f32x4& v) {
     if (p.tickets) {
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -1523,7 +1523,7 @@ static int gn_rows_for(const GemmParams& p, const GemmPlan& g, int batch) {
     if (batch != 1 || g.splits > 1 || g.m_split > 0 || p.geglu || p.split_out) return 0;
     // Layers with a residual are left to the consumer's statistics pass by default: the moment phase has to read the
     // residual tile a second time, which costs an HBM-bound layer as much as that pass saves (fp32-residual linear at
-    // 163840 x 320: 141 -> 171 us, the pass it replaces 42 us; VAE decode 107 -> 122 ms; profiles/r3d_gemm_gn.txt).
+    // 163840 x 320: 141 -> 171 us, the pass it replaces 42 us; VAE decode 107 -> 122 ms; profiles/archive/r3d_gemm_gn.txt).
     // Without a residual (resnet conv1 -> norm2, the up-sampling conv) the phase costs 2-3 us against a 25-40 us pass.
     if (p.residual && tuning("PF_GN_EPILOGUE_RES", 0) == 0) return 0;
     if (g.big && tuning("PF_GEMM8_WAVES", 8) == 4) return 0;       // (the one-wave-per-SIMD A/B instantiation has no moment variant)
@@ -1614,7 +1614,7 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     // In-launch combine: implemented, bit-identical (tests/test_gpu_kernels.py), and OFF by default -- it does not pay at these
     // tile sizes: the last-arriving workgroup reads splits x 164 KB of slabs through one CU (~65 GB/s per block cross-XCD,
     // MI355X_MICROARCH.md "handoff-payload") while the second kernel spreads the same reads over the whole chip: the step went
-    // 65.3 -> 67.8 ms with write-through slabs, -> 72.9 ms with a release fence per workgroup (profiles/r3k_ab_splitk.txt,
+    // 65.3 -> 67.8 ms with write-through slabs, -> 72.9 ms with a release fence per workgroup (profiles/archive/r3k_ab_splitk.txt,
     // r3l_ab_splitk.txt).  PF_SPLITK_INKERNEL=1 enables it for A/B.
     if (d->tickets && tuning("PF_SPLITK_INKERNEL", 0) && d->workspace_bytes < (1ULL << 32)) {      // (32-bit slab offsets)
         // enough zeroed counters for every (batch, tile) of the split launch?  (tile counts of split plans: <= 320 of the

@@ -11,7 +11,7 @@ between kernels; nothing here computes on the host.
 Two storage schemes (``precision``):
   * ``"fast"``  -- every activation 16-bit (bf16 / fp16), fp32 accumulation: the round-1 path.
   * ``"mixed"`` -- the scheme that meets north_star's 1e-3 rel-L2 with fp16 operands (error budget:
-    tools/precision_study.py, profiles/r2_precision_budget.txt).  MFMA operands stay 16-bit; the residual
+    tools/precision_study.py, profiles/archive/r2_precision_budget.txt).  MFMA operands stay 16-bit; the residual
     streams (block outputs, the token stream inside a transformer block, the shortcut) are fp32; and the few
     GEMMs that map the stream linearly onto itself -- resnet shortcut 1x1, proj_in, proj_out, the
     downsampling conv -- run as SPLIT-PRECISION GEMMs: A = A_hi + A_lo, W = W_hi + W_lo (16-bit each),

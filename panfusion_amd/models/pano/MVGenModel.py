@@ -283,7 +283,7 @@ class MultiViewBaseModel(nn.Module):
             if self._side is None:
                 # PF_PANO_PRIORITY=1: the panorama branch's stream gets HIGH priority.  Its ~1400 small kernels are the
                 # critical path at the deep levels (the view stream idles 3-4 ms per step at the joins there,
-                # profiles/r3f_streams.txt): with priority their workgroups take the first compute units that come free
+                # profiles/archive/r3f_streams.txt): with priority their workgroups take the first compute units that come free
                 # instead of queueing behind a whole round of the view branch's persistent GEMM blocks.
                 self._side = torch.cuda.Stream(dev, priority=-1 if os.environ.get("PF_PANO_PRIORITY", "0") == "1" else 0)
             side = self._side

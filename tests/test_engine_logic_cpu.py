@@ -48,7 +48,7 @@ def test_mixed_scheme_host_logic_and_emulated_error(fake_backend, oracle_model):
     """The mixed scheme's HOST logic (fp32 stream plumbing, [hi | lo] operands, [W_hi | W_hi | W_lo] weights, the
     kernel's two-source K walk) on the CPU test double: with fp32 "16-bit" types it is the oracle to round-off; with
     fp16 it emulates what the GPU path stores where and must sit under north_star's 1e-3 -- and well under the
-    all-16-bit scheme (profiles/r2_precision_budget.txt: 1.7e-3 -> 6.8e-4 at SD-2-base widths)."""
+    all-16-bit scheme (profiles/archive/r2_precision_budget.txt: 1.7e-3 -> 6.8e-4 at SD-2-base widths)."""
     g = golden("mvgen_tiny.npz")
     t = lambda k: torch.from_numpy(g[k])
     cams = {k: torch.stack([v, v]) for k, v in cam4().items()}

@@ -4,7 +4,7 @@ oracle and the golden fixtures generated from the reference's own MultiViewBaseM
 Stated tolerances (rel-L2 on the epsilon outputs, fp32 oracle as truth):
   * fp16 operands, MIXED scheme (fp32 residual streams + split-precision stream-path GEMMs; the default for
     fp16 and the benchmarked configuration): 1e-3 = north_star's bar (emulated on the oracle: 6.8e-4,
-    profiles/r2_precision_budget.txt)
+    profiles/archive/r2_precision_budget.txt)
   * bf16 storage / fp32 accumulate, FAST scheme (everything 16-bit): 3e-2 (8 significand bits; emulation 1.2e-2)
 Needs an MI355X: `-m gpu`."""
 import copy
