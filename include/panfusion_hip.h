@@ -308,10 +308,13 @@ pf_status pf_debug_gemm_profile(void* device_buffer, long capacity_blocks);
 pf_status pf_conv_gemm(const pf_conv_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Weight-stationary linear for the C = 320 token layers (K == 320, N a multiple of 320): the nn.Linear layers of the
- * finest level's transformer blocks and of the C = 320 EPA block (models/modules/transformer.py:57-74 to_q / to_k / to_v /
- * to_out, :8-38 GEGLU FeedForward; diffusers BasicTransformerBlock behind models/pano/MVGenModel.py:104-106).
- * A workgroup keeps 320 output channels of the weights in registers and streams 64-token tiles of `a` through LDS.
+ * Weight-stationary linear for the token layers of the two finest levels: the nn.Linear layers of their transformer blocks
+ * and EPA blocks (models/modules/transformer.py:57-74 to_q / to_k / to_v / to_out, :8-38 GEGLU FeedForward; diffusers
+ * BasicTransformerBlock behind models/pano/MVGenModel.py:104-106).  Two shapes:
+ *   K == 320, N a multiple of 320 (every mode): a workgroup keeps 320 output channels of the weights in registers and streams
+ *             64-token tiles of `a` through LDS;
+ *   K == 640, N a multiple of 256 (PF_LWS_16, PF_LWS_GEGLU: q | k and FF1 of the 32^2 level): 256 channels per workgroup,
+ *             32-token tiles.
  *   PF_LWS_16:    out 16-bit [M][out_ld]      = a w^T + bias
  *   PF_LWS_F32:   out fp32   [M][out_ld]      = a w^T + bias + residual (fp32 [M][res_ld] or NULL)
  *   PF_LWS_GEGLU: out 16-bit [M][out_ld], N/2 columns: w / bias rows interleaved (value_j, gate_j), out = value * gelu(gate)
@@ -321,7 +324,7 @@ pf_status pf_conv_gemm(const pf_conv_desc* desc, void* stream);
  *   PF_LWS_F32_LN: N == 320: PF_LWS_F32, and the LayerNorm of the result rides along (the norm2 / norm3 that follow the two
  *                 attention output projections of a BasicTransformerBlock): ln_out 16-bit [M][ln_ld] =
  *                 LayerNorm(out; ln_eps) * ln_gamma + ln_beta -- no separate pass over the stream tensor.
- * a 16-bit [M][a_ld]; w 16-bit [N][320]; bias fp32 [N] or NULL.  pf_linear_ws_supported: 1 if (M, N, K, mode) is served. */
+ * a 16-bit [M][a_ld]; w 16-bit [N][K]; bias fp32 [N] or NULL.  pf_linear_ws_supported: 1 if (M, N, K, mode) is served. */
 typedef struct {
     const void* a; int a_ld;
     const void* w;

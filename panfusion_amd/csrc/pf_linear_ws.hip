@@ -1,6 +1,7 @@
-// Weight-stationary linear layers for the C = 320 token stream of the finest UNet level (gfx950 / CDNA4).
+// Weight-stationary linear layers for the token streams of the two finest UNet levels (gfx950 / CDNA4).
 //
-//   out[m][n] = sum_k a[m][k] * w[n][k]  (+ bias[n]) (+ residual[m][n])        K = 320, N a multiple of 320
+//   out[m][n] = sum_k a[m][k] * w[n][k]  (+ bias[n]) (+ residual[m][n])        K = 320, N a multiple of 320   (64^2 level, every mode)
+//                                                                                K = 640, N a multiple of 256   (32^2 level: 16-bit and GEGLU outputs)
 //
 // Why a second GEMM structure: at K = 320 the tile kernel of pf_gemm.hip (256 x 160 tile, K loop of 5 steps) spends
 // 6.4 k clocks of a 32 k-clock tile in the matrix pipes (profiles/r4a_timeline.txt): 260 KB of operands per tile enter
@@ -34,6 +35,7 @@ struct LwsParams {
     const float* ln_gamma; const float* ln_beta; float ln_eps; unsigned short* ln_out; int ln_ld;   // mode LWS_F32_LN
     int M, N;
     int nblocks, splits_per_xcd, ntiles;
+    int flat_splits;              // > 0: block b -> (token range b / nblocks, channel block b % nblocks) without the XCD grouping
     unsigned a_bytes;
 };
 
@@ -48,8 +50,12 @@ template <> struct LwsMfma<F16> {
 };
 
 
-constexpr int LWS_K = 320, LWS_KS = LWS_K / 32, LWS_KB = LWS_K / 64, LWS_BM = 64, LWS_STAGES = 3;
-constexpr int LWS_STAGE_ELEMS = LWS_BM * LWS_K;                   // 16-bit elements per ring slot (40 KB)
+// Two shapes of the same kernel (K = reduction width, BM = tokens per ring slot, CHB = output channels per workgroup):
+//   K = 320: 64-token tiles, 320 channels per workgroup (4 waves x 48 + 4 x 32)      -- the 64^2 level
+//   K = 640: 32-token tiles, 256 channels per workgroup (8 waves x 32: the slab is 2 x 20 fragments = 160 registers) -- the 32^2 level
+// Either way a ring slot is 40 KB and a wavefront moves 5 one-KB pieces of it.
+constexpr int LWS_STAGES = 3, LWS_PIECES = 5;
+constexpr int LWS_STAGE_ELEMS = 64 * 320;                         // 16-bit elements per ring slot (40 KB) = BM * K for both shapes
 constexpr int LWS_STG_BYTES = 4096;                               // per-wave staging region (<= 48 channel rows x 80 B)
 enum { LWS_16 = 0, LWS_F32 = 1, LWS_GEGLU = 2, LWS_QKV = 3, LWS_F32_LN = 4 };
 constexpr int LWS_LN_BYTES = 2 * 8 * 32 * 8;                       // LayerNorm exchange: [half parity][wave][token] (mean, M2) fp32
@@ -57,21 +63,27 @@ constexpr int LWS_LN_BYTES = 2 * 8 * 32 * 8;                       // LayerNorm 
 // The body of one wavefront: NB output-channel sub-blocks of 16 (cb = first channel inside the 320-block).
 // Vector-memory operations a wavefront issues in the epilogues of ONE tile (stores only: a lower bound is what the counted wait
 // needs -- the compiler may add its own waits for the residual loads, it never removes an operation).
-template <int MODE, int NB> constexpr int lws_epilogue_ops() {
-    return MODE == LWS_F32 ? 4 * NB : MODE == LWS_F32_LN ? 6 * NB : MODE == LWS_GEGLU ? 2 * ((32 * NB + 63) / 64) : 2 * NB;
+template <int MODE, int NB, int BM> constexpr int lws_epilogue_ops() {
+    return (BM / 32) * (MODE == LWS_F32 ? 2 * NB : MODE == LWS_F32_LN ? 3 * NB : MODE == LWS_GEGLU ? (32 * NB + 63) / 64 : NB);
 }
 constexpr int lws_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }   // gfx9 s_waitcnt immediate: vmcnt(n) only
 
-template <typename T, int MODE, int NB, bool COUNTED>
+template <typename T, int MODE, int NB, bool COUNTED, int LWS_K, int LWS_BM, int CHB>
 __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* smem, unsigned char* stg, float2* lnx, int nblk, int cb,
                                          int t_lo, int t_hi, int wave, int lane) {
     typedef typename LwsMfma<T>::frag frag;
+    constexpr int LWS_KS = LWS_K / 32, LWS_KB = LWS_K / 64;
+    static_assert(LWS_BM * LWS_K == LWS_STAGE_ELEMS && LWS_KB * (LWS_BM / 8) == 8 * LWS_PIECES, "a ring slot is 40 KB = 8 waves x 5 pieces");
+    static_assert(MODE != LWS_F32_LN || CHB == 320, "the LayerNorm epilogue is written for the 48 / 32-channel wave split");
     const int frow = lane & 15, fchunk = lane >> 4, cq = 4 * fchunk;
-    const int n_base = nblk * 320 + cb;                           // first output channel of this wavefront
+    const int n_base = nblk * CHB + cb;                           // first output channel of this wavefront
 
-    // ---- DMA addressing (every wave moves rows [8 wave, 8 wave + 8) of each of the 5 K-block images of a tile)
-    const int chunk = lane & 7, lrow = wave * 8 + (lane >> 3);
-    const unsigned src_lane = static_cast<unsigned>(lrow * p.a_ld + ((chunk ^ ((lrow >> 1) & 7)) << 3)) * 2u;   // bytes
+    // ---- DMA addressing: a tile is KB images [BM rows][64 k] of 128-byte rows; a piece = 8 rows of one image.  Piece q = 5 wave + i of
+    // a wave is (K block, row group) = (q / (BM / 8), q % (BM / 8)): at BM = 64 rows [8 wave, 8 wave + 8) of each of the 5 K blocks.
+    constexpr int RG = LWS_BM / 8;
+    const int chunk = lane & 7;
+    auto piece_row = [&](int i) { return ((wave * LWS_PIECES + i) % RG) * 8 + (lane >> 3); };
+    auto piece_kb = [&](int i) { return (wave * LWS_PIECES + i) / RG; };
     auto uniform_ptr = [](const unsigned short* ptr) {
         const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
         const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
@@ -80,13 +92,17 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
     };
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.a), 0, __builtin_amdgcn_readfirstlane(p.a_bytes), 0x00020000);
     auto dma_tile = [&](int tile, int slot) {                     // rows past M: an offset beyond num_records reads as zero
-        unsigned short* dst = smem + slot * LWS_STAGE_ELEMS + wave * 8 * 64;
+        unsigned short* dst = smem + slot * LWS_STAGE_ELEMS;
         const int soff0 = __builtin_amdgcn_readfirstlane(tile * LWS_BM * p.a_ld * 2);
-        const unsigned voff = tile * LWS_BM + lrow < p.M ? src_lane : 0x80000000u;
 #pragma unroll
-        for (int kb = 0; kb < LWS_KB; ++kb)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + kb * LWS_BM * 64), 16,
+        for (int i = 0; i < LWS_PIECES; ++i) {
+            const int lrow = piece_row(i), kb = __builtin_amdgcn_readfirstlane(piece_kb(i));
+            const unsigned src_lane = static_cast<unsigned>(lrow * p.a_ld + ((chunk ^ ((lrow >> 1) & 7)) << 3)) * 2u;   // bytes
+            const unsigned voff = tile * LWS_BM + lrow < p.M ? src_lane : 0x80000000u;
+            const int rg8 = __builtin_amdgcn_readfirstlane(((wave * LWS_PIECES + i) % RG) * 8);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + kb * LWS_BM * 64 + rg8 * 64), 16,
                                                      voff, soff0 + kb * 128, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);                        // (program order of the vector-memory operations is what the counted wait counts)
     };
     if (t_lo < t_hi) dma_tile(t_lo, 0);
@@ -297,7 +313,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
         // The 5 DMA pieces of this tile were issued two tiles ago; younger than them are that tile's epilogue (E operations), the
         // next tile's 5 pieces and the previous tile's epilogue: a COUNTED wait leaves those 5 + 2 E in flight (the first two tiles
         // were drained before the loop).  COUNTED = false (PF_LWS_COUNTED=0): full drain, for A/B.
-        if constexpr (COUNTED) __builtin_amdgcn_s_waitcnt(lws_waitcnt_vm(LWS_KB + 2 * lws_epilogue_ops<MODE, NB>()));
+        if constexpr (COUNTED) __builtin_amdgcn_s_waitcnt(lws_waitcnt_vm(LWS_PIECES + 2 * lws_epilogue_ops<MODE, NB, LWS_BM>()));
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef PF_LWS_ABL_NOBAR   /* -DPF_LWS_ABL_*: timing-only ablation builds (wrong results), make -C panfusion_amd/csrc lws_ablate */
         __builtin_amdgcn_s_barrier();                             // tile landed (all waves' pieces); slot (tile + 2) % 3 no longer read
@@ -309,7 +325,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
         const unsigned short* As = smem + slot * LWS_STAGE_ELEMS;
         const int m_tile = tile * LWS_BM;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < LWS_BM / 32; ++half) {
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
@@ -356,46 +372,59 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
     }
 }
 
-template <typename T, int MODE, bool COUNTED>
+template <typename T, int MODE, bool COUNTED, int K>
 __global__ __launch_bounds__(512, 1) void k_linear_ws(const LwsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // block -> (token range, channel block): the channel blocks of one token range sit on one XCD (block b runs on XCD b % 8)
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int sl = idx / p.nblocks, nblk = idx - sl * p.nblocks;
-    if (sl >= p.splits_per_xcd) return;
-    const int s = xcd * p.splits_per_xcd + sl, S = 8 * p.splits_per_xcd;
+    // block -> (token range, channel block): the channel blocks of one token range sit on one XCD (block b runs on XCD b % 8) --
+    // unless that would leave too many CUs without a workgroup (20 channel blocks: 160 of 256), then plainly b -> (b / nblocks, b % nblocks)
+    int s, S, nblk;
+    if (p.flat_splits > 0) {
+        s = blockIdx.x / p.nblocks; nblk = blockIdx.x - s * p.nblocks; S = p.flat_splits;
+        if (s >= S) return;
+    } else {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int sl = idx / p.nblocks;
+        nblk = idx - sl * p.nblocks;
+        if (sl >= p.splits_per_xcd) return;
+        s = xcd * p.splits_per_xcd + sl; S = 8 * p.splits_per_xcd;
+    }
     const int t_lo = static_cast<int>(static_cast<long>(p.ntiles) * s / S), t_hi = static_cast<int>(static_cast<long>(p.ntiles) * (s + 1) / S);
     unsigned char* stg = reinterpret_cast<unsigned char*>(smem + LWS_STAGES * LWS_STAGE_ELEMS) + wave * LWS_STG_BYTES;
     float2* lnx = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(smem + LWS_STAGES * LWS_STAGE_ELEMS) + 8 * LWS_STG_BYTES);
-    // waves w and w + 4 share a SIMD: 48 + 32 channels each
-    if (wave < 4) lws_wave<T, MODE, 3, COUNTED>(p, smem, stg, lnx, nblk, wave * 48, t_lo, t_hi, wave, lane);
-    else lws_wave<T, MODE, 2, COUNTED>(p, smem, stg, lnx, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
+    if constexpr (K == 320) {                                     // waves w and w + 4 share a SIMD: 48 + 32 channels each
+        if (wave < 4) lws_wave<T, MODE, 3, COUNTED, 320, 64, 320>(p, smem, stg, lnx, nblk, wave * 48, t_lo, t_hi, wave, lane);
+        else lws_wave<T, MODE, 2, COUNTED, 320, 64, 320>(p, smem, stg, lnx, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
+    } else {                                                      // K = 640: 32 channels per wave (160 registers of weights)
+        lws_wave<T, MODE, 2, COUNTED, 640, 32, 256>(p, smem, stg, lnx, nblk, wave * 32, t_lo, t_hi, wave, lane);
+    }
 }
 
-template <typename T, int MODE, bool COUNTED>
+template <typename T, int MODE, bool COUNTED, int K>
 static pf_status lws_launch_c(const LwsParams& p, hipStream_t st) {
     const size_t smem = static_cast<size_t>(LWS_STAGES) * LWS_STAGE_ELEMS * 2 + 8 * LWS_STG_BYTES + LWS_LN_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ws<T, MODE, COUNTED>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ws<T, MODE, COUNTED, K>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_linear_ws<T, MODE, COUNTED>), dim3(256), dim3(512), smem, st, p);
+    hipLaunchKernelGGL((k_linear_ws<T, MODE, COUNTED, K>), dim3(256), dim3(512), smem, st, p);
     PF_CHECK_LAUNCH("pf_linear_ws");
     return PF_OK;
 }
-template <typename T, int MODE>
+template <typename T, int MODE, int K = 320>
 static pf_status lws_launch(const LwsParams& p, hipStream_t st) {
     static const bool counted = !(getenv("PF_LWS_COUNTED") && atoi(getenv("PF_LWS_COUNTED")) == 0);
-    return counted ? lws_launch_c<T, MODE, true>(p, st) : lws_launch_c<T, MODE, false>(p, st);
+    return counted ? lws_launch_c<T, MODE, true, K>(p, st) : lws_launch_c<T, MODE, false, K>(p, st);
 }
 
 }  // namespace pf
 
 extern "C" int pf_linear_ws_supported(long M, int N, int K, int mode) {
-    if (K != pf::LWS_K || N <= 0 || N % 320 != 0 || M < 64) return 0;
+    if (K == 640)                 // 256-channel workgroups; 16-bit and GEGLU outputs (FF1, q | k of the 32^2 level)
+        return N > 0 && N % 256 == 0 && N / 256 <= 32 && M >= 32 && (mode == PF_LWS_16 || mode == PF_LWS_GEGLU);
+    if (K != 320 || N <= 0 || N % 320 != 0 || M < 64) return 0;
     const int nb = N / 320;
     if (nb > 32) return 0;
     if (mode == PF_LWS_QKV && nb != 3) return 0;
@@ -407,7 +436,7 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     using namespace pf;
     PF_REQUIRE(d != nullptr, "pf_linear_ws: null descriptor");
     PF_REQUIRE(d->a && d->w && d->out, "pf_linear_ws: null operand");
-    PF_REQUIRE(pf_linear_ws_supported(d->M, d->N, d->K, d->mode), "pf_linear_ws: needs K == 320, N a multiple of 320 (<= 32 blocks; q|k|v: N == 960), M >= 64 (got M %ld N %d K %d mode %d)",
+    PF_REQUIRE(pf_linear_ws_supported(d->M, d->N, d->K, d->mode), "pf_linear_ws: needs K == 320, N a multiple of 320 (<= 32 blocks; q|k|v: N == 960), M >= 64 -- or K == 640, N a multiple of 256, 16-bit / GEGLU output (got M %ld N %d K %d mode %d)",
                static_cast<long>(d->M), d->N, d->K, d->mode);
     PF_REQUIRE(d->mode >= PF_LWS_16 && d->mode <= PF_LWS_F32_LN, "pf_linear_ws: unknown mode %d", d->mode);
     PF_REQUIRE(d->a_ld >= d->K && d->a_ld % 8 == 0 && aligned16(d->a) && aligned16(d->w) && aligned16(d->out), "pf_linear_ws: operands must be 16-byte aligned, a_ld a multiple of 8");
@@ -436,12 +465,18 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     p.out_vt = static_cast<unsigned short*>(d->out_vt); p.vt_ld = d->vt_ld; p.rows_per_batch = d->rows_per_batch; p.vt_bs = d->vt_bs;
     p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps; p.ln_out = static_cast<unsigned short*>(d->ln_out); p.ln_ld = d->ln_ld;
     p.M = d->M; p.N = d->N;
-    p.nblocks = d->N / 320;
+    const bool k640 = d->K == 640;
+    p.nblocks = d->N / (k640 ? 256 : 320);
     p.splits_per_xcd = 32 / p.nblocks;
-    p.ntiles = static_cast<int>(cdiv(d->M, LWS_BM));
+    p.flat_splits = 8 * p.splits_per_xcd * p.nblocks >= 200 ? 0 : 256 / p.nblocks;
+    p.ntiles = static_cast<int>(cdiv(d->M, k640 ? 32 : 64));
     p.a_bytes = static_cast<unsigned>(static_cast<long>(d->M) * d->a_ld * 2);
     hipStream_t st = as_stream(stream);
 #define PF_LWS_MODE(MODE) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, MODE>(p, st)))
+    if (k640) {
+        if (d->mode == PF_LWS_GEGLU) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_GEGLU, 640>(p, st)));
+        PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_16, 640>(p, st)));
+    }
     switch (d->mode) {
         case PF_LWS_16: PF_LWS_MODE(LWS_16);
         case PF_LWS_F32: PF_LWS_MODE(LWS_F32);

@@ -540,14 +540,21 @@ def gemm_workspace_bytes(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, k
 # ---- weight-stationary linear (pf_linear_ws): the C = 320 token layers
 LWS_16, LWS_F32, LWS_GEGLU, LWS_QKV, LWS_F32_LN = 0, 1, 2, 3, 4
 LINEAR_WS = os.environ.get("PF_LINEAR_WS", "1") != "0"          # A/B: 0 = every linear on the tile kernel (pf_conv_gemm)
+LINEAR_WS_K640 = os.environ.get("PF_LINEAR_WS_K640", "1") != "0"   # A/B: 0 = the K = 640 layers (32^2 level: FF1, q | k) stay on the tile kernel
 LINEAR_WS_MIN_ROWS = int(os.environ.get("PF_LINEAR_WS_MIN_ROWS", "8192"))   # fewer 64-token tiles than workgroups: the tile kernel
 
 
 def linear_ws_ok(rows, N, K, mode, x=None):
-    """Does pf_linear_ws serve this problem (K == 320, N a multiple of 320, enough token tiles to stream)?"""
-    if not LINEAR_WS or rows < LINEAR_WS_MIN_ROWS or K != 320 or N % 320:
+    """Does pf_linear_ws serve this problem?  K == 320 (N a multiple of 320, every mode) or K == 640 (N a multiple of 256, 16-bit and
+    GEGLU outputs), and enough token tiles to stream."""
+    if not LINEAR_WS or rows < LINEAR_WS_MIN_ROWS:
         return False
-    if N == 320 and rows < 4 * LINEAR_WS_MIN_ROWS:       # one channel block: 256 token ranges -- under 2 tiles each the tile kernel wins
+    if K == 640:
+        if not LINEAR_WS_K640 or N % 256 or mode not in (LWS_16, LWS_GEGLU):
+            return False
+    elif K != 320 or N % 320:
+        return False
+    elif N == 320 and rows < 4 * LINEAR_WS_MIN_ROWS:     # one channel block: 256 token ranges -- under 2 tiles each the tile kernel wins
         return False                                      # (M = 16384: 0.88 - 0.94 x; q | k | v and FF1 win from 8192 rows, profiles/r4_lws_notes.txt)
     if x is not None and (x.dtype not in (torch.float16, torch.bfloat16) or x.stride(-1) != 1 or x.stride(-2) % 8):
         return False
@@ -555,7 +562,7 @@ def linear_ws_ok(rows, N, K, mode, x=None):
 
 
 def linear_ws(x, w, mode, bias=None, residual=None, out=None, out_vt=None, rows_per_batch=0, ln=None):
-    """pf_linear_ws: x [rows, 320] 16-bit, w [N, 320].  mode LWS_16 -> [rows, N] 16-bit; LWS_F32 -> fp32 [rows, N] (+ fp32 residual);
+    """pf_linear_ws: x [rows, K] 16-bit, w [N, K] (K = 320; K = 640 for the 16-bit and GEGLU modes).  mode LWS_16 -> [rows, N] 16-bit; LWS_F32 -> fp32 [rows, N] (+ fp32 residual);
     LWS_GEGLU -> [rows, N/2]; LWS_QKV (N = 960) -> ((q | k) [rows, 640], V^T [rows / rows_per_batch, 320, rows_per_batch]);
     LWS_F32_LN (N = 320, ln = (gamma, beta, eps)) -> (fp32 [rows, 320], LayerNorm of it in 16 bit [rows, 320])."""
     rows, K = x.shape
@@ -614,14 +621,17 @@ def linear(x, w, bias=None, residual=None, out=None, out_dtype=None, geglu=False
     consumer's images must be whole runs, which groupnorm_scale_shift's entry point checks).
     The C = 320 layers with enough tokens go to the weight-stationary kernel (pf_linear_ws)."""
     rows, K = x.shape
-    if not (split_out or gn_stats) and x.dim() == 2 and linear_ws_ok(rows, w.shape[0], K, LWS_16, x) and w.is_contiguous():
+    if not (split_out or gn_stats) and x.dim() == 2 and w.is_contiguous():
         odt = out.dtype if out is not None else (out_dtype or (residual.dtype if residual is not None else x.dtype))
+        mode = None
         if geglu and residual is None and odt == x.dtype:
-            return linear_ws(x, w, LWS_GEGLU, bias=bias, out=out)
-        if not geglu and odt == torch.float32 and (residual is None or residual.dtype == torch.float32):
-            return linear_ws(x, w, LWS_F32, bias=bias, residual=residual, out=out)
-        if not geglu and residual is None and odt == x.dtype:
-            return linear_ws(x, w, LWS_16, bias=bias, out=out)
+            mode = LWS_GEGLU
+        elif not geglu and odt == torch.float32 and (residual is None or residual.dtype == torch.float32):
+            mode = LWS_F32
+        elif not geglu and residual is None and odt == x.dtype:
+            mode = LWS_16
+        if mode is not None and linear_ws_ok(rows, w.shape[0], K, mode, x):
+            return linear_ws(x, w, mode, bias=bias, residual=residual, out=out)
     return conv_gemm(x, w, w.shape[0], w_in=rows, bias=bias, residual=residual, out=out, out_dtype=out_dtype,
                      geglu=geglu, split_out=split_out, gn_stats=gn_stats)
 

@@ -374,6 +374,35 @@ def test_linear_ws_modes_vs_fp32(dtype, M):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [32 * 37 + 20, 32, 32 * 1300])
+def test_linear_ws_k640_vs_fp32(dtype, M):
+    """The K = 640 shape of pf_linear_ws (32-token tiles, 256 channels per workgroup: FF1 and q | k of the 32^2 level): 16-bit out at
+    N = 256 / 1280 (5 channel blocks: XCD-grouped grid) and GEGLU at N = 5120 (20 channel blocks: flat grid) -- ragged last tile, a
+    single tile, more tiles than workgroups; then through ops.linear as the engine routes it."""
+    o = ops()
+    K = 640
+    x, xf = q16(rnd(M, K, seed=160), dtype)
+    for N, seed in ((256, 161), (1280, 162), (5120, 163)):
+        w, wf = q16(rnd(N, K, seed=seed) / K ** 0.5, dtype)
+        b = rnd(N, seed=seed + 10)
+        want = xf @ wf.T + b
+        if N < 5120:
+            check("linear_ws K640 16-bit N%d" % N, o.linear_ws(x, w, o.LWS_16, bias=b.to(DEV)), want, TOL[dtype])
+            check("linear_ws K640 no bias N%d" % N, o.linear_ws(x, w, o.LWS_16), xf @ wf.T, TOL[dtype])
+        else:
+            wi, bi = o.interleave_geglu(w, b.to(DEV))
+            got = o.linear_ws(x, wi, o.LWS_GEGLU, bias=bi)
+            assert got.shape == (M, N // 2)
+            check("linear_ws K640 geglu", got, want[:, :N // 2] * F.gelu(want[:, N // 2:]), TOL[dtype])
+            routed = o.linear(x, wi, bias=bi, geglu=True)
+            if o.linear_ws_ok(M, N, K, o.LWS_GEGLU, x):
+                assert torch.equal(routed, got)
+            else:
+                check("routed geglu (tile kernel)", routed, want[:, :N // 2] * F.gelu(want[:, N // 2:]), TOL[dtype])
+    assert not o.linear_ws_ok(1 << 16, 640, K, o.LWS_16, x) and not o.linear_ws_ok(1 << 16, 1280, K, o.LWS_F32, x)   # N % 256, fp32 out: tile kernel
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M", [64 * 37 + 40, 64 * 600])
 def test_linear_ws_with_layernorm_epilogue(dtype, M):
     """PF_LWS_F32_LN: output projection + fp32 residual, and the LayerNorm of the result from the same launch (a row of 320

@@ -6,7 +6,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd /tmp
 rm -rf /tmp/mi1 /tmp/mi2
 PF_STREAMS=1 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/mi1 -o g -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-training-leg --no-graphs > $R/gpurun_out/${TAG}_mfma_instep_1.log 2>&1
@@ -28,8 +28,8 @@ def load(path):
     return [d[k] for k in order]
 a, b = load(sys.argv[1]), load(sys.argv[2])
 # the two runs issue the same dispatch sequence; keep the LAST denoiser pass (the instrumented eager step) = tail of both
-mf = [x for x in a if x["name"].startswith(("k_conv_gemm", "k_attention"))]
-gb = [x for x in b if x["name"].startswith(("k_conv_gemm", "k_attention"))]
+mf = [x for x in a if x["name"].startswith(MF)]
+gb = [x for x in b if x["name"].startswith(MF)]
 n = min(len(mf), len(gb))
 mf, gb = mf[-n:], gb[-n:]
 assert all(x["name"] == y["name"] for x, y in zip(mf, gb)), "dispatch sequences differ"
@@ -44,13 +44,15 @@ for x, y in zip(mf, gb):
 with open(sys.argv[3], "w") as fh:
     fh.write("MFMA-pipe utilisation inside the step (all dispatches of the last denoiser passes of `bench.py --steps 1 --no-graphs`, PF_STREAMS=1)\n")
     fh.write("%-44s %9s %12s %12s\n" % ("kernel", "launches", "MFMA busy %", "VALU busy %"))
-    tot_a = [0.0, 0.0]
+    tot_a, tot_g = [0.0, 0.0], [0.0, 0.0]
     for k, (m, c, v, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         fh.write("%-44s %9d %12.1f %12.1f\n" % (k, cnt, 100 * m / c, 100 * v / c))
-        if k.startswith("attention"):
-            tot_a[0] += m
-            tot_a[1] += c
+        tot = tot_a if k.startswith("attention") else tot_g
+        tot[0] += m
+        tot[1] += c
     if tot_a[1]:
         fh.write("attention, all launches, cycle-weighted: MFMA busy %.1f %%\n" % (100 * tot_a[0] / tot_a[1]))
+    if tot_g[1]:
+        fh.write("GEMM family (tile kernels + weight-stationary linear), all launches, cycle-weighted: MFMA busy %.1f %%\n" % (100 * tot_g[0] / tot_g[1]))
 print(open(sys.argv[3]).read())
 PY

@@ -74,7 +74,7 @@ for SEC in "$@"; do
         PF_STREAMS=1 timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pf_pmc_$C -o bench -- python $R/bench.py $ARG --steps 1 --warmup 0 $NOLEGS --no-graphs > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
         python $R/tools/prof_summary.py pmc $(find /tmp/pf_pmc_$C -name '*counter_collection.csv' | head -1) $R/gpurun_out/${TAG}${S:+_$S}_pmc_$C.txt
         rm -rf /tmp/pf_pmc_$C
-        grep -E "k_conv_gemm|k_attention|k_halo" $R/gpurun_out/${TAG}${S:+_$S}_pmc_$C.txt | cut -c1-200
+        grep -E "k_conv_gemm|k_linear_ws|k_attention" $R/gpurun_out/${TAG}${S:+_$S}_pmc_$C.txt | cut -c1-200
       done
       python $R/tools/prof_summary.py traffic $R/gpurun_out/${TAG}${S:+_$S}_pmc_FETCH_SIZE.txt $R/gpurun_out/${TAG}${S:+_$S}_pmc_WRITE_SIZE.txt $R/gpurun_out/${TAG}${S:+_$S}_traffic.json
       cat $R/gpurun_out/${TAG}${S:+_$S}_traffic.json | cut -c1-400 ;;
