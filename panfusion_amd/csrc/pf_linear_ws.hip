@@ -372,7 +372,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
     }
 }
 
-template <typename T, int MODE, bool COUNTED, int K>
+template <typename T, int MODE, bool COUNTED, int K, int CHB = (K == 320 ? 320 : 256)>
 __global__ __launch_bounds__(512, 1) void k_linear_ws(const LwsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -396,34 +396,39 @@ __global__ __launch_bounds__(512, 1) void k_linear_ws(const LwsParams p) {
     if constexpr (K == 320) {                                     // waves w and w + 4 share a SIMD: 48 + 32 channels each
         if (wave < 4) lws_wave<T, MODE, 3, COUNTED, 320, 64, 320>(p, smem, stg, lnx, nblk, wave * 48, t_lo, t_hi, wave, lane);
         else lws_wave<T, MODE, 2, COUNTED, 320, 64, 320>(p, smem, stg, lnx, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
-    } else {                                                      // K = 640: 32 channels per wave (160 registers of weights)
+    } else if constexpr (CHB == 256) {                            // K = 640: 32 channels per wave (160 registers of weights)
         lws_wave<T, MODE, 2, COUNTED, 640, 32, 256>(p, smem, stg, lnx, nblk, wave * 32, t_lo, t_hi, wave, lane);
+    } else {                                                      // K = 640, N a multiple of 128 only (to_q: N = 640): 16 channels per wave
+        lws_wave<T, MODE, 1, COUNTED, 640, 32, 128>(p, smem, stg, lnx, nblk, wave * 16, t_lo, t_hi, wave, lane);
     }
 }
 
-template <typename T, int MODE, bool COUNTED, int K>
+template <typename T, int MODE, bool COUNTED, int K, int CHB>
 static pf_status lws_launch_c(const LwsParams& p, hipStream_t st) {
     const size_t smem = static_cast<size_t>(LWS_STAGES) * LWS_STAGE_ELEMS * 2 + 8 * LWS_STG_BYTES + LWS_LN_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ws<T, MODE, COUNTED, K>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ws<T, MODE, COUNTED, K, CHB>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_linear_ws<T, MODE, COUNTED, K>), dim3(256), dim3(512), smem, st, p);
+    hipLaunchKernelGGL((k_linear_ws<T, MODE, COUNTED, K, CHB>), dim3(256), dim3(512), smem, st, p);
     PF_CHECK_LAUNCH("pf_linear_ws");
     return PF_OK;
 }
-template <typename T, int MODE, int K = 320>
+template <typename T, int MODE, int K = 320, int CHB = (K == 320 ? 320 : 256)>
 static pf_status lws_launch(const LwsParams& p, hipStream_t st) {
     static const bool counted = !(getenv("PF_LWS_COUNTED") && atoi(getenv("PF_LWS_COUNTED")) == 0);
-    return counted ? lws_launch_c<T, MODE, true, K>(p, st) : lws_launch_c<T, MODE, false, K>(p, st);
+    return counted ? lws_launch_c<T, MODE, true, K, CHB>(p, st) : lws_launch_c<T, MODE, false, K, CHB>(p, st);
 }
 
 }  // namespace pf
 
 extern "C" int pf_linear_ws_supported(long M, int N, int K, int mode) {
-    if (K == 640)                 // 256-channel workgroups; 16-bit and GEGLU outputs (FF1, q | k of the 32^2 level)
-        return N > 0 && N % 256 == 0 && N / 256 <= 32 && M >= 32 && (mode == PF_LWS_16 || mode == PF_LWS_GEGLU);
+    if (K == 640) {               // 256-channel workgroups: 16-bit and GEGLU outputs (FF1, q | k of the 32^2 level);
+        if (N <= 0 || M < 32) return 0;                                        // 128-channel workgroups: 16-bit output (to_q: N = 640).  (fp32 + residual
+        if (N % 256 == 0 && N / 256 <= 32 && (mode == PF_LWS_16 || mode == PF_LWS_GEGLU)) return 1;   // was built and measured: 98 vs 89 us for the tile kernel)
+        return N % 128 == 0 && N / 128 <= 32 && mode == PF_LWS_16;
+    }
     if (K != 320 || N <= 0 || N % 320 != 0 || M < 64) return 0;
     const int nb = N / 320;
     if (nb > 32) return 0;
@@ -436,7 +441,7 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     using namespace pf;
     PF_REQUIRE(d != nullptr, "pf_linear_ws: null descriptor");
     PF_REQUIRE(d->a && d->w && d->out, "pf_linear_ws: null operand");
-    PF_REQUIRE(pf_linear_ws_supported(d->M, d->N, d->K, d->mode), "pf_linear_ws: needs K == 320, N a multiple of 320 (<= 32 blocks; q|k|v: N == 960), M >= 64 -- or K == 640, N a multiple of 256, 16-bit / GEGLU output (got M %ld N %d K %d mode %d)",
+    PF_REQUIRE(pf_linear_ws_supported(d->M, d->N, d->K, d->mode), "pf_linear_ws: needs K == 320, N a multiple of 320 (<= 32 blocks; q|k|v: N == 960), M >= 64 -- or K == 640 with N a multiple of 256 (16-bit / GEGLU output) or of 128 (16-bit output) (got M %ld N %d K %d mode %d)",
                static_cast<long>(d->M), d->N, d->K, d->mode);
     PF_REQUIRE(d->mode >= PF_LWS_16 && d->mode <= PF_LWS_F32_LN, "pf_linear_ws: unknown mode %d", d->mode);
     PF_REQUIRE(d->a_ld >= d->K && d->a_ld % 8 == 0 && aligned16(d->a) && aligned16(d->w) && aligned16(d->out), "pf_linear_ws: operands must be 16-byte aligned, a_ld a multiple of 8");
@@ -466,13 +471,15 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps; p.ln_out = static_cast<unsigned short*>(d->ln_out); p.ln_ld = d->ln_ld;
     p.M = d->M; p.N = d->N;
     const bool k640 = d->K == 640;
-    p.nblocks = d->N / (k640 ? 256 : 320);
+    const bool chb128 = k640 && !(d->N % 256 == 0 && (d->mode == PF_LWS_16 || d->mode == PF_LWS_GEGLU));
+    p.nblocks = d->N / (chb128 ? 128 : k640 ? 256 : 320);
     p.splits_per_xcd = 32 / p.nblocks;
     p.flat_splits = 8 * p.splits_per_xcd * p.nblocks >= 200 ? 0 : 256 / p.nblocks;
     p.ntiles = static_cast<int>(cdiv(d->M, k640 ? 32 : 64));
     p.a_bytes = static_cast<unsigned>(static_cast<long>(d->M) * d->a_ld * 2);
     hipStream_t st = as_stream(stream);
 #define PF_LWS_MODE(MODE) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, MODE>(p, st)))
+    if (chb128) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_16, 640, 128>(p, st)));
     if (k640) {
         if (d->mode == PF_LWS_GEGLU) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_GEGLU, 640>(p, st)));
         PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_16, 640>(p, st)));

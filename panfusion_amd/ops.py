@@ -549,8 +549,8 @@ def linear_ws_ok(rows, N, K, mode, x=None):
     GEGLU outputs), and enough token tiles to stream."""
     if not LINEAR_WS or rows < LINEAR_WS_MIN_ROWS:
         return False
-    if K == 640:
-        if not LINEAR_WS_K640 or N % 256 or mode not in (LWS_16, LWS_GEGLU):
+    if K == 640:                  # 256-channel workgroups (16-bit, GEGLU) or 128-channel workgroups (16-bit: to_q, N = 640)
+        if not LINEAR_WS_K640 or not ((N % 256 == 0 and mode in (LWS_16, LWS_GEGLU)) or (N % 128 == 0 and mode == LWS_16)):
             return False
     elif K != 320 or N % 320:
         return False

@@ -399,7 +399,15 @@ def test_linear_ws_k640_vs_fp32(dtype, M):
                 assert torch.equal(routed, got)
             else:
                 check("routed geglu (tile kernel)", routed, want[:, :N // 2] * F.gelu(want[:, N // 2:]), TOL[dtype])
-    assert not o.linear_ws_ok(1 << 16, 640, K, o.LWS_16, x) and not o.linear_ws_ok(1 << 16, 1280, K, o.LWS_F32, x)   # N % 256, fp32 out: tile kernel
+    # N = 640 (to_q of the 32^2 level): 128-channel workgroups, 16-bit output
+    w, wf = q16(rnd(640, K, seed=170) / K ** 0.5, dtype)
+    b = rnd(640, seed=171)
+    want = xf @ wf.T + b
+    got = o.linear_ws(x, w, o.LWS_16, bias=b.to(DEV))
+    check("linear_ws K640 N640 16-bit", got, want, TOL[dtype])
+    if o.linear_ws_ok(M, 640, K, o.LWS_16, x):
+        assert torch.equal(o.linear(x, w, bias=b.to(DEV)), got)
+    assert not o.linear_ws_ok(1 << 16, 640, K, o.LWS_F32, x) and not o.linear_ws_ok(1 << 16, 320, K, o.LWS_16, x)   # fp32 + residual at N = 640, N % 128: tile kernel
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -58,13 +58,17 @@ def main():
     # the K = 640 shape (32^2 level: 40 views x 1024 tokens)
     M, K = args.rows // 4, 640
     x = torch.randn(M, K, device=dev, generator=g).to(T)
-    for name, N in (("q|k K640", 1280), ("FF1 GEGLU K640", 5120)):
+    res = torch.randn(M, 640, device=dev, generator=g)
+    for name, N in (("q|k K640", 1280), ("FF1 GEGLU K640", 5120), ("q K640", 640)):
         w = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(T)
         b = torch.randn(N, device=dev, generator=g)
         fl = 2.0 * M * N * K
         if name.startswith("FF1"):
             new = lambda: ops.linear_ws(x, w, ops.LWS_GEGLU, bias=b)
             old = lambda: ops.conv_gemm(x, w, N, w_in=M, bias=b, geglu=True)
+        elif name.startswith("out-proj"):
+            new = lambda: ops.linear_ws(x, w, ops.LWS_F32, bias=b, residual=res)
+            old = lambda: ops.conv_gemm(x, w, N, w_in=M, bias=b, residual=res)
         else:
             new = lambda: ops.linear_ws(x, w, ops.LWS_16, bias=b)
             old = lambda: ops.conv_gemm(x, w, N, w_in=M, bias=b)
