@@ -28,6 +28,7 @@ def load(path):
     return [d[k] for k in order]
 a, b = load(sys.argv[1]), load(sys.argv[2])
 # the two runs issue the same dispatch sequence; keep the LAST denoiser pass (the instrumented eager step) = tail of both
+MF = ("k_conv_gemm", "k_linear_ws", "k_attention")
 mf = [x for x in a if x["name"].startswith(MF)]
 gb = [x for x in b if x["name"].startswith(MF)]
 n = min(len(mf), len(gb))
