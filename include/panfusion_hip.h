@@ -314,7 +314,8 @@ pf_status pf_conv_gemm(const pf_conv_desc* desc, void* stream);
  *   K == 320, N a multiple of 320 (every mode): a workgroup keeps 320 output channels of the weights in registers and streams
  *             64-token tiles of `a` through LDS;
  *   K == 640, N a multiple of 256 (PF_LWS_16, PF_LWS_GEGLU: q | k and FF1 of the 32^2 level): 256 channels per workgroup,
- *             32-token tiles; N a multiple of 128 only (PF_LWS_16: to_q, N = 640): 128 channels per workgroup.
+ *             32-token tiles; N a multiple of 128 only (PF_LWS_16: to_q, N = 640): 128 channels per workgroup;
+ *   K == 1280, N a multiple of 128 (PF_LWS_16, PF_LWS_GEGLU: the 16^2 level): 128 channels per workgroup, 16-token tiles.
  *   PF_LWS_16:    out 16-bit [M][out_ld]      = a w^T + bias
  *   PF_LWS_F32:   out fp32   [M][out_ld]      = a w^T + bias + residual (fp32 [M][res_ld] or NULL)
  *   PF_LWS_GEGLU: out 16-bit [M][out_ld], N/2 columns: w / bias rows interleaved (value_j, gate_j), out = value * gelu(gate)

@@ -1,7 +1,8 @@
 // Weight-stationary linear layers for the token streams of the two finest UNet levels (gfx950 / CDNA4).
 //
 //   out[m][n] = sum_k a[m][k] * w[n][k]  (+ bias[n]) (+ residual[m][n])        K = 320, N a multiple of 320   (64^2 level, every mode)
-//                                                                                K = 640, N a multiple of 256   (32^2 level: 16-bit and GEGLU outputs)
+//                                                                                K = 640, N a multiple of 256   (32^2 level: 16-bit and GEGLU outputs; of 128: 16-bit)
+//                                                                                K = 1280, N a multiple of 128  (16^2 level: 16-bit and GEGLU outputs)
 //
 // Why a second GEMM structure: at K = 320 the tile kernel of pf_gemm.hip (256 x 160 tile, K loop of 5 steps) spends
 // 6.4 k clocks of a 32 k-clock tile in the matrix pipes (profiles/r4a_timeline.txt): 260 KB of operands per tile enter
@@ -22,6 +23,7 @@
 // models/modules/transformer.py:57-74 (to_q / to_k / to_v / to_out), :8-38 (GEGLU FeedForward) at C = 320.
 #include "pf_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace pf {
 
@@ -53,6 +55,7 @@ template <> struct LwsMfma<F16> {
 // Two shapes of the same kernel (K = reduction width, BM = tokens per ring slot, CHB = output channels per workgroup):
 //   K = 320: 64-token tiles, 320 channels per workgroup (4 waves x 48 + 4 x 32)      -- the 64^2 level
 //   K = 640: 32-token tiles, 256 channels per workgroup (8 waves x 32: the slab is 2 x 20 fragments = 160 registers) -- the 32^2 level
+//   K = 1280: 16-token tiles, 128 channels per workgroup (8 waves x 16: 1 x 40 fragments)                            -- the 16^2 level
 // Either way a ring slot is 40 KB and a wavefront moves 5 one-KB pieces of it.
 constexpr int LWS_STAGES = 3, LWS_PIECES = 5;
 constexpr int LWS_STAGE_ELEMS = 64 * 320;                         // 16-bit elements per ring slot (40 KB) = BM * K for both shapes
@@ -64,7 +67,8 @@ constexpr int LWS_LN_BYTES = 2 * 8 * 32 * 8;                       // LayerNorm 
 // Vector-memory operations a wavefront issues in the epilogues of ONE tile (stores only: a lower bound is what the counted wait
 // needs -- the compiler may add its own waits for the residual loads, it never removes an operation).
 template <int MODE, int NB, int BM> constexpr int lws_epilogue_ops() {
-    return (BM / 32) * (MODE == LWS_F32 ? 2 * NB : MODE == LWS_F32_LN ? 3 * NB : MODE == LWS_GEGLU ? (32 * NB + 63) / 64 : NB);
+    constexpr int PB = BM >= 32 ? 2 : 1, HALVES = BM >= 32 ? BM / 32 : 1;      // 16-token blocks per epilogue slice, slices per tile
+    return HALVES * (MODE == LWS_F32 ? PB * NB : MODE == LWS_F32_LN ? 3 * NB : MODE == LWS_GEGLU ? (16 * PB * NB + 63) / 64 : (PB * NB + 1) / 2);
 }
 constexpr int lws_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }   // gfx9 s_waitcnt immediate: vmcnt(n) only
 
@@ -75,6 +79,8 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
     constexpr int LWS_KS = LWS_K / 32, LWS_KB = LWS_K / 64;
     static_assert(LWS_BM * LWS_K == LWS_STAGE_ELEMS && LWS_KB * (LWS_BM / 8) == 8 * LWS_PIECES, "a ring slot is 40 KB = 8 waves x 5 pieces");
     static_assert(MODE != LWS_F32_LN || CHB == 320, "the LayerNorm epilogue is written for the 48 / 32-channel wave split");
+    constexpr int PB = LWS_BM >= 32 ? 2 : 1, HALVES = LWS_BM >= 32 ? LWS_BM / 32 : 1;   // an epilogue slice = PB blocks of 16 tokens
+    static_assert(PB == 2 || MODE == LWS_16 || MODE == LWS_GEGLU || MODE == LWS_F32, "16-token tiles: plain and GEGLU outputs only");
     const int frow = lane & 15, fchunk = lane >> 4, cq = 4 * fchunk;
     const int n_base = nblk * CHB + cb;                           // first output channel of this wavefront
 
@@ -128,7 +134,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
     auto epilogue = [&](f32x4 (&acc)[2][NB], int m_half) {
 #ifdef PF_LWS_ABL_NOEPI
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
+        for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
             for (int j = 0; j < NB; ++j) asm volatile("" :: "v"(acc[pb][j]));
         return;
@@ -217,7 +223,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
             const float* rp = p.residual;
             float* op = static_cast<float*>(p.out);
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
+            for (int pb = 0; pb < PB; ++pb) {
                 const int m = m_half + pb * 16 + frow;
                 const long mc = m < p.M ? m : p.M - 1;
                 float4 r[NB];
@@ -235,7 +241,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
             // wave kinds (a 32-byte row stride puts rows r, r + 4, ... on the same banks)
             constexpr int RS = 48;
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
+            for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const unsigned lo = from_f32<T>(geglu_value(acc[pb][j][0], acc[pb][j][1]));
@@ -246,9 +252,9 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
             unsigned short* op = static_cast<unsigned short*>(p.out);
             const int ncol = (n_base >> 1);
 #pragma unroll
-            for (int i = 0; i < (32 * NB + 63) / 64; ++i) {
+            for (int i = 0; i < (16 * PB * NB + 63) / 64; ++i) {
                 const int q = i * 64 + lane, row = q / NB, cc = q - row * NB;
-                if (q < 32 * NB) {
+                if (q < 16 * PB * NB) {
                     const u16x8 x = *reinterpret_cast<const u16x8*>(stg + row * RS + cc * 16);
                     const int m = m_half + row;
                     if (m < p.M) *reinterpret_cast<u16x8*>(op + static_cast<long>(m) * p.out_ld + ncol + cc * 8) = x;
@@ -281,7 +287,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
             // leaves as 16-byte chunks
             constexpr int RS = NB * 32 + 16;
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
+            for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     u16x4 w4;
@@ -292,11 +298,13 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             unsigned short* op = static_cast<unsigned short*>(p.out);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {                         // 32 rows x 2 NB chunks = NB x 64 lanes
+            for (int i = 0; i < (PB * NB + 1) / 2; ++i) {          // 16 PB rows x 2 NB chunks = PB NB x 32 lanes
                 const int q = i * 64 + lane, row = q / (2 * NB), cc = q - row * 2 * NB;
-                const u16x8 x = *reinterpret_cast<const u16x8*>(stg + row * RS + cc * 16);
-                const int m = m_half + row;
-                if (m < p.M) *reinterpret_cast<u16x8*>(op + static_cast<long>(m) * p.out_ld + n_base + cc * 8) = x;
+                if (q < 16 * PB * 2 * NB) {
+                    const u16x8 x = *reinterpret_cast<const u16x8*>(stg + row * RS + cc * 16);
+                    const int m = m_half + row;
+                    if (m < p.M) *reinterpret_cast<u16x8*>(op + static_cast<long>(m) * p.out_ld + n_base + cc * 8) = x;
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -325,9 +333,9 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
         const unsigned short* As = smem + slot * LWS_STAGE_ELEMS;
         const int m_tile = tile * LWS_BM;
 #pragma unroll
-        for (int half = 0; half < LWS_BM / 32; ++half) {
+        for (int half = 0; half < HALVES; ++half) {
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
+            for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) acc[pb][j] = f32x4{bias[j].x, bias[j].y, bias[j].z, bias[j].w};
             // activation fragments: tokens half*32 + pb*16 + frow, K slab ks = (K block ks >> 1, 32-k half ks & 1)
@@ -350,7 +358,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                    for (int pb = 0; pb < 2; ++pb) af[buf][h2][pb] = afrag(pb, 2 * st + h2);
+                    for (int pb = 0; pb < PB; ++pb) af[buf][h2][pb] = afrag(pb, 2 * st + h2);
             };
             load_step(0, 0);
 #pragma unroll
@@ -362,7 +370,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
 #pragma unroll
-                        for (int pb = 0; pb < 2; ++pb)
+                        for (int pb = 0; pb < PB; ++pb)
                             acc[pb][j] = LwsMfma<T>::run(wf[j][2 * st + h2], af[st & 1][h2][pb], acc[pb][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -372,7 +380,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
     }
 }
 
-template <typename T, int MODE, bool COUNTED, int K, int CHB = (K == 320 ? 320 : 256)>
+template <typename T, int MODE, bool COUNTED, int K, int CHB = (K == 320 ? 320 : K == 640 ? 256 : 128)>
 __global__ __launch_bounds__(512, 1) void k_linear_ws(const LwsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -396,6 +404,8 @@ __global__ __launch_bounds__(512, 1) void k_linear_ws(const LwsParams p) {
     if constexpr (K == 320) {                                     // waves w and w + 4 share a SIMD: 48 + 32 channels each
         if (wave < 4) lws_wave<T, MODE, 3, COUNTED, 320, 64, 320>(p, smem, stg, lnx, nblk, wave * 48, t_lo, t_hi, wave, lane);
         else lws_wave<T, MODE, 2, COUNTED, 320, 64, 320>(p, smem, stg, lnx, nblk, 192 + (wave - 4) * 32, t_lo, t_hi, wave, lane);
+    } else if constexpr (K == 1280) {                             // 16-token tiles, 16 channels per wave (1 x 40 fragments = 160 registers)
+        lws_wave<T, MODE, 1, COUNTED, 1280, 16, 128>(p, smem, stg, lnx, nblk, wave * 16, t_lo, t_hi, wave, lane);
     } else if constexpr (CHB == 256) {                            // K = 640: 32 channels per wave (160 registers of weights)
         lws_wave<T, MODE, 2, COUNTED, 640, 32, 256>(p, smem, stg, lnx, nblk, wave * 32, t_lo, t_hi, wave, lane);
     } else {                                                      // K = 640, N a multiple of 128 only (to_q: N = 640): 16 channels per wave
@@ -415,7 +425,7 @@ static pf_status lws_launch_c(const LwsParams& p, hipStream_t st) {
     PF_CHECK_LAUNCH("pf_linear_ws");
     return PF_OK;
 }
-template <typename T, int MODE, int K = 320, int CHB = (K == 320 ? 320 : 256)>
+template <typename T, int MODE, int K = 320, int CHB = (K == 320 ? 320 : K == 640 ? 256 : 128)>
 static pf_status lws_launch(const LwsParams& p, hipStream_t st) {
     static const bool counted = !(getenv("PF_LWS_COUNTED") && atoi(getenv("PF_LWS_COUNTED")) == 0);
     return counted ? lws_launch_c<T, MODE, true, K, CHB>(p, st) : lws_launch_c<T, MODE, false, K, CHB>(p, st);
@@ -429,6 +439,8 @@ extern "C" int pf_linear_ws_supported(long M, int N, int K, int mode) {
         if (N % 256 == 0 && N / 256 <= 32 && (mode == PF_LWS_16 || mode == PF_LWS_GEGLU)) return 1;   // was built and measured: 98 vs 89 us for the tile kernel)
         return N % 128 == 0 && N / 128 <= 32 && mode == PF_LWS_16;
     }
+    if (K == 1280)                // 16-token tiles, 128-channel workgroups: 16-bit and GEGLU outputs (q | k, to_q, FF1 of the 16^2 level)
+        return N > 0 && N % 128 == 0 && N / 128 <= 128 && M >= 16 && (mode == PF_LWS_16 || mode == PF_LWS_GEGLU);
     if (K != 320 || N <= 0 || N % 320 != 0 || M < 64) return 0;
     const int nb = N / 320;
     if (nb > 32) return 0;
@@ -441,7 +453,7 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     using namespace pf;
     PF_REQUIRE(d != nullptr, "pf_linear_ws: null descriptor");
     PF_REQUIRE(d->a && d->w && d->out, "pf_linear_ws: null operand");
-    PF_REQUIRE(pf_linear_ws_supported(d->M, d->N, d->K, d->mode), "pf_linear_ws: needs K == 320, N a multiple of 320 (<= 32 blocks; q|k|v: N == 960), M >= 64 -- or K == 640 with N a multiple of 256 (16-bit / GEGLU output) or of 128 (16-bit output) (got M %ld N %d K %d mode %d)",
+    PF_REQUIRE(pf_linear_ws_supported(d->M, d->N, d->K, d->mode), "pf_linear_ws: needs K == 320, N a multiple of 320 (<= 32 blocks; q|k|v: N == 960), M >= 64 -- or K == 640 with N a multiple of 256 (16-bit / GEGLU output) or of 128 (16-bit output), or K == 1280 with N a multiple of 128 (16-bit / GEGLU output) (got M %ld N %d K %d mode %d)",
                static_cast<long>(d->M), d->N, d->K, d->mode);
     PF_REQUIRE(d->mode >= PF_LWS_16 && d->mode <= PF_LWS_F32_LN, "pf_linear_ws: unknown mode %d", d->mode);
     PF_REQUIRE(d->a_ld >= d->K && d->a_ld % 8 == 0 && aligned16(d->a) && aligned16(d->w) && aligned16(d->out), "pf_linear_ws: operands must be 16-byte aligned, a_ld a multiple of 8");
@@ -470,15 +482,19 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     p.out_vt = static_cast<unsigned short*>(d->out_vt); p.vt_ld = d->vt_ld; p.rows_per_batch = d->rows_per_batch; p.vt_bs = d->vt_bs;
     p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps; p.ln_out = static_cast<unsigned short*>(d->ln_out); p.ln_ld = d->ln_ld;
     p.M = d->M; p.N = d->N;
-    const bool k640 = d->K == 640;
+    const bool k640 = d->K == 640, k1280 = d->K == 1280;
     const bool chb128 = k640 && !(d->N % 256 == 0 && (d->mode == PF_LWS_16 || d->mode == PF_LWS_GEGLU));
-    p.nblocks = d->N / (chb128 ? 128 : k640 ? 256 : 320);
+    p.nblocks = d->N / (chb128 || k1280 ? 128 : k640 ? 256 : 320);
     p.splits_per_xcd = 32 / p.nblocks;
-    p.flat_splits = 8 * p.splits_per_xcd * p.nblocks >= 200 ? 0 : 256 / p.nblocks;
-    p.ntiles = static_cast<int>(cdiv(d->M, k640 ? 32 : 64));
+    p.flat_splits = 8 * p.splits_per_xcd * p.nblocks >= 200 ? 0 : std::max(1, 256 / p.nblocks);
+    p.ntiles = static_cast<int>(cdiv(d->M, k1280 ? 16 : k640 ? 32 : 64));
     p.a_bytes = static_cast<unsigned>(static_cast<long>(d->M) * d->a_ld * 2);
     hipStream_t st = as_stream(stream);
 #define PF_LWS_MODE(MODE) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, MODE>(p, st)))
+    if (k1280) {
+        if (d->mode == PF_LWS_GEGLU) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_GEGLU, 1280>(p, st)));
+        PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_16, 1280>(p, st)));
+    }
     if (chb128) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_16, 640, 128>(p, st)));
     if (k640) {
         if (d->mode == PF_LWS_GEGLU) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_GEGLU, 640>(p, st)));

@@ -541,16 +541,20 @@ def gemm_workspace_bytes(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, k
 LWS_16, LWS_F32, LWS_GEGLU, LWS_QKV, LWS_F32_LN = 0, 1, 2, 3, 4
 LINEAR_WS = os.environ.get("PF_LINEAR_WS", "1") != "0"          # A/B: 0 = every linear on the tile kernel (pf_conv_gemm)
 LINEAR_WS_K640 = os.environ.get("PF_LINEAR_WS_K640", "1") != "0"   # A/B: 0 = the K = 640 layers (32^2 level: FF1, q | k) stay on the tile kernel
+LINEAR_WS_K1280 = os.environ.get("PF_LINEAR_WS_K1280", "1") != "0"  # A/B: 0 = the K = 1280 layers (16^2 level: FF1, q | k, to_q) stay on the tile kernel
 LINEAR_WS_MIN_ROWS = int(os.environ.get("PF_LINEAR_WS_MIN_ROWS", "8192"))   # fewer 64-token tiles than workgroups: the tile kernel
 
 
 def linear_ws_ok(rows, N, K, mode, x=None):
-    """Does pf_linear_ws serve this problem?  K == 320 (N a multiple of 320, every mode) or K == 640 (N a multiple of 256, 16-bit and
-    GEGLU outputs), and enough token tiles to stream."""
+    """Does pf_linear_ws serve this problem?  K == 320 (N a multiple of 320, every mode), K == 640 (N a multiple of 256: 16-bit and GEGLU
+    outputs; of 128: 16-bit) or K == 1280 (N a multiple of 128: 16-bit and GEGLU), and enough token tiles to stream."""
     if not LINEAR_WS or rows < LINEAR_WS_MIN_ROWS:
         return False
     if K == 640:                  # 256-channel workgroups (16-bit, GEGLU) or 128-channel workgroups (16-bit: to_q, N = 640)
         if not LINEAR_WS_K640 or not ((N % 256 == 0 and mode in (LWS_16, LWS_GEGLU)) or (N % 128 == 0 and mode == LWS_16)):
+            return False
+    elif K == 1280:               # 16^2 level: 128-channel workgroups, 16-token tiles (16-bit, GEGLU)
+        if not LINEAR_WS_K1280 or N % 128 or mode not in (LWS_16, LWS_GEGLU):
             return False
     elif K != 320 or N % 320:
         return False

@@ -411,6 +411,31 @@ def test_linear_ws_k640_vs_fp32(dtype, M):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [16 * 37 + 9, 16, 10240])
+def test_linear_ws_k1280_vs_fp32(dtype, M):
+    """The K = 1280 shape of pf_linear_ws (16-token tiles, 16 channels per wavefront, 128 per workgroup: q | k, to_q and FF1 of the
+    16^2 level): 16-bit out at N = 128 / 1280 / 2560 and GEGLU at N = 10240 (80 channel blocks: flat grid of 3 token ranges)."""
+    o = ops()
+    K = 1280
+    x, xf = q16(rnd(M, K, seed=180), dtype)
+    for N, seed in ((128, 181), (1280, 182), (2560, 183), (10240, 184)):
+        w, wf = q16(rnd(N, K, seed=seed) / K ** 0.5, dtype)
+        b = rnd(N, seed=seed + 10)
+        want = xf @ wf.T + b
+        if N < 10240:
+            got = o.linear_ws(x, w, o.LWS_16, bias=b.to(DEV))
+            check("linear_ws K1280 16-bit N%d" % N, got, want, TOL[dtype])
+            if o.linear_ws_ok(M, N, K, o.LWS_16, x):
+                assert torch.equal(o.linear(x, w, bias=b.to(DEV)), got)
+        else:
+            wi, bi = o.interleave_geglu(w, b.to(DEV))
+            got = o.linear_ws(x, wi, o.LWS_GEGLU, bias=bi)
+            assert got.shape == (M, N // 2)
+            check("linear_ws K1280 geglu", got, want[:, :N // 2] * F.gelu(want[:, N // 2:]), TOL[dtype])
+    assert not o.linear_ws_ok(1 << 16, 1280, K, o.LWS_F32, x)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M", [64 * 37 + 40, 64 * 600])
 def test_linear_ws_with_layernorm_epilogue(dtype, M):
     """PF_LWS_F32_LN: output projection + fp32 residual, and the LayerNorm of the result from the same launch (a row of 320

@@ -76,6 +76,23 @@ def main():
         print("%-20s M%-7d N%-5d  tile kernel %7.1f us %6.1f TF/s | weight-stationary %7.1f us %6.1f TF/s  (x%.2f)"
               % (name, M, N, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, t_old / t_new), flush=True)
 
+    # the K = 1280 shape (16^2 level: 40 views x 256 tokens)
+    M, K = args.rows // 16, 1280
+    x = torch.randn(M, K, device=dev, generator=g).to(T)
+    for name, N in (("to_q K1280", 1280), ("q|k K1280", 2560), ("FF1 GEGLU K1280", 10240)):
+        w = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(T)
+        b = torch.randn(N, device=dev, generator=g)
+        fl = 2.0 * M * N * K
+        if name.startswith("FF1"):
+            new = lambda: ops.linear_ws(x, w, ops.LWS_GEGLU, bias=b)
+            old = lambda: ops.conv_gemm(x, w, N, w_in=M, bias=b, geglu=True)
+        else:
+            new = lambda: ops.linear_ws(x, w, ops.LWS_16, bias=b)
+            old = lambda: ops.conv_gemm(x, w, N, w_in=M, bias=b)
+        t_old, t_new = timeit(old, args.reps), timeit(new, args.reps)
+        print("%-20s M%-7d N%-5d  tile kernel %7.1f us %6.1f TF/s | weight-stationary %7.1f us %6.1f TF/s  (x%.2f)"
+              % (name, M, N, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, t_old / t_new), flush=True)
+
 
 if __name__ == "__main__":
     main()
