@@ -468,6 +468,61 @@ __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4
     }
 }
 
+// fp32 tile WITH the GroupNorm moments of the finished output (bias + residual included) from the same registers: column block by
+// column block (j outermost), so that only the 4 running sums of ONE block are live next to the two residual buffers (4 fragment rows
+// each: 32 registers against the 40 of epilogue_f32; 256 registers, no scratch) -- the separate moment phase above has to read the
+// residual tile a second time, which cost a residual layer as much as the consumer's statistics pass saves
+// (profiles/archive/r3d_gemm_gn.txt).  (Row group by row group with all 20 sums live -- the store order of epilogue_f32 -- spills 10-73
+// registers in the persistent kernel, whichever way the bias and the residual buffer are arranged.)  Whole N tiles (gn_rows_for);
+// rows past M are clamped and masked.
+template <typename T, int MREP, int NREP, bool RES>
+__device__ __forceinline__ void epilogue_f32_stats(const GemmParams& p, long bz, f32x4 (&acc)[MREP][NREP],
+                                                   int m0, int n0, int row_base, int col_base, int lane) {
+    const int cq = 4 * (lane >> 4), rl = lane & 15;
+    const int NP = p.N >> 1;
+    const int mw = m0 + row_base;                                 // first row of this wavefront
+    if (mw >= p.M) return;
+    float* base = p.gn_partial + static_cast<long>(mw / p.gn_rows) * 2 * NP;
+    const float* resp = RES ? static_cast<const float*>(p.residual) + bz * p.res_bs : nullptr;
+    float* outp = static_cast<float*>(p.out) + bz * p.out_bs;
+    const int nb = n0 + col_base + cq;
+    float4 res[2][MREP];
+    auto request = [&](int j, int bf) {
+        if (!RES) return;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+            res[bf][i] = *reinterpret_cast<const float4*>(resp + static_cast<long>(min(mw + i * 16 + rl, p.M - 1)) * p.res_ld + nb + 16 * j);
+    };
+    request(0, 0);
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+        if (j + 1 < NREP) request(j + 1, (j + 1) & 1);
+        const float4 b = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb + 16 * j) : float4{0.f, 0.f, 0.f, 0.f};
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            const int m = mw + i * 16 + rl;
+            float4 v = float4{acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w};
+            if (RES) {
+                const float4 r = res[j & 1][i];
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            const bool live = m < p.M;
+            if (live) *reinterpret_cast<float4*>(outp + static_cast<long>(m) * p.out_ld + nb + 16 * j) = v;
+            const float lf = live ? 1.f : 0.f;
+            v.x *= lf; v.y *= lf; v.z *= lf; v.w *= lf;
+            s0 += v.x + v.y; s1 += v.z + v.w;
+            q0 += v.x * v.x + v.y * v.y; q1 += v.z * v.z + v.w * v.w;
+        }
+        s0 = row16_allreduce(s0); s1 = row16_allreduce(s1);
+        q0 = row16_allreduce(q0); q1 = row16_allreduce(q1);
+        if (rl == 0) {
+            *reinterpret_cast<float2*>(base + ((nb + 16 * j) >> 1)) = float2{s0, s1};
+            *reinterpret_cast<float2*>(base + NP + ((nb + 16 * j) >> 1)) = float2{q0, q1};
+        }
+    }
+}
+
 // Block epilogue.  All arithmetic (bias, per-image row vector, residual, GEGLU) runs in the MFMA
 // fragment layout on the fp32 accumulators -- one rounding to 16 bit.  16-bit outputs with 16-byte
 // aligned rows take one of the staged specialisations above; everything else (fp32 output, ragged or
@@ -484,13 +539,20 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, long bz, f32x
         // default kernels keep their code and register allocation untouched).  Ahead of the ring barrier and of the next
         // tile's DMA requests: the phase's own loads would otherwise queue behind them in vmcnt order (it cost 8 k clocks
         // per tile there), and the waves that arrive early spend their barrier wait on it.
-        gn_moments_phase<T, MREP, NREP>(p, bz, acc, m0, n0, row_base, col_base, lane);
+        // (fp32 tiles with an fp32 residual produce their moments inside the store loop instead: epilogue_f32_stats)
+        if (!(p.out_f32 && p.residual)) gn_moments_phase<T, MREP, NREP>(p, bz, acc, m0, n0, row_base, col_base, lane);
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                                              // every wave is done reading the operand ring
     stamp(p, 4);
     after_ring();
     stamp(p, 5);
+    if constexpr (STATS) {
+        if (p.out_f32 && p.residual) {                            // (gn_rows_for admitted it: fp32 residual, aligned rows, no row vector)
+            epilogue_f32_stats<T, MREP, NREP, true>(p, bz, acc, m0, n0, row_base, col_base, lane);
+            return;
+        }
+    }
     const int n_store = p.geglu ? p.N >> 1 : p.N;
     if (p.split_out && !p.rowvec && (p.N & 3) == 0 && (p.out_ld & 3) == 0 && p.N >= 4) {
         if (!p.residual) { epilogue_f32<T, MREP, NREP, false, true>(p, bz, acc, m0, n0, row_base, col_base, lane); return; }
@@ -1521,9 +1583,13 @@ static void params_from_desc(const pf_conv_desc* d, GemmParams& p) {
 // images that are not whole parts, or an operand mix that takes the per-fragment (generic) epilogue.
 static int gn_rows_for(const GemmParams& p, const GemmPlan& g, int batch) {
     if (batch != 1 || g.splits > 1 || g.m_split > 0 || p.geglu || p.split_out) return 0;
-    // Layers with a residual are left to the consumer's statistics pass by default: the moment phase has to read the
+    // Layers with a residual are left to the consumer's statistics pass by default.  Round 3: the moment phase has to read the
     // residual tile a second time, which costs an HBM-bound layer as much as that pass saves (fp32-residual linear at
-    // 163840 x 320: 141 -> 171 us, the pass it replaces 42 us; VAE decode 107 -> 122 ms; profiles/archive/r3d_gemm_gn.txt).
+    // 163840 x 320: 141 -> 171 us, the pass it replaces 42 us; VAE decode 107 -> 122 ms; profiles/archive/r3d_gemm_gn.txt).  Round 4: fp32
+    // tiles with an fp32 residual form their moments inside the store loop instead (epilogue_f32_stats: no second read, no extra
+    // registers) -- and the step still does not move: 63.17 vs 63.33 / 63.54 ms on one box, 61.23 / 61.40 vs 61.00 on another
+    // (profiles/r4ah_ab_gn_moments_residual.txt): ~30 statistics passes of 10-55 us leave the critical stream, the column-block-major
+    // store order of the fused epilogue gives as much back.  Off; PF_GN_EPILOGUE_RES=1 enables it (tests run both).
     // Without a residual (resnet conv1 -> norm2, the up-sampling conv) the phase costs 2-3 us against a 25-40 us pass.
     if (p.residual && tuning("PF_GN_EPILOGUE_RES", 0) == 0) return 0;
     if (g.big && tuning("PF_GEMM8_WAVES", 8) == 4) return 0;       // (the one-wave-per-SIMD A/B instantiation has no moment variant)
