@@ -63,13 +63,7 @@ constexpr int LWS_STG_BYTES = 4096;                               // per-wave st
 enum { LWS_16 = 0, LWS_F32 = 1, LWS_GEGLU = 2, LWS_QKV = 3, LWS_F32_LN = 4 };
 constexpr int LWS_LN_BYTES = 2 * 8 * 32 * 8;                       // LayerNorm exchange: [half parity][wave][token] (mean, M2) fp32
 
-// The body of one wavefront: NB output-channel sub-blocks of 16 (cb = first channel inside the 320-block).
-// Vector-memory operations a wavefront issues in the epilogues of ONE tile (stores only: a lower bound is what the counted wait
-// needs -- the compiler may add its own waits for the residual loads, it never removes an operation).
-template <int MODE, int NB, int BM> constexpr int lws_epilogue_ops() {
-    constexpr int PB = BM >= 32 ? 2 : 1, HALVES = BM >= 32 ? BM / 32 : 1;      // 16-token blocks per epilogue slice, slices per tile
-    return HALVES * (MODE == LWS_F32 ? PB * NB : MODE == LWS_F32_LN ? 3 * NB : MODE == LWS_GEGLU ? (16 * PB * NB + 63) / 64 : (PB * NB + 1) / 2);
-}
+// The body of one wavefront: NB output-channel sub-blocks of 16 (cb = first channel inside the channel block).
 constexpr int lws_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }   // gfx9 s_waitcnt immediate: vmcnt(n) only
 
 template <typename T, int MODE, int NB, bool COUNTED, int LWS_K, int LWS_BM, int CHB>
@@ -318,11 +312,9 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
     f32x4 acc[2][NB];                                             // [token block][channel sub-block]
     int slot = 0;
     for (int tile = t_lo; tile < t_hi; ++tile) {
-        // The 5 DMA pieces of this tile were issued two tiles ago; younger than them are that tile's epilogue (E operations), the
-        // next tile's 5 pieces and the previous tile's epilogue: a COUNTED wait leaves those 5 + 2 E in flight (the first two tiles
-        // were drained before the loop).  COUNTED = false (PF_LWS_COUNTED=0): full drain, for A/B.
-        if constexpr (COUNTED) __builtin_amdgcn_s_waitcnt(lws_waitcnt_vm(LWS_PIECES + 2 * lws_epilogue_ops<MODE, NB, LWS_BM>()));
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // This tile's 5 DMA pieces were waited for in the PREVIOUS iteration (below, ahead of its last epilogue slice; the first two
+        // tiles before the loop).  COUNTED = false (PF_LWS_COUNTED=0): full drain here instead, for A/B.
+        if constexpr (!COUNTED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef PF_LWS_ABL_NOBAR   /* -DPF_LWS_ABL_*: timing-only ablation builds (wrong results), make -C panfusion_amd/csrc lws_ablate */
         __builtin_amdgcn_s_barrier();                             // tile landed (all waves' pieces); slot (tile + 2) % 3 no longer read
 #endif
@@ -373,6 +365,17 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
                         for (int pb = 0; pb < PB; ++pb)
                             acc[pb][j] = LwsMfma<T>::run(wf[j][2 * st + h2], af[st & 1][h2][pb], acc[pb][j]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (COUNTED) {
+                // Wait for the NEXT tile's pieces (issued one iteration ago) here, where the only younger LOADS are the 5 pieces just
+                // issued for tile + 2: loads retire in order among themselves, so "at most 5 operations outstanding" implies the next
+                // tile has landed -- whatever the stores of the epilogues are doing (stores and loads retire out of order with respect
+                // to each other on the one vmcnt of gfx9: a count that included the epilogues' stores let a tile be read before it
+                // had arrived, once in ~40 launches at 16-token tiles).  The older stores had a slice of matrix work to complete.
+                if (half == HALVES - 1) {
+                    if (tile + 2 < t_hi) __builtin_amdgcn_s_waitcnt(lws_waitcnt_vm(LWS_PIECES));
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
             }
             epilogue(acc, m_tile + half * 32);
         }

@@ -435,6 +435,44 @@ def test_linear_ws_k1280_vs_fp32(dtype, M):
     assert not o.linear_ws_ok(1 << 16, 1280, K, o.LWS_F32, x)
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(10240, 1280, 1280, "16"), (10240, 10240, 1280, "geglu"), (40960, 1280, 640, "16"), (40960, 5120, 640, "geglu"),
+                                        (163840, 960, 320, "qkv"), (163840, 320, 320, "f32")])
+def test_linear_ws_is_bit_reproducible_under_contention(M, N, K, mode):
+    """pf_linear_ws reads a token tile out of LDS only after its LDS-DMA pieces have landed: 24 launches on the same operands -- into
+    output buffers pre-filled with NaN / a constant, some of them beside a large GEMM on another stream -- give bit-identical results.
+    (Regression: a counted s_waitcnt that included the epilogues' STORES let a tile be read early, once in ~40 launches at 16-token
+    tiles -- stores and loads retire out of order with respect to each other; the wait now counts loads only.)"""
+    o = ops()
+    T = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(M, K, device=DEV, generator=g).to(T)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(T)
+    b = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g) if mode == "f32" else None
+    side, big = torch.cuda.Stream(), torch.randn(6144, 6144, device=DEV)
+    ref = None
+    for it in range(24):
+        fill = float("nan") if it % 2 else 3.0
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                big @ big
+        if mode == "qkv":
+            out = torch.full((M, 640), fill, device=DEV, dtype=T)
+            vt = torch.full((40, 320, M // 40), fill, device=DEV, dtype=T)
+            got = o.linear_ws(x, w, o.LWS_QKV, out=out, out_vt=vt, rows_per_batch=M // 40)
+        elif mode == "f32":
+            got = (o.linear_ws(x, w, o.LWS_F32, bias=b, residual=res, out=torch.full((M, N), fill, device=DEV)),)
+        else:
+            out = torch.full((M, N // 2 if mode == "geglu" else N), fill, device=DEV, dtype=T)
+            got = (o.linear_ws(x, w, o.LWS_GEGLU if mode == "geglu" else o.LWS_16, bias=b, out=out),)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = [t.clone() for t in got]
+            assert all(torch.isfinite(t.float()).all() for t in ref)
+        else:
+            assert all(torch.equal(a, r) for a, r in zip(got, ref)), "launch %d differs from the first" % it
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M", [64 * 37 + 40, 64 * 600])
 def test_linear_ws_with_layernorm_epilogue(dtype, M):
