@@ -93,6 +93,12 @@ def test_linear_ws_rejects_bad_arguments_before_any_launch():
     assert lib.pf_linear_ws_supported(163840, 960, 320, 3) == 1 and lib.pf_linear_ws_supported(163840, 640, 320, 3) == 0
     assert lib.pf_linear_ws_supported(163840, 2560, 320, 2) == 1 and lib.pf_linear_ws_supported(163840, 320, 640, 0) == 0
     assert lib.pf_linear_ws_supported(32, 320, 320, 0) == 0 and lib.pf_linear_ws_supported(4096, 300, 320, 0) == 0
+    # the K = 640 / K = 1280 shapes: 256- (or 128-) channel workgroups, 16-bit and GEGLU outputs only
+    S = lib.pf_linear_ws_supported
+    assert S(40960, 5120, 640, 2) == 1 and S(40960, 1280, 640, 0) == 1 and S(40960, 640, 640, 0) == 1
+    assert S(40960, 640, 640, 1) == 0 and S(40960, 640, 640, 2) == 0 and S(40960, 1920, 640, 3) == 0 and S(40960, 320, 640, 0) == 0
+    assert S(10240, 10240, 1280, 2) == 1 and S(10240, 2560, 1280, 0) == 1 and S(16, 128, 1280, 0) == 1
+    assert S(10240, 1280, 1280, 1) == 0 and S(10240, 1280, 1280, 4) == 0 and S(10240, 320, 1280, 0) == 0 and S(8, 1280, 1280, 0) == 0
 
     def desc(**kw):
         d = _lib.LinearWsDesc()
