@@ -721,6 +721,61 @@ def test_attention_fused_qk_buffer_and_bias(dtype):
     check("shift invariance", want, want2, 1e-5)
 
 
+def test_gemm_and_attention_are_bit_reproducible_under_contention():
+    """The tile GEMM kernels (persistent 8-wave kernel with its counted LDS-DMA waits: plain 3x3 conv with fp32 output + residual +
+    GroupNorm moments, the split-precision K step, a short-K GEGLU linear; the 4-wave kernel with split K) and both attention
+    instantiations: 12 launches each on the same operands, every third beside a large GEMM on another stream, into buffers pre-filled
+    with NaN / a constant -- bit-identical results (a tile read before its DMA has landed shows up as a rare wrong tile, not as a
+    parity failure: the weight-stationary kernel had exactly that, tests above)."""
+    from panfusion_amd import engine
+    o = ops()
+    T = torch.float16
+    g = torch.Generator(device=DEV).manual_seed(9)
+    rn = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    n, h, w, c = 20, 64, 64, 320
+    x = rn(n, h, w, c).to(T)
+    w3 = (rn(c, 9 * c) / (9 * c) ** 0.5).to(T)
+    res = rn(n * h * w, c)
+    xs = rn(n * h * w, c)
+    w1 = rn(c, c) / c ** 0.5
+    pair = engine.split_operand(xs.view(n, h * w, c), dtype=T)
+    ws3 = engine._split_weight(w1, 1, torch.device(DEV), T)
+    wg, bg = o.interleave_geglu((rn(5120, 640) / 25.0).to(T), rn(5120))
+    xg = rn(4096, 640).to(T)
+    xk, wk = rn(256, 5120).to(T), (rn(1280, 5120) / 70.0).to(T)
+    B, H, nq = 4, 5, 1024
+    q, k = rn(B * nq, H * 64).to(T), rn(B * nq, H * 64).to(T)
+    vt = rn(B, H * 64, nq).to(T)
+    q32, k32, vt32 = rn(2 * 512, 160).to(T), rn(2 * 2048, 160).to(T), rn(2, 160, 2048).to(T)
+    bias = torch.zeros(512, 2048, device=DEV)
+    bias[::7, ::5] = 1.5
+    flags = (bias.view(16, 32, 64, 32).abs().amax((1, 3)) > 0).to(torch.uint8).contiguous()
+    cases = {
+        "conv3x3 fp32 + residual + moments": lambda: o.conv_gemm(x, w3, c, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, residual=res, gn_stats=True, out_dtype=torch.float32),
+        "conv3x3 16-bit + moments": lambda: o.conv_gemm(x, w3, c, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, gn_stats=True),
+        "split-precision 1x1": lambda: engine.exact_gemm(pair, ws3, c, w_in=n * h * w, residual=res, out_dtype=torch.float32),
+        "GEGLU linear": lambda: o.conv_gemm(xg, wg, 5120, w_in=4096, bias=bg, geglu=True),
+        "split-K linear": lambda: o.conv_gemm(xk, wk, 1280, w_in=256),
+        "attention D64": lambda: o.attention(q, k, vt, B, H, 64, nq, nq, q_ld=H * 64, k_ld=H * 64, vt_ld=nq, q_bs=nq * H * 64, k_bs=nq * H * 64, vt_bs=H * 64 * nq),
+        "attention D32 + bias": lambda: o.attention(q32, k32, vt32, 2, 5, 32, 512, 2048, q_ld=160, k_ld=160, vt_ld=2048, q_bs=512 * 160, k_bs=2048 * 160,
+                                                    vt_bs=160 * 2048, bias=bias, flags=flags),
+    }
+    side, big = torch.cuda.Stream(), rn(6144, 6144)
+    for name, run in cases.items():
+        ref = None
+        for it in range(12):
+            if it % 3 == 0:
+                with torch.cuda.stream(side):
+                    big @ big
+            out = run()
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = out.clone()
+                assert torch.isfinite(ref.float()).all(), name
+            else:
+                assert torch.equal(out, ref), "%s: launch %d differs from the first" % (name, it)
+
+
 def test_attention_online_softmax_rescale_branch():
     """A key row that dominates late forces the running-max rescale (guide rule 26)."""
     dtype = torch.float16
