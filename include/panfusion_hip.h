@@ -322,6 +322,9 @@ pf_status pf_conv_gemm(const pf_conv_desc* desc, void* stream);
  *   PF_LWS_QKV:   N == 960 = (q | k | v): out 16-bit [M][out_ld] receives the 640 columns (q | k); V leaves TRANSPOSED as
  *                 out_vt[b][c][key] (b = m / rows_per_batch, key = m % rows_per_batch, row stride vt_ld, batch stride vt_bs):
  *                 the layout pf_attention reads.  rows_per_batch a multiple of 64.
+ *   PF_LWS_VT:    the whole output TRANSPOSED to out_vt[b][n][key] as in PF_LWS_QKV (the V projection of the 32^2 / 16^2 self-attentions and of
+ *                 the EPA blocks: replaces the operand-swapped pf_conv_gemm launch); out unused.  K == 320: N a multiple of 320; K == 640 / 1280:
+ *                 N a multiple of 128.  rows_per_batch a multiple of 64 / 32 / 16.
  *   PF_LWS_F32_LN: N == 320: PF_LWS_F32, and the LayerNorm of the result rides along (the norm2 / norm3 that follow the two
  *                 attention output projections of a BasicTransformerBlock): ln_out 16-bit [M][ln_ld] =
  *                 LayerNorm(out; ln_eps) * ln_gamma + ln_beta -- no separate pass over the stream tensor.
@@ -337,7 +340,7 @@ typedef struct {
     int M, N, K;
     int dtype; int mode;
 } pf_linear_ws_desc;
-enum { PF_LWS_16 = 0, PF_LWS_F32 = 1, PF_LWS_GEGLU = 2, PF_LWS_QKV = 3, PF_LWS_F32_LN = 4 };
+enum { PF_LWS_16 = 0, PF_LWS_F32 = 1, PF_LWS_GEGLU = 2, PF_LWS_QKV = 3, PF_LWS_F32_LN = 4, PF_LWS_VT = 5 };
 int pf_linear_ws_supported(long M, int N, int K, int mode);
 pf_status pf_linear_ws(const pf_linear_ws_desc* desc, void* stream);
 

@@ -60,7 +60,7 @@ template <> struct LwsMfma<F16> {
 constexpr int LWS_STAGES = 3, LWS_PIECES = 5;
 constexpr int LWS_STAGE_ELEMS = 64 * 320;                         // 16-bit elements per ring slot (40 KB) = BM * K for both shapes
 constexpr int LWS_STG_BYTES = 4096;                               // per-wave staging region (<= 48 channel rows x 80 B)
-enum { LWS_16 = 0, LWS_F32 = 1, LWS_GEGLU = 2, LWS_QKV = 3, LWS_F32_LN = 4 };
+enum { LWS_16 = 0, LWS_F32 = 1, LWS_GEGLU = 2, LWS_QKV = 3, LWS_F32_LN = 4, LWS_VT = 5 };
 constexpr int LWS_LN_BYTES = 2 * 8 * 32 * 8;                       // LayerNorm exchange: [half parity][wave][token] (mean, M2) fp32
 
 // The body of one wavefront: NB output-channel sub-blocks of 16 (cb = first channel inside the channel block).
@@ -74,7 +74,7 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
     static_assert(LWS_BM * LWS_K == LWS_STAGE_ELEMS && LWS_KB * (LWS_BM / 8) == 8 * LWS_PIECES, "a ring slot is 40 KB = 8 waves x 5 pieces");
     static_assert(MODE != LWS_F32_LN || CHB == 320, "the LayerNorm epilogue is written for the 48 / 32-channel wave split");
     constexpr int PB = LWS_BM >= 32 ? 2 : 1, HALVES = LWS_BM >= 32 ? LWS_BM / 32 : 1;   // an epilogue slice = PB blocks of 16 tokens
-    static_assert(PB == 2 || MODE == LWS_16 || MODE == LWS_GEGLU || MODE == LWS_F32, "16-token tiles: plain and GEGLU outputs only");
+    static_assert(PB == 2 || MODE == LWS_16 || MODE == LWS_GEGLU || MODE == LWS_F32 || MODE == LWS_VT, "16-token tiles: plain, GEGLU and transposed outputs only");
     const int frow = lane & 15, fchunk = lane >> 4, cq = 4 * fchunk;
     const int n_base = nblk * CHB + cb;                           // first output channel of this wavefront
 
@@ -255,6 +255,29 @@ __device__ __forceinline__ void lws_wave(const LwsParams& p, unsigned short* sme
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // staging region read out before the next slice overwrites it
+        } else if constexpr (MODE == LWS_VT) {
+            // the whole output transposed (the V projection of a self-attention at K = 640 / 1280): staged [channel][16 PB tokens], leaves as
+            // 32 PB-byte key runs of out_vt[b][channel][key]
+            constexpr int RS = PB * 32 + 16, CH = 2 * PB;
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        *reinterpret_cast<unsigned short*>(stg + (j * 16 + cq + e) * RS + (pb * 16 + frow) * 2) = from_f32<T>(acc[pb][j][e]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int bidx = m_half / p.rows_per_batch, key0 = m_half - bidx * p.rows_per_batch;
+            unsigned short* op = p.out_vt + bidx * p.vt_bs + static_cast<long>(n_base) * p.vt_ld + key0;
+#pragma unroll
+            for (int i = 0; i < (NB * 16 * CH + 63) / 64; ++i) {
+                const int q = i * 64 + lane, ch = q / CH, cc = q - ch * CH;
+                if (q < NB * 16 * CH) {
+                    const u16x8 x = *reinterpret_cast<const u16x8*>(stg + ch * RS + cc * 16);
+                    if (m_half + cc * 8 < p.M) *reinterpret_cast<u16x8*>(op + static_cast<long>(ch) * p.vt_ld + cc * 8) = x;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else if (MODE == LWS_QKV && nblk == 2) {
             // V transposed: staged [channel][32 tokens] (64 B of tokens in 80-byte rows), leaves as 64-byte key runs of out_vt[b][channel][key]
             constexpr int RS = 80;
@@ -440,10 +463,10 @@ extern "C" int pf_linear_ws_supported(long M, int N, int K, int mode) {
     if (K == 640) {               // 256-channel workgroups: 16-bit and GEGLU outputs (FF1, q | k of the 32^2 level);
         if (N <= 0 || M < 32) return 0;                                        // 128-channel workgroups: 16-bit output (to_q: N = 640).  (fp32 + residual
         if (N % 256 == 0 && N / 256 <= 32 && (mode == PF_LWS_16 || mode == PF_LWS_GEGLU)) return 1;   // was built and measured: 98 vs 89 us for the tile kernel)
-        return N % 128 == 0 && N / 128 <= 32 && mode == PF_LWS_16;
+        return N % 128 == 0 && N / 128 <= 32 && (mode == PF_LWS_16 || mode == PF_LWS_VT);
     }
     if (K == 1280)                // 16-token tiles, 128-channel workgroups: 16-bit and GEGLU outputs (q | k, to_q, FF1 of the 16^2 level)
-        return N > 0 && N % 128 == 0 && N / 128 <= 128 && M >= 16 && (mode == PF_LWS_16 || mode == PF_LWS_GEGLU);
+        return N > 0 && N % 128 == 0 && N / 128 <= 128 && M >= 16 && (mode == PF_LWS_16 || mode == PF_LWS_GEGLU || mode == PF_LWS_VT);
     if (K != 320 || N <= 0 || N % 320 != 0 || M < 64) return 0;
     const int nb = N / 320;
     if (nb > 32) return 0;
@@ -455,16 +478,16 @@ extern "C" int pf_linear_ws_supported(long M, int N, int K, int mode) {
 extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     using namespace pf;
     PF_REQUIRE(d != nullptr, "pf_linear_ws: null descriptor");
-    PF_REQUIRE(d->a && d->w && d->out, "pf_linear_ws: null operand");
+    PF_REQUIRE(d->a && d->w && (d->out || d->mode == PF_LWS_VT), "pf_linear_ws: null operand");
     PF_REQUIRE(pf_linear_ws_supported(d->M, d->N, d->K, d->mode), "pf_linear_ws: needs K == 320, N a multiple of 320 (<= 32 blocks; q|k|v: N == 960), M >= 64 -- or K == 640 with N a multiple of 256 (16-bit / GEGLU output) or of 128 (16-bit output), or K == 1280 with N a multiple of 128 (16-bit / GEGLU output) (got M %ld N %d K %d mode %d)",
                static_cast<long>(d->M), d->N, d->K, d->mode);
-    PF_REQUIRE(d->mode >= PF_LWS_16 && d->mode <= PF_LWS_F32_LN, "pf_linear_ws: unknown mode %d", d->mode);
-    PF_REQUIRE(d->a_ld >= d->K && d->a_ld % 8 == 0 && aligned16(d->a) && aligned16(d->w) && aligned16(d->out), "pf_linear_ws: operands must be 16-byte aligned, a_ld a multiple of 8");
+    PF_REQUIRE(d->mode >= PF_LWS_16 && d->mode <= PF_LWS_VT, "pf_linear_ws: unknown mode %d", d->mode);
+    PF_REQUIRE(d->a_ld >= d->K && d->a_ld % 8 == 0 && aligned16(d->a) && aligned16(d->w) && (!d->out || aligned16(d->out)), "pf_linear_ws: operands must be 16-byte aligned, a_ld a multiple of 8");
     PF_REQUIRE(static_cast<long>(d->M) * d->a_ld * 2 < (2L << 30), "pf_linear_ws: activation matrix must be smaller than 2 GiB");
     PF_REQUIRE(!d->bias || aligned16(d->bias), "pf_linear_ws: bias must be 16-byte aligned");
     const int n_store = d->mode == PF_LWS_GEGLU ? d->N / 2 : d->mode == PF_LWS_QKV ? 640 : d->N;
     const bool f32out = d->mode == PF_LWS_F32 || d->mode == PF_LWS_F32_LN;
-    PF_REQUIRE(d->out_ld >= n_store && d->out_ld % (f32out ? 4 : 8) == 0, "pf_linear_ws: out_ld %d does not hold %d columns in 16-byte chunks", d->out_ld, n_store);
+    PF_REQUIRE(d->mode == PF_LWS_VT || (d->out_ld >= n_store && d->out_ld % (f32out ? 4 : 8) == 0), "pf_linear_ws: out_ld %d does not hold %d columns in 16-byte chunks", d->out_ld, n_store);
     if (f32out)
         PF_REQUIRE(!d->residual || (aligned16(d->residual) && d->res_ld >= d->N && d->res_ld % 4 == 0), "pf_linear_ws: residual must be 16-byte aligned fp32 rows");
     else
@@ -473,6 +496,12 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
         PF_REQUIRE(d->N == 320 && d->ln_gamma && d->ln_beta && d->ln_out && aligned16(d->ln_gamma) && aligned16(d->ln_beta) && aligned16(d->ln_out) &&
                    d->ln_ld >= 320 && d->ln_ld % 8 == 0 && d->ln_eps > 0.f,
                    "pf_linear_ws: the LayerNorm mode needs N == 320 (a whole row per workgroup), gamma / beta / ln_out 16-byte aligned");
+    if (d->mode == PF_LWS_VT) {
+        const int tok = d->K == 1280 ? 16 : d->K == 640 ? 32 : 64;
+        PF_REQUIRE(d->out_vt && aligned16(d->out_vt) && d->rows_per_batch > 0 && d->rows_per_batch % tok == 0 && d->M % d->rows_per_batch == 0 &&
+                   d->vt_ld >= d->rows_per_batch && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0,
+                   "pf_linear_ws: the transposed mode needs out_vt with 16-byte aligned key runs and batches of a multiple of %d tokens", tok);
+    }
     if (d->mode == PF_LWS_QKV)
         PF_REQUIRE(d->out_vt && aligned16(d->out_vt) && d->rows_per_batch > 0 && d->rows_per_batch % 64 == 0 && d->M % d->rows_per_batch == 0 &&
                    d->vt_ld >= d->rows_per_batch && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0,
@@ -486,7 +515,7 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps; p.ln_out = static_cast<unsigned short*>(d->ln_out); p.ln_ld = d->ln_ld;
     p.M = d->M; p.N = d->N;
     const bool k640 = d->K == 640, k1280 = d->K == 1280;
-    const bool chb128 = k640 && !(d->N % 256 == 0 && (d->mode == PF_LWS_16 || d->mode == PF_LWS_GEGLU));
+    const bool chb128 = k640 && (d->mode == PF_LWS_VT || !(d->N % 256 == 0 && (d->mode == PF_LWS_16 || d->mode == PF_LWS_GEGLU)));
     p.nblocks = d->N / (chb128 || k1280 ? 128 : k640 ? 256 : 320);
     p.splits_per_xcd = 32 / p.nblocks;
     p.flat_splits = 8 * p.splits_per_xcd * p.nblocks >= 200 ? 0 : std::max(1, 256 / p.nblocks);
@@ -494,6 +523,8 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
     p.a_bytes = static_cast<unsigned>(static_cast<long>(d->M) * d->a_ld * 2);
     hipStream_t st = as_stream(stream);
 #define PF_LWS_MODE(MODE) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, MODE>(p, st)))
+    if (k1280 && d->mode == PF_LWS_VT) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_VT, 1280>(p, st)));
+    if (chb128 && d->mode == PF_LWS_VT) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_VT, 640, 128>(p, st)));
     if (k1280) {
         if (d->mode == PF_LWS_GEGLU) PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_GEGLU, 1280>(p, st)));
         PF_DISPATCH_16(d->dtype, "pf_linear_ws", return (lws_launch<T, LWS_16, 1280>(p, st)));
@@ -508,6 +539,7 @@ extern "C" pf_status pf_linear_ws(const pf_linear_ws_desc* d, void* stream) {
         case PF_LWS_F32: PF_LWS_MODE(LWS_F32);
         case PF_LWS_GEGLU: PF_LWS_MODE(LWS_GEGLU);
         case PF_LWS_F32_LN: PF_LWS_MODE(LWS_F32_LN);
+        case PF_LWS_VT: PF_LWS_MODE(LWS_VT);
         default: PF_LWS_MODE(LWS_QKV);
     }
 #undef PF_LWS_MODE

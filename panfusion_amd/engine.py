@@ -493,7 +493,9 @@ def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv
     if kv is not None:
         vt = kv[1]
     elif vt is None:
-        vt = ops.linear_t(kv_tokens.view(n, nk, -1), a.wv)    # [n, C, ld_v] keys contiguous
+        vt = ops.linear_vt(kv_tokens, a.wv, n) if self_attn else None     # weight-stationary kernel, transposed epilogue (C = 640 / 1280)
+        if vt is None:
+            vt = ops.linear_t(kv_tokens.view(n, nk, -1), a.wv)            # [n, C, ld_v] keys contiguous
     o = ops.attention(q, k, vt, n, a.heads, head_dim, nq, nk,
                       q_ld=ld, k_ld=(ld if self_attn else Cq), vt_ld=vt.shape[-1],
                       q_bs=nq * ld, k_bs=nk * (ld if self_attn else Cq), vt_bs=vt.shape[1] * vt.shape[2])
@@ -740,7 +742,9 @@ def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None, pers_hw=None):
     out_e = None
     if owner:
         qk_p = ops.linear(lnp, e.wqk)
-        vt_p = ops.linear_t(lnp.view(1, mP, Cc), e.wv)
+        vt_p = ops.linear_vt(lnp, e.wv, 1)
+        if vt_p is None:
+            vt_p = ops.linear_t(lnp.view(1, mP, Cc), e.wv)
         a_e = ops.attention(qk_e, qk_p[:, Cc:], vt_p, 1, e.heads, 32, E, mP, q_ld=ld, k_ld=ld, vt_ld=vt_p.shape[-1],
                             q_bs=E * ld, k_bs=mP * ld, vt_bs=vt_p.shape[1] * vt_p.shape[2],
                             bias=t.bias_e, flags=t.flags_e)

@@ -538,10 +538,11 @@ def gemm_workspace_bytes(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, k
 
 
 # ---- weight-stationary linear (pf_linear_ws): the C = 320 token layers
-LWS_16, LWS_F32, LWS_GEGLU, LWS_QKV, LWS_F32_LN = 0, 1, 2, 3, 4
+LWS_16, LWS_F32, LWS_GEGLU, LWS_QKV, LWS_F32_LN, LWS_VT = 0, 1, 2, 3, 4, 5
 LINEAR_WS = os.environ.get("PF_LINEAR_WS", "1") != "0"          # A/B: 0 = every linear on the tile kernel (pf_conv_gemm)
 LINEAR_WS_K640 = os.environ.get("PF_LINEAR_WS_K640", "1") != "0"   # A/B: 0 = the K = 640 layers (32^2 level: FF1, q | k) stay on the tile kernel
 LINEAR_WS_K1280 = os.environ.get("PF_LINEAR_WS_K1280", "1") != "0"  # A/B: 0 = the K = 1280 layers (16^2 level: FF1, q | k, to_q) stay on the tile kernel
+LINEAR_VT = os.environ.get("PF_LINEAR_VT", "1") != "0"              # A/B: 0 = V^T projections by the operand-swapped tile GEMM (linear_t)
 LINEAR_WS_MIN_ROWS = int(os.environ.get("PF_LINEAR_WS_MIN_ROWS", "8192"))   # fewer 64-token tiles than workgroups: the tile kernel
 
 
@@ -551,10 +552,10 @@ def linear_ws_ok(rows, N, K, mode, x=None):
     if not LINEAR_WS or rows < LINEAR_WS_MIN_ROWS:
         return False
     if K == 640:                  # 256-channel workgroups (16-bit, GEGLU) or 128-channel workgroups (16-bit: to_q, N = 640)
-        if not LINEAR_WS_K640 or not ((N % 256 == 0 and mode in (LWS_16, LWS_GEGLU)) or (N % 128 == 0 and mode == LWS_16)):
+        if not LINEAR_WS_K640 or not ((N % 256 == 0 and mode in (LWS_16, LWS_GEGLU)) or (N % 128 == 0 and mode in (LWS_16, LWS_VT))):
             return False
     elif K == 1280:               # 16^2 level: 128-channel workgroups, 16-token tiles (16-bit, GEGLU)
-        if not LINEAR_WS_K1280 or N % 128 or mode not in (LWS_16, LWS_GEGLU):
+        if not LINEAR_WS_K1280 or N % 128 or mode not in (LWS_16, LWS_GEGLU, LWS_VT):
             return False
     elif K != 320 or N % 320:
         return False
@@ -568,7 +569,8 @@ def linear_ws_ok(rows, N, K, mode, x=None):
 def linear_ws(x, w, mode, bias=None, residual=None, out=None, out_vt=None, rows_per_batch=0, ln=None):
     """pf_linear_ws: x [rows, K] 16-bit, w [N, K] (K = 320; K = 640 for the 16-bit and GEGLU modes).  mode LWS_16 -> [rows, N] 16-bit; LWS_F32 -> fp32 [rows, N] (+ fp32 residual);
     LWS_GEGLU -> [rows, N/2]; LWS_QKV (N = 960) -> ((q | k) [rows, 640], V^T [rows / rows_per_batch, 320, rows_per_batch]);
-    LWS_F32_LN (N = 320, ln = (gamma, beta, eps)) -> (fp32 [rows, 320], LayerNorm of it in 16 bit [rows, 320])."""
+    LWS_F32_LN (N = 320, ln = (gamma, beta, eps)) -> (fp32 [rows, 320], LayerNorm of it in 16 bit [rows, 320]); LWS_VT (K = 640 / 1280)
+    -> the output transposed, [rows / rows_per_batch, N, rows_per_batch]."""
     rows, K = x.shape
     N = w.shape[0]
     d = LinearWsDesc()
@@ -583,19 +585,37 @@ def linear_ws(x, w, mode, bias=None, residual=None, out=None, out_vt=None, rows_
         if out_vt is None:
             out_vt = torch.empty(nb, 320, rows_per_batch, device=x.device, dtype=x.dtype)
         d.out_vt, d.vt_ld, d.rows_per_batch, d.vt_bs = _p(out_vt), out_vt.stride(1), rows_per_batch, out_vt.stride(0)
+    elif mode == LWS_VT:
+        nb = rows // rows_per_batch
+        if out_vt is None:
+            out_vt = torch.empty(nb, N, rows_per_batch, device=x.device, dtype=x.dtype)
+        d.out_vt, d.vt_ld, d.rows_per_batch, d.vt_bs = _p(out_vt), out_vt.stride(1), rows_per_batch, out_vt.stride(0)
     elif out is None:
         out = torch.empty(rows, N // 2 if mode == LWS_GEGLU else N, device=x.device,
                           dtype=torch.float32 if mode in (LWS_F32, LWS_F32_LN) else x.dtype)
     d.a, d.a_ld, d.w, d.bias = _p(x), _ld(x), _p(w), _p(bias)
     d.residual, d.res_ld = _p(residual), (_ld(residual) if residual is not None else 0)
-    d.out, d.out_ld = _p(out), _ld(out)
+    d.out, d.out_ld = _p(out), (_ld(out) if out is not None else 0)
     d.M, d.N, d.K, d.dtype, d.mode = rows, N, K, dt(x), mode
     if TRACE is None:
         check(_lib.lib().pf_linear_ws(C.byref(d), _stream()), "pf_linear_ws")
     else:
         _traced("k_linear_ws", 2.0 * rows * N * K, lambda: check(_lib.lib().pf_linear_ws(C.byref(d), _stream()), "pf_linear_ws"),
                 "M%d N%d K%d mode%d" % (rows, N, K, mode))
-    return (out, out_vt) if mode == LWS_QKV else (out, ln_out) if mode == LWS_F32_LN else out
+    return (out, out_vt) if mode == LWS_QKV else (out, ln_out) if mode == LWS_F32_LN else out_vt if mode == LWS_VT else out
+
+
+def linear_vt(x, w, n_batch):
+    """The V projection of a self-attention written transposed, x [n_batch * nk, K] layer-normed tokens, w [N, K] -> V^T [n_batch, N, nk] (what
+    pf_attention reads) -- on the weight-stationary kernel where it serves the shape, or None: the caller then takes the operand-swapped tile GEMM
+    (linear_t)."""
+    rows, K = x.shape
+    nk = rows // n_batch
+    if not LINEAR_VT:
+        return None
+    if nk * n_batch != rows or nk % (16 if K == 1280 else 32 if K == 640 else 64) or not w.is_contiguous() or not linear_ws_ok(rows, w.shape[0], K, LWS_VT, x):
+        return None
+    return linear_ws(x, w, LWS_VT, rows_per_batch=nk)
 
 
 def linear_ln(x, w, bias, residual, gamma, beta, eps):

@@ -98,6 +98,7 @@ def test_linear_ws_rejects_bad_arguments_before_any_launch():
     assert S(40960, 5120, 640, 2) == 1 and S(40960, 1280, 640, 0) == 1 and S(40960, 640, 640, 0) == 1
     assert S(40960, 640, 640, 1) == 0 and S(40960, 640, 640, 2) == 0 and S(40960, 1920, 640, 3) == 0 and S(40960, 320, 640, 0) == 0
     assert S(10240, 10240, 1280, 2) == 1 and S(10240, 2560, 1280, 0) == 1 and S(16, 128, 1280, 0) == 1
+    assert S(40960, 640, 640, 5) == 1 and S(10240, 1280, 1280, 5) == 1 and S(81920, 320, 320, 5) == 1 and S(40960, 320, 640, 5) == 0   # PF_LWS_VT
     assert S(10240, 1280, 1280, 1) == 0 and S(10240, 1280, 1280, 4) == 0 and S(10240, 320, 1280, 0) == 0 and S(8, 1280, 1280, 0) == 0
 
     def desc(**kw):

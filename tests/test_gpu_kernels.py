@@ -435,7 +435,28 @@ def test_linear_ws_k1280_vs_fp32(dtype, M):
     assert not o.linear_ws_ok(1 << 16, 1280, K, o.LWS_F32, x)
 
 
-@pytest.mark.parametrize("M,N,K,mode", [(10240, 1280, 1280, "16"), (10240, 10240, 1280, "geglu"), (40960, 1280, 640, "16"), (40960, 5120, 640, "geglu"),
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n_batch,nk,N,K", [(40, 1024, 640, 640), (40, 256, 1280, 1280), (1, 20480, 640, 640), (3, 96, 128, 640), (2, 48, 256, 1280),
+                                            (1, 81920, 320, 320), (2, 192, 640, 320)])
+def test_linear_ws_transposed_output(dtype, n_batch, nk, N, K):
+    """PF_LWS_VT: the V projection written as V^T [batch][channel][key] (the operand layout of pf_attention) at all three shapes of the
+    kernel, and through ops.linear_vt as engine._attend / the EPA block route it."""
+    o = ops()
+    M = n_batch * nk
+    x, xf = q16(rnd(M, K, seed=190), dtype)
+    w, wf = q16(rnd(N, K, seed=191) / K ** 0.5, dtype)
+    want = (xf @ wf.T).reshape(n_batch, nk, N).transpose(1, 2)
+    vt = o.linear_ws(x, w, o.LWS_VT, rows_per_batch=nk)
+    assert vt.shape == (n_batch, N, nk)
+    check("linear_ws V^T", vt, want, TOL[dtype])
+    routed = o.linear_vt(x, w, n_batch)
+    if o.linear_ws_ok(M, N, K, o.LWS_VT, x):
+        assert routed is not None and torch.equal(routed, vt)
+    else:
+        assert routed is None
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(10240, 1280, 1280, "vt"), (40960, 640, 640, "vt"), (10240, 1280, 1280, "16"), (10240, 10240, 1280, "geglu"), (40960, 1280, 640, "16"), (40960, 5120, 640, "geglu"),
                                         (163840, 960, 320, "qkv"), (163840, 320, 320, "f32")])
 def test_linear_ws_is_bit_reproducible_under_contention(M, N, K, mode):
     """pf_linear_ws reads a token tile out of LDS only after its LDS-DMA pieces have landed: 24 launches on the same operands -- into
@@ -456,7 +477,10 @@ def test_linear_ws_is_bit_reproducible_under_contention(M, N, K, mode):
         if it % 3 == 0:
             with torch.cuda.stream(side):
                 big @ big
-        if mode == "qkv":
+        if mode == "vt":
+            vt = torch.full((40, N, M // 40), fill, device=DEV, dtype=T)
+            got = (o.linear_ws(x, w, o.LWS_VT, out_vt=vt, rows_per_batch=M // 40),)
+        elif mode == "qkv":
             out = torch.full((M, 640), fill, device=DEV, dtype=T)
             vt = torch.full((40, 320, M // 40), fill, device=DEV, dtype=T)
             got = o.linear_ws(x, w, o.LWS_QKV, out=out, out_vt=vt, rows_per_batch=M // 40)
