@@ -222,6 +222,16 @@ pf_status pf_cfg_ddim_step(const float* x, const float* eps_uncond, const float*
                            float guidance, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
                            float sqrt_1m_a_prev, long rows, int W, int roll, float* out, void* stream);
 
+/* The same update as ONE launch per latent with everything the NEXT denoiser call needs (round 5: no torch.cat / copy_ / fill_
+ * kernels between two calls of the loop, PanFusion.py:149-162): out may alias x for ANY roll (a block owns whole rows);
+ * out2 (or NULL) receives a second copy -- the other half of the CFG pair torch.cat([x] * 2) of PanoGenerator.py:240-251;
+ * tstep (or NULL): n_tstep int64 words set to t_next, the timestep tensor of the next call (PanFusion.py:147).
+ * W <= 16384; out2 must not alias x / out. */
+pf_status pf_cfg_ddim_step_pair(const float* x, const float* eps_uncond, const float* eps_cond,
+                                float guidance, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
+                                float sqrt_1m_a_prev, long rows, int W, int roll, float* out, float* out2,
+                                int64_t* tstep, int n_tstep, int64_t t_next, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * MFMA GEMM / implicit-GEMM convolution (replaces cuDNN/cuBLAS behind diffusers Conv2d/Linear:
  * MVGenModel.py:86-144,174-198,224-294 and transformer.py:57-74,8-38).

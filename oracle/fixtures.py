@@ -49,6 +49,54 @@ def build_full_width(controlnet=False, cfg=None):
     return om.eval()
 
 
+def reference_denoiser(om):
+    """The REFERENCE's own ``models.pano.MVGenModel.MultiViewBaseModel`` (imported from /root/reference by oracle/ref_import.py,
+    third-party modules shimmed) around the same UNet objects and EPA weights as the port ``om`` -- what
+    tools/make_golden_cfg.py drives for the cfg 1 fixture and tests/test_oracle_vs_reference.py pins the port against at
+    SD-2-base widths.  Build container only (the GPU box has no /root/reference)."""
+    from . import ref_import
+    ref = ref_import.load()
+    rm = ref.MultiViewBaseModel(om.unet, om.pano_unet, None, om.pano_cn, True).eval()
+    res = rm.load_state_dict({k: v for k, v in om.state_dict().items() if k.startswith("cp_blocks")}, strict=False)
+    assert not res.unexpected_keys and not [k for k in res.missing_keys if k.startswith("cp_blocks")], res
+    return rm
+
+
+STRESS_LAYERS = ("conv2", "conv_shortcut", "proj_out", "downsamplers.0.conv", "upsamplers.0.conv")
+
+
+def apply_range_stress(om, seed=7, decades=3.0):
+    """Range-stress variant of the synthetic weights: every layer that WRITES INTO a residual stream --
+    conv_in, ResnetBlock2D.conv2 / conv_shortcut, Transformer2DModel.proj_out, the down / up-sampling convs of both UNets and
+    the EPA blocks' attention / feed-forward output projections -- gets its output channels (weight rows and bias) multiplied by
+    a per-channel scale drawn log-uniformly over ``decades`` decades, 1 ... 10^decades, ONE vector per stream width (the same
+    channel is the outlier in every layer of that width, as in trained SD-2 weights).  The fan-in-scaled Gaussians of
+    init_synthetic keep every stream at O(1); with this the stream channels reach 1e3 ... 1e4 and a GroupNorm group is dominated
+    by its largest channel -- what fp16 operands (5 exponent bits) have to survive.  In place; returns the scale vectors."""
+    scales = {}
+
+    def vec(c):
+        if c not in scales:
+            g = torch.Generator().manual_seed(seed * 100003 + c)
+            scales[c] = 10.0 ** (torch.rand(c, generator=g) * decades)
+        return scales[c]
+
+    def scale_out(mod):
+        s = vec(mod.weight.shape[0])
+        with torch.no_grad():
+            mod.weight.mul_(s.reshape(-1, *([1] * (mod.weight.dim() - 1))))
+            if mod.bias is not None:
+                mod.bias.mul_(s)
+    for unet in (om.unet, om.pano_unet):
+        for name, mod in unet.named_modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)) and (name == "conv_in" or name.endswith(STRESS_LAYERS)):
+                scale_out(mod)
+    for blk in [*om.cp_blocks_encoder, om.cp_blocks_mid, *om.cp_blocks_decoder]:
+        scale_out(blk.transformer.attn1.to_out)
+        scale_out(blk.transformer.ff.net[2])
+    return scales
+
+
 def ico_cameras(b=1):
     th, ph = G.icosahedron_cameras()
     th, ph = np.degrees(th), np.degrees(ph)

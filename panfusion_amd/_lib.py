@@ -123,6 +123,8 @@ SIGNATURES = {
     "pf_tensor_to_image": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,
                                  c_long, c_int, c_int, c_void_p, c_void_p]),
+    "pf_cfg_ddim_step_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,
+                                      c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, C.c_int64, c_void_p]),
     "pf_conv_gemm": (c_int, [C.POINTER(ConvDesc), c_void_p]),
     "pf_conv_gemm_workspace_size": (c_size_t, [C.POINTER(ConvDesc)]),
     "pf_conv_gemm_gn_rows": (c_int, [C.POINTER(ConvDesc)]),

@@ -570,6 +570,33 @@ __global__ void k_cfg_ddim(const float* __restrict__ x, const float* __restrict_
     out[r * W + wo] = xn;
 }
 
+// Loop-state update in ONE launch (round 5: no torch.cat / copy_ / fill_ kernels between two denoiser calls): one block per row,
+// the row is updated into LDS at its rolled position and leaves in order, so `out` may alias `x` for ANY roll; a second copy
+// `out2` (the CFG pair's other half -- the denoiser reads [x ; x]) and the next step's timestep words ride along.
+__global__ __launch_bounds__(256) void k_cfg_ddim_rows(const float* __restrict__ x, const float* __restrict__ eu,
+                                                       const float* __restrict__ ec, float g, float sa, float sb, float sap,
+                                                       float sbp, int W, int roll, float* out, float* out2,
+                                                       long long* tstep, int n_tstep, long long t_next) {
+    extern __shared__ float row[];
+    const long base = static_cast<long>(blockIdx.x) * W;
+    for (int w = threadIdx.x; w < W; w += 256) {
+        const float u = eu[base + w];
+        const float eps = u + g * (ec[base + w] - u);
+        const float x0 = (x[base + w] - sb * eps) / sa;
+        int wo = w + roll;
+        wo -= wo >= W ? W : 0;
+        row[wo] = sap * x0 + sbp * eps;
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < W; w += 256) {
+        const float v = row[w];
+        out[base + w] = v;
+        if (out2) out2[base + w] = v;
+    }
+    if (tstep && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_tstep; i += 256) tstep[i] = t_next;
+}
+
 // ---- token + position embedding gather (CLIP text encoder, transformers CLIPTextEmbeddings) -------------
 // out[b][t][:] = tok[ids[b][t]][:] + pos[t][:] for t < L, zeros for the padding rows L <= t < Lp.
 template <typename SO>
@@ -1170,6 +1197,21 @@ extern "C" pf_status pf_cfg_ddim_step(const float* x, const float* eu, const flo
     hipLaunchKernelGGL(k_cfg_ddim, dim3(cdiv(rows * W, 256)), dim3(256), 0, as_stream(stream), x, eu, ec, g, sa,
                        sb, sap, sbp, rows, W, roll, out);
     PF_CHECK_LAUNCH("pf_cfg_ddim_step");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_cfg_ddim_step_pair(const float* x, const float* eu, const float* ec, float g, float sa, float sb, float sap,
+                                           float sbp, long rows, int W, int roll, float* out, float* out2,
+                                           int64_t* tstep, int n_tstep, int64_t t_next, void* stream) {
+    PF_REQUIRE(x && eu && ec && out && rows > 0 && W > 0, "pf_cfg_ddim_step_pair: bad arguments");
+    PF_REQUIRE(rows < (1L << 31) && W <= 16384, "pf_cfg_ddim_step_pair: rows=%ld must be < 2^31 and W=%d <= 16384 (one row per block, staged in LDS)", rows, W);
+    PF_REQUIRE(out2 != x && out2 != out && out != eu && out != ec, "pf_cfg_ddim_step_pair: out2 must be a buffer of its own, out must not alias the predictions");
+    PF_REQUIRE(!tstep || n_tstep > 0, "pf_cfg_ddim_step_pair: n_tstep must be positive with tstep");
+    int r = roll % W;
+    if (r < 0) r += W;
+    hipLaunchKernelGGL(k_cfg_ddim_rows, dim3(static_cast<unsigned>(rows)), dim3(256), static_cast<size_t>(W) * sizeof(float), as_stream(stream),
+                       x, eu, ec, g, sa, sb, sap, sbp, W, r, out, out2, reinterpret_cast<long long*>(tstep), n_tstep, static_cast<long long>(t_next));
+    PF_CHECK_LAUNCH("pf_cfg_ddim_step_pair");
     return PF_OK;
 }
 

@@ -309,7 +309,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x
         }
     }
     u16x4 res[2][G][NREP];                                        // residual, requested one group ahead (MODE 2)
-    auto request = [&](auto g_tag, auto buf_tag) {
+    auto request = [&](auto g_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr int g = decltype(g_tag)::value, bf = decltype(buf_tag)::value;
         if (MODE != 2) return;
 #pragma unroll
@@ -320,7 +320,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x
             for (int j = 0; j < NREP; ++j) res[bf][ii][j] = *reinterpret_cast<const u16x4*>(rp + ncl[j]);
         }
     };
-    auto arithmetic = [&](auto g_tag, auto buf_tag) {
+    auto arithmetic = [&](auto g_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr int g = decltype(g_tag)::value, bf = decltype(buf_tag)::value;
 #pragma unroll
         for (int ii = 0; ii < G; ++ii) {
@@ -359,7 +359,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x
         }
     };
     unsigned short* outp = static_cast<unsigned short*>(p.out) + bz * p.out_bs;
-    auto copy_out = [&](int h) {
+    auto copy_out = [&](int h) __attribute__((always_inline)) {
         constexpr int CPR = MODE == 3 ? BN / 16 : BN / 8;         // 16-byte chunks per tile row
         const int nbase = MODE == 3 ? n0 >> 1 : n0;
 #pragma unroll
@@ -372,7 +372,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x
             }
         }
     };
-    auto group = [&](auto g_tag) {
+    auto group = [&](auto g_tag) __attribute__((always_inline)) {
         constexpr int g = decltype(g_tag)::value;
         if constexpr (g + 1 < NG) request(std::integral_constant<int, g + 1>(), std::integral_constant<int, (g + 1) & 1>());
         arithmetic(g_tag, std::integral_constant<int, g & 1>());
@@ -423,7 +423,7 @@ __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4
     float* outp = static_cast<float*>(p.out) + bz * p.out_bs;
     unsigned short* outp16 = static_cast<unsigned short*>(p.out) + bz * p.out_bs;    // PAIR: [M][per 32 columns: hi(32) | lo(32)] 16-bit
     float4 res[2][G][NREP];
-    auto request = [&](int g, int bf) {
+    auto request = [&](int g, int bf) __attribute__((always_inline)) {
         if (!RES) return;
 #pragma unroll
         for (int ii = 0; ii < G; ++ii) {
@@ -487,7 +487,7 @@ __device__ __forceinline__ void epilogue_f32_stats(const GemmParams& p, long bz,
     float* outp = static_cast<float*>(p.out) + bz * p.out_bs;
     const int nb = n0 + col_base + cq;
     float4 res[2][MREP];
-    auto request = [&](int j, int bf) {
+    auto request = [&](int j, int bf) __attribute__((always_inline)) {
         if (!RES) return;
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
@@ -856,12 +856,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
 // by the lower 32 lanes of all 8 waves), so one immediate serves all.
 // Tile boundary: right after the barrier that retires the ring the block decodes its next tile and requests
 // that tile's first two stages into slots 0 / 1; the epilogue runs meanwhile in two row slices through slot 2.
-template <typename T, int NREP, int NW, bool STATS = false, bool S3 = false>
-__global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
-    // NW = 8: 4 x 2 waves, 64x80 per wave, two waves per SIMD.  NW = 4: 2 x 2 waves, 128x80 per wave, ONE wave
+template <typename T, int NREP, int NW, bool STATS = false, bool S3 = false, int BM_ = 256>
+__global__ __launch_bounds__(64 * NW, BM_ == 128 ? 2 : 1) void k_conv_gemm8(const GemmParams p) {
+    // NW = 8: 4 x 2 waves, 64x80 per wave, two waves per SIMD.  NW = 4, BM_ = 256: 2 x 2 waves, 128x80 per wave, ONE wave
     // per SIMD with the whole register file (160 accumulator + 104 fragment registers): twice the MFMAs per
     // LDS read / DMA piece / barrier, and no second wave competing for the issue port.
-    constexpr int NT = 64 * NW, WMG = NW / 2, BM = 256, BN = 32 * NREP, MREP = BM / (16 * WMG), STAGES = 3;
+    // NW = 4, BM_ = 128 (round 5, "two tiles in flight"): 2 x 2 waves with the SAME 64x80 wave tile and K-step schedule, block tile
+    // 128 x (32*NREP), a TWO-slot ring (74 KB) so that TWO blocks share a CU: one block's ramp / epilogue overlaps the other's K loop
+    // (the 8-wave block idles its CU's matrix pipes for 10-50 % of every tile there).  One K step of DMA look-ahead instead of two --
+    // a block that waits for its stage leaves the SIMDs to its neighbour.
+    constexpr int NT = 64 * NW, WMG = NW / 2, BM = BM_, BN = 32 * NREP, MREP = BM / (16 * WMG), STAGES = BM_ == 128 ? 2 : 3;
+    constexpr bool ONEWAVE = NW == 4 && BM_ == 256;
+    static_assert(BM_ == 256 || (BM_ == 128 && NW == 4), "tile shapes: 256 rows (8 or 4 waves) or 128 rows (4 waves, two blocks per CU)");
     constexpr int RPP = NT / 8;                      // tile rows staged by one DMA pass of the block
     constexpr int STAGE = (BM + BN) * 64;            // 16-bit elements per ring slot
     constexpr int BFULL = BN / RPP;                  // full DMA passes of the weight tile
@@ -892,7 +898,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     constexpr unsigned OOB = 0x80000000u;                         // launcher guarantees tensors < 2 GiB
     // descriptors are built from readfirstlane'd words: hipcc otherwise treats a selected descriptor as
     // divergent and wraps every DMA in a waterfall loop (cdna_hip_programming.md T20)
-    auto uniform_ptr = [](const unsigned short* ptr) {
+    auto uniform_ptr = [](const unsigned short* ptr) __attribute__((always_inline)) {
         const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
         const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
         const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     int kg = 0, tap = 0, cc = 0;
     unsigned a_off[APASS];                                        // bytes, or OOB
     bool seg1 = false;                                            // current source is a1
-    auto set_segment = [&]() {
+    auto set_segment = [&]() __attribute__((always_inline)) {
         const int ky = p.ksize == 3 ? tap / 3 : 0, kx = p.ksize == 3 ? tap - 3 * ky : 0;
         seg1 = __builtin_amdgcn_readfirstlane(cc >= p.c0 ? 1 : 0) != 0;
         const int ld = seg1 ? p.a1_ld : p.a0_ld;
@@ -938,7 +944,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     };
     // Persistent over tiles: a block walks tiles blockIdx.x, + gridDim.x, ...; all per-tile state is set here.
     // (XCD-aware, bijective remap of the tile id: block b and all its tiles live on XCD b % 8.)
-    auto set_tile = [&](int tile) {
+    auto set_tile = [&](int tile) __attribute__((always_inline)) {
         int tid_lin = tile;
         {
             const int q = ntile_total >> 3, r = ntile_total & 7;
@@ -997,22 +1003,22 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // for ~900 clocks: the CU's vector-memory pipe moves ~64 B/clk).
     constexpr int NPIECE = APASS + BFULL + (BHALF ? 1 : 0);
     int st_soff_a = 0, st_soff_w = 0;
-    auto stage_begin = [&]() {
+    auto stage_begin = [&]() __attribute__((always_inline)) {
         st_soff_a = __builtin_amdgcn_readfirstlane((seg1 ? cc - p.c0 : cc) * 2);
         st_soff_w = __builtin_amdgcn_readfirstlane(kg * 2);
         return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(seg1 ? a1 : a0), 0,
                                                  __builtin_amdgcn_readfirstlane(seg1 ? p.a1_bytes : p.a0_bytes), 0x00020000);
     };
-    auto stage_end = [&]() {
+    auto stage_end = [&]() __attribute__((always_inline)) {
         kg += 64;
         cc += 64;
         if (cc == Ctot) { cc = 0; ++tap; set_segment(); }
         else if (cc == p.c0) set_segment();
     };
-    auto lds_dma = [&](const __amdgpu_buffer_rsrc_t& r, unsigned short* dst, unsigned voff, int soff) {
+    auto lds_dma = [&](const __amdgpu_buffer_rsrc_t& r, unsigned short* dst, unsigned voff, int soff) __attribute__((always_inline)) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
     };
-    auto dma_piece = [&](const __amdgpu_buffer_rsrc_t& rs_a, int slot, int k) {
+    auto dma_piece = [&](const __amdgpu_buffer_rsrc_t& rs_a, int slot, int k) __attribute__((always_inline)) {
         unsigned short* As = smem + slot * STAGE;
         unsigned short* Bs = As + BM * 64;
         if (k < APASS) {
@@ -1028,7 +1034,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             if (lane < 32) lds_dma(rs_w, Bs + (BFULL * RPP + wave * 4) * 64, w_off[BFULL], st_soff_w);
         }
     };
-    auto dma_stage = [&](int slot) {
+    auto dma_stage = [&](int slot) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rs_a = stage_begin();
 #pragma unroll
         for (int k = 0; k < NPIECE; ++k) dma_piece(rs_a, slot, k);
@@ -1055,13 +1061,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         fb1[j] = __builtin_bit_cast(frag, z);
     }
 #endif
-    auto load_frags_a = [&](int slot, int slab, frag (&fa)[MREP]) {
+    auto load_frags_a = [&](int slot, int slab, frag (&fa)[MREP]) __attribute__((always_inline)) {
         const unsigned short* As = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
             fa[i] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(As + lds_off(wm * 16 * MREP + i * 16 + frow, slab * 4 + fchunk)));
     };
-    auto load_frags_b = [&](int slot, int slab, frag (&fb)[NREP], int kadd) {
+    auto load_frags_b = [&](int slot, int slab, frag (&fb)[NREP], int kadd) __attribute__((always_inline)) {
 #ifdef PF_GEMM_BDIRECT
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         const int soff = __builtin_amdgcn_readfirstlane((kw + kadd + slab * 32) * 2);
@@ -1086,14 +1092,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             fb[j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Bs + lds_off(wn * 16 * NREP + j * 16 + frow, slab * 4 + fchunk)));
 #endif
     };
-    auto load_frags = [&](int slot, int slab, frag (&fa)[MREP], frag (&fb)[NREP], int kadd) {   // kadd: 64 for the NEXT stage (PF_GEMM_BDIRECT)
+    auto load_frags = [&](int slot, int slab, frag (&fa)[MREP], frag (&fb)[NREP], int kadd) __attribute__((always_inline)) {   // kadd: 64 for the NEXT stage (PF_GEMM_BDIRECT)
         load_frags_a(slot, slab, fa);
 #ifndef PF_ABL_NOLDS_B        /* timing-only: what the weight fragments' share of the LDS reads costs */
         load_frags_b(slot, slab, fb, kadd);
 #endif
     };
 
-    auto issue_prologue = [&]() {
+    auto issue_prologue = [&]() __attribute__((always_inline)) {
         dma_stage(0);
         if (n_it > 1) dma_stage(1);
     };
@@ -1109,10 +1115,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
     // insertion sees exact counts (a conditional around the prefetch made it drain lgkmcnt to 0 right
     // after issuing it, exposing the LDS latency once per step).
     // (-DPF_ABL_NOBARRIER / NODMA / NOLDS: timing-only ablations of this loop -- wrong results -- for tools/gpu_gemm_ablate.sh)
-    auto step_l = [&](auto more_tag, auto dma_tag, auto wait_tag, auto flead_tag) {
+    auto step_l = [&](auto more_tag, auto dma_tag, auto wait_tag, auto flead_tag) __attribute__((always_inline)) {
         constexpr bool MORE = decltype(more_tag)::value, DMA = decltype(dma_tag)::value;
         constexpr int WAIT = decltype(wait_tag)::value;           // DMA instructions that may stay in flight at the mid-step wait
-        constexpr int NM = MREP * NREP, LEAD = 4, FLEAD = decltype(flead_tag)::value;   // fragment requests go out after FLEAD MFMAs:
+        constexpr int NM = MREP * NREP, LEAD0 = NM - 1 - 2 * (NPIECE - 1), LEAD = LEAD0 < 4 ? LEAD0 : 4, FLEAD = decltype(flead_tag)::value;   // fragment requests go out after FLEAD MFMAs:
         // at every s_waitcnt lgkmcnt the only outstanding LDS reads are then the ones being waited for
         // (the compiler drains to 0, it does not count), and they were issued >= NM - LEAD MFMAs earlier.
 #pragma unroll
@@ -1120,7 +1126,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             // (S3: weight-fragment-major order -- the fragment fb0[j] of THIS step was requested j-th during the previous step's last
             // group, so the later ones have time to arrive)
             const int fi = S3 ? idx % MREP : idx / NREP, fj = S3 ? idx / MREP : idx % NREP;
-            if constexpr (NW == 4) Mfma<T>::acc_agpr(fb0[fj], fa0[fi], acc[fi][fj]);
+            if constexpr (ONEWAVE) Mfma<T>::acc_agpr(fb0[fj], fa0[fi], acc[fi][fj]);
             else acc[fi][fj] = Mfma<T>::run(fb0[fj], fa0[fi], acc[fi][fj]);
 #ifdef PF_GEMM_FLEAD2          /* two bursts: A fragments after FLEAD MFMAs, B fragments after FLEAD2 (A/B build) */
             if (idx == FLEAD - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_a(cur, 1, fa1); __builtin_amdgcn_sched_barrier(0); }
@@ -1148,6 +1154,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
 #endif
             else if constexpr (WAIT == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
             else if constexpr (WAIT == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+            else if constexpr (WAIT == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if constexpr (WAIT == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
             else if constexpr (WAIT == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
             else if constexpr (WAIT == 13) asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");
             else static_assert(WAIT == 0, "add the immediate");
@@ -1191,7 +1199,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         } else {
 #pragma unroll
         for (int idx = 0; idx < NM; ++idx) {
-            if constexpr (NW == 4) Mfma<T>::acc_agpr(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
+            if constexpr (ONEWAVE) Mfma<T>::acc_agpr(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
             else acc[idx / NREP][idx % NREP] = Mfma<T>::run(fb1[idx % NREP], fa1[idx / NREP], acc[idx / NREP][idx % NREP]);
 #ifdef PF_GEMM_FLEAD2
             if (MORE && idx == FLEAD - 1) { __builtin_amdgcn_sched_barrier(0); load_frags_a(nx1, 0, fa0); __builtin_amdgcn_sched_barrier(0); }
@@ -1220,7 +1228,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             }
         }
         }
-        static_assert(LEAD + 2 * (NPIECE - 1) < NM, "DMA pieces must fit behind the MFMAs of the second half");
+        static_assert(LEAD >= 0 && LEAD + 2 * (NPIECE - 1) < NM, "DMA pieces must fit behind the MFMAs of the second half");
         if constexpr (DMA) stage_end();
         cur = cur == STAGES - 1 ? 0 : cur + 1;
         nx1 = nx1 == STAGES - 1 ? 0 : nx1 + 1;
@@ -1236,7 +1244,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
 #ifndef PF_GEMM_FLEAD
 #define PF_GEMM_FLEAD 4
 #endif
-    auto step = [&](auto more_tag, auto dma_tag, auto wait_tag) { step_l(more_tag, dma_tag, wait_tag, std::integral_constant<int, PF_GEMM_FLEAD>()); };
+    auto step = [&](auto more_tag, auto dma_tag, auto wait_tag) __attribute__((always_inline)) { step_l(more_tag, dma_tag, wait_tag, std::integral_constant<int, PF_GEMM_FLEAD>()); };
 
     stamp(p, 0);
 #ifdef PF_GEMM_SETPRIO
@@ -1262,6 +1270,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             if constexpr (NPIECE == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
 #endif
             else if constexpr (NPIECE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (NPIECE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (NPIECE == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
             else if constexpr (NPIECE == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
             else if constexpr (NPIECE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1273,20 +1283,28 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
         if (first) stamp(p, 1);
         first = false;
         PF_TL(p, tl_tile == 1, 13);
-        if (n_it > 2) dma_stage(2);                       // third stage in flight (slot 2 staged the previous tile's epilogue)
+        if constexpr (STAGES == 3) { if (n_it > 2) dma_stage(2); }   // third stage in flight (slot 2 staged the previous tile's epilogue)
         load_frags(0, 0, fa0, fb0, 0);
-        cur = 0; nx1 = 1; nx2 = 2;
+        cur = 0; nx1 = 1; nx2 = 2 % STAGES;
         PF_TL(p, tl_tile == 1, 14);
         // The slot of stage `it` is retired at the mid-step barrier of step `it` (its last fragments are
         // requested in the first half), and stage it+3 is requested into it right behind that barrier: with
         // three slots a stage has TWO K steps to arrive, the mid-step wait leaves the younger one in flight.
         const std::integral_constant<int, NPIECE> W1;
         const std::integral_constant<int, 0> W0;
-        for (int it = 0; it + 3 < n_it; ++it) step(YES, YES, W1);
-        if (n_it >= 3) step(YES, NO, W1);
-        if (n_it >= 2) step(YES, NO, W0);
-        step(NO, NO, W0);
-        if constexpr (NW == 4) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // inline-asm MFMA results -> vector ALU reads
+        if constexpr (STAGES == 3) {
+            for (int it = 0; it + 3 < n_it; ++it) step(YES, YES, W1);
+            if (n_it >= 3) step(YES, NO, W1);
+            if (n_it >= 2) step(YES, NO, W0);
+            step(NO, NO, W0);
+        } else {
+            // two slots: stage it+2 goes into the slot of stage it right behind the mid-step barrier of step it and is awaited
+            // (full drain: nothing younger is in flight) at the mid-step wait of step it+1
+            for (int it = 0; it + 2 < n_it; ++it) step(YES, YES, W0);
+            if (n_it >= 2) step(YES, NO, W0);
+            step(NO, NO, W0);
+        }
+        if constexpr (ONEWAVE) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // inline-asm MFMA results -> vector ALU reads
         stamp(p, 2);
 
         const int em0 = m0, en0 = n0;
@@ -1304,7 +1322,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
                     slab_store(p, ((static_cast<long>(blockIdx.y) * p.batch + bz) * (p.M - p.m_begin) + (m - p.m_begin)) * p.N + n4, acc[i][j]);
                 }
             }
-            if (p.tickets) splitk_finish<T, BM, BN, NT>(p, bz, tile, em0, en0, reinterpret_cast<int*>(smem + 2 * STAGE), t);
+            if (p.tickets) splitk_finish<T, BM, BN, NT>(p, bz, tile, em0, en0, reinterpret_cast<int*>(smem + (STAGES - 1) * STAGE), t);
             if (!has_next) break;
             __syncthreads();                              // every wave is done reading the operand ring
             set_tile(next);
@@ -1317,8 +1335,19 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_gemm8(const GemmParams p) {
             // of the tile loop and stay live -- in registers the K loop has none to spare of)
             int e_lane = lane, e_t = t;
             asm volatile("" : "+v"(e_lane), "+v"(e_t));
-            epilogue_tile<T, MREP, NREP, NT, BM, BN, 2, STATS>(p, bz, acc, smem + 2 * STAGE, em0, en0, wm * 16 * MREP, wn * 16 * NREP,
-                                                        e_lane, e_t, [&]() { if (has_next) { set_tile(next); issue_prologue(); } });
+            if constexpr (STAGES == 3) {
+                epilogue_tile<T, MREP, NREP, NT, BM, BN, 2, STATS>(p, bz, acc, smem + 2 * STAGE, em0, en0, wm * 16 * MREP, wn * 16 * NREP,
+                                                            e_lane, e_t, [&]() __attribute__((always_inline)) { if (has_next) { set_tile(next); issue_prologue(); } });
+            } else {
+                // two slots: the whole 128-row tile is staged through the (dead) ring at once; the next tile's first stages are
+                // requested only when every wave has read its rows back out -- the neighbour block owns the matrix pipes meanwhile
+                epilogue_tile<T, MREP, NREP, NT, BM, BN, 1, STATS>(p, bz, acc, smem, em0, en0, wm * 16 * MREP, wn * 16 * NREP, e_lane, e_t);
+                if (has_next) {
+                    __syncthreads();
+                    set_tile(next);
+                    issue_prologue();
+                }
+            }
             PF_TL(p, tl_tile == 1, 23);
             if (!has_next) break;
         }
@@ -1394,9 +1423,9 @@ static pf_status launch(const GemmParams& gp, int batch, hipStream_t st) {
 }
 
 static int tuning(const char* name, int dflt);
-template <typename T, int NREP, int NW, bool STATS = false, bool S3 = false>
+template <typename T, int NREP, int NW, bool STATS = false, bool S3 = false, int BM = 256>
 static pf_status launch8w_s(const GemmParams& gp, int batch, hipStream_t st) {
-    constexpr int BM = 256, BN = 32 * NREP;
+    constexpr int BN = 32 * NREP, STAGES = BM == 128 ? 2 : 3;
     GemmParams p = gp;
     p.mtiles = static_cast<int>(cdiv(p.M - p.m_begin, BM));
     p.ntiles = static_cast<int>(cdiv(p.N, BN));
@@ -1408,23 +1437,24 @@ static pf_status launch8w_s(const GemmParams& gp, int batch, hipStream_t st) {
     }
     const ProfState ps = prof_snapshot();
     p.prof = (ps.buf && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= ps.blocks) ? ps.buf : nullptr;
-    const size_t smem = static_cast<size_t>(3) * (BM + BN) * 64 * sizeof(unsigned short);
+    const size_t smem = static_cast<size_t>(STAGES) * (BM + BN) * 64 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm8<T, NREP, NW, STATS, S3>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm8<T, NREP, NW, STATS, S3, BM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
         attr_set = true;
     }
     // persistent over tiles: one block per CU walks tiles b, b + grid, ... (a multiple of 8 keeps a tile on
     // the XCD its id maps to); PF_GEMM8_PERSIST=0 launches one block per tile
-    static const int cap = tuning("PF_GEMM8_PERSIST", 256);
+    static const int cap1 = tuning("PF_GEMM8_PERSIST", 256);
+    const int cap = BM == 128 ? 2 * cap1 : cap1;                  // (two resident 128-row blocks per CU)
     int grid = p.mtiles * p.ntiles;
     if (cap > 0) {
         int gx = std::max(1, cap / (p.splits * batch));           // blockIdx.y / z multiply the resident blocks
         if (gx >= 8) gx = gx / 8 * 8;
         grid = std::min(grid, gx);
     }
-    hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW, STATS, S3>), dim3(grid, p.splits, batch), dim3(64 * NW), smem, st, p);
+    hipLaunchKernelGGL((k_conv_gemm8<T, NREP, NW, STATS, S3, BM>), dim3(grid, p.splits, batch), dim3(64 * NW), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm (8-wave)");
     if (p.splits > 1 && !p.tickets) {
         const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
@@ -1434,18 +1464,19 @@ static pf_status launch8w_s(const GemmParams& gp, int batch, hipStream_t st) {
     return PF_OK;
 }
 
-template <typename T, int NREP, int NW>
+template <typename T, int NREP, int NW, int BM = 256>
 static pf_status launch8w(const GemmParams& gp, int batch, hipStream_t st) {
-    if constexpr (NW == 8) {
-        if (gp.s3) return gp.gn_partial ? launch8w_s<T, NREP, NW, true, true>(gp, batch, st) : launch8w_s<T, NREP, NW, false, true>(gp, batch, st);
-        if (gp.gn_partial) return launch8w_s<T, NREP, NW, true>(gp, batch, st);
+    if constexpr (NW == 8 || BM == 128) {
+        if (gp.s3) return gp.gn_partial ? launch8w_s<T, NREP, NW, true, true, BM>(gp, batch, st) : launch8w_s<T, NREP, NW, false, true, BM>(gp, batch, st);
+        if (gp.gn_partial) return launch8w_s<T, NREP, NW, true, false, BM>(gp, batch, st);
     }
-    return launch8w_s<T, NREP, NW, false>(gp, batch, st);
+    return launch8w_s<T, NREP, NW, false, false, BM>(gp, batch, st);
 }
 
 static int tuning(const char* name, int dflt);
 template <typename T, int NREP>
-static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st) {
+static pf_status launch8(const GemmParams& gp, int batch, hipStream_t st, int bm = 256) {
+    if (bm == 128) return launch8w<T, NREP, 4, 128>(gp, batch, st);       // two 128-row blocks per CU (round 5)
     // NW = 4 (one 128x80 wave per SIMD, accumulators in AGPRs) is implemented and correct but measured slower
     // (K step 2520 vs 2222 clocks, epilogue 2x): a lone in-order wave exposes every lgkmcnt / vmcnt / barrier wait.
     // PF_GEMM8_WAVES=4 selects it (A/B: it moves 28 % fewer fragment bytes through the LDS).
@@ -1460,9 +1491,21 @@ static int tuning(const char* name, int dflt) {     // A/B switches for benchmar
 }
 
 // Tile shape + split-K plan of one problem (shared by the launcher and the workspace query).
-struct GemmPlan { int mrep, nrep, splits, kb_per_split; bool big; int m_split; int tail_splits, tail_kb; };
+struct GemmPlan { int mrep, nrep, splits, kb_per_split; bool big; int m_split; int tail_splits, tail_kb; int bm = 256; };
 static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split);
+static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split);
+// Which plans of the 8-wave kernel run as 128-row blocks, two per CU (k_conv_gemm8<..., BM_ = 128>): PF_GEMM_BM128 = 0 none,
+// 1 all of them (A/B), 2 (default) the measured per-shape rule below.
 static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
+    GemmPlan g = plan_gemm0(M, N, K, batch, allow_split);
+    static const int mode = tuning("PF_GEMM_BM128", 2);
+    static const int max_k = tuning("PF_GEMM_BM128_MAXK", 0);     // rule: K <= this (0: rule off until measured)
+    if (!g.big) return g;
+    if (mode == 1) g.bm = 128;
+    else if (mode == 2 && K <= max_k) g.bm = 128;
+    return g;
+}
+static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split) {
     static const int big_min_tiles = tuning("PF_GEMM8_MIN_TILES", 128);   // 0 disables the 8-wave kernel
     const int nrep = (N % 160 == 0) ? 5 : 4;
     const long tiles256 = cdiv(M, 256) * cdiv(N, 32 * nrep) * batch;
@@ -1685,7 +1728,7 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     if (d->tickets && tuning("PF_SPLITK_INKERNEL", 0) && d->workspace_bytes < (1ULL << 32)) {      // (32-bit slab offsets)
         // enough zeroed counters for every (batch, tile) of the split launch?  (tile counts of split plans: <= 320 of the
         // 4-wave kernel, <= 255 of the 8-wave one)
-        const int bm = g.big ? 256 : 32 * g.mrep, bn = 32 * g.nrep;
+        const int bm = g.big ? g.bm : 32 * g.mrep, bn = 32 * g.nrep;
         const long rows = g.big && g.m_split > 0 ? p.M - g.m_split : p.M;
         const long need = cdiv(rows, bm) * cdiv(p.N, bn) * d->batch;
         PF_REQUIRE(d->n_tickets >= need && (reinterpret_cast<uintptr_t>(d->tickets) & 3) == 0,
@@ -1702,8 +1745,8 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
         p1.M = g.m_split; p1.splits = 1; p1.kb_per_split = p.K / 64;
         p2.m_begin = g.m_split; p2.splits = g.tail_splits; p2.kb_per_split = g.tail_kb;
         PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
-            if (g.nrep == 5) { pf_status s1 = launch8<T, 5>(p1, 1, st); if (s1 != PF_OK) return s1; return launch8<T, 5>(p2, 1, st); }
-            else { pf_status s1 = launch8<T, 4>(p1, 1, st); if (s1 != PF_OK) return s1; return launch8<T, 4>(p2, 1, st); });
+            if (g.nrep == 5) { pf_status s1 = launch8<T, 5>(p1, 1, st, g.bm); if (s1 != PF_OK) return s1; return launch8<T, 5>(p2, 1, st, g.bm); }
+            else { pf_status s1 = launch8<T, 4>(p1, 1, st, g.bm); if (s1 != PF_OK) return s1; return launch8<T, 4>(p2, 1, st, g.bm); });
     }
     if (p.splits > 1) {
         const size_t need = static_cast<size_t>(p.splits) * d->batch * p.M * p.N * sizeof(float);
@@ -1712,8 +1755,8 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     }
     if (g.big) {
         PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
-            if (g.nrep == 5) return launch8<T, 5>(p, d->batch, st);
-            else return launch8<T, 4>(p, d->batch, st));
+            if (g.nrep == 5) return launch8<T, 5>(p, d->batch, st, g.bm);
+            else return launch8<T, 4>(p, d->batch, st, g.bm));
     }
     PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
         if (g.nrep == 5) return g.mrep == 2 ? launch<T, 2, 5>(p, d->batch, st) : launch<T, 4, 5>(p, d->batch, st);

@@ -428,6 +428,23 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
     return out
 
 
+def cfg_ddim_step_pair(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None, out2=None, tstep=None, t_next=0):
+    """cfg_ddim_step as the loop's one-launch state update: ``out`` may be ``x`` itself for any roll, ``out2`` receives a second
+    copy (the other half of the CFG pair the next denoiser call reads), ``tstep`` (int64 device tensor) is set to ``t_next``."""
+    W = x.shape[-1]
+    rows = x.numel() // W
+    if out is None:
+        out = torch.empty_like(x)
+    assert x.is_contiguous() and out.is_contiguous() and (out2 is None or out2.is_contiguous())
+    assert tstep is None or (tstep.dtype == torch.int64 and tstep.is_contiguous())
+    sa, sb, sap, sbp = (float(c) for c in coef)
+    check(_lib.lib().pf_cfg_ddim_step_pair(_p(x), _p(eps_uncond), _p(eps_cond), float(guidance), sa, sb, sap, sbp,
+                                           rows, W, int(roll), _p(out), _p(out2) if out2 is not None else None,
+                                           _p(tstep) if tstep is not None else None, tstep.numel() if tstep is not None else 0,
+                                           int(t_next), _stream()), "pf_cfg_ddim_step_pair")
+    return out
+
+
 # ---------------------------------------------------------------------------- GEMM / conv
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,

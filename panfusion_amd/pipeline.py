@@ -65,8 +65,11 @@ class DenoiseLoop:
         prompt_embd (2, m, L, D) / pano_prompt_embd (2, 1, L, D) = [null ; prompt];
         cameras: dict of (1, m) CPU tensors (FoV, theta, phi in degrees)."""
         self.model, self.guidance, self.rot_diff = model, guidance_scale, rot_diff
-        self.lat = latents.float().contiguous().clone()
-        self.pano = pano_latent.float().contiguous().clone()
+        # The loop's state lives as the CFG PAIR the denoiser reads ([x ; x], gen_cls_free_guide_pair, PanoGenerator.py:240-251):
+        # the DDIM kernel writes both halves, so no torch.cat runs between two calls.  self.lat / self.pano are the first halves.
+        self.lat2 = torch.stack([latents.float()[0]] * 2).contiguous()
+        self.pano2 = torch.stack([pano_latent.float()[0]] * 2).contiguous()
+        self.lat, self.pano = self.lat2[:1], self.pano2[:1]
         self.prompt, self.pano_prompt = prompt_embd, pano_prompt_embd
         self.cameras = {k: v.detach().cpu() for k, v in cameras.items()}
         self.m = latents.shape[1]
@@ -75,6 +78,7 @@ class DenoiseLoop:
         self.sched = DDIMSchedule()
         self.timesteps = self.sched.set_timesteps(steps)
         self.tstep = torch.empty(2, self.m, dtype=torch.long, device=latents.device)
+        self._tstep_value = None                          # what self.tstep holds (the DDIM kernel writes the next step's value)
         self.i = 0
         self.total_rot = 0.0
         self.use_graphs = use_graphs
@@ -86,10 +90,9 @@ class DenoiseLoop:
         self.eps = self.pano_eps = None
         # the loop rolls the panorama BEFORE each denoiser call (PanFusion.py:149); afterwards the
         # DDIM kernel writes the next latent already rolled for the following step.
-        self._pano_tmp = torch.empty_like(self.pano)
         self._rot_of = {}                                  # camera-theta key -> accumulated rotation (degrees)
         if rot_diff % 360:
-            self.pano.copy_(ops.roll_width(self.pano, self.shift, out=self._pano_tmp))
+            self.pano2.copy_(ops.roll_width(self.pano2, self.shift))       # (one-off set-up, not part of a step)
         self.cameras = rotate_cameras(self.cameras, rot_diff)
         self.total_rot += rot_diff
         self._rot_of[tuple(float(v) for v in self.cameras["theta"].reshape(-1))] = self.total_rot
@@ -106,10 +109,14 @@ class DenoiseLoop:
         return self._layout_rot[rot]
 
     def _denoise(self, cams):
-        pair = lambda x: torch.cat([x, x])
-        cams2 = {k: torch.cat([v, v]) for k, v in cams.items()}
-        return self.model(pair(self.lat), pair(self.pano), self.tstep, self.prompt, self.pano_prompt, cams2,
+        cams2 = {k: torch.cat([v, v]) for k, v in cams.items()}                 # (host tensors)
+        return self.model(self.lat2, self.pano2, self.tstep, self.prompt, self.pano_prompt, cams2,
                           None, self._layout_for(cams))
+
+    def _set_tstep(self, t):
+        if self._tstep_value != t:
+            self.tstep.fill_(t)
+            self._tstep_value = t
 
     MAX_GRAPHS = 8        # distinct rotation offsets kept as graphs (4 at rot_diff = 90); beyond that: eager launches
 
@@ -148,7 +155,7 @@ class DenoiseLoop:
         """Untimed set-up: build the geometry tables (and capture one hipGraph) for every rotation
         offset the loop will visit (4 at rot_diff = 90)."""
         cams, seen = self.cameras, set()
-        self.tstep.fill_(self.timesteps[0])
+        self._set_tstep(self.timesteps[0])
         rot = self.total_rot
         for _ in range(64):
             key = tuple(float(v) for v in cams["theta"].reshape(-1))
@@ -171,17 +178,19 @@ class DenoiseLoop:
     def step(self):
         """One iteration of the loop body (PanFusion.py:146-162)."""
         t = self.timesteps[self.i]
-        self.tstep.fill_(t)
+        self._set_tstep(t)                                # (a no-op after the first step: the DDIM kernel left it there)
         run = self._denoise_graphed if self.use_graphs else self._denoise
         eps, pano_eps = run(self.cameras)
         coef = self.sched.coefficients(t)
         last = self.i == len(self.timesteps) - 1
-        # views: plain update; panorama: update + roll for the next iteration
-        ops.cfg_ddim_step(self.lat, eps[0], eps[1], self.guidance, coef, 0, out=self.lat)
-        # (self.pano keeps its storage: captured graphs read it by address)
-        ops.cfg_ddim_step(self.pano, pano_eps[0], pano_eps[1], self.guidance, coef,
-                          0 if last else self.shift, out=self._pano_tmp)
-        self.pano.copy_(self._pano_tmp)
+        # Two launches update the whole loop state IN PLACE (captured graphs read it by address): views -- plain update, both
+        # halves of the CFG pair; panorama -- update + roll for the next iteration (a block owns whole rows, so in place for any
+        # roll), both halves, and the next call's timestep words.
+        ops.cfg_ddim_step_pair(self.lat, eps[0], eps[1], self.guidance, coef, 0, out=self.lat, out2=self.lat2[1:])
+        t_next = t if last else self.timesteps[self.i + 1]
+        ops.cfg_ddim_step_pair(self.pano, pano_eps[0], pano_eps[1], self.guidance, coef, 0 if last else self.shift,
+                               out=self.pano, out2=self.pano2[1:], tstep=self.tstep, t_next=t_next)
+        self._tstep_value = t_next
         self.i += 1
         if not last:
             self.cameras = rotate_cameras(self.cameras, self.rot_diff)

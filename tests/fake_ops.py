@@ -271,6 +271,16 @@ def cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None):
     return y
 
 
+def cfg_ddim_step_pair(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None, out2=None, tstep=None, t_next=0):
+    y = cfg_ddim_step(x, eps_uncond, eps_cond, guidance, coef, roll)
+    out = y if out is None else out.copy_(y)
+    if out2 is not None:
+        out2.copy_(y)
+    if tstep is not None:
+        tstep.fill_(int(t_next))
+    return out
+
+
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, c1=None,
               a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, split_out=False, pad_hi=0,

@@ -293,6 +293,29 @@ def test_cfg_ddim_step_vs_oracle():
         assert float((got.cpu() - torch.roll(want, 8, -1)).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 4, 16, 32), (1, 1, 4, 64, 128), (1, 1, 4, 8, 600)])
+def test_cfg_ddim_step_pair_in_place_roll_second_copy_and_timestep(shape):
+    """The loop's one-launch state update (pf_cfg_ddim_step_pair): BIT-identical to pf_cfg_ddim_step + roll, in place for any
+    roll, second copy for the CFG pair, next timestep written to the int64 tensor (PanFusion.py:147-162)."""
+    o = ops()
+    sched = oddim.DDIM()
+    sched.set_timesteps(50)
+    x, eu, ec = rnd(*shape, seed=27), rnd(*shape, seed=28), rnd(*shape, seed=29)
+    W = shape[-1]
+    for t, roll in ((981, 0), (501, W // 4), (21, -3), (1, 5 * W + 7)):
+        coef = [float(c) for c in sched.coefficients(t)]
+        want = o.cfg_ddim_step(x.to(DEV), eu.to(DEV), ec.to(DEV), 9.0, coef, roll)
+        assert torch.equal(want.cpu(), torch.roll(o.cfg_ddim_step(x.to(DEV), eu.to(DEV), ec.to(DEV), 9.0, coef, 0).cpu(), roll, -1))
+        pair = torch.stack([x[0], x[0]]).to(DEV)
+        tstep = torch.full((2, 5), 7, dtype=torch.long, device=DEV)
+        got = o.cfg_ddim_step_pair(pair[:1], eu.to(DEV), ec.to(DEV), 9.0, coef, roll, out=pair[:1], out2=pair[1:], tstep=tstep, t_next=t - 20)
+        assert got.data_ptr() == pair.data_ptr()
+        assert torch.equal(pair[0].cpu(), want[0].cpu()) and torch.equal(pair[1].cpu(), want[0].cpu())
+        assert torch.equal(tstep.cpu(), torch.full((2, 5), t - 20, dtype=torch.long))
+        ref = sched.step(oddim.cfg_merge(torch.cat([eu, ec]), 9.0), t, x)
+        assert float((pair[:1].cpu() - torch.roll(ref, roll, -1)).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("wrap", [False, True])
 def test_boundary_convs(dtype, wrap):

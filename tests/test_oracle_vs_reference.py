@@ -126,6 +126,30 @@ def test_denoiser_matches(ref):
     assert not torch.equal(torch.roll(m0, 4, dims=2), m90)
 
 
+def test_denoiser_matches_at_full_width_cfg1_first_call(ref):
+    """The port against the REFERENCE CLASS ITSELF at SD-2-base widths: BASELINE.json configs[0]'s first
+    denoiser call of the loop -- m = 4 views of 32x32 latents + the 64x128 panorama latent, the CFG pair, t = 981, cameras and
+    panorama rotated by the loop's first 90 degrees, weights / inputs from oracle/fixtures.py seeds.  ``ref.MultiViewBaseModel``
+    (models/pano/MVGenModel.py:38-297 with its WarpAttn / get_masks / SphericalPE / xformers-shimmed CrossAttention) wraps the same
+    UNet objects as ``oracle.mvgen.DualBranchDenoiser``; both epsilon outputs agree to fp32 round-off (measured 2.6e-6).
+    The same reference object drives tests/golden/cfg1_ddim10.npz (tools/make_golden_cfg.py cfg1)."""
+    from oracle import fixtures as FX
+    om = FX.build_full_width()
+    rm = FX.reference_denoiser(om)
+    assert type(rm).__module__ == "models.pano.MVGenModel"
+    args = FX.first_step_call(FX.horizon4_cameras(), (32, 32), (64, 128), cfg_pair=True)
+
+    def call(model):
+        with torch.no_grad(), FX.chunked_attention():
+            return model(args["latents"], args["pano_latent"], args["timestep"], args["prompt_embd"],
+                         args["pano_prompt_embd"], args["cameras"])
+    a, o = call(rm), call(om)
+    assert a[0].shape == (2, 4, 4, 32, 32) and a[1].shape == (2, 1, 4, 64, 128)
+    ev, ep = rel_l2(o[0], a[0]), rel_l2(o[1], a[1])
+    print("\nport vs reference class at SD-2-base widths (cfg 1 first call): views %.2e  pano %.2e" % (ev, ep))
+    assert ev < 1e-5 and ep < 1e-5, (ev, ep)
+
+
 def test_py360_e2p_bit_exact(ref):
     """oracle/py360.py (numpy restatement incl. scipy's map_coordinates 'wrap' semantics) against the reference's own
     external/py360convert running on scipy: random cameras, odd sizes, uint8 / float32 / 2-D, both modes, an

@@ -9,9 +9,14 @@ same seeded weights / inputs on the GPU box (oracle/fixtures.py) and compare the
                                            widths: both epsilon outputs + 8-channel slices of both streams after each of
                                            the 7 EPA blocks (the 20-view EPA softmax has K = 20 480 keys)
   cfg1  -> tests/golden/cfg1_ddim10.npz    configs[0]: m = 4, 256^2 views, 10 DDIM steps at full widths: latents after
-                                           every step (drift per step)
+                                           every step (drift per step).  Round 5: the denoiser of this fixture is the REFERENCE's
+                                           own class (models/pano/MVGenModel.py imported from /root/reference, third-party modules
+                                           shimmed: oracle/fixtures.reference_denoiser), not the port -- PF_GOLDEN_PORT=1 restores the port
   cfg2b -> tests/golden/cfg2b_eps.npz      the same configuration at a LATE step of the loop: timestep t = 21, accumulated rotation 180
                                            degrees (m = 20 x CFG pair; both epsilon outputs)
+  cfg1s -> tests/golden/cfg1_stress_eps.npz  RANGE STRESS: cfg1's first denoiser call (CFG pair) with the stream-writing layers' output
+                                           channels scaled log-uniformly over 3 decades (oracle/fixtures.apply_range_stress): both epsilon
+                                           outputs + the largest |value| of every residual-stream tensor (reference class as denoiser)
   cfg4  -> tests/golden/cfg4_eps.npz       128x256 panorama latent + 20 views, the CFG pair (b = 2) as the loop calls it
   cfg5  -> tests/golden/cfg5_eps.npz       cfg2's geometry + panorama ControlNet on a 512x1024 layout image, the CFG pair (b = 2)
 """
@@ -80,6 +85,9 @@ def cfg2b():
 
 def cfg1():
     model = FX.build_full_width()
+    if os.environ.get("PF_GOLDEN_PORT", "0") != "1":
+        model = FX.reference_denoiser(model)          # the reference class itself drives the fixture
+        print("cfg1: denoiser =", type(model).__module__, type(model).__name__, flush=True)
     cams = FX.horizon4_cameras()
     latents, pano_latent, pe, ppe = FX.loop_inputs(cams, (32, 32), (64, 128))
     sched = oddim.DDIM()
@@ -94,6 +102,36 @@ def cfg1():
             traj_p.append(oddim.rotate_latent(pano_latent, cams, -total)[0].numpy().copy())     # un-rotated frame
             print("cfg1 step t=%d  %.0f s" % (int(t), time.time() - t0), flush=True)
     np.savez_compressed(os.path.join(OUT, "cfg1_ddim10.npz"), latents=np.stack(traj_v), pano_latent=np.stack(traj_p))
+
+
+def cfg1s():
+    om = FX.build_full_width()
+    FX.apply_range_stress(om)
+    model = FX.reference_denoiser(om) if os.environ.get("PF_GOLDEN_PORT", "0") != "1" else om
+    args = FX.first_step_call(FX.horizon4_cameras(), (32, 32), (64, 128), cfg_pair=True)
+    peaks = {}
+
+    def hook(name):
+        def fn(mod, a, out):
+            peaks[name] = max(peaks.get(name, 0.0), float(out.abs().max()))
+        return fn
+    hooks = []
+    for tag, unet in (("views", om.unet), ("pano", om.pano_unet)):
+        hooks.append(unet.conv_in.register_forward_hook(hook(tag + ".conv_in")))
+        for name, mod in unet.named_modules():
+            if type(mod).__name__ in ("ResnetBlock2D", "Transformer2DModel"):
+                hooks.append(mod.register_forward_hook(hook(tag + "." + name)))
+    t0 = time.time()
+    s, ps = call(model, args)
+    print("cfg1s oracle forward %.0f s" % (time.time() - t0), flush=True)
+    for h in hooks:
+        h.remove()
+    names = sorted(peaks)
+    top = sorted(peaks.items(), key=lambda kv: -kv[1])[:5]
+    print("cfg1s: largest |stream| values:", ", ".join("%s %.3g" % kv for kv in top), flush=True)
+    print("cfg1s: eps finite:", bool(torch.isfinite(s).all() and torch.isfinite(ps).all()), " |eps| rms %.3g / %.3g" % (float(s.pow(2).mean().sqrt()), float(ps.pow(2).mean().sqrt())))
+    np.savez_compressed(os.path.join(OUT, "cfg1_stress_eps.npz"), sample=s.numpy(), pano_sample=ps.numpy(),
+                        stream_names=np.array(names), stream_peaks=np.array([peaks[n] for n in names], dtype=np.float32))
 
 
 def cfg4():
