@@ -364,18 +364,34 @@ def main():
             loop.step()
         if world > 1:
             dist.barrier()
+            sharding.reset_comm()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loop.step()
         torch.cuda.synchronize()
+    t_steps_done = time.perf_counter()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    distributed = None
     if world > 1:
+        # what a SCALE record needs to check itself: the world this process group REALLY has, every rank's own time for the
+        # timed steps (before / without the closing barrier), what each collective moved
+        t_rank = torch.tensor([t_steps_done - t0], device=dev, dtype=torch.float64)
+        all_t = [torch.zeros_like(t_rank) for _ in range(world)]
+        dist.all_gather(all_t, t_rank)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in all_t]
         tt = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        distributed = {"backend": dist.get_backend(), "world_size_initialised": dist.get_world_size(),
+                       "devices_visible": torch.cuda.device_count(),
+                       "rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms), "per_rank": [round(v, 3) for v in per_rank_ms]},
+                       "layout": getattr(loop, "layout_desc", None),
+                       "collectives_rank0": sharding.comm_stats(args.steps),
+                       "note": "rank_ms = each rank's own wall time of the timed steps up to its final synchronize (no closing barrier); "
+                               "collectives: issued per step on rank 0, bytes = what that rank contributes per call"}
 
     # ---- instrumented step: device events around every GEMM / attention launch ------------------
     trace = []
@@ -429,7 +445,7 @@ def main():
             pass
     if dom:
         fl, sec, n = fam[dom]
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS,
+        roofline = {"bound": "mfma", "kernel": "k_conv_gemm+k_linear_ws" if dom == "k_conv_gemm" else dom, "achieved": fl / sec / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS,
                     "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_DENSE_TFLOPS,
                     "traffic": traffic["bytes_per_launch"] if traffic and dom in traffic.get("kernel", "") else None,
                     "traffic_note": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, L2<->fabric incl. Infinity-Cache hits: an upper bound on HBM bytes) from the "
@@ -459,6 +475,8 @@ def main():
                           "parallelism": "single" if world == 1 else getattr(loop, "layout_desc", "sharded")},
                "tflops_per_step": flop / 1e12, "frac_of_mfma_ceiling": (flop * args.steps / elapsed) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
                "roofline": roofline}
+        if distributed is not None:
+            res["distributed"] = distributed
         if not args.no_cpu_baseline and world == 1 and not args.small:
             res["cpu_baseline"] = cpu_baseline(cfg, cfg["cross_attention_dim"], lat_hw, pano_hw, m, cams_deg, flop)
         # (skipped with --no-cpu-baseline as well: that flag marks the quick / profiled runs of tools/*.sh -- under

@@ -62,13 +62,14 @@ def reference_denoiser(om):
     return rm
 
 
-STRESS_LAYERS = ("conv2", "conv_shortcut", "proj_out", "downsamplers.0.conv", "upsamplers.0.conv")
+STRESS_LAYERS = ("conv2", "proj_out")
 
 
 def apply_range_stress(om, seed=7, decades=3.0):
-    """Range-stress variant of the synthetic weights: every layer that WRITES INTO a residual stream --
-    conv_in, ResnetBlock2D.conv2 / conv_shortcut, Transformer2DModel.proj_out, the down / up-sampling convs of both UNets and
-    the EPA blocks' attention / feed-forward output projections -- gets its output channels (weight rows and bias) multiplied by
+    """Range-stress variant of the synthetic weights: every layer that writes a NORMALISED activation INTO a
+    residual stream -- conv_in, ResnetBlock2D.conv2, Transformer2DModel.proj_out of both UNets and the EPA blocks' attention /
+    feed-forward output projections (the stream -> stream maps conv_shortcut / Downsample2D / Upsample2D keep their gain: scaled too,
+    the range would compound by 10^decades per layer -- 7e22 after the decoder, fp32 itself overflows) -- gets its output channels (weight rows and bias) multiplied by
     a per-channel scale drawn log-uniformly over ``decades`` decades, 1 ... 10^decades, ONE vector per stream width (the same
     channel is the outlier in every layer of that width, as in trained SD-2 weights).  The fan-in-scaled Gaussians of
     init_synthetic keep every stream at O(1); with this the stream channels reach 1e3 ... 1e4 and a GroupNorm group is dominated

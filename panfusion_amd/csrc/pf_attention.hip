@@ -502,6 +502,255 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
     }
 }
 
+
+// ---- 8-wave ping-pong variant (round 5; D = 64, no bias: the UNet self-attentions) -------------------------------------
+// MI355X_MICROARCH.md, "Two waves per SIMD": a 512-thread workgroup places waves w and w + 4 on one SIMD.  The key walk is cut
+// into PHASES separated by s_barrier; in every phase one wave of a SIMD runs its MATRIX segment (O^T += V_j^T P_j^T, then
+// S_{j+1}^T = K_{j+1} Q^T: 16 MFMAs, fragments already in registers) while its partner runs its VECTOR segment (online softmax
+// of its own S_j, conversion to the 16-bit P operand, LDS -> register prefetch of the fragments of its next matrix segment) --
+// the two pipes of the SIMD work side by side by construction instead of by the accident of three drifting waves
+// (k_attention_lds: 26-31 % matrix-pipe busy, profiles/r4k_attn_ablate.txt).  Group A = waves 0..3, group B = waves 4..7, B runs
+// half a period behind A:
+//     phase 2j      A: vector_j            B: matrix_{j-1}
+//     phase 2j + 1  A: matrix_j            B: vector_j
+// K [64 keys][64] and V^T [64][64 keys] tiles reach LDS by LDS-DMA (buffer_load ... lds, no registers, no ds_write): every wave
+// moves one 1-KB piece of each; "set j" = (K_{j+2}, V_{j+1}) is requested by ALL waves at the start of phase 2j and awaited
+// (vmcnt(0)) at the end of phase 2j + 1 -- two phases to land -- into the buffers last read (register prefetch) in phases
+// 2j - 2 / 2j - 1.  Rows are 128 B with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 (applied to the SOURCE offset, the
+// DMA writes lane-linear): conflict-free ds_read_b128 for both tiles.  To make a V^T fragment ONE 16-byte read, tile row i of K
+// holds key pi(i) = i with bits 2 and 3 swapped: the score registers of lane (q, hi) then cover, per 16-key slab, the 8 CONSECUTIVE
+// keys 16 s + 8 hi .. + 7 -- exactly one chunk of a V^T row (the MFMA k-slot order is free as long as P and V^T agree).
+// Needs nk % 8 == 0 (whole chunks are either keys or zero fill); everything else stays on k_attention_lds.
+template <typename T>
+__global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
+    constexpr int D = 64, KS = 4, DB = 2, KT = 64, TILE = KT * D;
+    typedef typename Mfma32<T>::frag frag;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[4 * TILE];      // K tiles [2], V^T tiles [2]: 32 KB
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ql = lane & 31, hi = lane >> 5;
+    const int q0 = (blockIdx.x * 8 + wave) * 32;
+    const int h = blockIdx.y;
+    const long b = blockIdx.z;
+    const unsigned short* qp = p.q + b * p.q_bs + h * D;
+    const unsigned short* kp = p.k + b * p.k_bs + h * D;
+    const unsigned short* vp = p.vt + b * p.vt_bs + static_cast<long>(h) * D * p.vt_ld;
+    const int qrow = min(q0 + ql, p.nq - 1);
+
+    frag qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        qf[s] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(qp + static_cast<long>(qrow) * p.q_ld + 16 * s + 8 * hi));
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = p.scale_log2e;
+    const int nkt = (p.nk + KT - 1) / KT;
+    const bool ragged = (p.nk % KT) != 0;
+
+    // ---- LDS-DMA staging: wave w moves rows 8 w .. 8 w + 7 of a tile (1 KB), lane l -> row 8 w + l / 8, physical chunk l % 8
+    constexpr unsigned OOB = 0x80000000u;
+    auto uniform_ptr = [](const unsigned short* ptr) __attribute__((always_inline)) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+        const unsigned hi32 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+        return reinterpret_cast<unsigned short*>(static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi32) << 32));
+    };
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(kp), 0, __builtin_amdgcn_readfirstlane(((p.nk - 1) * p.k_ld + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(vp), 0, __builtin_amdgcn_readfirstlane(D * p.vt_ld * 2), 0x00020000);
+    const int srow = wave * 8 + (lane >> 3);
+    const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);                           // logical chunk that belongs in this lane's physical slot
+    const int krow = (srow & ~12) | ((srow & 4) << 1) | ((srow & 8) >> 1);       // pi: tile row srow holds key krow of the tile
+    const unsigned kvoff0 = static_cast<unsigned>(krow * p.k_ld + lchunk * 8) * 2u;
+    const unsigned vvoff0 = static_cast<unsigned>(srow * p.vt_ld + lchunk * 8) * 2u;
+    const unsigned kstep = static_cast<unsigned>(KT * p.k_ld) * 2u;
+    auto lds_dma = [&](const __amdgpu_buffer_rsrc_t& r, unsigned short* dst, unsigned voff) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+    };
+    auto dma_k = [&](int j) __attribute__((always_inline)) {                     // K tile j -> K buffer j & 1
+        if (j >= nkt) return;
+        unsigned voff = kvoff0 + static_cast<unsigned>(j) * kstep;
+        if (ragged && j == nkt - 1 && j * KT + krow >= p.nk) voff = OOB;
+        lds_dma(rs_k, smem + (j & 1) * TILE + wave * 512, voff);
+    };
+    auto dma_v = [&](int j) __attribute__((always_inline)) {                     // V^T tile j -> V buffer j & 1
+        if (j >= nkt) return;
+        unsigned voff = vvoff0 + static_cast<unsigned>(j) * (KT * 2u);
+        if (ragged && j == nkt - 1 && j * KT + lchunk * 8 >= p.nk) voff = OOB;
+        lds_dma(rs_v, smem + (2 + (j & 1)) * TILE + wave * 512, voff);
+    };
+    auto frag_off = [&](int row, int chunk) __attribute__((always_inline)) { return row * D + ((chunk ^ ((row >> 1) & 7)) << 3); };
+
+    frag kf[2][KS], vf[DB][2][2];
+    auto load_kfrags = [&](int j) __attribute__((always_inline)) {
+        const unsigned short* Ks = smem + (j & 1) * TILE;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kf[hh][ks] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Ks + frag_off(hh * 32 + ql, 2 * ks + hi)));
+    };
+    auto load_vfrags = [&](int j) __attribute__((always_inline)) {
+        const unsigned short* Vs = smem + (2 + (j & 1)) * TILE;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    vf[d][hh][s2] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Vs + frag_off(d * 32 + ql, 4 * hh + 2 * s2 + hi)));
+    };
+    float sv[2][16];
+    u16x8 pb[2][2];
+    auto mm_qk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s = Mfma32<T>::run(kf[hh][ks], qf[ks], s);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[hh][r] = s[r];
+        }
+    };
+    auto mm_pv = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+                    o[d] = Mfma32<T>::run(vf[d][hh][s2], __builtin_bit_cast(frag, pb[hh][s2]), o[d]);
+    };
+    // score register r of half hh <-> key  k0 + 32 hh + 16 (g >> 1) + 8 hi + 4 (g & 1) + e,  g = r >> 2, e = r & 3  (pi above)
+    auto mask_tail = [&](int j) __attribute__((always_inline)) {
+        if (!(ragged && j == nkt - 1)) return;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int g = r >> 2, e = r & 3;
+                if (j * KT + 32 * hh + 16 * (g >> 1) + 8 * hi + 4 * (g & 1) + e >= p.nk) sv[hh][r] = -INFINITY;
+            }
+    };
+    auto softmax = [&]() __attribute__((always_inline)) {                        // sv -> pb (16-bit P), running max / sum, deferred rescale of O
+        float mt = sv[0][0];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sv[hh][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        {
+            constexpr float DEFER_LOG2 = 8.0f;                                    // (see k_attention_lds)
+            const float m_new = fmaxf(m_run, mt);
+            const bool grow = (m_new - m_run) * c2 > DEFER_LOG2;
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+        }
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const f32x2 c22 = {c2, c2}, mc2 = {m_run * c2, m_run * c2};
+        f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 x = f32x2{sv[hh][r], sv[hh][r + 1]} * c22 - mc2;
+                const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                sv[hh][r] = e[0];
+                sv[hh][r + 1] = e[1];
+                ls2 += e;
+            }
+        float ls = ls2[0] + ls2[1];
+        ls += __shfl_xor(ls, 32);
+        l_run += ls;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[hh][s2][e] = from_f32<T>(sv[hh][8 * s2 + e]);
+    };
+    auto barrier = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: K_0, V_0, K_1 resident; S_0 for every wave
+    dma_k(0);
+    dma_v(0);
+    dma_k(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
+    load_kfrags(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mm_qk();
+    barrier();                                                                   // K buffer 0 read by everyone: set 0 may overwrite it
+
+    if (wave < 4) {
+        // group A: vector_j in phase 2 j, matrix_j in phase 2 j + 1
+        for (int j = 0; j < nkt; ++j) {
+            dma_k(j + 2);                                                        // set j
+            dma_v(j + 1);
+            mask_tail(j);
+            softmax();
+            load_vfrags(j);
+            if (j + 1 < nkt) load_kfrags(j + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            barrier();
+            mm_pv();
+            if (j + 1 < nkt) mm_qk();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // set j landed (mine): readable by all after the barrier
+            barrier();
+        }
+    } else {
+        // group B: half a period behind -- matrix_{j-1} in phase 2 j, vector_j in phase 2 j + 1
+        dma_k(2);                                                                // set 0, phase 0
+        dma_v(1);
+        barrier();
+        for (int j = 0; j < nkt; ++j) {
+            mask_tail(j);
+            softmax();
+            load_vfrags(j);
+            if (j + 1 < nkt) load_kfrags(j + 1);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // set j landed (mine); my fragments are in registers
+            barrier();
+            dma_k(j + 3);                                                        // set j + 1, phase 2 j + 2
+            dma_v(j + 2);
+            mm_pv();
+            if (j + 1 < nkt) mm_qk();
+            if (j + 1 < nkt) barrier();                                          // (A executes 2 nkt barriers in its loop, B 1 + 2 nkt - 1)
+        }
+    }
+
+    if (q0 + ql < p.nq) {
+        const float inv = 1.0f / l_run;
+        unsigned short* op = p.out + b * p.o_bs + static_cast<long>(q0 + ql) * p.o_ld + h * D;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u16x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(o[d][4 * g + e] * inv);
+                *reinterpret_cast<u16x4*>(op + d * 32 + 8 * g + 4 * hi) = w;
+            }
+        if (p.lse && hi == 0) p.lse[(b * p.H + h) * p.nq + q0 + ql] = m_run * c2 + __log2f(l_run);
+    }
+}
+
 static bool use_lds_attention() {
     static int v = -1;                     // PF_ATTENTION_IMPL=direct selects the no-LDS kernel (A/B switch)
     if (v < 0) { const char* e = getenv("PF_ATTENTION_IMPL"); v = (e && e[0] == 'd') ? 0 : 1; }
@@ -549,9 +798,13 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     PF_DISPATCH_16(d->dtype, "pf_attention",
         if (lds) {
             static const int occ64 = attention_occupancy("PF_ATTENTION_OCC", 3), occ32 = attention_occupancy("PF_ATTENTION_OCC32", 3);
+            static const int pingpong = attention_occupancy("PF_ATTENTION_PP", 1);      // 0: k_attention_lds for the D = 64 self-attentions too (A/B)
             if (d->D == 64) {
                 if (d->bias) {                 // (not pipelined it needs 169 registers at three waves per SIMD)
                     hipLaunchKernelGGL((k_attention_lds<T, 64, true>), grid, block, 0, st, p);
+                } else if (pingpong && d->nk % 8 == 0 && d->nk >= 128 && static_cast<long>(d->nk) * d->k_ld * 2 < (1L << 31) &&
+                           static_cast<long>(d->vt_ld) * 64 * 2 < (1L << 31)) {
+                    hipLaunchKernelGGL((k_attention_pp<T>), dim3(cdiv(d->nq, 256), d->H, d->B), dim3(512), 0, st, p);
                 } else {
                     if (occ64 == 2) hipLaunchKernelGGL((k_attention_lds<T, 64, false>), grid, block, 0, st, p);
                     else hipLaunchKernelGGL((k_attention_lds<T, 64, false, false, 3>), grid, block, 0, st, p);

@@ -554,6 +554,14 @@ __global__ void k_permute(const void* x, int n, int C, long hw, void* y) {
 }
 
 // ---- CFG + DDIM ------------------------------------------------------------------------------
+// one element of the CFG merge + DDIM update; explicit fused multiply-adds so that both kernels below round identically
+// whatever contraction the compiler would pick per loop copy
+__device__ __forceinline__ float cfg_ddim_value(float x, float u, float c, float g, float sa, float sb, float sap, float sbp) {
+    const float eps = __builtin_fmaf(g, c - u, u);
+    const float x0 = __builtin_fmaf(-sb, eps, x) / sa;
+    return __builtin_fmaf(sap, x0, sbp * eps);
+}
+
 __global__ void k_cfg_ddim(const float* __restrict__ x, const float* __restrict__ eu,
                            const float* __restrict__ ec, float g, float sa, float sb, float sap,
                            float sbp, long rows, int W, int roll, float* __restrict__ out) {
@@ -561,10 +569,7 @@ __global__ void k_cfg_ddim(const float* __restrict__ x, const float* __restrict_
     if (i >= rows * W) return;
     const int w = i % W;
     const long r = i / W;
-    const float u = eu[i];
-    const float eps = u + g * (ec[i] - u);
-    const float x0 = (x[i] - sb * eps) / sa;
-    const float xn = sap * x0 + sbp * eps;
+    const float xn = cfg_ddim_value(x[i], eu[i], ec[i], g, sa, sb, sap, sbp);
     int wo = (w + roll) % W;
     if (wo < 0) wo += W;
     out[r * W + wo] = xn;
@@ -573,19 +578,16 @@ __global__ void k_cfg_ddim(const float* __restrict__ x, const float* __restrict_
 // Loop-state update in ONE launch (round 5: no torch.cat / copy_ / fill_ kernels between two denoiser calls): one block per row,
 // the row is updated into LDS at its rolled position and leaves in order, so `out` may alias `x` for ANY roll; a second copy
 // `out2` (the CFG pair's other half -- the denoiser reads [x ; x]) and the next step's timestep words ride along.
-__global__ __launch_bounds__(256) void k_cfg_ddim_rows(const float* __restrict__ x, const float* __restrict__ eu,
+__global__ __launch_bounds__(256) void k_cfg_ddim_rows(const float* x, const float* __restrict__ eu,
                                                        const float* __restrict__ ec, float g, float sa, float sb, float sap,
                                                        float sbp, int W, int roll, float* out, float* out2,
                                                        long long* tstep, int n_tstep, long long t_next) {
     extern __shared__ float row[];
     const long base = static_cast<long>(blockIdx.x) * W;
     for (int w = threadIdx.x; w < W; w += 256) {
-        const float u = eu[base + w];
-        const float eps = u + g * (ec[base + w] - u);
-        const float x0 = (x[base + w] - sb * eps) / sa;
         int wo = w + roll;
         wo -= wo >= W ? W : 0;
-        row[wo] = sap * x0 + sbp * eps;
+        row[wo] = cfg_ddim_value(x[base + w], eu[base + w], ec[base + w], g, sa, sb, sap, sbp);
     }
     __syncthreads();
     for (int w = threadIdx.x; w < W; w += 256) {

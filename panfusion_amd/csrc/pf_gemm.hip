@@ -1495,14 +1495,23 @@ struct GemmPlan { int mrep, nrep, splits, kb_per_split; bool big; int m_split; i
 static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split);
 static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split);
 // Which plans of the 8-wave kernel run as 128-row blocks, two per CU (k_conv_gemm8<..., BM_ = 128>): PF_GEMM_BM128 = 0 none,
-// 1 all of them (A/B), 2 (default) the measured per-shape rule below.
+// 1 all of them (A/B), 2 (default) the measured rule: the 128-row blocks win where the tile is ramp / epilogue-bound -- short K
+// (K <= PF_GEMM_BM128_MAXK: isolated +7 % at K = 320, +15...22 % at K = 640, +12...16 % at K = 1280; long-K convolutions lose
+// 3-5 % to the shorter DMA look-ahead and the doubled weight traffic, profiles/r5a_gemm_bm128.txt): same-box step A/B 62.06 -> 61.39 /
+// 61.36 ms (profiles/r5b_ab_gemm_bm128.txt).  PF_GEMM_BM128_ONEROUND=1 also takes every problem that is ONE round of 256-row tiles
+// (a CU then runs a single ramp + K loop + epilogue with nothing to overlap -- the per-rank GEMMs of the sharded layouts): measured
+// neutral to slightly slower on the simulated ranks (8 ranks 14.35 -> 14.48 ms, 4 ranks 19.9 -> 20.4), so off.
 static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
     GemmPlan g = plan_gemm0(M, N, K, batch, allow_split);
     static const int mode = tuning("PF_GEMM_BM128", 2);
-    static const int max_k = tuning("PF_GEMM_BM128_MAXK", 0);     // rule: K <= this (0: rule off until measured)
-    if (!g.big) return g;
+    static const int max_k = tuning("PF_GEMM_BM128_MAXK", 1280);
+    static const int one_round = tuning("PF_GEMM_BM128_ONEROUND", 0);
+    if (!g.big || g.m_split > 0) return g;
     if (mode == 1) g.bm = 128;
-    else if (mode == 2 && K <= max_k) g.bm = 128;
+    else if (mode == 2) {
+        const long tiles256 = cdiv(M, 256) * cdiv(N, 32 * g.nrep) * batch * g.splits;
+        if (K <= max_k || (one_round && tiles256 <= 256)) g.bm = 128;
+    }
     return g;
 }
 static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split) {

@@ -22,6 +22,7 @@
 // Replaces cuBLAS behind the nn.Linear layers of diffusers' BasicTransformerBlock / the reference's
 // models/modules/transformer.py:57-74 (to_q / to_k / to_v / to_out), :8-38 (GEGLU FeedForward) at C = 320.
 #include "pf_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <algorithm>
 
@@ -442,10 +443,16 @@ __global__ __launch_bounds__(512, 1) void k_linear_ws(const LwsParams p) {
 template <typename T, int MODE, bool COUNTED, int K, int CHB>
 static pf_status lws_launch_c(const LwsParams& p, hipStream_t st) {
     const size_t smem = static_cast<size_t>(LWS_STAGES) * LWS_STAGE_ELEMS * 2 + 8 * LWS_STG_BYTES + LWS_LN_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ws<T, MODE, COUNTED, K, CHB>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
-        attr_set = true;
+    // per (instantiation, device): the attribute is a property of the function ON a device; the status is checked (a failed
+    // call used to surface as an opaque launch failure).  std::atomic: concurrent first launches both set it, harmlessly.
+    static std::atomic<unsigned long long> attr_devs{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ULL << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ws<T, MODE, COUNTED, K, CHB>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+        PF_REQUIRE(e == hipSuccess, "pf_linear_ws: the device does not grant %zu bytes of LDS per workgroup (%s)", smem, hipGetErrorString(e));
+        attr_devs.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_linear_ws<T, MODE, COUNTED, K, CHB>), dim3(256), dim3(512), smem, st, p);
     PF_CHECK_LAUNCH("pf_linear_ws");

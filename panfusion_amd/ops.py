@@ -612,6 +612,9 @@ def linear_ws(x, w, mode, bias=None, residual=None, out=None, out_vt=None, rows_
                           dtype=torch.float32 if mode in (LWS_F32, LWS_F32_LN) else x.dtype)
     d.a, d.a_ld, d.w, d.bias = _p(x), _ld(x), _p(w), _p(bias)
     d.residual, d.res_ld = _p(residual), (_ld(residual) if residual is not None else 0)
+    for buf in (out, out_vt):            # caller-supplied buffers: GroupNorm moments they carried described their OLD contents
+        if buf is not None:
+            _written(buf)
     d.out, d.out_ld = _p(out), (_ld(out) if out is not None else 0)
     d.M, d.N, d.K, d.dtype, d.mode = rows, N, K, dt(x), mode
     if TRACE is None:

@@ -85,6 +85,7 @@ TIME_MODEL = {
     ((128, 256), (64, 64), False): dict(base=7.75, per_view=0.956, pano=20.6, pano_only=20.75),   # cfg 4
 }
 _DEFAULT_KEY = ((64, 128), (64, 64), False)
+_WARNED = set()
 
 
 def time_model(pano_hw=None, lat_hw=None, layout_cond=False):
@@ -93,7 +94,15 @@ def time_model(pano_hw=None, lat_hw=None, layout_cond=False):
     key = (tuple(pano_hw), tuple(lat_hw), bool(layout_cond)) if pano_hw is not None and lat_hw is not None else _DEFAULT_KEY
     if key in TIME_MODEL:
         return dict(TIME_MODEL[key], measured=True)
-    ref = TIME_MODEL[_DEFAULT_KEY]
+    # unmeasured: scale the cfg-2 row that matches the layout condition (a ControlNet rides on the owner: ADVICE r4) and say so once
+    ref = TIME_MODEL[(_DEFAULT_KEY[0], _DEFAULT_KEY[1], key[2])]
+    if key not in _WARNED:
+        _WARNED.add(key)
+        if not dist.is_initialized() or dist.get_rank() == 0:
+            import warnings
+            warnings.warn("panfusion_amd.sharding: no measured time model for panorama latent %s / view latent %s / layout_cond=%s -- the "
+                          "view split scales the cfg-2 constants by token count (the panorama self-attention grows faster: the owner may "
+                          "carry too many views); pass split=... or PF_SHARD_SPLIT to override" % (key[0], key[1], key[2]))
     r_p = (key[0][0] * key[0][1]) / (64.0 * 128.0)
     r_v = (key[1][0] * key[1][1]) / (64.0 * 64.0)
     return dict(base=ref["base"], per_view=ref["per_view"] * r_v, pano=ref["pano"] * r_p, pano_only=ref["pano_only"] * r_p, measured=False)
@@ -273,6 +282,26 @@ class SegmentedGraph:
 
 RECORDER = None                     # the SegmentedGraph being recorded, if any
 
+# What this rank put on the wire since reset_comm(): collective -> [calls, bytes this rank contributed].  Counted where the
+# collective is ISSUED (eagerly, also between replayed graph segments), so bench.py --gpus N can print bytes per collective
+# next to the timing and a SCALE record checks itself.
+COMM = {}
+
+
+def _note(name, t):
+    c = COMM.setdefault(name, [0, 0])
+    c[0] += 1
+    c[1] += t.numel() * t.element_size()
+
+
+def reset_comm():
+    COMM.clear()
+
+
+def comm_stats(steps=1):
+    return {k: {"calls_per_step": v[0] / steps, "bytes_per_rank_per_call": v[1] // max(v[0], 1),
+                "bytes_per_rank_per_step": v[1] / steps} for k, v in sorted(COMM.items())}
+
 
 def _collective(call):
     if RECORDER is not None:
@@ -297,7 +326,10 @@ def gather_view_tokens(x_local, shard, P=None):
         padded[:x_local.shape[0]] = x_local
         x_local = padded
     out = torch.empty(shard.G * rows, x_local.shape[1], dtype=x_local.dtype, device=x_local.device)
-    _collective(lambda: dist.all_gather_into_tensor(out, x_local, group=shard.group))
+    def call():
+        _note("all_gather view tokens (EPA, group of %d)" % shard.G, x_local)
+        dist.all_gather_into_tensor(out, x_local, group=shard.group)
+    _collective(call)
     if len(set(counts)) == 1:
         return out
     return torch.cat([out[g * rows:g * rows + counts[g] * P] for g in range(shard.G)])
@@ -308,7 +340,10 @@ def share_pano_tokens(x, rows, cols, like, shard):
     if shard.pano_g is None or shard.G == 1:
         return x
     buf = x.contiguous() if x is not None else torch.empty(rows, cols, dtype=like.dtype, device=like.device)
-    _collective(lambda: dist.broadcast(buf, src=shard.pano_src, group=shard.group))
+    def call():
+        _note("broadcast panorama tokens (EPA, group of %d)" % shard.G, buf)
+        dist.broadcast(buf, src=shard.pano_src, group=shard.group)
+    _collective(call)
     return buf
 
 
@@ -322,6 +357,7 @@ def gather_eps(eps_local, pano_eps_local, shard, pano_shape=None):
         pad[:, :e.shape[1]] = e
         e = pad
     out = torch.empty(shard.world, *e.shape[1:], dtype=e.dtype, device=e.device)
+    _note("all_gather eps views (world)", e)
     dist.all_gather_into_tensor(out, e)                   # concatenated along dim 0 in rank order
     if len(set(counts)) == 1:
         eps = out.view(2, shard.m, *e.shape[2:])          # [(c, g), m/G, ...] is [2, m, ...] in memory
@@ -332,6 +368,7 @@ def gather_eps(eps_local, pano_eps_local, shard, pano_shape=None):
     else:
         p = pano_eps_local.contiguous()                   # [1, 1, 4, H, W]
     pout = torch.empty(shard.world * p.shape[0], *p.shape[1:], dtype=p.dtype, device=p.device)
+    _note("all_gather eps panorama (world)", p)
     dist.all_gather_into_tensor(pout, p)
     pano_eps = pout[(shard.pano_g or 0)::shard.G].contiguous()    # the owner's (replicas are identical otherwise)
     return eps, pano_eps

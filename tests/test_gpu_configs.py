@@ -136,6 +136,31 @@ def test_cfg1_ten_ddim_steps_vs_oracle(full_oracle, graphs):
     assert el <= 1.3e-3 and ep <= 1.3e-3, (el, ep)
 
 
+STRESS_TOL = 1e-3
+
+
+@pytest.mark.skipif(not _have("cfg1_stress_eps.npz"), reason="fixture not generated")
+def test_cfg1_range_stress_vs_oracle():
+    """RANGE STRESS: the fan-in-scaled synthetic weights keep every residual stream at O(1); here the layers
+    that write into the streams carry per-channel output scales drawn log-uniformly over 3 decades (oracle/fixtures.apply_range_stress),
+    so the fp32 oracle's stream tensors peak at ~1e4 (recorded in the fixture) and a GroupNorm group is dominated by its outlier
+    channel.  fp16 operands have 5 exponent bits: the default path must stay finite and within the same 1e-3 of the fp32 oracle
+    (reference class as denoiser, tools/make_golden_cfg.py cfg1s) on cfg 1's first denoiser call, CFG pair, SD-2-base widths."""
+    from oracle import fixtures as FX
+    gd = np.load(os.path.join(GOLDEN, "cfg1_stress_eps.npz"))
+    assert float(gd["stream_peaks"].max()) >= 1e3, "the fixture must actually stress the range"
+    om = FX.build_full_width()
+    FX.apply_range_stress(om)
+    model = _hip_model(om)
+    args = FX.first_step_call(FX.horizon4_cameras(), (32, 32), (64, 128), cfg_pair=True)
+    s, ps = _call(model, args)
+    assert bool(torch.isfinite(s).all()) and bool(torch.isfinite(ps).all()), "non-finite epsilon under range stress"
+    es, ep = rel_l2(s.cpu(), torch.from_numpy(gd["sample"])), rel_l2(ps.cpu(), torch.from_numpy(gd["pano_sample"]))
+    print("\ncfg1 RANGE STRESS (stream peaks %.2g in the fp32 oracle) rel-L2 vs oracle: views %.3e  pano %.3e  (tolerance %.0e)"
+          % (float(gd["stream_peaks"].max()), es, ep, STRESS_TOL))
+    assert es <= STRESS_TOL and ep <= STRESS_TOL, (es, ep)
+
+
 @pytest.mark.skipif(not _have("cfg4_eps.npz"), reason="fixture not generated")
 def test_cfg4_large_panorama_vs_oracle(full_oracle):
     """BASELINE.json configs[3]: 1024x2048 panorama (128x256 latent, 32 768 self-attention tokens) + 20 views, the CFG pair."""

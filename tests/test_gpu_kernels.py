@@ -310,7 +310,9 @@ def test_cfg_ddim_step_pair_in_place_roll_second_copy_and_timestep(shape):
         tstep = torch.full((2, 5), 7, dtype=torch.long, device=DEV)
         got = o.cfg_ddim_step_pair(pair[:1], eu.to(DEV), ec.to(DEV), 9.0, coef, roll, out=pair[:1], out2=pair[1:], tstep=tstep, t_next=t - 20)
         assert got.data_ptr() == pair.data_ptr()
-        assert torch.equal(pair[0].cpu(), want[0].cpu()) and torch.equal(pair[1].cpu(), want[0].cpu())
+        bad = (pair[0] != want[0])
+        assert int(bad.sum()) == 0, (t, roll, int(bad.sum()), float((pair[0] - want[0]).abs().max()), bad.nonzero()[:4].tolist())
+        assert torch.equal(pair[1].cpu(), want[0].cpu())
         assert torch.equal(tstep.cpu(), torch.full((2, 5), t - 20, dtype=torch.long))
         ref = sched.step(oddim.cfg_merge(torch.cat([eu, ec]), 9.0), t, x)
         assert float((pair[:1].cpu() - torch.roll(ref, roll, -1)).abs().max()) <= 2e-5 * float(ref.abs().max())

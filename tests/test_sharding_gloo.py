@@ -63,6 +63,8 @@ def _worker(rank, world, port, out, split=None, layout=None, precision="fast", c
     try:
         lat, pano = _run_loop(True, split=split, layout=layout, precision=precision, controlnet=controlnet)
         torch.save((lat, pano), os.path.join(out, "r%d.pt" % rank))
+        from panfusion_amd import sharding
+        torch.save(sharding.comm_stats(2), os.path.join(out, "comm%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
@@ -142,6 +144,17 @@ def test_sharded_loop_equals_single_process(world, split, layout, precision):
     with tempfile.TemporaryDirectory() as out:
         mp.spawn(_worker, args=(world, _free_port(), out, split, layout, precision), nprocs=world, join=True)
         res = [torch.load(os.path.join(out, "r%d.pt" % r)) for r in range(world)]
+        comm = torch.load(os.path.join(out, "comm0.pt"))
+    # what bench.py --gpus N prints per collective (sharding.comm_stats): 7 EPA blocks per step, each one all-gather of the
+    # view tokens inside the CFG half (+ one broadcast of the panorama tokens in the panorama-rank layout), 2 epsilon all-gathers
+    if world > 2:
+        G = world // 2
+        assert comm["all_gather view tokens (EPA, group of %d)" % G]["calls_per_step"] == 7
+        assert ("broadcast panorama tokens (EPA, group of %d)" % G in comm) == (layout != "even")
+    else:
+        assert not any("EPA" in k for k in comm)          # the pure CFG split: no traffic inside the step
+    assert comm["all_gather eps views (world)"]["calls_per_step"] == 1 and comm["all_gather eps panorama (world)"]["calls_per_step"] == 1
+    assert comm["all_gather eps panorama (world)"]["bytes_per_rank_per_call"] == want[1].numel() * 4
     for lat, pano in res:                       # every rank holds the full, identical latents
         rel = lambda a, b: float((a - b).norm() / b.norm())       # fp32 round-off of differently batched convs
         assert rel(lat, want[0]) < 1e-4 and rel(pano, want[1]) < 1e-4, (rel(lat, want[0]), rel(pano, want[1]))

@@ -5,6 +5,9 @@
 #
 # Every section writes gpurun_out/<tag>_*; copy what is to be judged into profiles/.  Sections:
 #   tests[:<pytest -k expr>]   the -m gpu suite (optionally filtered)          -> <tag>_pytest_gpu.log
+#   envtests:"VAR=v":<-k expr> the (filtered) suite under environment switches         -> <tag>_pytest_gpu_<env>.log
+#   gemmenv:"VAR=v;VAR2=v"     GEMM microbenchmark under each setting (baseline first)  -> <tag>_gemm_env.txt
+#   attnenv:"VAR=v;VAR2=v"     attention microbenchmark under each setting (baseline first) -> <tag>_attn_env.txt
 #   smoke                      __graft_entry__.smoke()                         -> <tag>_smoke.log
 #   bench[:<bench.py args>]    one bench line (+ per-shape table)              -> <tag>_bench[_<args>].json, <tag>_shapes.txt
 #   env:"VAR=v VAR2=v;VAR3=v"  same-box A/B (settings separated by ;) of environment switches on the default bench (baseline first and last; the two
@@ -45,6 +48,19 @@ for SEC in "$@"; do
     tests)
       timeout 1700 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -n 4 ${ARG:+-k "$ARG"} 2>&1 | q | tail -n 40 | cut -c1-300 > gpurun_out/${TAG}_pytest_gpu.log
       tail -n 6 gpurun_out/${TAG}_pytest_gpu.log ;;
+    envtests)    # envtests:"VAR=v VAR2=v":<pytest -k expr>  -- the (filtered) suite under environment switches (A/B kernels behind a switch)
+      EV=${ARG%%:*}; KX=""; [ "$ARG" != "$EV" ] && KX=${ARG#*:}
+      env $EV timeout 1700 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -n 4 ${KX:+-k "$KX"} 2>&1 | q | tail -n 40 | cut -c1-300 > gpurun_out/${TAG}_pytest_gpu_$(slug "$EV").log
+      tail -n 6 gpurun_out/${TAG}_pytest_gpu_$(slug "$EV").log ;;
+    gemmenv)     # gemmenv:"VAR=v;VAR2=v"  -- GEMM microbenchmark (16-bit and fp32-stream epilogues) under each setting, baseline first
+      { IFS=';' read -ra KVS <<< "$ARG"
+        for kv in "PF_NOP=0" "${KVS[@]}"; do
+          echo "## $kv"; env $kv python tools/gemm_bench.py --reps 20 $GEMM_ARGS 2>&1 | q
+          echo "## $kv --stream32"; env $kv python tools/gemm_bench.py --reps 20 --stream32 --shapes lin320,ff2_320,lin640,lin1280,lin_mid $GEMM_ARGS 2>&1 | q
+        done; } | tee gpurun_out/${TAG}_gemm_env.txt | tail -n 90 ;;
+    attnenv)     # attnenv:"VAR=v;VAR2=v"  -- attention microbenchmark under each setting, baseline first
+      { IFS=';' read -ra KVS <<< "$ARG"
+        for kv in "PF_NOP=0" "${KVS[@]}"; do echo "## $kv"; env $kv python tools/attn_bench.py $ATTN_ARGS 2>&1 | q; done; } | tee gpurun_out/${TAG}_attn_env.txt ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | q | tail -n 3 | tee gpurun_out/${TAG}_smoke.log ;;
     bench)

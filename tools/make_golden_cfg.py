@@ -113,6 +113,8 @@ def cfg1s():
 
     def hook(name):
         def fn(mod, a, out):
+            out = getattr(out, "sample", out)
+            out = out[0] if isinstance(out, (tuple, list)) else out
             peaks[name] = max(peaks.get(name, 0.0), float(out.abs().max()))
         return fn
     hooks = []
