@@ -173,6 +173,9 @@ pf_status pf_geglu(const void* in, int dtype, long rows, int inner, void* out, v
 /* Sinusoidal timestep features [cos | sin] (diffusers Timesteps, flip_sin_to_cos, shift 0)
  * followed by nothing: t [n] int64 -> out [n][dim] in `dtype`. */
 pf_status pf_timestep_features(const int64_t* t, int n, int dim, int out_dtype, void* out, void* stream);
+/* The same with the n timesteps t_stride words apart: `timestep[:, 0]` of the (b, m) tensor the reference hands the panorama
+ * branch (MVGenModel.py:49-50, :85) read in place -- no strided-copy kernel in the step. */
+pf_status pf_timestep_features_strided(const int64_t* t, long t_stride, int n, int dim, int out_dtype, void* out, void* stream);
 
 /* y = silu(x) element-wise, n elements. */
 pf_status pf_silu(const void* x, int dtype, long n, void* y, void* stream);

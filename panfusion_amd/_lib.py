@@ -110,6 +110,7 @@ SIGNATURES = {
     "pf_vae_sample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_float, c_void_p, c_void_p]),
     "pf_geglu": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p]),
     "pf_timestep_features": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_timestep_features_strided": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_silu": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "pf_pad_width": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_crop_width": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

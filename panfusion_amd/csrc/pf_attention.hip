@@ -32,6 +32,7 @@ struct AttnParams {
     float scale_log2e;
     const float* bias; long bias_ld; const uint8_t* flags; int flags_ld;
     float* lse;
+    int pp_role;                 // k_attention_pp: how a wave finds its phase group (PF_ATTENTION_PP_ROLE, see the kernel)
 };
 
 template <typename T, int D>
@@ -514,9 +515,12 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
 //     phase 2j      A: vector_j            B: matrix_{j-1}
 //     phase 2j + 1  A: matrix_j            B: vector_j
 // K [64 keys][64] and V^T [64][64 keys] tiles reach LDS by LDS-DMA (buffer_load ... lds, no registers, no ds_write): every wave
-// moves one 1-KB piece of each; "set j" = (K_{j+2}, V_{j+1}) is requested by ALL waves at the start of phase 2j and awaited
-// (vmcnt(0)) at the end of phase 2j + 1 -- two phases to land -- into the buffers last read (register prefetch) in phases
-// 2j - 2 / 2j - 1.  Rows are 128 B with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 (applied to the SOURCE offset, the
+// moves one 1-KB piece of each, into rings of NB = L + 1 tiles.  "Set j" = (K_{j+1+L}, V_{j+L}) is requested by ALL waves at the
+// start of phase 2j -- into the slots last read (register prefetch) in phases 2j - 2 / 2j - 1 -- and must have landed when
+// phase 2(j+L) begins: 2 L phases.  At the end of phase 2j + 1 a wave waits for set j + 1 - L with a COUNTED vmcnt(2 (L - 1)): its
+// loads retire in order and nothing else is in flight in the loop.  (First version: L = 1, two slots, vmcnt(0) -- correct and 15-35 %
+// SLOWER than k_attention_lds: one period of look-ahead is less than the L2 / fabric latency under load, every tile waited for its
+// DMA; profiles/r5c_attn_pp_first.txt.)  Rows are 128 B with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 (applied to the SOURCE offset, the
 // DMA writes lane-linear): conflict-free ds_read_b128 for both tiles.  To make a V^T fragment ONE 16-byte read, tile row i of K
 // holds key pi(i) = i with bits 2 and 3 swapped: the score registers of lane (q, hi) then cover, per 16-key slab, the 8 CONSECUTIVE
 // keys 16 s + 8 hi .. + 7 -- exactly one chunk of a V^T row (the MFMA k-slot order is free as long as P and V^T agree).
@@ -524,14 +528,27 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
 template <typename T>
 __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
     constexpr int D = 64, KS = 4, DB = 2, KT = 64, TILE = KT * D;
+    constexpr int L = 3, NB = L + 1;                                            // look-ahead in tiles, ring slots per operand
     typedef typename Mfma32<T>::frag frag;
-    __shared__ __attribute__((aligned(16))) unsigned short smem[4 * TILE];      // K tiles [2], V^T tiles [2]: 32 KB
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NB * TILE];  // K tiles [NB], V^T tiles [NB]: 64 KB
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ql = lane & 31, hi = lane >> 5;
-    const int q0 = (blockIdx.x * 8 + wave) * 32;
-    const int h = blockIdx.y;
-    const long b = blockIdx.z;
+    // 1-D grid, XCD-aware: block id l runs on XCD l % 8 (speed only).  When the (batch, head) pairs divide by 8, pair g lives on XCD
+    // g % 8 with its query blocks back to back there -- a head's K / V^T (1 MB at 4096 keys) is fetched into ONE L2, not eight.
+    const int nqb = (p.nq + 255) / 256, BH = static_cast<int>(gridDim.x) / nqb;
+    int qb, bh;
+    if ((BH & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bh = xcd + 8 * (idx / nqb);
+        qb = idx - (idx / nqb) * nqb;
+    } else {
+        bh = blockIdx.x / nqb;
+        qb = blockIdx.x - bh * nqb;
+    }
+    const int q0 = (qb * 8 + wave) * 32;
+    const int h = bh % p.H;
+    const long b = bh / p.H;
     const unsigned short* qp = p.q + b * p.q_bs + h * D;
     const unsigned short* kp = p.k + b * p.k_bs + h * D;
     const unsigned short* vp = p.vt + b * p.vt_bs + static_cast<long>(h) * D * p.vt_ld;
@@ -573,23 +590,29 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
     auto lds_dma = [&](const __amdgpu_buffer_rsrc_t& r, unsigned short* dst, unsigned voff) __attribute__((always_inline)) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
     };
-    auto dma_k = [&](int j) __attribute__((always_inline)) {                     // K tile j -> K buffer j & 1
+    auto dma_k = [&](int j) __attribute__((always_inline)) {                     // K tile j -> K slot j % NB
         if (j >= nkt) return;
         unsigned voff = kvoff0 + static_cast<unsigned>(j) * kstep;
         if (ragged && j == nkt - 1 && j * KT + krow >= p.nk) voff = OOB;
-        lds_dma(rs_k, smem + (j & 1) * TILE + wave * 512, voff);
+        lds_dma(rs_k, smem + (j % NB) * TILE + wave * 512, voff);
     };
-    auto dma_v = [&](int j) __attribute__((always_inline)) {                     // V^T tile j -> V buffer j & 1
+    auto dma_v = [&](int j) __attribute__((always_inline)) {                     // V^T tile j -> V slot j % NB
         if (j >= nkt) return;
         unsigned voff = vvoff0 + static_cast<unsigned>(j) * (KT * 2u);
         if (ragged && j == nkt - 1 && j * KT + lchunk * 8 >= p.nk) voff = OOB;
-        lds_dma(rs_v, smem + (2 + (j & 1)) * TILE + wave * 512, voff);
+        lds_dma(rs_v, smem + (NB + j % NB) * TILE + wave * 512, voff);
+    };
+    // set (j + 1 - L) has landed: the L - 1 younger sets (2 pieces each, all real while j + 1 + L < nkt) may stay in flight
+    auto wait_set = [&](int j) __attribute__((always_inline)) {
+        static_assert(L == 3, "the counted wait is written for L = 3");
+        if (j + 1 + L < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     auto frag_off = [&](int row, int chunk) __attribute__((always_inline)) { return row * D + ((chunk ^ ((row >> 1) & 7)) << 3); };
 
     frag kf[2][KS], vf[DB][2][2];
     auto load_kfrags = [&](int j) __attribute__((always_inline)) {
-        const unsigned short* Ks = smem + (j & 1) * TILE;
+        const unsigned short* Ks = smem + (j % NB) * TILE;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -597,7 +620,7 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
                 kf[hh][ks] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Ks + frag_off(hh * 32 + ql, 2 * ks + hi)));
     };
     auto load_vfrags = [&](int j) __attribute__((always_inline)) {
-        const unsigned short* Vs = smem + (2 + (j & 1)) * TILE;
+        const unsigned short* Vs = smem + (NB + j % NB) * TILE;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -630,6 +653,7 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
     // score register r of half hh <-> key  k0 + 32 hh + 16 (g >> 1) + 8 hi + 4 (g & 1) + e,  g = r >> 2, e = r & 3  (pi above)
     auto mask_tail = [&](int j) __attribute__((always_inline)) {
         if (!(ragged && j == nkt - 1)) return;
+        asm volatile("; ragged last tile" ::: "memory");                         // (a real branch: if-converted, the 32 selects ran on every tile)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -682,16 +706,42 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pb[hh][s2][e] = from_f32<T>(sv[hh][8 * s2 + e]);
     };
+#ifdef PF_ATTN_PP_TIMING      /* debug build (make attn_pp_timing): per-wave clock totals of the vector segments, the matrix segments and the
+                               * barrier waits, written over the lse output -- tools/attn_bench.py --pp-timing prints the per-tile averages */
+    unsigned long long tm_vec = 0, tm_mat = 0, tm_bar = 0, tm_last = __builtin_amdgcn_s_memtime();
+#define PF_PP_MARK(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tm_last; tm_last = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PF_PP_MARK(acc) do { } while (0)
+#endif
     auto barrier = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- prologue: K_0, V_0, K_1 resident; S_0 for every wave
-    dma_k(0);
-    dma_v(0);
-    dma_k(1);
+    // ---- which phase group?  The two waves of a SIMD must be in DIFFERENT groups (one runs its matrix segment while the other runs
+    // its vector segment); how the 8 waves of a workgroup land on the 4 SIMDs is the dispatcher's business, so the default asks the
+    // hardware: every wave publishes its SIMD id (HW_REG_HW_ID bits 5:4), and of the waves that share a SIMD the lowest-numbered
+    // is group A, the next group B, alternating.  pp_role 0 / 1 / 2 are the fixed guesses wave >> 2, wave & 1, (wave >> 1) & 1 (A/B).
+    int group_b;
+    if (p.pp_role == 0) group_b = wave >> 2;
+    else if (p.pp_role == 1) group_b = wave & 1;
+    else if (p.pp_role == 2) group_b = (wave >> 1) & 1;
+    else {
+        int* simd_of = reinterpret_cast<int*>(smem);                             // (the ring is not in use yet)
+        const int my_simd = (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)) & 3;   // HW_REG_HW_ID, offset 4, 2 bits: SIMD_ID
+        if (lane == 0) simd_of[wave] = my_simd;
+        __syncthreads();
+        int rank_on_simd = 0;
+        for (int w = 0; w < 8; ++w) rank_on_simd += (w < wave && simd_of[w] == my_simd) ? 1 : 0;
+        group_b = __builtin_amdgcn_readfirstlane(rank_on_simd & 1);
+        __syncthreads();                                                         // (before the DMA overwrites the table)
+    }
+
+    // ---- prologue: K_0 .. K_L, V_0 .. V_{L-1} resident; S_0 for every wave
+#pragma unroll
+    for (int i = 0; i < L; ++i) { dma_k(i); dma_v(i); }
+    dma_k(L);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     barrier();
     load_kfrags(0);
@@ -699,39 +749,54 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
     mm_qk();
     barrier();                                                                   // K buffer 0 read by everyone: set 0 may overwrite it
 
-    if (wave < 4) {
+    if (!group_b) {
         // group A: vector_j in phase 2 j, matrix_j in phase 2 j + 1
         for (int j = 0; j < nkt; ++j) {
-            dma_k(j + 2);                                                        // set j
-            dma_v(j + 1);
+            dma_k(j + 1 + L);                                                    // set j
+            dma_v(j + L);
             mask_tail(j);
             softmax();
             load_vfrags(j);
             if (j + 1 < nkt) load_kfrags(j + 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PF_PP_MARK(tm_vec);
             barrier();
+            PF_PP_MARK(tm_bar);
             mm_pv();
             if (j + 1 < nkt) mm_qk();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // set j landed (mine): readable by all after the barrier
+            wait_set(j);                                                         // set j + 1 - L landed (mine): readable by all after the barrier
+#ifdef PF_ATTN_PP_TIMING
+            asm volatile("s_nop 0" :: "v"(sv[0][0]), "v"(sv[1][15]), "v"(o[0][0]), "v"(o[1][15]));   // (the MFMA results: the stamp waits for them)
+#endif
+            PF_PP_MARK(tm_mat);
             barrier();
+            PF_PP_MARK(tm_bar);
         }
     } else {
         // group B: half a period behind -- matrix_{j-1} in phase 2 j, vector_j in phase 2 j + 1
-        dma_k(2);                                                                // set 0, phase 0
-        dma_v(1);
+        dma_k(1 + L);                                                            // set 0, phase 0
+        dma_v(L);
         barrier();
         for (int j = 0; j < nkt; ++j) {
             mask_tail(j);
             softmax();
             load_vfrags(j);
             if (j + 1 < nkt) load_kfrags(j + 1);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // set j landed (mine); my fragments are in registers
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // my fragments are in registers
+            wait_set(j);                                                         // set j + 1 - L landed (mine)
+            PF_PP_MARK(tm_vec);
             barrier();
-            dma_k(j + 3);                                                        // set j + 1, phase 2 j + 2
-            dma_v(j + 2);
+            PF_PP_MARK(tm_bar);
+            dma_k(j + 2 + L);                                                    // set j + 1, phase 2 j + 2
+            dma_v(j + 1 + L);
             mm_pv();
             if (j + 1 < nkt) mm_qk();
+#ifdef PF_ATTN_PP_TIMING
+            asm volatile("s_nop 0" :: "v"(sv[0][0]), "v"(sv[1][15]), "v"(o[0][0]), "v"(o[1][15]));
+#endif
+            PF_PP_MARK(tm_mat);
             if (j + 1 < nkt) barrier();                                          // (A executes 2 nkt barriers in its loop, B 1 + 2 nkt - 1)
+            PF_PP_MARK(tm_bar);
         }
     }
 
@@ -749,6 +814,14 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
             }
         if (p.lse && hi == 0) p.lse[(b * p.H + h) * p.nq + q0 + ql] = m_run * c2 + __log2f(l_run);
     }
+#ifdef PF_ATTN_PP_TIMING
+    if (p.lse && lane == 0 && q0 + 8 <= p.nq) {
+        float* dst = p.lse + (b * p.H + h) * p.nq + q0;
+        dst[0] = static_cast<float>(tm_vec) / nkt; dst[1] = static_cast<float>(tm_mat) / nkt; dst[2] = static_cast<float>(tm_bar) / nkt;
+        dst[3] = static_cast<float>(group_b); dst[4] = static_cast<float>((__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)) & 3);
+        dst[5] = static_cast<float>(wave);
+    }
+#endif
 }
 
 static bool use_lds_attention() {
@@ -792,6 +865,7 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     p.scale_log2e = d->scale * 1.44269504088896340736f;
     p.bias = d->bias; p.bias_ld = d->bias_ld; p.flags = d->flags; p.flags_ld = d->flags_ld;
     p.lse = d->lse;
+    p.pp_role = attention_occupancy("PF_ATTENTION_PP_ROLE", 3);
     dim3 grid(cdiv(d->nq, 128), d->H, d->B), block(256);
     hipStream_t st = as_stream(stream);
     const bool lds = use_lds_attention() && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0;
@@ -804,7 +878,7 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
                     hipLaunchKernelGGL((k_attention_lds<T, 64, true>), grid, block, 0, st, p);
                 } else if (pingpong && d->nk % 8 == 0 && d->nk >= 128 && static_cast<long>(d->nk) * d->k_ld * 2 < (1L << 31) &&
                            static_cast<long>(d->vt_ld) * 64 * 2 < (1L << 31)) {
-                    hipLaunchKernelGGL((k_attention_pp<T>), dim3(cdiv(d->nq, 256), d->H, d->B), dim3(512), 0, st, p);
+                    hipLaunchKernelGGL((k_attention_pp<T>), dim3(static_cast<unsigned>(cdiv(d->nq, 256) * d->H * d->B)), dim3(512), 0, st, p);
                 } else {
                     if (occ64 == 2) hipLaunchKernelGGL((k_attention_lds<T, 64, false>), grid, block, 0, st, p);
                     else hipLaunchKernelGGL((k_attention_lds<T, 64, false, false, 3>), grid, block, 0, st, p);

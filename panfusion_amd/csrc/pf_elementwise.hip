@@ -486,14 +486,14 @@ __global__ void k_silu(const unsigned short* __restrict__ x, long n, unsigned sh
 
 // diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0): [cos(t f_i) | sin(t f_i)], fp32 math.
 template <typename T>
-__global__ void k_timestep_features(const int64_t* __restrict__ t, int n, int dim,
+__global__ void k_timestep_features(const int64_t* __restrict__ t, long t_stride, int n, int dim,
                                     unsigned short* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int half = dim / 2;
     if (i >= n * half) return;
     const int r = i / half, k = i % half;
     const float e = (-9.210340371976184f * static_cast<float>(k)) / static_cast<float>(half);
-    const float arg = static_cast<float>(t[r]) * expf(e);
+    const float arg = static_cast<float>(t[r * t_stride]) * expf(e);
     out[static_cast<long>(r) * dim + k] = from_f32<T>(cosf(arg));
     out[static_cast<long>(r) * dim + half + k] = from_f32<T>(sinf(arg));
 }
@@ -1074,14 +1074,19 @@ extern "C" pf_status pf_geglu(const void* in, int dtype, long rows, int inner, v
     return PF_OK;
 }
 
-extern "C" pf_status pf_timestep_features(const int64_t* t, int n, int dim, int out_dtype, void* out,
-                                          void* stream) {
-    PF_REQUIRE(t && out && n > 0 && dim > 0 && dim % 2 == 0, "pf_timestep_features: bad arguments");
+extern "C" pf_status pf_timestep_features_strided(const int64_t* t, long t_stride, int n, int dim, int out_dtype, void* out,
+                                                  void* stream) {
+    PF_REQUIRE(t && out && n > 0 && dim > 0 && dim % 2 == 0 && t_stride >= 0, "pf_timestep_features: bad arguments");
     PF_DISPATCH_16(out_dtype, "pf_timestep_features",
         hipLaunchKernelGGL(k_timestep_features<T>, dim3(cdiv(static_cast<long>(n) * (dim / 2), 256)), dim3(256),
-                           0, as_stream(stream), t, n, dim, static_cast<unsigned short*>(out)));
+                           0, as_stream(stream), t, t_stride, n, dim, static_cast<unsigned short*>(out)));
     PF_CHECK_LAUNCH("pf_timestep_features");
     return PF_OK;
+}
+
+extern "C" pf_status pf_timestep_features(const int64_t* t, int n, int dim, int out_dtype, void* out,
+                                          void* stream) {
+    return pf_timestep_features_strided(t, 1, n, dim, out_dtype, out, stream);
 }
 
 extern "C" pf_status pf_silu(const void* x, int dtype, long n, void* y, void* stream) {

@@ -474,7 +474,7 @@ def all_transformers(u):
             yield t
 
 
-def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv=None, next_ln=None):
+def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv=None, next_ln=None, split=None):
     """q_src [n*nq, C] already layer-normed; kv_tokens [n*nk, Ckv] (or kv = precomputed (k, vt)).
     next_ln: the LayerNorm that follows the output projection -> (tokens, its output or None): where the output projection runs on
     the weight-stationary kernel the norm rides in its epilogue (ops.linear_ln)."""
@@ -496,15 +496,20 @@ def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv
         vt = ops.linear_vt(kv_tokens, a.wv, n) if self_attn else None     # weight-stationary kernel, transposed epilogue (C = 640 / 1280)
         if vt is None:
             vt = ops.linear_t(kv_tokens.view(n, nk, -1), a.wv)            # [n, C, ld_v] keys contiguous
-    o = ops.attention(q, k, vt, n, a.heads, head_dim, nq, nk,
-                      q_ld=ld, k_ld=(ld if self_attn else Cq), vt_ld=vt.shape[-1],
-                      q_bs=nq * ld, k_bs=nk * (ld if self_attn else Cq), vt_bs=vt.shape[1] * vt.shape[2])
+    if split is not None and self_attn and n == 1 and vt.shape[-1] == nk:
+        # sharded panorama owner: the query rows of this self-attention are computed by all ranks of the CFG half (sharding.py)
+        from . import sharding
+        o = sharding.split_pano_attention(split, q.contiguous(), vt.contiguous(), a.heads, head_dim, nq, Cq)
+    else:
+        o = ops.attention(q, k, vt, n, a.heads, head_dim, nq, nk,
+                          q_ld=ld, k_ld=(ld if self_attn else Cq), vt_ld=vt.shape[-1],
+                          q_bs=nq * ld, k_bs=nk * (ld if self_attn else Cq), vt_bs=vt.shape[1] * vt.shape[2])
     if next_ln is not None:
         return ops.linear_ln(o.view(n * nq, Cq), a.wo, a.bo, residual, next_ln.g, next_ln.b, next_ln.eps)
     return ops.linear(o.view(n * nq, Cq), a.wo, bias=a.bo, residual=residual)
 
 
-def run_transformer(t, x, text, kv=None):
+def run_transformer(t, x, text, kv=None, split=None):
     """diffusers Transformer2DModel (linear projections) on x [n, h, w, C] (stream dtype); text [n, L, Dt]
     (kv: the text K / V^T of this block computed ahead of time, text_kv)."""
     n, h, w, Cc = x.shape
@@ -518,7 +523,7 @@ def run_transformer(t, x, text, kv=None):
         tok = ops.linear(y.view(n * hw, Cc), t.w_in, bias=t.b_in)
     dh = t.attn1.dim // t.attn1.heads
     ln = ops.layernorm(tok, t.ln1.g, t.ln1.b, t.ln1.eps, out_dtype=t.dtype)
-    tok, ln = _attend(t.attn1, ln, ln, n, hw, hw, dh, self_attn=True, residual=tok, next_ln=t.ln2)
+    tok, ln = _attend(t.attn1, ln, ln, n, hw, hw, dh, self_attn=True, residual=tok, next_ln=t.ln2, split=split)
     if ln is None:
         ln = ops.layernorm(tok, t.ln2.g, t.ln2.b, t.ln2.eps, out_dtype=t.dtype)
     L = text.shape[1]
@@ -558,6 +563,10 @@ class Branch:
         self.skips = [self.h]
         self.text_kv = {}               # id(transformer pack) -> (k, vt) of the text tokens, if computed ahead
         self.text_ready = None          # event to wait for before the first use (computed on another stream)
+        # sharded runs (MVGenModel sets them): the panorama owner's branch splits its big self-attentions over the CFG half
+        # (attn_split = its ShardInfo), a view rank's branch helps right after its own (attn_help = callable(transformer pack))
+        self.attn_split = None
+        self.attn_help = None
 
     def precompute_text_kv(self):
         """All 16 cross-attentions' K / V^T of the text tokens in one go: 32 tiny GEMMs that would otherwise sit
@@ -592,7 +601,14 @@ class Branch:
         if self.text_ready is not None:
             torch.cuda.current_stream(self.h.device).wait_event(self.text_ready)
             self.text_ready = None
-        self.h = run_transformer(t, self.h, self.text, self.text_kv.get(id(t)))
+        split = None
+        if self.attn_split is not None:
+            from . import sharding
+            if sharding.splits_pano_attention(self.attn_split, self.h.shape[1] * self.h.shape[2]) and self.h.shape[0] == 1:
+                split = self.attn_split
+        self.h = run_transformer(t, self.h, self.text, self.text_kv.get(id(t)), split=split)
+        if self.attn_help is not None:
+            self.attn_help(t, self.h)
 
     def push(self):
         self.skips.append(self.h)

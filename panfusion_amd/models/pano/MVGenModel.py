@@ -269,6 +269,18 @@ class MultiViewBaseModel(nn.Module):
             pers = make_branch(self.packed("unet", dev), latents.flatten(0, 1), timestep.reshape(-1),
                                self._prompt16(prompt_embd), pano=False, pad=False)
             branches.append(pers)
+            if shard is not None and shard.pano_g is not None and not shard.has_pano and tape is None:
+                # a view rank of the panorama-rank layout: after each of its own self-attentions it computes its share of the
+                # owner's panorama self-attention at the same UNet position, where that one is split (sharding.splits_pano_attention)
+                from ... import sharding as _sh
+                lat_h, pano_tokens = latents.shape[-2], pano_latent.shape[-2] * pano_latent.shape[-1]
+
+                def help_owner(t_pack, h, lat_h=lat_h, pano_tokens=pano_tokens):
+                    sc = lat_h // h.shape[1]
+                    tokens = pano_tokens // (sc * sc)
+                    if _sh.splits_pano_attention(shard, tokens):
+                        _sh.help_pano_attention(shard, t_pack, tokens, h)
+                pers.attn_help = help_owner
             if pers_layout_cond is not None:        # reference :66-74 (ControlNet on the view branch)
                 controlnet("pers_cn", pers, latents.flatten(0, 1), timestep.reshape(-1), pers_layout_cond.flatten(0, 1))
         else:
@@ -317,6 +329,8 @@ class MultiViewBaseModel(nn.Module):
                 pano = make_branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
                                    self._prompt16(pano_prompt_embd), pano=True, pad=self.pano_pad)
                 pano.on_side = side is not None     # (train_engine.backward walks its entries on the same stream)
+                if shard is not None and shard.pano_g is not None and tape is None:
+                    pano.attn_split = shard
                 if not keeps:
                     pano.precompute_text_kv()
                 if pano_layout_cond is not None:    # reference :75-83: plain convolutions on the un-padded latent

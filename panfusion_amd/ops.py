@@ -267,9 +267,11 @@ def geglu(x, out=None):
 
 
 def timestep_features(t, dim, dtype):
-    t = t.to(torch.int64).contiguous()
+    """t: 1-D int64 (any stride: `timestep[:, 0]` of a (b, m) tensor is read in place)."""
+    if t.dtype != torch.int64 or t.dim() != 1:
+        t = t.to(torch.int64).reshape(-1).contiguous()
     out = torch.empty(t.numel(), dim, device=t.device, dtype=dtype)
-    check(_lib.lib().pf_timestep_features(_p(t), t.numel(), dim, dt(dtype), _p(out), _stream()),
+    check(_lib.lib().pf_timestep_features_strided(_p(t), t.stride(0) if t.numel() > 1 else 1, t.numel(), dim, dt(dtype), _p(out), _stream()),
           "pf_timestep_features")
     return out
 

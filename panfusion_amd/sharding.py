@@ -20,11 +20,13 @@ Exchanges per step:
     which every rank applies the CFG merge + DDIM update to its replica of the latents.
 All collectives are small and latency bound on xGMI; none is a translation of a reference call.
 """
+import os
 from dataclasses import dataclass
 
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .pipeline import DenoiseLoop
 
 
@@ -82,7 +84,9 @@ TIME_MODEL = {
     # (cfg 4) / 16.54 (cfg 5), owner with 6 views 19.98 / 34.10 (cfg 4))
     ((64, 128), (64, 64), False): dict(base=7.75, per_view=0.956, pano=6.5, pano_only=4.0),       # cfg 2 / 3
     ((64, 128), (64, 64), True): dict(base=7.75, per_view=0.956, pano=11.3, pano_only=8.8),       # cfg 5: + the panorama ControlNet
-    ((128, 256), (64, 64), False): dict(base=7.75, per_view=0.956, pano=20.6, pano_only=20.75),   # cfg 4
+    # cfg 4; attn = the five 32 768-token self-attentions of the panorama branch (part of pano / pano_only): what the query split
+    # (split_pano_attention) spreads over the ranks of the CFG half
+    ((128, 256), (64, 64), False): dict(base=7.75, per_view=0.956, pano=20.6, pano_only=20.75, attn=11.0),
 }
 _DEFAULT_KEY = ((64, 128), (64, 64), False)
 _WARNED = set()
@@ -108,10 +112,26 @@ def time_model(pano_hw=None, lat_hw=None, layout_cond=False):
     return dict(base=ref["base"], per_view=ref["per_view"] * r_v, pano=ref["pano"] * r_p, pano_only=ref["pano_only"] * r_p, measured=False)
 
 
-def owner_cost(m0, tm=None):
+def _attn_shares(tm, G):
+    """(ms the owner sheds, ms every other rank of the half takes on) under the self-attention query split."""
+    a = tm.get("attn", 0.0)
+    if not a or G is None or G < max(2, ATTN_SPLIT_MIN_GROUP):
+        return 0.0, 0.0
+    return a * (1.0 - 1.0 / G), a / G
+
+
+def owner_cost(m0, tm=None, G=None):
     """Step time of the panorama owner holding m0 views, in view units (per_view = 1) above a view-only rank's base."""
     tm = tm or time_model()
-    return (tm["pano_only"] if m0 == 0 else m0 * tm["per_view"] + tm["pano"]) / tm["per_view"]
+    shed, _ = _attn_shares(tm, G)
+    return ((tm["pano_only"] if m0 == 0 else m0 * tm["per_view"] + tm["pano"]) - shed) / tm["per_view"]
+
+
+def helper_cost(views, tm=None, G=None):
+    """A view-only rank of the panorama-rank layout, in view units: its views + its share of the split self-attentions."""
+    tm = tm or time_model()
+    _, extra = _attn_shares(tm, G)
+    return views + extra / tm["per_view"]
 
 
 def pano_rank_split(m, G, tm=None):
@@ -123,7 +143,7 @@ def pano_rank_split(m, G, tm=None):
     best, best_cost = None, None
     for m0 in range(0, m - (G - 1) + 1):
         rest = m - m0
-        cost = max(owner_cost(m0, tm), -(-rest // (G - 1)))
+        cost = max(owner_cost(m0, tm, G), helper_cost(-(-rest // (G - 1)), tm, G))
         if best_cost is None or cost < best_cost - 1e-9:
             best, best_cost = m0, cost
     rest, q, r = m - best, (m - best) // (G - 1), (m - best) % (G - 1)
@@ -135,7 +155,7 @@ def split_cost(split, pano_replicated, tm=None):
     tm = tm or time_model()
     if pano_replicated:
         return max(split) + tm["pano"] / tm["per_view"]
-    return max(owner_cost(split[0], tm), max(split[1:]))
+    return max(owner_cost(split[0], tm, len(split)), helper_cost(max(split[1:]), tm, len(split)))
 
 
 def step_time_ms(split, pano_replicated, tm=None):
@@ -345,6 +365,63 @@ def share_pano_tokens(x, rows, cols, like, shard):
         dist.broadcast(buf, src=shard.pano_src, group=shard.group)
     _collective(call)
     return buf
+
+
+# ---- query-split of the panorama branch's big self-attentions ("mandatory for cfg 4") -----------------------------
+# At configs[3] (128 x 256 panorama latent) the panorama owner of a CFG half is the slowest rank: its two + three level-0
+# self-attentions walk 32 768 keys for 32 768 queries (11 ms of its 28 ms) while the view ranks of the half
+# finish earlier.  With this on (panorama-rank layout, tokens >= PF_SHARD_ATTN_MIN_TOKENS) the owner broadcasts (q | k) and V^T of such
+# an attention inside the half, EVERY rank of the half computes the rows [g nq / G, (g + 1) nq / G) of the output, one all-gather
+# returns them.  Per attention and rank: 2 C nq + C nq 16-bit words in (63 MB at C = 320, nq = 32 768), C nq / G words out; the
+# view ranks call help_pano_attention right after their own self-attention of the same UNet position, so every rank issues the same
+# collective sequence.  A query row's result does not depend on which rank computes it: replicas stay bit-identical.
+ATTN_SPLIT_MIN_TOKENS = int(os.environ.get("PF_SHARD_ATTN_MIN_TOKENS", "16384"))
+# ... and from this many ranks per CFG half: with G = 2 the one view rank of the half (13-20 views) is the slowest already, and
+# handing it half of the panorama's attention makes the step slower (cfg 4, 4 ranks, one-GPU simulation: 34.1 -> 41.5 ms; 8 ranks:
+# owner 33.0 -> 25.7, view ranks 18.0 -> 21.8: profiles/r5e_sim_cfg4_attn_split.txt)
+ATTN_SPLIT_MIN_GROUP = int(os.environ.get("PF_SHARD_ATTN_MIN_GROUP", "3"))
+
+
+def splits_pano_attention(shard, tokens):
+    """The rule both sides evaluate (owner: in its panorama self-attention; view ranks: after their own)."""
+    return (shard is not None and shard.pano_g is not None and shard.G >= max(2, ATTN_SPLIT_MIN_GROUP)
+            and tokens >= ATTN_SPLIT_MIN_TOKENS and tokens % (32 * shard.G) == 0)
+
+
+def split_pano_attention(shard, qk, vt, heads, head_dim, nq, C, dtype=None, device=None):
+    """qk [nq, 2 C] = (q | k) and vt [1, C, nq] of ONE panorama self-attention on the owner (None on the other ranks of the
+    half) -> the attention output [nq, C] on every rank of the half (only the owner uses it)."""
+    G, g = shard.G, shard.g
+    if qk is None:
+        qk = torch.empty(nq, 2 * C, dtype=dtype, device=device)
+        vt = torch.empty(1, C, nq, dtype=dtype, device=device)
+    assert qk.is_contiguous() and vt.is_contiguous() and tuple(vt.shape) == (1, C, nq), (tuple(qk.shape), tuple(vt.shape))
+
+    def bcast():
+        _note("broadcast panorama q|k (self-attention split, group of %d)" % G, qk)
+        dist.broadcast(qk, src=shard.pano_src, group=shard.group)
+        _note("broadcast panorama V^T (self-attention split, group of %d)" % G, vt)
+        dist.broadcast(vt, src=shard.pano_src, group=shard.group)
+    _collective(bcast)
+    rows = nq // G
+    r0 = g * rows
+    ld = 2 * C
+    o_loc = ops.attention(qk[r0:r0 + rows], qk[:, C:], vt, 1, heads, head_dim, rows, nq, q_ld=ld, k_ld=ld, vt_ld=nq,
+                          q_bs=rows * ld, k_bs=nq * ld, vt_bs=C * nq)
+    o_loc = o_loc.reshape(rows, C)
+    out = torch.empty(nq, C, dtype=o_loc.dtype, device=o_loc.device)
+
+    def gather():
+        _note("all_gather panorama attention rows (self-attention split, group of %d)" % G, o_loc)
+        dist.all_gather_into_tensor(out, o_loc, group=shard.group)
+    _collective(gather)
+    return out
+
+
+def help_pano_attention(shard, t_pack, tokens, like):
+    """A view rank's share of the owner's panorama self-attention at the UNet position of its own transformer pack t_pack."""
+    a = t_pack.attn1
+    split_pano_attention(shard, None, None, a.heads, a.dim // a.heads, tokens, a.dim, dtype=t_pack.dtype, device=like.device)
 
 
 def gather_eps(eps_local, pano_eps_local, shard, pano_shape=None):

@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_loop(sharded, steps=2, split=None, layout=None, precision="fast", controlnet=False):
+def _run_loop(sharded, steps=2, split=None, layout=None, precision="fast", controlnet=False, attn_min=None):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import fake_ops
@@ -31,6 +31,9 @@ def _run_loop(sharded, steps=2, split=None, layout=None, precision="fast", contr
         importlib.import_module(name).ops = fake_ops
     from panfusion_amd import sharding
     from panfusion_amd.pipeline import DenoiseLoop
+    if attn_min is not None:                     # query-split of the panorama self-attentions from this many tokens (toy sizes),
+        sharding.ATTN_SPLIT_MIN_TOKENS = attn_min    # also with two ranks per CFG half (the default starts at three)
+        sharding.ATTN_SPLIT_MIN_GROUP = 2
     g = golden("mvgen_tiny.npz")
     t = lambda k: torch.from_numpy(g[k])
     om = build_tiny_oracle()
@@ -56,12 +59,12 @@ def _run_loop(sharded, steps=2, split=None, layout=None, precision="fast", contr
     return loop.run()
 
 
-def _worker(rank, world, port, out, split=None, layout=None, precision="fast", controlnet=False):
+def _worker(rank, world, port, out, split=None, layout=None, precision="fast", controlnet=False, attn_min=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        lat, pano = _run_loop(True, split=split, layout=layout, precision=precision, controlnet=controlnet)
+        lat, pano = _run_loop(True, split=split, layout=layout, precision=precision, controlnet=controlnet, attn_min=attn_min)
         torch.save((lat, pano), os.path.join(out, "r%d.pt" % rank))
         from panfusion_amd import sharding
         torch.save(sharding.comm_stats(2), os.path.join(out, "comm%d.pt" % rank))
@@ -112,7 +115,10 @@ def test_plan_uses_the_time_model_of_the_configuration():
     assert s2.counts == (7, 13) and s4.counts == (0, 20)      # at cfg 4 the owner of 4 ranks keeps no views at all
     assert sharding.time_model((64, 128), (64, 64), True)["pano_only"] > 2 * tm2["pano_only"]       # cfg 5: the ControlNet rides on the owner
     assert sharding.plan(8, 0, 20, pano_hw=(128, 256), lat_hw=(64, 64)).counts == (0, 7, 7, 6)
-    assert sharding.step_time_ms((0, 7, 7, 6), False, tm4) > 1.9 * sharding.step_time_ms((0, 7, 7, 6), False, tm2)
+    # the query split of the 32 768-token self-attentions (G >= 3) takes 3/4 of 11 ms off the cfg-4 owner and adds 1/4 to the others
+    assert abs(sharding.step_time_ms((0, 7, 7, 6), False, tm4) - (7.75 + 20.75 - 0.75 * 11.0)) < 1e-6
+    assert abs(sharding.split_cost((0, 20), False, tm4) * tm4["per_view"] - 20.75) < 1e-6          # G = 2: no split, the owner alone
+    assert sharding.step_time_ms((0, 7, 7, 6), False, tm4) > 1.35 * sharding.step_time_ms((0, 7, 7, 6), False, tm2)
 
 
 def test_sharded_loop_with_panorama_controlnet_equals_single_process():
@@ -160,3 +166,27 @@ def test_sharded_loop_equals_single_process(world, split, layout, precision):
         assert rel(lat, want[0]) < 1e-4 and rel(pano, want[1]) < 1e-4, (rel(lat, want[0]), rel(pano, want[1]))
     # replicas must not drift apart: every rank applies the same update to the same gathered epsilons
     assert all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
+
+
+@pytest.mark.parametrize("world,split,precision", [(4, None, "fast"), (4, (1, 3), "mixed"), (8, None, "fast")])
+def test_panorama_self_attention_split_over_the_cfg_half(world, split, precision):
+    """SURVEY.md 8e, configs[3]: the panorama owner's big self-attentions are query-split over the ranks of its CFG half
+    (sharding.split_pano_attention: broadcast of q | k and V^T, every rank computes nq / G rows, one all-gather) -- here forced at toy
+    sizes (>= 128 tokens: the 16 x 32 and 8 x 16 levels).  Same result as the single process, bit-identical replicas, and the
+    collectives show up in the accounting bench.py prints."""
+    want = _run_loop(False, precision=precision)
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_worker, args=(world, _free_port(), out, split, None, precision, False, 128), nprocs=world, join=True)
+        res = [torch.load(os.path.join(out, "r%d.pt" % r)) for r in range(world)]
+        comm = [torch.load(os.path.join(out, "comm%d.pt" % r)) for r in range(world)]
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for lat, pano in res:
+        assert rel(lat, want[0]) < 1e-4 and rel(pano, want[1]) < 1e-4, (rel(lat, want[0]), rel(pano, want[1]))
+    assert all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
+    G = world // 2
+    key = "all_gather panorama attention rows (self-attention split, group of %d)" % G
+    n_split = comm[0][key]["calls_per_step"]
+    assert n_split >= 5                                     # the five level-0 self-attentions at least (512 tokens at 16 x 32)
+    for c in comm:                                          # owner and helpers issue the same sequence
+        assert c[key]["calls_per_step"] == n_split
+        assert c["broadcast panorama q|k (self-attention split, group of %d)" % G]["calls_per_step"] == n_split

@@ -26,6 +26,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--pp-timing", action="store_true", help="with PF_HIP_LIB=panfusion_amd/abl/lib_attn_pp_timing.so (make -C panfusion_amd/csrc "
+                    "attn_pp_timing): per-wave clocks per key tile of the ping-pong kernel's vector / matrix segments and barrier waits")
     args = ap.parse_args()
     dev = "cuda"
     for name in args.shapes.split(","):
@@ -52,6 +54,16 @@ def main():
         fl = 4.0 * B * H * nq * nk * D
         gb = 2.0 * (2 * B * nq * C + B * nk * C + B * C * ld)          # q + out, k + vt: the bytes that must move once
         print("%-8s B%-3d H%-3d D%-3d nq%-6d nk%-6d %9.1f us  %7.1f TF/s  %5.2f TB/s algorithmic" % (name, B, H, D, nq, nk, us, fl / us / 1e6, gb / us / 1e6), flush=True)
+        if args.pp_timing and D == 64 and nk % 8 == 0 and nk >= 128:
+            lse = torch.zeros(B, H, nq, device=dev, dtype=torch.float32)
+            ops.attention(q, k, vt, B, H, D, nq, nk, lse=lse, **kw)
+            torch.cuda.synchronize()
+            r = lse.view(-1, 32)[:, :6].cpu()                     # one record per wave (32 query rows)
+            for grp in (0, 1):
+                g = r[r[:, 3] == grp]
+                if len(g):
+                    print("   group %s: %5d waves  per key tile: vector segment %6.0f  matrix segment %6.0f  barrier wait %6.0f  (s_memtime ticks)   waves %s on SIMDs %s"
+                          % ("AB"[grp], len(g), g[:, 0].mean(), g[:, 1].mean(), g[:, 2].mean(), sorted(set(int(v) for v in g[:64, 5])), sorted(set(int(v) for v in g[:64, 4]))))
 
 
 if __name__ == "__main__":

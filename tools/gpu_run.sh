@@ -83,6 +83,8 @@ for SEC in "$@"; do
       S=$(slug "$ARG"); cd /tmp
       PF_STREAMS=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_s -o bench -- python $R/bench.py $ARG --steps 4 --warmup 1 $NOLEGS --no-graphs > $R/gpurun_out/${TAG}_rocprof_serial.log 2>&1
       python $R/tools/prof_summary.py trace $(find /tmp/pf_s -name '*kernel_trace.csv' | head -1) $R/gpurun_out/${TAG}_kernels_serial${S:+_$S}.txt 10
+      python $R/tools/prof_summary.py trace_steady $(find /tmp/pf_s -name '*kernel_trace.csv' | head -1) $R/gpurun_out/${TAG}_kernels_steady${S:+_$S}.txt 4 1
+      head -n 4 $R/gpurun_out/${TAG}_kernels_steady${S:+_$S}.txt | cut -c1-400
       rm -rf /tmp/pf_s; head -n 16 $R/gpurun_out/${TAG}_kernels_serial${S:+_$S}.txt ;;
     pmc)
       S=$(slug "$ARG"); cd /tmp

@@ -1,6 +1,7 @@
 """Condense rocprofv3 CSV output (too large to keep) into small per-kernel tables.
 
     python tools/prof_summary.py trace  <kernel_trace.csv>  <out.txt>  [denoiser passes in the run]
+    python tools/prof_summary.py trace_steady <kernel_trace.csv> <out.txt> <steps> <warmup>     (the timed steps only)
     python tools/prof_summary.py pmc    <counter_collection.csv> <out.txt>
 """
 import csv
@@ -41,6 +42,47 @@ def trace(path, out, passes):
         fh.write("\nper (kernel, grid): calls/pass, ms/pass, us/call\n")
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:120]:
             fh.write("%-60s grid %8s %4s %4s  calls %6.1f  %8.3f ms  %8.1f us\n" % (k[0][:60], k[1], k[2], k[3], v[0] / passes, v[1] / passes, 1e3 * v[1] / v[0]))
+
+
+def trace_steady(path, out, steps, warmup):
+    """Per-kernel table of the TIMED steps only (the whole-run table mixes in weight packing, table building
+    and warm-up).  The loop ends every step with two k_cfg_ddim_rows launches (views, panorama): the window runs from the end of
+    the last warm-up step's second one to the end of the last timed step's -- exactly `steps` steps, nothing else."""
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    ddim = [i for i, r in enumerate(rows) if "k_cfg_ddim" in r["Kernel_Name"]]
+    need = 2 * (warmup + steps)
+    if len(ddim) < need:
+        raise SystemExit("trace_steady: %d DDIM launches in the trace, %d expected" % (len(ddim), need))
+    lo = ddim[2 * warmup - 1] + 1 if warmup else 0
+    hi = ddim[need - 1] + 1
+    if not warmup:      # no warm-up step: start at the first kernel after the set-up (the first step's first launch is unknown): refuse
+        raise SystemExit("trace_steady needs at least one warm-up step")
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in rows[lo:hi]:
+        key = (short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))
+        a = agg[key]
+        a[0] += 1
+        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+    tot = sum(v[1] for v in agg.values())
+    n = sum(v[0] for v in agg.values())
+    fam = defaultdict(lambda: [0, 0.0])
+    for k, v in agg.items():
+        fam[k[0]][0] += v[0]
+        fam[k[0]][1] += v[1]
+    foreign = {k: v for k, v in fam.items() if not k.startswith("k_")}
+    mfma = ("k_conv_gemm", "k_linear_ws", "k_attention")
+    tail = sum(v[1] for k, v in fam.items() if not k.startswith(mfma))
+    tail_n = sum(v[0] for k, v in fam.items() if not k.startswith(mfma))
+    with open(out, "w") as fh:
+        fh.write("steady-state window: %d timed steps (one stream, no graphs) = %.2f ms of kernels and %.0f launches per step\n" % (steps, tot / steps, n / steps))
+        fh.write("non-MFMA tail (everything but k_conv_gemm* / k_linear_ws / k_attention*): %.2f ms and %.0f launches per step\n" % (tail / steps, tail_n / steps))
+        fh.write("kernels that are not this library's (torch / runtime copies, fills, casts) inside the window: %s\n\n"
+                 % (", ".join("%s x%.1f %.3f ms" % (k, v[0] / steps, v[1] / steps) for k, v in sorted(foreign.items())) or "NONE"))
+        for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+            fh.write("%-72s %7.1f launches %9.3f ms/step %5.1f %%\n" % (k, v[0] / steps, v[1] / steps, 100 * v[1] / tot))
+        fh.write("\nper (kernel, grid): calls/step, ms/step, us/call\n")
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:120]:
+            fh.write("%-60s grid %8s %4s %4s  calls %6.1f  %8.3f ms  %8.1f us\n" % (k[0][:60], k[1], k[2], k[3], v[0] / steps, v[1] / steps, 1e3 * v[1] / v[0]))
 
 
 def pmc(path, out):
@@ -91,6 +133,8 @@ def traffic(fetch_txt, write_txt, out, family=("k_conv_gemm", "k_linear_ws")):
 if __name__ == "__main__":
     if sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "trace_steady":
+        trace_steady(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]))
     elif sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     else:
