@@ -33,6 +33,8 @@ struct AttnParams {
     const float* bias; long bias_ld; const uint8_t* flags; int flags_ld;
     float* lse;
     int pp_role;                 // k_attention_pp: how a wave finds its phase group (PF_ATTENTION_PP_ROLE, see the kernel)
+    int xcd_map;                 // k_attention_lds: 1 = heads pinned to XCDs (PF_ATTENTION_XCD, default), 0 = plain block order
+    int pp_prio;                 // k_attention_pp: wave priorities (PF_ATTENTION_PP_PRIO): 0 none, 1 group B static 1, 2 raised inside matrix segments
 };
 
 template <typename T, int D>
@@ -211,9 +213,21 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int ql = lane & 31, hi = lane >> 5;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
-    const int h = blockIdx.y;
-    const long b = blockIdx.z;
+    // 1-D grid, XCD-aware (round 5): block id l runs on XCD l % 8; when the (batch, head) pairs divide by 8, pair g lives on XCD g % 8
+    // with its query blocks back to back there -- a head's K / V^T is fetched into ONE L2 instead of eight
+    const int nqb = (p.nq + 127) / 128, BH = static_cast<int>(gridDim.x) / nqb;
+    int qb, bh;
+    if ((BH & 7) == 0 && p.xcd_map) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bh = xcd + 8 * (idx / nqb);
+        qb = idx - (idx / nqb) * nqb;
+    } else {
+        bh = blockIdx.x / nqb;
+        qb = blockIdx.x - bh * nqb;
+    }
+    const int q0 = (qb * 4 + wave) * 32;
+    const int h = bh % p.H;
+    const long b = bh / p.H;
     const unsigned short* qp = p.q + b * p.q_bs + h * D;
     const unsigned short* kp = p.k + b * p.k_bs + h * D;
     const unsigned short* vp = p.vt + b * p.vt_bs + static_cast<long>(h) * D * p.vt_ld;
@@ -342,7 +356,15 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sv[hh][r]);
+#ifdef PF_ATTN_BPERMUTE
         mt = fmaxf(mt, __shfl_xor(mt, 32));
+#else
+        {   // lanes l <-> l + 32 by v_permlane32_swap (gfx950) instead of ds_bpermute: no LDS round trip in the in-order wave
+            float a_ = mt, b_ = mt;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+            mt = fmaxf(a_, b_);
+        }
+#endif
         {   // Deferred rescale: the running maximum is advanced (and O / l rescaled by exp2(c2 * (old - new))) only when
             // some row of the wavefront grew by more than 2^DEFER_LOG2 in the exponent; otherwise the STALE maximum stays
             // the reference point and this tile's probabilities are bounded by 2^DEFER_LOG2 instead of 1 -- exact
@@ -387,7 +409,15 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
                 ls2 += e;
             }
         float ls = ls2[0] + ls2[1];
+#ifdef PF_ATTN_BPERMUTE
         ls += __shfl_xor(ls, 32);
+#else
+        {
+            float a_ = ls, b_ = ls;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+            ls = a_ + b_;
+        }
+#endif
         l_run += ls;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
@@ -528,9 +558,9 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
 template <typename T>
 __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
     constexpr int D = 64, KS = 4, DB = 2, KT = 64, TILE = KT * D;
-    constexpr int L = 3, NB = L + 1;                                            // look-ahead in tiles, ring slots per operand
+    constexpr int L = 3, NB = L + 2;                                            // look-ahead in tiles, ring slots per operand
     typedef typename Mfma32<T>::frag frag;
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NB * TILE];  // K tiles [NB], V^T tiles [NB]: 64 KB
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NB * TILE];  // K tiles [NB], V^T tiles [NB]: 80 KB
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ql = lane & 31, hi = lane >> 5;
@@ -564,7 +594,18 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    // The softmax denominator comes out of the MATRIX pipe: a third accumulator block osum^T += 1 P^T (A operand = ones) -- every row of
+    // it is sum_k P[q][k] over both lane halves, so the vector segment loses its 16 packed adds and one lane exchange per key tile (it is
+    // the VALU-issue-bound side: profiles/r5i_attn_pp_ablate.txt), and the sum is taken over the SAME 16-bit P the numerator uses.
+    f32x16 osum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) osum[r] = 0.f;
+    u16x8 ones8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones8[e] = from_f32<T>(1.0f);
+    asm volatile("" : "+v"(ones8));                                             // (kept in registers, not rematerialised per MFMA)
+    const frag ones = __builtin_bit_cast(frag, ones8);
+    float m_run = -INFINITY;
     const float c2 = p.scale_log2e;
     const int nkt = (p.nk + KT - 1) / KT;
     const bool ragged = (p.nk % KT) != 0;
@@ -602,10 +643,10 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
         if (ragged && j == nkt - 1 && j * KT + lchunk * 8 >= p.nk) voff = OOB;
         lds_dma(rs_v, smem + (NB + j % NB) * TILE + wave * 512, voff);
     };
-    // set (j + 1 - L) has landed: the L - 1 younger sets (2 pieces each, all real while j + 1 + L < nkt) may stay in flight
-    auto wait_set = [&](int j) __attribute__((always_inline)) {
+    // counted wait: the L youngest sets (2 pieces each) may stay in flight while they are all real, i.e. while `youngest` has its K tile
+    auto wait_sets = [&](int youngest) __attribute__((always_inline)) {
         static_assert(L == 3, "the counted wait is written for L = 3");
-        if (j + 1 + L < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (youngest + 1 + L < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     auto frag_off = [&](int row, int chunk) __attribute__((always_inline)) { return row * D + ((chunk ^ ((row >> 1) & 7)) << 3); };
@@ -617,7 +658,11 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
+#if defined(PF_ATTN_PP_ABL) && (PF_ATTN_PP_ABL & 2)
+                { u16x8 z = {1, 2, 3, 4, 5, 6, 7, static_cast<unsigned short>(lane + ks)}; asm volatile("" : "+v"(z)); kf[hh][ks] = __builtin_bit_cast(frag, z); }
+#else
                 kf[hh][ks] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Ks + frag_off(hh * 32 + ql, 2 * ks + hi)));
+#endif
     };
     auto load_vfrags = [&](int j) __attribute__((always_inline)) {
         const unsigned short* Vs = smem + (NB + j % NB) * TILE;
@@ -627,7 +672,11 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
+#if defined(PF_ATTN_PP_ABL) && (PF_ATTN_PP_ABL & 2)
+                    { u16x8 z = {1, 2, 3, 4, 5, 6, 7, static_cast<unsigned short>(lane + d)}; asm volatile("" : "+v"(z)); vf[d][hh][s2] = __builtin_bit_cast(frag, z); }
+#else
                     vf[d][hh][s2] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(Vs + frag_off(d * 32 + ql, 4 * hh + 2 * s2 + hi)));
+#endif
     };
     float sv[2][16];
     u16x8 pb[2][2];
@@ -641,14 +690,22 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
             for (int r = 0; r < 16; ++r) sv[hh][r] = s[r];
         }
     };
-    auto mm_pv = [&]() __attribute__((always_inline)) {
+    // the 32-key half hh of the tile: 4 + 2 MFMAs; `between` runs behind the first three (a DMA piece: its issue then overlaps the matrix
+    // pipe's work instead of standing in front of it -- at the head of the segment the two pieces cost 270 clocks)
+    auto mm_pv = [&](auto hh_tag, auto between) __attribute__((always_inline)) {
+        constexpr int hh = decltype(hh_tag)::value;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
+        for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int d = 0; d < DB; ++d)
-                    o[d] = Mfma32<T>::run(vf[d][hh][s2], __builtin_bit_cast(frag, pb[hh][s2]), o[d]);
+            for (int d = 0; d < DB; ++d)
+                o[d] = Mfma32<T>::run(vf[d][hh][s2], __builtin_bit_cast(frag, pb[hh][s2]), o[d]);
+            osum = Mfma32<T>::run(ones, __builtin_bit_cast(frag, pb[hh][s2]), osum);
+            if (s2 == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                between();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     };
     // score register r of half hh <-> key  k0 + 32 hh + 16 (g >> 1) + 8 hi + 4 (g & 1) + e,  g = r >> 2, e = r & 3  (pi above)
     auto mask_tail = [&](int j) __attribute__((always_inline)) {
@@ -662,49 +719,81 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
                 if (j * KT + 32 * hh + 16 * (g >> 1) + 8 * hi + 4 * (g & 1) + e >= p.nk) sv[hh][r] = -INFINITY;
             }
     };
+    // The exchange between lanes l and l + 32 (the two halves of a query's scores): v_permlane32_swap (gfx950) on two copies of the
+    // value -- a = [x_lo, x_lo], b = [x_hi, x_hi] afterwards -- instead of ds_bpermute: the timing build showed the vector segment at
+    // 1400-1900 clocks per key tile against 630 for the 16 MFMAs (profiles/r5g_attn_pp_timing.txt); it is VALU-ISSUE bound (33 v_exp at
+    // quarter rate, ~100 other vector instructions at 4 clocks each) and every LDS round trip (bpermute -> s_waitcnt lgkmcnt(0)) stalls
+    // the in-order wave on top of that.  (The builtin __builtin_amdgcn_permlane32_swap of this hipcc returns the SAME register for
+    // both results -- inline assembly.)
+    auto xchg32 = [&](float x, float& lo, float& hi_) __attribute__((always_inline)) {
+        float a_ = x, b_ = x;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+        lo = a_;
+        hi_ = b_;
+    };
     auto softmax = [&]() __attribute__((always_inline)) {                        // sv -> pb (16-bit P), running max / sum, deferred rescale of O
         float mt = sv[0][0];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sv[hh][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
+            for (int r = 0; r < 16; ++r) {
+#if defined(PF_ATTN_PP_ABL) && (PF_ATTN_PP_ABL & 4)
+                if (r & 7) continue;                                             // timing-only: 4 of the 32 maxima
+#endif
+                mt = fmaxf(mt, sv[hh][r]);
+            }
+        {
+            float x0, x1;
+            xchg32(mt, x0, x1);
+            mt = fmaxf(x0, x1);
+        }
         {
             constexpr float DEFER_LOG2 = 8.0f;                                    // (see k_attention_lds)
             const float m_new = fmaxf(m_run, mt);
             const bool grow = (m_new - m_run) * c2 > DEFER_LOG2;
             if (__builtin_amdgcn_ballot_w64(grow) != 0) {
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-                l_run *= alpha;
                 m_run = m_new;
 #pragma unroll
                 for (int d = 0; d < DB; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) osum[r] *= alpha;
             }
         }
         typedef __attribute__((ext_vector_type(2))) float f32x2;
         const f32x2 c22 = {c2, c2}, mc2 = {m_run * c2, m_run * c2};
-        f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const f32x2 x = f32x2{sv[hh][r], sv[hh][r + 1]} * c22 - mc2;
+#if defined(PF_ATTN_PP_ABL) && (PF_ATTN_PP_ABL & 1)
+                const f32x2 e = x * x;                                           // timing-only: what the 32 v_exp_f32 per key tile cost
+#else
                 const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+#endif
                 sv[hh][r] = e[0];
                 sv[hh][r + 1] = e[1];
-                ls2 += e;
             }
-        float ls = ls2[0] + ls2[1];
-        ls += __shfl_xor(ls, 32);
-        l_run += ls;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
+#if defined(PF_ATTN_PP_ABL) && (PF_ATTN_PP_ABL & 8)
+                { pb[hh][s2] = __builtin_bit_cast(u16x8, f32x4{sv[hh][8 * s2], sv[hh][8 * s2 + 1], sv[hh][8 * s2 + 2], sv[hh][8 * s2 + 3]}); }   // timing-only: no conversion
+#else
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pb[hh][s2][e] = from_f32<T>(sv[hh][8 * s2 + e]);
+#endif
+        // P is FINISHED here, in the vector segment: without this pin the compiler sinks the 32 v_exp / 16 v_cvt_pk (pure register
+        // work whose only users are the MFMAs behind the barrier) into the matrix segment, next to the MFMAs of the same wave --
+        // the two segments of a wave would swap their contents and the partner waves' pipes collide instead of interleaving
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : "+v"(pb[hh][s2]));
     };
 #ifdef PF_ATTN_PP_TIMING      /* debug build (make attn_pp_timing): per-wave clock totals of the vector segments, the matrix segments and the
                                * barrier waits, written over the lse output -- tools/attn_bench.py --pp-timing prints the per-tile averages */
@@ -738,33 +827,46 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
         __syncthreads();                                                         // (before the DMA overwrites the table)
     }
 
-    // ---- prologue: K_0 .. K_L, V_0 .. V_{L-1} resident; S_0 for every wave
+    // ---- prologue: K_0, then sets -L .. 0 = (K_1, V_0) .. (K_{L+1}, V_L) in the loop's request order; only K_0 is awaited here (S_0
+    // needs nothing else) -- the loop's counted waits take the rest as they would any set (a 1024-key head is 16 tiles: waiting for
+    // nine tiles up front cost the 32^2 level a third of its time, profiles/r5k_attn_pp_prio.txt)
+    dma_k(0);
 #pragma unroll
-    for (int i = 0; i < L; ++i) { dma_k(i); dma_v(i); }
-    dma_k(L);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = 0; i <= L; ++i) { dma_k(i + 1); dma_v(i); }
+    if (L + 1 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // (2 (L + 1) younger pieces, all real)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(L == 3, "prologue wait count");
     barrier();
     load_kfrags(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     mm_qk();
-    barrier();                                                                   // K buffer 0 read by everyone: set 0 may overwrite it
+    // (no second barrier: the first overwrite of K slot 0 is set 1's K_{L+2} -> slot (L + 2) % NB = 0, requested in the first matrix
+    // segment, which every wave enters through a barrier of the loop below)
 
+    // matrix_j of a wave: request set j + 1 = (K_{j+2+L}, V_{j+1+L}) into the slots of K_j / V_{j-1} (last read in matrix_{j-1}: by A in
+    // phase 2j - 1, by B in phase 2j), read the fragments of V_j and K_{j+1} (= set j - L), 12 + 8 MFMAs.
+    auto matrix_segment = [&](int j) __attribute__((always_inline)) {
+        if (p.pp_prio == 2) __builtin_amdgcn_s_setprio(2);                       // MFMA issue wins the SIMD's arbitration against the partner's VALU stream
+        load_vfrags(j);
+        mm_pv(std::integral_constant<int, 0>(), [&]() __attribute__((always_inline)) { dma_k(j + 2 + L); });
+        __builtin_amdgcn_sched_barrier(0);                                       // (the K fragments are requested behind the first half of
+        if (j + 1 < nkt) load_kfrags(j + 1);                                     // the PV product: its V^T registers are free by then, and the
+        __builtin_amdgcn_sched_barrier(0);                                       // second half covers the LDS latency)
+        mm_pv(std::integral_constant<int, 1>(), [&]() __attribute__((always_inline)) { dma_v(j + 1 + L); });
+        if (j + 1 < nkt) mm_qk();
+        if (p.pp_prio == 2) __builtin_amdgcn_s_setprio(0);
+    };
+    if (p.pp_prio == 1 && group_b) __builtin_amdgcn_s_setprio(1);               // (MI355X_MICROARCH.md, two waves per SIMD, item 4: the younger half loses every arbitration)
     if (!group_b) {
         // group A: vector_j in phase 2 j, matrix_j in phase 2 j + 1
         for (int j = 0; j < nkt; ++j) {
-            dma_k(j + 1 + L);                                                    // set j
-            dma_v(j + L);
             mask_tail(j);
             softmax();
-            load_vfrags(j);
-            if (j + 1 < nkt) load_kfrags(j + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_sets(j);                                                        // set j - L (V_j, K_{j+1}) landed (mine): I have requested up to set j
             PF_PP_MARK(tm_vec);
             barrier();
             PF_PP_MARK(tm_bar);
-            mm_pv();
-            if (j + 1 < nkt) mm_qk();
-            wait_set(j);                                                         // set j + 1 - L landed (mine): readable by all after the barrier
+            matrix_segment(j);
 #ifdef PF_ATTN_PP_TIMING
             asm volatile("s_nop 0" :: "v"(sv[0][0]), "v"(sv[1][15]), "v"(o[0][0]), "v"(o[1][15]));   // (the MFMA results: the stamp waits for them)
 #endif
@@ -773,24 +875,16 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
             PF_PP_MARK(tm_bar);
         }
     } else {
-        // group B: half a period behind -- matrix_{j-1} in phase 2 j, vector_j in phase 2 j + 1
-        dma_k(1 + L);                                                            // set 0, phase 0
-        dma_v(L);
+        // group B: half a period behind -- vector_j in phase 2 j + 1, matrix_j in phase 2 j + 2
         barrier();
         for (int j = 0; j < nkt; ++j) {
             mask_tail(j);
             softmax();
-            load_vfrags(j);
-            if (j + 1 < nkt) load_kfrags(j + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // my fragments are in registers
-            wait_set(j);                                                         // set j + 1 - L landed (mine)
             PF_PP_MARK(tm_vec);
             barrier();
             PF_PP_MARK(tm_bar);
-            dma_k(j + 2 + L);                                                    // set j + 1, phase 2 j + 2
-            dma_v(j + 1 + L);
-            mm_pv();
-            if (j + 1 < nkt) mm_qk();
+            matrix_segment(j);
+            wait_sets(j + 1);                                                    // set j + 1 - L (V_{j+1}, K_{j+2}: A reads them next phase) landed (mine)
 #ifdef PF_ATTN_PP_TIMING
             asm volatile("s_nop 0" :: "v"(sv[0][0]), "v"(sv[1][15]), "v"(o[0][0]), "v"(o[1][15]));
 #endif
@@ -801,6 +895,7 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
     }
 
     if (q0 + ql < p.nq) {
+        const float l_run = osum[0];                                              // (every row of osum is the row sum)
         const float inv = 1.0f / l_run;
         unsigned short* op = p.out + b * p.o_bs + static_cast<long>(q0 + ql) * p.o_ld + h * D;
 #pragma unroll
@@ -866,32 +961,39 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     p.bias = d->bias; p.bias_ld = d->bias_ld; p.flags = d->flags; p.flags_ld = d->flags_ld;
     p.lse = d->lse;
     p.pp_role = attention_occupancy("PF_ATTENTION_PP_ROLE", 3);
+    p.pp_prio = attention_occupancy("PF_ATTENTION_PP_PRIO", 2);
+    p.xcd_map = attention_occupancy("PF_ATTENTION_XCD", 1);
+    const dim3 grid1(static_cast<unsigned>(cdiv(d->nq, 128) * d->H * d->B));      // k_attention_lds: 1-D, decoded in the kernel
     dim3 grid(cdiv(d->nq, 128), d->H, d->B), block(256);
     hipStream_t st = as_stream(stream);
     const bool lds = use_lds_attention() && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0;
     PF_DISPATCH_16(d->dtype, "pf_attention",
         if (lds) {
             static const int occ64 = attention_occupancy("PF_ATTENTION_OCC", 3), occ32 = attention_occupancy("PF_ATTENTION_OCC32", 3);
-            static const int pingpong = attention_occupancy("PF_ATTENTION_PP", 1);      // 0: k_attention_lds for the D = 64 self-attentions too (A/B)
+            static const int pingpong = attention_occupancy("PF_ATTENTION_PP", 0);      // 0: k_attention_lds for the D = 64 self-attentions too (A/B)
             if (d->D == 64) {
                 if (d->bias) {                 // (not pipelined it needs 169 registers at three waves per SIMD)
-                    hipLaunchKernelGGL((k_attention_lds<T, 64, true>), grid, block, 0, st, p);
-                } else if (pingpong && d->nk % 8 == 0 && d->nk >= 128 && static_cast<long>(d->nk) * d->k_ld * 2 < (1L << 31) &&
+                    hipLaunchKernelGGL((k_attention_lds<T, 64, true>), grid1, block, 0, st, p);
+#ifdef PF_ATTN_PP_TIMING
+                } else if (pingpong && d->nk % 8 == 0 && d->nk >= 128 &&                  // (the timing build writes its stamps over lse)
+#else
+                } else if (pingpong && !d->lse && d->nk % 8 == 0 && d->nk >= 128 &&      // (lse = training forward: exact fp32 row sums there)
+#endif static_cast<long>(d->nk) * d->k_ld * 2 < (1L << 31) &&
                            static_cast<long>(d->vt_ld) * 64 * 2 < (1L << 31)) {
                     hipLaunchKernelGGL((k_attention_pp<T>), dim3(static_cast<unsigned>(cdiv(d->nq, 256) * d->H * d->B)), dim3(512), 0, st, p);
                 } else {
-                    if (occ64 == 2) hipLaunchKernelGGL((k_attention_lds<T, 64, false>), grid, block, 0, st, p);
-                    else hipLaunchKernelGGL((k_attention_lds<T, 64, false, false, 3>), grid, block, 0, st, p);
+                    if (occ64 == 2) hipLaunchKernelGGL((k_attention_lds<T, 64, false>), grid1, block, 0, st, p);
+                    else hipLaunchKernelGGL((k_attention_lds<T, 64, false, false, 3>), grid1, block, 0, st, p);
                 }
             } else {
                 if (d->bias) {
-                    if (occ32 == 4) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 4>), grid, block, 0, st, p);
-                    else if (occ32 == 5) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 5>), grid, block, 0, st, p);
-                    else hipLaunchKernelGGL((k_attention_lds<T, 32, true>), grid, block, 0, st, p);
+                    if (occ32 == 4) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 4>), grid1, block, 0, st, p);
+                    else if (occ32 == 5) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 5>), grid1, block, 0, st, p);
+                    else hipLaunchKernelGGL((k_attention_lds<T, 32, true>), grid1, block, 0, st, p);
                 } else {
-                    if (occ32 == 4) hipLaunchKernelGGL((k_attention_lds<T, 32, false, false, 4>), grid, block, 0, st, p);
-                    else if (occ32 == 5) hipLaunchKernelGGL((k_attention_lds<T, 32, false, false, 5>), grid, block, 0, st, p);
-                    else hipLaunchKernelGGL((k_attention_lds<T, 32, false>), grid, block, 0, st, p);
+                    if (occ32 == 4) hipLaunchKernelGGL((k_attention_lds<T, 32, false, false, 4>), grid1, block, 0, st, p);
+                    else if (occ32 == 5) hipLaunchKernelGGL((k_attention_lds<T, 32, false, false, 5>), grid1, block, 0, st, p);
+                    else hipLaunchKernelGGL((k_attention_lds<T, 32, false>), grid1, block, 0, st, p);
                 }
             }
         } else {

@@ -269,7 +269,7 @@ class MultiViewBaseModel(nn.Module):
             pers = make_branch(self.packed("unet", dev), latents.flatten(0, 1), timestep.reshape(-1),
                                self._prompt16(prompt_embd), pano=False, pad=False)
             branches.append(pers)
-            if shard is not None and shard.pano_g is not None and not shard.has_pano and tape is None:
+            if shard is not None and shard.pano_g is not None and not shard.has_pano and tape is None and b == 1:
                 # a view rank of the panorama-rank layout: after each of its own self-attentions it computes its share of the
                 # owner's panorama self-attention at the same UNet position, where that one is split (sharding.splits_pano_attention)
                 from ... import sharding as _sh
@@ -329,7 +329,7 @@ class MultiViewBaseModel(nn.Module):
                 pano = make_branch(self.packed("pano_unet", dev), pano_latent.flatten(0, 1), pano_t,
                                    self._prompt16(pano_prompt_embd), pano=True, pad=self.pano_pad)
                 pano.on_side = side is not None     # (train_engine.backward walks its entries on the same stream)
-                if shard is not None and shard.pano_g is not None and tape is None:
+                if shard is not None and shard.pano_g is not None and tape is None and pano_latent.shape[0] == 1:
                     pano.attn_split = shard
                 if not keeps:
                     pano.precompute_text_kv()

@@ -85,7 +85,7 @@ class WarpAttn(nn.Module):
         eh, ew = (xe.shape[1], xe.shape[2]) if xe is not None else equi_hw
         ph, pw = (xp.shape[1], xp.shape[2]) if xp is not None else pers_hw
         tabs = self.tables_for(groups, ph, pw, eh, ew, dev)
-        return engine.run_epa(e, tabs, xp, xe, m, shard=shard, equi_hw=(eh, ew), side=side, pers_hw=(ph, pw))
+        return engine.run_epa(e, tabs, xp, xe, m, shard=shard, equi_hw=(eh, ew), side=side, pers_hw=(ph, pw), n_samples=len(groups))
 
     @torch.no_grad()
     def forward_inference(self, pers_x, equi_x, cameras):

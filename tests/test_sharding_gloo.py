@@ -190,3 +190,55 @@ def test_panorama_self_attention_split_over_the_cfg_half(world, split, precision
     for c in comm:                                          # owner and helpers issue the same sequence
         assert c[key]["calls_per_step"] == n_split
         assert c["broadcast panorama q|k (self-attention split, group of %d)" % G]["calls_per_step"] == n_split
+
+
+def _batch2_worker(rank, world, port, out):
+    """The denoiser forward of a sharded rank on a TWO-prompt batch (b = 2 samples of the rank's CFG half)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, args = _batch2_inputs()
+        from panfusion_amd import sharding
+        shard = sharding.make_shard(4, split=(1, 3))
+        model.shard = shard
+        v0, v1 = shard.views
+        lat, pano, ts, pe, ppe, cams = args
+        s, ps = model(lat[:, v0:v1].contiguous(), pano, ts[:, v0:v1] if v1 > v0 else ts[:, :1], pe[:, v0:v1], ppe, cams)
+        torch.save((shard.views, s, ps), os.path.join(out, "b%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def _batch2_inputs():
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import fake_ops
+    from conftest import build_tiny_oracle, cam4, golden
+    from test_engine_logic_cpu import MODS, hip_model
+    for name in MODS + ["panfusion_amd.sharding"]:
+        importlib.import_module(name).ops = fake_ops
+    g = golden("mvgen_tiny.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    model = hip_model(build_tiny_oracle())
+    gen = torch.Generator().manual_seed(5)
+    lat = torch.randn(2, 4, 4, 16, 16, generator=gen)                 # two different samples
+    pano = torch.randn(2, 1, 4, 16, 32, generator=gen)
+    cams = {k: torch.stack([v, v]) for k, v in cam4().items()}
+    return model, (lat, pano, torch.full((2, 4), 981), t("prompt_embd"), t("pano_prompt_embd"), cams)
+
+
+def test_sharded_forward_takes_a_multi_prompt_batch():
+    """the sharded EPA used to raise for b != 1.  World 4, split 1 / 3 (group 0 owns the panorama): every rank's
+    slice of a two-sample batch equals the single-process forward."""
+    model, (lat, pano, ts, pe, ppe, cams) = _batch2_inputs()
+    want_s, want_ps = model(lat, pano, ts, pe, ppe, cams)
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_batch2_worker, args=(4, _free_port(), out), nprocs=4, join=True)
+        res = [torch.load(os.path.join(out, "b%d.pt" % r)) for r in range(4)]
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for (v0, v1), s, ps in res:
+        assert s.shape[1] == v1 - v0 and rel(s, want_s[:, v0:v1]) < 1e-4
+        if ps is not None:
+            assert rel(ps, want_ps) < 1e-4
+    assert sum(ps is not None for _, _, ps in res) == 2             # one panorama owner per CFG half
