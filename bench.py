@@ -436,7 +436,7 @@ def main():
     roofline = None
     traffic = None                                    # PMC-derived bytes per launch of the dominant kernel (profiles/)
     traffic_file = None
-    for name in ("r4_traffic.json", "archive/r3_traffic.json", "archive/r2_traffic.json", "archive/r1_traffic.json"):   # newest committed PMC summary (r2+: fp16 mixed; r1: bf16 all-16-bit)
+    for name in ("r5_traffic.json", "r4_traffic.json", "archive/r3_traffic.json", "archive/r2_traffic.json", "archive/r1_traffic.json"):   # newest committed PMC summary (r2+: fp16 mixed; r1: bf16 all-16-bit)
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 traffic, traffic_file = json.load(fh), name

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_attention(const AttnParams p) {
 // PIPE: scores of tile j+1 held in registers while the softmax of tile j runs (three LDS buffers, two
 // waves per SIMD at D = 64).  !PIPE: one score array, two LDS buffers, OCC waves per SIMD -- the
 // MFMA / vector-ALU overlap then comes from the other waves of the SIMD instead of from inside a wave.
-template <typename T, int D, bool BIAS, bool PIPE = true, int OCC = (D == 64 ? 2 : 3)>
+template <typename T, int D, bool BIAS, bool PIPE = true, int OCC = (D == 64 ? 2 : 3), bool MSUM = false>
 __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) {
     // (256, 2): at most 256 registers per lane -> the MFMA accumulators live in the VGPR file; with the
     // default budget the compiler parks S and O in AGPRs and pays ~145 v_accvgpr moves per key tile.
@@ -244,6 +244,19 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;              // running max of the RAW scores (q.k), running sum
+    // MSUM (round 5, learnt on k_attention_pp below): the softmax denominator as a third accumulator block osum^T += 1 P^T on the
+    // MATRIX pipe (A operand = ones; every row is sum_k P[q][k] over both lane halves) instead of 16 packed adds + a lane exchange per
+    // key tile on the vector side, which is the side that bounds the kernel; the sum is then over the same 16-bit P the numerator uses
+    // (the lse output of the training forward keeps the fp32 sums: MSUM is never launched with p.lse).
+    f32x16 osum;
+    u16x8 ones8;
+    if constexpr (MSUM) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) osum[r] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones8[e] = from_f32<T>(1.0f);
+        asm volatile("" : "+v"(ones8));
+    }
     const float c2 = p.scale_log2e;                    // softmax(scale * s) = exp2(c2 * s - c2 * max)
 
     auto k_off = [](int row, int chunk) {
@@ -388,6 +401,10 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
                 for (int d = 0; d < DB; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                if constexpr (MSUM) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) osum[r] *= alpha;
+                }
             }
         }
         // p = exp2(c2 * s - c2 * max), two scores per instruction (v_pk_fma_f32), two running sums
@@ -406,8 +423,9 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
 #endif
                 sv[hh][r] = e[0];
                 sv[hh][r + 1] = e[1];
-                ls2 += e;
+                if constexpr (!MSUM) ls2 += e;
             }
+        if constexpr (!MSUM) {
         float ls = ls2[0] + ls2[1];
 #ifdef PF_ATTN_BPERMUTE
         ls += __shfl_xor(ls, 32);
@@ -419,6 +437,7 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
         }
 #endif
         l_run += ls;
+        }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -439,6 +458,7 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
 #endif
                     o[d] = Mfma32<T>::run(__builtin_bit_cast(frag, vf), __builtin_bit_cast(frag, pb), o[d]);
                 }
+                if constexpr (MSUM) osum = Mfma32<T>::run(__builtin_bit_cast(frag, ones8), __builtin_bit_cast(frag, pb), osum);
             }
     };
 
@@ -516,6 +536,7 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
     }
     }
 
+    if constexpr (MSUM) l_run = osum[0];                // (every row of osum is the row sum)
     if (q0 + ql < p.nq) {
         const float inv = 1.0f / l_run;
         unsigned short* op = p.out + b * p.o_bs + static_cast<long>(q0 + ql) * p.o_ld + h * D;
@@ -970,6 +991,8 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     PF_DISPATCH_16(d->dtype, "pf_attention",
         if (lds) {
             static const int occ64 = attention_occupancy("PF_ATTENTION_OCC", 3), occ32 = attention_occupancy("PF_ATTENTION_OCC32", 3);
+            static const int msum = attention_occupancy("PF_ATTENTION_MSUM", 1);      // 0: softmax row sums on the vector ALU (A/B)
+            static const int msum32 = attention_occupancy("PF_ATTENTION_MSUM32", 0);  // the same for the EPA (D = 32, bias) kernel: 168 registers + 3 spilled
             static const int pingpong = attention_occupancy("PF_ATTENTION_PP", 0);      // 0: k_attention_lds for the D = 64 self-attentions too (A/B)
             if (d->D == 64) {
                 if (d->bias) {                 // (not pipelined it needs 169 registers at three waves per SIMD)
@@ -983,12 +1006,14 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
                     hipLaunchKernelGGL((k_attention_pp<T>), dim3(static_cast<unsigned>(cdiv(d->nq, 256) * d->H * d->B)), dim3(512), 0, st, p);
                 } else {
                     if (occ64 == 2) hipLaunchKernelGGL((k_attention_lds<T, 64, false>), grid1, block, 0, st, p);
+                    else if (msum && !d->lse && d->nk >= 256) hipLaunchKernelGGL((k_attention_lds<T, 64, false, false, 3, true>), grid1, block, 0, st, p);   // (77 text keys: the 4 extra MFMAs of two tiles cost 2 %)
                     else hipLaunchKernelGGL((k_attention_lds<T, 64, false, false, 3>), grid1, block, 0, st, p);
                 }
             } else {
                 if (d->bias) {
                     if (occ32 == 4) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 4>), grid1, block, 0, st, p);
                     else if (occ32 == 5) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 5>), grid1, block, 0, st, p);
+                    else if (msum32 && !d->lse) hipLaunchKernelGGL((k_attention_lds<T, 32, true, true, 3, true>), grid1, block, 0, st, p);
                     else hipLaunchKernelGGL((k_attention_lds<T, 32, true>), grid1, block, 0, st, p);
                 } else {
                     if (occ32 == 4) hipLaunchKernelGGL((k_attention_lds<T, 32, false, false, 4>), grid1, block, 0, st, p);

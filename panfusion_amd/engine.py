@@ -474,18 +474,35 @@ def all_transformers(u):
             yield t
 
 
+def self_qkv(a, tokens, n, nk):
+    """(q | k) [n * nk, 2C] and V^T [n, C, ld] of a self-attention from its layer-normed tokens: one launch where the shape allows
+    (C = 320), else q | k + a transposed V projection."""
+    fused = ops.linear_qkv(tokens, a.wqkv, n)
+    if fused is not None:
+        return fused
+    qk = ops.linear(tokens, a.wqk)                            # [rows, 2C]  (q | k)
+    vt = ops.linear_vt(tokens, a.wv, n)                       # weight-stationary kernel, transposed epilogue (C = 640 / 1280)
+    if vt is None:
+        vt = ops.linear_t(tokens.view(n, nk, -1), a.wv)       # [n, C, ld_v] keys contiguous
+    return qk, vt
+
+
 def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv=None, next_ln=None, split=None):
     """q_src [n*nq, C] already layer-normed; kv_tokens [n*nk, Ckv] (or kv = precomputed (k, vt)).
     next_ln: the LayerNorm that follows the output projection -> (tokens, its output or None): where the output projection runs on
     the weight-stationary kernel the norm rides in its epilogue (ops.linear_ln)."""
     Cq = a.dim
     vt = None
+    if split is not None and self_attn and n == 1:
+        # sharded panorama owner: the query rows of this self-attention are computed by all ranks of the CFG half (sharding.py):
+        # the layer-normed tokens travel, every rank projects q | k | V^T itself
+        from . import sharding
+        o = sharding.split_pano_attention(split, a, q_src, nq)
+        if next_ln is not None:
+            return ops.linear_ln(o.view(n * nq, Cq), a.wo, a.bo, residual, next_ln.g, next_ln.b, next_ln.eps)
+        return ops.linear(o.view(n * nq, Cq), a.wo, bias=a.bo, residual=residual)
     if self_attn:
-        fused = ops.linear_qkv(q_src, a.wqkv, n)              # q | k | v in one launch where the shape allows it (C = 320)
-        if fused is not None:
-            qk, vt = fused
-        else:
-            qk = ops.linear(q_src, a.wqk)                     # [rows, 2C]  (q | k)
+        qk, vt = self_qkv(a, q_src, n, nk)
         q, k, ld = qk, qk[:, Cq:], 2 * Cq
     else:
         q, ld = ops.linear(q_src, a.wq), Cq
@@ -493,17 +510,10 @@ def _attend(a, q_src, kv_tokens, n, nq, nk, head_dim, *, self_attn, residual, kv
     if kv is not None:
         vt = kv[1]
     elif vt is None:
-        vt = ops.linear_vt(kv_tokens, a.wv, n) if self_attn else None     # weight-stationary kernel, transposed epilogue (C = 640 / 1280)
-        if vt is None:
-            vt = ops.linear_t(kv_tokens.view(n, nk, -1), a.wv)            # [n, C, ld_v] keys contiguous
-    if split is not None and self_attn and n == 1 and vt.shape[-1] == nk:
-        # sharded panorama owner: the query rows of this self-attention are computed by all ranks of the CFG half (sharding.py)
-        from . import sharding
-        o = sharding.split_pano_attention(split, q.contiguous(), vt.contiguous(), a.heads, head_dim, nq, Cq)
-    else:
-        o = ops.attention(q, k, vt, n, a.heads, head_dim, nq, nk,
-                          q_ld=ld, k_ld=(ld if self_attn else Cq), vt_ld=vt.shape[-1],
-                          q_bs=nq * ld, k_bs=nk * (ld if self_attn else Cq), vt_bs=vt.shape[1] * vt.shape[2])
+        vt = ops.linear_t(kv_tokens.view(n, nk, -1), a.wv)                # [n, C, ld_v] keys contiguous
+    o = ops.attention(q, k, vt, n, a.heads, head_dim, nq, nk,
+                      q_ld=ld, k_ld=(ld if self_attn else Cq), vt_ld=vt.shape[-1],
+                      q_bs=nq * ld, k_bs=nk * (ld if self_attn else Cq), vt_bs=vt.shape[1] * vt.shape[2])
     if next_ln is not None:
         return ops.linear_ln(o.view(n * nq, Cq), a.wo, a.bo, residual, next_ln.g, next_ln.b, next_ln.eps)
     return ops.linear(o.view(n * nq, Cq), a.wo, bias=a.bo, residual=residual)

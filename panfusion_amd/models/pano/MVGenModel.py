@@ -210,7 +210,14 @@ class MultiViewBaseModel(nn.Module):
             # K / V^T of the cached prompts depend on to_k / to_v: recomputed INTO the cached buffers -- a DenoiseLoop graph
             # captured before the optimizer step reads them (like the folded weights) by address, and a replay must not mix
             # the new to_q / to_out with K / V^T of the old to_k / to_v
-            for hit in getattr(u, "text_kv_cache", {}).values():
+            # Only the entries a captured graph can still read (DenoiseLoop._graph_keepalive pins them) are refreshed; the others are
+            # dropped and recomputed on their next use (up to 4 prompts x 16 cross-attentions x 2 GEMMs per optimizer step
+            # for tensors nobody would read again).  The refresh runs on the CURRENT stream: a caller that replays a DenoiseLoop graph
+            # on another stream while training on this one must order the two itself (wait_stream), as for any shared weight.
+            cache = getattr(u, "text_kv_cache", {})
+            for ck in [ck for ck, hit in cache.items() if not hit.get("pinned")]:
+                del cache[ck]
+            for hit in cache.values():
                 for t in engine.all_transformers(u):
                     k, vt = engine.text_kv(t.attn2, hit["text"])
                     hit[id(t)][0].copy_(k)
@@ -274,12 +281,17 @@ class MultiViewBaseModel(nn.Module):
                 # owner's panorama self-attention at the same UNet position, where that one is split (sharding.splits_pano_attention)
                 from ... import sharding as _sh
                 lat_h, pano_tokens = latents.shape[-2], pano_latent.shape[-2] * pano_latent.shape[-1]
+                # (the PANORAMA UNet's attention weights: packed on this rank too -- its self-attentions are met in call order)
+                pano_ts = list(engine.all_transformers(self.packed("pano_unet", dev))) if _sh.splits_pano_attention(shard, pano_tokens) else []
+                seen = [0]
 
                 def help_owner(t_pack, h, lat_h=lat_h, pano_tokens=pano_tokens):
+                    k = seen[0]
+                    seen[0] += 1
                     sc = lat_h // h.shape[1]
                     tokens = pano_tokens // (sc * sc)
                     if _sh.splits_pano_attention(shard, tokens):
-                        _sh.help_pano_attention(shard, t_pack, tokens, h)
+                        _sh.help_pano_attention(shard, pano_ts[k], tokens, h)
                 pers.attn_help = help_owner
             if pers_layout_cond is not None:        # reference :66-74 (ControlNet on the view branch)
                 controlnet("pers_cn", pers, latents.flatten(0, 1), timestep.reshape(-1), pers_layout_cond.flatten(0, 1))

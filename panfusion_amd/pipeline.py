@@ -148,7 +148,10 @@ class DenoiseLoop:
         casts, text K / V^T per UNet): referenced from the graph entry so that an eviction cannot free them under it."""
         keep = [list(getattr(self.model, "_prompt_cache", {}).values())]
         for packed in getattr(self.model, "_packed", {}).values():
-            keep.append(list(getattr(packed, "text_kv_cache", {}).values()))
+            hits = list(getattr(packed, "text_kv_cache", {}).values())
+            for hit in hits:
+                hit["pinned"] = True          # a captured graph reads these buffers by address: refold_lora refreshes them IN PLACE
+            keep.append(hits)
         return keep
 
     def prepare(self):

@@ -370,11 +370,12 @@ def share_pano_tokens(x, rows, cols, like, shard):
 # ---- query-split of the panorama branch's big self-attentions ("mandatory for cfg 4") -----------------------------
 # At configs[3] (128 x 256 panorama latent) the panorama owner of a CFG half is the slowest rank: its two + three level-0
 # self-attentions walk 32 768 keys for 32 768 queries (11 ms of its 28 ms) while the view ranks of the half
-# finish earlier.  With this on (panorama-rank layout, tokens >= PF_SHARD_ATTN_MIN_TOKENS) the owner broadcasts (q | k) and V^T of such
-# an attention inside the half, EVERY rank of the half computes the rows [g nq / G, (g + 1) nq / G) of the output, one all-gather
-# returns them.  Per attention and rank: 2 C nq + C nq 16-bit words in (63 MB at C = 320, nq = 32 768), C nq / G words out; the
-# view ranks call help_pano_attention right after their own self-attention of the same UNet position, so every rank issues the same
-# collective sequence.  A query row's result does not depend on which rank computes it: replicas stay bit-identical.
+# finish earlier.  With this on (panorama-rank layout, tokens >= PF_SHARD_ATTN_MIN_TOKENS) the owner broadcasts the layer-normed
+# TOKENS of such an attention inside the half, EVERY rank of the half projects q | k | V^T and computes the rows [g nq / G, (g + 1) nq / G)
+# of the output, one all-gather returns them.  Per attention and rank: C nq 16-bit words in (21 MB at C = 320, nq = 32 768; the first
+# version sent q | k and V^T: 63 MB), C nq / G words out; the view ranks call help_pano_attention right after their own self-attention
+# of the same UNet position, so every rank issues the same collective sequence.  A query row's result does not depend on which rank
+# computes it: replicas stay bit-identical.
 ATTN_SPLIT_MIN_TOKENS = int(os.environ.get("PF_SHARD_ATTN_MIN_TOKENS", "16384"))
 # ... and from this many ranks per CFG half: with G = 2 the one view rank of the half (13-20 views) is the slowest already, and
 # handing it half of the panorama's attention makes the step slower (cfg 4, 4 ranks, one-GPU simulation: 34.1 -> 41.5 ms; 8 ranks:
@@ -388,40 +389,43 @@ def splits_pano_attention(shard, tokens):
             and tokens >= ATTN_SPLIT_MIN_TOKENS and tokens % (32 * shard.G) == 0)
 
 
-def split_pano_attention(shard, qk, vt, heads, head_dim, nq, C, dtype=None, device=None):
-    """qk [nq, 2 C] = (q | k) and vt [1, C, nq] of ONE panorama self-attention on the owner (None on the other ranks of the
-    half) -> the attention output [nq, C] on every rank of the half (only the owner uses it)."""
+def split_pano_attention(shard, a, tokens, nq, dtype=None, device=None):
+    """ONE panorama self-attention of the owner, query-split over its CFG half.  a: the packed attention of the PANORAMA UNet at
+    this position (every rank packs that UNet: the weights are replicated anyway); tokens [nq, C]: its layer-normed input on the
+    owner, None elsewhere.  The tokens are broadcast (C nq 16-bit words: 21 MB at C = 320, nq = 32 768 -- a third of what q | k and
+    V^T would be), every rank projects q | k | V^T itself (the same launch on the same data: bit-identical), computes the rows
+    [g nq / G, (g + 1) nq / G) of the output, and one all-gather returns [nq, C] to every rank (only the owner uses it)."""
+    from . import engine
     G, g = shard.G, shard.g
-    if qk is None:
-        qk = torch.empty(nq, 2 * C, dtype=dtype, device=device)
-        vt = torch.empty(1, C, nq, dtype=dtype, device=device)
-    assert qk.is_contiguous() and vt.is_contiguous() and tuple(vt.shape) == (1, C, nq), (tuple(qk.shape), tuple(vt.shape))
+    C = a.dim
+    if tokens is None:
+        tokens = torch.empty(nq, C, dtype=dtype, device=device)
+    tokens = tokens.contiguous()
 
     def bcast():
-        _note("broadcast panorama q|k (self-attention split, group of %d)" % G, qk)
-        dist.broadcast(qk, src=shard.pano_src, group=shard.group)
-        _note("broadcast panorama V^T (self-attention split, group of %d)" % G, vt)
-        dist.broadcast(vt, src=shard.pano_src, group=shard.group)
+        _note("broadcast panorama self-attention tokens (query split, group of %d)" % G, tokens)
+        dist.broadcast(tokens, src=shard.pano_src, group=shard.group)
     _collective(bcast)
+    qk, vt = engine.self_qkv(a, tokens, 1, nq)
     rows = nq // G
     r0 = g * rows
     ld = 2 * C
-    o_loc = ops.attention(qk[r0:r0 + rows], qk[:, C:], vt, 1, heads, head_dim, rows, nq, q_ld=ld, k_ld=ld, vt_ld=nq,
-                          q_bs=rows * ld, k_bs=nq * ld, vt_bs=C * nq)
+    o_loc = ops.attention(qk[r0:r0 + rows], qk[:, C:], vt, 1, a.heads, C // a.heads, rows, nq, q_ld=ld, k_ld=ld, vt_ld=vt.shape[-1],
+                          q_bs=rows * ld, k_bs=nq * ld, vt_bs=vt.shape[1] * vt.shape[2])
     o_loc = o_loc.reshape(rows, C)
     out = torch.empty(nq, C, dtype=o_loc.dtype, device=o_loc.device)
 
     def gather():
-        _note("all_gather panorama attention rows (self-attention split, group of %d)" % G, o_loc)
+        _note("all_gather panorama attention rows (query split, group of %d)" % G, o_loc)
         dist.all_gather_into_tensor(out, o_loc, group=shard.group)
     _collective(gather)
     return out
 
 
-def help_pano_attention(shard, t_pack, tokens, like):
-    """A view rank's share of the owner's panorama self-attention at the UNet position of its own transformer pack t_pack."""
-    a = t_pack.attn1
-    split_pano_attention(shard, None, None, a.heads, a.dim // a.heads, tokens, a.dim, dtype=t_pack.dtype, device=like.device)
+def help_pano_attention(shard, pano_t_pack, tokens, like):
+    """A view rank's share of the owner's panorama self-attention; pano_t_pack: the packed transformer of the PANORAMA UNet at
+    the UNet position of the view rank's own self-attention."""
+    split_pano_attention(shard, pano_t_pack.attn1, None, tokens, dtype=pano_t_pack.dtype, device=like.device)
 
 
 def gather_eps(eps_local, pano_eps_local, shard, pano_shape=None):

@@ -184,12 +184,12 @@ def test_panorama_self_attention_split_over_the_cfg_half(world, split, precision
         assert rel(lat, want[0]) < 1e-4 and rel(pano, want[1]) < 1e-4, (rel(lat, want[0]), rel(pano, want[1]))
     assert all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
     G = world // 2
-    key = "all_gather panorama attention rows (self-attention split, group of %d)" % G
+    key = "all_gather panorama attention rows (query split, group of %d)" % G
     n_split = comm[0][key]["calls_per_step"]
     assert n_split >= 5                                     # the five level-0 self-attentions at least (512 tokens at 16 x 32)
     for c in comm:                                          # owner and helpers issue the same sequence
         assert c[key]["calls_per_step"] == n_split
-        assert c["broadcast panorama q|k (self-attention split, group of %d)" % G]["calls_per_step"] == n_split
+        assert c["broadcast panorama self-attention tokens (query split, group of %d)" % G]["calls_per_step"] == n_split
 
 
 def _batch2_worker(rank, world, port, out):

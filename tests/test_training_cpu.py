@@ -254,7 +254,13 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
     res_before = pack_before.down[0].resnets[1].train       # (resnets[0] sits before the first LoRA-carrying layer: never walked)
     with torch.no_grad():
         hip(*args)                                        # an inference forward (validation, DenoiseLoop): caches the prompts' K / V^T
-    kv_before = {k: (hit, {i: (v[0].data_ptr(), v[0].clone()) for i, v in hit.items() if i != "text"})
+    # (a captured DenoiseLoop graph pins the entries it reads by address -- pipeline.DenoiseLoop._graph_keepalive; the panorama
+    # UNet's entry stays unpinned here: the re-fold must DROP it instead of recomputing K / V^T nobody will read)
+    for hit in pack_before.text_kv_cache.values():
+        hit["pinned"] = True
+    pano_pack = hip.packed("pano_unet", args[1].device)
+    assert getattr(pano_pack, "text_kv_cache", {})
+    kv_before = {k: (hit, {i: (v[0].data_ptr(), v[0].clone()) for i, v in hit.items() if isinstance(i, int)})
                  for k, hit in getattr(pack_before, "text_kv_cache", {}).items()}
     opt.step()                                            # oracle shares the UNet modules: it steps with it
     for name in ("cp_blocks_encoder", "cp_blocks_mid", "cp_blocks_decoder"):
@@ -269,6 +275,7 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
         s2, ps2 = hip(*args)                              # served from the cache
     assert rel_l2(s2, want_s) < 5e-5 and rel_l2(ps2, want_ps) < 5e-5
     assert kv_before
+    assert all(h.get("pinned") is None for h in pano_pack.text_kv_cache.values())      # dropped at the re-fold, rebuilt on use
     for k, (hit, olds) in kv_before.items():                 # same entries, same storage, new contents
         assert pack_before.text_kv_cache[k] is hit
         for i, (ptr, old) in olds.items():

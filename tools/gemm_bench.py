@@ -31,6 +31,10 @@ SHAPES = {
     "pano_conv32": (2, 32, 68, 640, 640, 3, {}),
     "conv8cat": (40, 8, 8, 2560, 1280, 3, {}),
     "lin_mid": (1, 1, 2560, 1280, 1280, 1, {"res": True}),
+    # resnet conv2: + residual (fp32 stream in / out with --stream32: the 17-25 k-clock epilogue of DESIGN.md section 3.1)
+    "conv64res": (40, 64, 64, 320, 320, 3, {"res": True}),
+    "conv32res": (40, 32, 32, 640, 640, 3, {"res": True}),
+    "conv16res": (40, 16, 16, 1280, 1280, 3, {"res": True}),
 }
 
 

@@ -56,7 +56,7 @@ for SEC in "$@"; do
       { IFS=';' read -ra KVS <<< "$ARG"
         for kv in "PF_NOP=0" "${KVS[@]}"; do
           echo "## $kv"; env $kv python tools/gemm_bench.py --reps 20 $GEMM_ARGS 2>&1 | q
-          echo "## $kv --stream32"; env $kv python tools/gemm_bench.py --reps 20 --stream32 --shapes lin320,ff2_320,lin640,lin1280,lin_mid $GEMM_ARGS 2>&1 | q
+          echo "## $kv --stream32"; env $kv python tools/gemm_bench.py --reps 20 --stream32 --shapes ${GEMM_SHAPES32:-lin320,ff2_320,lin640,lin1280,lin_mid} 2>&1 | q
         done; } | tee gpurun_out/${TAG}_gemm_env.txt | tail -n 90 ;;
     attnenv)     # attnenv:"VAR=v;VAR2=v"  -- attention microbenchmark under each setting, baseline first
       { IFS=';' read -ra KVS <<< "$ARG"
