@@ -897,7 +897,8 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
         }
     } else {
         // group B: half a period behind -- vector_j in phase 2 j + 1, matrix_j in phase 2 j + 2
-        barrier();
+        wait_sets(0);                                                            // my pieces of set -L (K_1, V_0): group A reads them in phase 1 (found by the
+        barrier();                                                               // bit-reproducibility-under-contention test on k_attention_pp2, same prologue)
         for (int j = 0; j < nkt; ++j) {
             mask_tail(j);
             softmax();
@@ -938,6 +939,319 @@ __global__ __launch_bounds__(512, 1) void k_attention_pp(const AttnParams p) {
         dst[5] = static_cast<float>(wave);
     }
 #endif
+}
+
+#ifndef PF_PP2_MSUM
+#define PF_PP2_MSUM 0          /* 1: row sums as ones-operand MFMAs (20 more registers: the kernel then spills) */
+#endif
+// ---- ping-pong, TWO key tiles per phase (round 5, second structure) -------------------------------------------------------------------
+// tools/ubench/valu_rate.hip settled what the hardware can do (profiles/r5t_valu_rate.txt): on one SIMD a wave issuing 16 MFMAs (520 clocks) and
+// a partner issuing the softmax's vector mix (606 clocks alone) run SIDE BY SIDE at 527 / 711 -- the pipes do overlap.  k_attention_pp's phases
+// carried ~450 clocks of fixed cost each (barrier skew, DMA issue, the first exposed LDS read) against ~640 of work; here a phase covers a PAIR
+// of 64-key tiles (40 MFMAs / ~1150 clocks of vector issue), so the fixed costs are paid once per 128 keys.  Same DMA rings (tile slots, six
+// per operand = three pairs), same K-row permutation, same row sums on the matrix pipe; fragments go through four 16-register buffers in a
+// fixed software pipeline (the reads of the next half tile are issued in front of the MFMAs of the current one).  nk % 128 == 0 (every
+// UNet self-attention), no bias, no lse.
+template <typename T>
+__global__ __launch_bounds__(512, 1) void k_attention_pp2(const AttnParams p) {
+    constexpr bool MSUM = PF_PP2_MSUM;
+    constexpr int D = 64, KS = 4, DB = 2, KT = 64, TILE = KT * D;
+    constexpr int LP = 1, NB = 2 * (LP + 2);                                    // look-ahead in PAIRS; ring slots per operand in tiles
+    typedef typename Mfma32<T>::frag frag;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NB * TILE + 8 * KS * 64 * 8];  // 96 KB of rings + 32 KB: the waves' Q fragments
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ql = lane & 31, hi = lane >> 5;
+    const int nqb = (p.nq + 255) / 256, BH = static_cast<int>(gridDim.x) / nqb;
+    int qb, bh;
+    if ((BH & 7) == 0) {                                                         // (batch, head) pairs pinned to XCDs, as in k_attention_lds
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bh = xcd + 8 * (idx / nqb);
+        qb = idx - (idx / nqb) * nqb;
+    } else {
+        bh = blockIdx.x / nqb;
+        qb = blockIdx.x - bh * nqb;
+    }
+    const int q0 = (qb * 8 + wave) * 32;
+    const int h = bh % p.H;
+    const long b = bh / p.H;
+    const unsigned short* qp = p.q + b * p.q_bs + h * D;
+    const unsigned short* kp = p.k + b * p.k_bs + h * D;
+    const unsigned short* vp = p.vt + b * p.vt_bs + static_cast<long>(h) * D * p.vt_ld;
+    const int qrow = min(q0 + ql, p.nq - 1);
+
+    // Q fragments live in LDS in fragment layout (a wave re-reads its four 16-byte fragments per key tile): 16 registers the spilling
+    // first version kept in scratch -- and every scratch reload is a VMEM load whose compiler-inserted vmcnt(0) also waits for the
+    // LDS-DMA pieces just requested (1881 us against 1228 for k_attention_lds at 64^2)
+    unsigned short* const qs = smem + 2 * NB * TILE + wave * (KS * 64 * 8) + lane * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        *reinterpret_cast<u16x8*>(qs + s * 64 * 8) = *reinterpret_cast<const u16x8*>(qp + static_cast<long>(qrow) * p.q_ld + 16 * s + 8 * hi);
+    f32x16 o[DB], osum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; osum[r] = 0.f; }
+    u16x8 ones8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (MSUM) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones8[e] = from_f32<T>(1.0f);
+        asm volatile("" : "+v"(ones8));
+    }
+    const frag ones = __builtin_bit_cast(frag, ones8);
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = p.scale_log2e;
+    const int nkt = p.nk / KT, npair = nkt / 2;                                  // (launcher: nk % 128 == 0)
+
+    auto uniform_ptr = [](const unsigned short* ptr) __attribute__((always_inline)) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+        const unsigned hi32 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+        return reinterpret_cast<unsigned short*>(static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi32) << 32));
+    };
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(kp), 0, __builtin_amdgcn_readfirstlane(((p.nk - 1) * p.k_ld + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(vp), 0, __builtin_amdgcn_readfirstlane(D * p.vt_ld * 2), 0x00020000);
+    const int srow = wave * 8 + (lane >> 3);
+    const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);
+    const int krow = (srow & ~12) | ((srow & 4) << 1) | ((srow & 8) >> 1);       // pi (see k_attention_pp)
+    const unsigned kvoff0 = static_cast<unsigned>(krow * p.k_ld + lchunk * 8) * 2u;
+    const unsigned vvoff0 = static_cast<unsigned>(srow * p.vt_ld + lchunk * 8) * 2u;
+    const unsigned kstep = static_cast<unsigned>(KT * p.k_ld) * 2u;
+    auto lds_dma = [&](const __amdgpu_buffer_rsrc_t& r, unsigned short* dst, unsigned voff) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+    };
+    auto dma_k = [&](int j) __attribute__((always_inline)) {                     // K tile j -> K slot j % NB
+        if (j < nkt) lds_dma(rs_k, smem + (j % NB) * TILE + wave * 512, kvoff0 + static_cast<unsigned>(j) * kstep);
+    };
+    auto dma_v = [&](int j) __attribute__((always_inline)) {                     // V^T tile j -> V slot j % NB
+        if (j < nkt) lds_dma(rs_v, smem + (NB + j % NB) * TILE + wave * 512, vvoff0 + static_cast<unsigned>(j) * (KT * 2u));
+    };
+    // set s = (K pair s + 1 + LP, V pair s + LP), 4 pieces per wave; the LP youngest sets may stay in flight while `youngest` is whole
+    auto wait_sets = [&](int youngest) __attribute__((always_inline)) {
+        static_assert(LP == 1, "the counted wait is written for LP = 1");
+        if (youngest + 1 + LP < npair) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto frag_off = [&](int row, int chunk) __attribute__((always_inline)) { return row * D + ((chunk ^ ((row >> 1) & 7)) << 3); };
+    // fragments of one 32-key half of a tile: V^T (d 0 | d 1) x (slab 0 | slab 1), or K slabs 0..3
+    // Fragment addresses from ONE per-lane register: row (32 r + ql), logical chunk (even c + hi) sits at element
+    // (32 r + ql) 64 + (((c + hi) ^ swz) << 3) = 2048 r + (lane_base ^ (c << 3)),  lane_base = 64 ql + ((swz ^ hi) << 3)  (c even, swz = (ql >> 1) & 7):
+    // an XOR with an immediate per read (volatile: left to itself the compiler hoists all eight XORs out of the loop into eight registers
+    // -- registers this kernel does not have: with them it spilled a lane constant and reloaded it through VMEM inside the loop).
+    const int lane_base = (64 * ql + ((((ql >> 1) & 7) ^ hi) << 3)) * 2;        // bytes
+    auto frag_at = [&](const unsigned short* tile, int r32, int c_even) __attribute__((always_inline)) {
+        int off;
+        asm volatile("v_xor_b32 %0, %2, %1" : "=v"(off) : "v"(lane_base), "s"(c_even << 4));
+        return __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(reinterpret_cast<const char*>(tile) + 4096 * r32 + off));
+    };
+    auto ld_v = [&](int j, int hh, frag (&f)[4]) __attribute__((always_inline)) {
+        const unsigned short* Vs = smem + (NB + j % NB) * TILE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) f[2 * s2 + d] = frag_at(Vs, d, 4 * hh + 2 * s2);
+    };
+    auto ld_k = [&](int j, int hh, frag (&f)[4]) __attribute__((always_inline)) {
+        const unsigned short* Ks = smem + (j % NB) * TILE;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) f[ks] = frag_at(Ks, hh, 2 * ks);
+    };
+    float sv[2][2][16];                                                          // [tile of the pair][32-key half][score register]
+    u16x8 pb[2][2][2];                                                           // 16-bit P: [tile][half][16-key slab]
+    auto pv = [&](frag (&f)[4], int u, int hh) __attribute__((always_inline)) {  // 4 + 2 MFMAs
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            o[0] = Mfma32<T>::run(f[2 * s2], __builtin_bit_cast(frag, pb[u][hh][s2]), o[0]);
+            o[1] = Mfma32<T>::run(f[2 * s2 + 1], __builtin_bit_cast(frag, pb[u][hh][s2]), o[1]);
+            if constexpr (MSUM) osum = Mfma32<T>::run(ones, __builtin_bit_cast(frag, pb[u][hh][s2]), osum);
+        }
+    };
+    auto qk = [&](frag (&f0)[4], frag (&f1)[4], int u) __attribute__((always_inline)) {   // both halves of a tile: two interleaved chains of 4
+        f32x16 s0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        frag qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(qs + ks * 64 * 8));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            s0 = Mfma32<T>::run(f0[ks], qf[ks], s0);
+            s1 = Mfma32<T>::run(f1[ks], qf[ks], s1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sv[u][0][r] = s0[r]; sv[u][1][r] = s1[r]; }
+    };
+    auto xchg32 = [&](float x, float& lo, float& hi_) __attribute__((always_inline)) {
+        float a_ = x, b_ = x;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+        lo = a_;
+        hi_ = b_;
+    };
+    auto softmax = [&]() __attribute__((always_inline)) {                        // the pair's 128 keys at once: one maximum, one rescale decision
+        float mt = sv[0][0][0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sv[u][hh][r]);
+        {
+            float x0, x1;
+            xchg32(mt, x0, x1);
+            mt = fmaxf(x0, x1);
+        }
+        {
+            constexpr float DEFER_LOG2 = 8.0f;                                    // (see k_attention_lds)
+            const float m_new = fmaxf(m_run, mt);
+            const bool grow = (m_new - m_run) * c2 > DEFER_LOG2;
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                if constexpr (MSUM) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) osum[r] *= alpha;
+                } else l_run *= alpha;
+            }
+        }
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const f32x2 c22 = {c2, c2}, mc2 = {m_run * c2, m_run * c2};
+        f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 x = f32x2{sv[u][hh][r], sv[u][hh][r + 1]} * c22 - mc2;
+                    const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    sv[u][hh][r] = e[0];
+                    sv[u][hh][r + 1] = e[1];
+                    if constexpr (!MSUM) ls2 += e;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pb[u][hh][s2][e] = from_f32<T>(sv[u][hh][8 * s2 + e]);
+                    asm volatile("" : "+v"(pb[u][hh][s2]));                      // P is finished in the vector segment (see k_attention_pp)
+                }
+            }
+        if constexpr (!MSUM) {
+            float x0, x1;
+            xchg32(ls2[0] + ls2[1], x0, x1);
+            l_run += x0 + x1;
+        }
+    };
+    auto barrier = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define PF_SB() __builtin_amdgcn_sched_barrier(0)
+
+    // phase groups from the hardware SIMD id (see k_attention_pp)
+    int group_b;
+    {
+        int* simd_of = reinterpret_cast<int*>(smem);
+        const int my_simd = (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)) & 3;
+        if (lane == 0) simd_of[wave] = my_simd;
+        __syncthreads();
+        int rank_on_simd = 0;
+        for (int w = 0; w < 8; ++w) rank_on_simd += (w < wave && simd_of[w] == my_simd) ? 1 : 0;
+        group_b = __builtin_amdgcn_readfirstlane(rank_on_simd & 1);
+        __syncthreads();
+    }
+
+    frag fa[4], fb[4], fc[4], fd[4];
+    // ---- prologue: K pair 0, then sets -LP .. 0 in the loop's request order; only K pair 0 is awaited here
+    dma_k(0);
+    dma_k(1);
+#pragma unroll
+    for (int s = -LP; s <= 0; ++s) {
+        dma_k(2 * (s + 1 + LP));
+        dma_k(2 * (s + 1 + LP) + 1);
+        dma_v(2 * (s + LP));
+        dma_v(2 * (s + LP) + 1);
+    }
+    if (1 + LP < npair) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // (4 (LP + 1) younger pieces, all real)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(LP == 1, "prologue wait count");
+    barrier();
+    ld_k(0, 0, fa); ld_k(0, 1, fb); ld_k(1, 0, fc); ld_k(1, 1, fd);
+    qk(fa, fb, 0);
+    qk(fc, fd, 1);
+
+    // matrix segment of pair i: tiles a = 2 i, a + 1: O^T += V^T P^T (+ row sums), then S^T of pair i + 1; requests set i + 1 between the MFMAs.
+    // Fragment buffers rotate fa -> fb -> ...: the reads of the next half tile are issued in front of the MFMAs of the current one.
+    auto matrix_segment = [&](int i) __attribute__((always_inline)) {
+        const int a = 2 * i, c = 2 * i + 2;
+        const bool more = i + 1 < npair;
+        __builtin_amdgcn_s_setprio(2);
+        ld_v(a, 0, fa);
+        ld_v(a, 1, fb);
+        PF_SB();
+        pv(fa, 0, 0);
+        PF_SB();
+        dma_k(2 * (i + 2 + LP));
+        ld_v(a + 1, 0, fc);
+        PF_SB();
+        pv(fb, 0, 1);
+        PF_SB();
+        dma_k(2 * (i + 2 + LP) + 1);
+        ld_v(a + 1, 1, fd);
+        PF_SB();
+        pv(fc, 1, 0);
+        PF_SB();
+        dma_v(2 * (i + 1 + LP));
+        if (more) { ld_k(c, 0, fa); ld_k(c, 1, fb); }
+        PF_SB();
+        pv(fd, 1, 1);
+        PF_SB();
+        dma_v(2 * (i + 1 + LP) + 1);
+        if (more) {
+            ld_k(c + 1, 0, fc);
+            PF_SB();
+            qk(fa, fb, 0);
+            PF_SB();
+            ld_k(c + 1, 1, fd);
+            PF_SB();
+            qk(fc, fd, 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    if (!group_b) {
+        for (int i = 0; i < npair; ++i) {                                        // group A: vector_i in phase 2 i, matrix_i in phase 2 i + 1
+            softmax();
+            wait_sets(i);                                                        // set i - LP (K pair i + 1, V pair i) landed (mine)
+            barrier();
+            matrix_segment(i);
+            barrier();
+        }
+    } else {
+        wait_sets(0);                                                            // my pieces of set -LP (K pair 1, V pair 0): group A reads them in phase 1
+        barrier();                                                               // group B: half a period behind
+        for (int i = 0; i < npair; ++i) {
+            softmax();
+            barrier();
+            matrix_segment(i);
+            wait_sets(i + 1);                                                    // set i + 1 - LP landed (mine): A reads it next phase
+            if (i + 1 < npair) barrier();
+        }
+    }
+#undef PF_SB
+
+    if (q0 + ql < p.nq) {
+        const float inv = 1.0f / (MSUM ? osum[0] : l_run);                       // (every row of osum is the row sum)
+        unsigned short* op = p.out + b * p.o_bs + static_cast<long>(q0 + ql) * p.o_ld + h * D;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u16x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(o[d][4 * g + e] * inv);
+                *reinterpret_cast<u16x4*>(op + d * 32 + 8 * g + 4 * hi) = w;
+            }
+    }
 }
 
 static bool use_lds_attention() {
@@ -997,6 +1311,9 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
             if (d->D == 64) {
                 if (d->bias) {                 // (not pipelined it needs 169 registers at three waves per SIMD)
                     hipLaunchKernelGGL((k_attention_lds<T, 64, true>), grid1, block, 0, st, p);
+                } else if (pingpong == 2 && !d->lse && d->nk % 128 == 0 && d->nk >= 256 && static_cast<long>(d->nk) * d->k_ld * 2 < (1L << 31) &&
+                           static_cast<long>(d->vt_ld) * 64 * 2 < (1L << 31)) {
+                    hipLaunchKernelGGL((k_attention_pp2<T>), dim3(static_cast<unsigned>(cdiv(d->nq, 256) * d->H * d->B)), dim3(512), 0, st, p);
 #ifdef PF_ATTN_PP_TIMING
                 } else if (pingpong && d->nk % 8 == 0 && d->nk >= 128 &&                  // (the timing build writes its stamps over lse)
 #else
