@@ -1307,7 +1307,7 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
             static const int occ64 = attention_occupancy("PF_ATTENTION_OCC", 3), occ32 = attention_occupancy("PF_ATTENTION_OCC32", 3);
             static const int msum = attention_occupancy("PF_ATTENTION_MSUM", 1);      // 0: softmax row sums on the vector ALU (A/B)
             static const int msum32 = attention_occupancy("PF_ATTENTION_MSUM32", 0);  // the same for the EPA (D = 32, bias) kernel: 168 registers + 3 spilled
-            static const int pingpong = attention_occupancy("PF_ATTENTION_PP", 0);      // 0: k_attention_lds for the D = 64 self-attentions too (A/B)
+            const int pingpong = attention_occupancy("PF_ATTENTION_PP", 0);                // (read per call: the tests switch it)      // 0: k_attention_lds for the D = 64 self-attentions too (A/B)
             if (d->D == 64) {
                 if (d->bias) {                 // (not pipelined it needs 169 registers at three waves per SIMD)
                     hipLaunchKernelGGL((k_attention_lds<T, 64, true>), grid1, block, 0, st, p);

@@ -770,6 +770,35 @@ def test_attention_fused_qk_buffer_and_bias(dtype):
     check("shift invariance", want, want2, 1e-5)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("pp,cfg", [(1, (2, 5, 64, 512, 512)), (1, (1, 3, 64, 300, 1000)), (1, (1, 2, 64, 64, 136)), (1, (3, 2, 64, 257, 4096)),
+                                    (2, (2, 5, 64, 512, 512)), (2, (1, 3, 64, 300, 1152)), (2, (1, 2, 64, 33, 256)), (2, (3, 2, 64, 257, 4096))])
+def test_pingpong_attention_kernels(dtype, pp, cfg):
+    """The two experimental 8-wave ping-pong kernels (PF_ATTENTION_PP = 1: one key tile per phase, ragged key counts that are
+    multiples of 8; = 2: two tiles per phase, multiples of 128) against the fp32 reference and against the shipped kernel --
+    DESIGN.md section 3.4: they are kept for what they measure, and have to stay correct to measure anything."""
+    import os
+    B, H, D, nq, nk = cfg
+    Cq = H * D
+    q, qf = q16(rnd(B, nq, Cq, seed=46), dtype)
+    k, kf = q16(rnd(B, nk, Cq, seed=47), dtype)
+    v, vf = q16(rnd(B, nk, Cq, seed=48), dtype)
+    ld = ((nk + 31) // 32) * 32
+    vt = torch.full((B, Cq, ld), float("nan"), dtype=dtype, device=DEV)     # padding must never be read as data
+    vt[:, :, :nk] = v.transpose(1, 2)
+    kw = dict(q_ld=Cq, k_ld=Cq, vt_ld=ld, q_bs=nq * Cq, k_bs=nk * Cq, vt_bs=Cq * ld)
+    base = ops().attention(q, k, vt, B, H, D, nq, nk, **kw)
+    os.environ["PF_ATTENTION_PP"] = str(pp)
+    try:
+        outs = [ops().attention(q, k, vt, B, H, D, nq, nk, **kw) for _ in range(3)]
+    finally:
+        del os.environ["PF_ATTENTION_PP"]
+    want = attn_ref(qf, kf, vf, H, D ** -0.5)
+    check("ping-pong attention", outs[0], want, 2.5 * TOL[dtype])
+    check("ping-pong vs shipped kernel", outs[0], base.float(), 2.5 * TOL[dtype])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])          # (no scheduling dependence)
+
+
 def test_gemm_and_attention_are_bit_reproducible_under_contention():
     """The tile GEMM kernels (persistent 8-wave kernel with its counted LDS-DMA waits: plain 3x3 conv with fp32 output + residual +
     GroupNorm moments, the split-precision K step, a short-K GEGLU linear; the 4-wave kernel with split K) and both attention
