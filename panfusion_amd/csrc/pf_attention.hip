@@ -1295,9 +1295,11 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     p.scale_log2e = d->scale * 1.44269504088896340736f;
     p.bias = d->bias; p.bias_ld = d->bias_ld; p.flags = d->flags; p.flags_ld = d->flags_ld;
     p.lse = d->lse;
-    p.pp_role = attention_occupancy("PF_ATTENTION_PP_ROLE", 3);
-    p.pp_prio = attention_occupancy("PF_ATTENTION_PP_PRIO", 2);
-    p.xcd_map = attention_occupancy("PF_ATTENTION_XCD", 1);
+    static const int env_role = attention_occupancy("PF_ATTENTION_PP_ROLE", 3), env_prio = attention_occupancy("PF_ATTENTION_PP_PRIO", 2),
+                     env_xcd = attention_occupancy("PF_ATTENTION_XCD", 1);       // (read once; PF_ATTENTION_PP below is read per call)
+    p.pp_role = env_role;
+    p.pp_prio = env_prio;
+    p.xcd_map = env_xcd;
     const dim3 grid1(static_cast<unsigned>(cdiv(d->nq, 128) * d->H * d->B));      // k_attention_lds: 1-D, decoded in the kernel
     dim3 grid(cdiv(d->nq, 128), d->H, d->B), block(256);
     hipStream_t st = as_stream(stream);
