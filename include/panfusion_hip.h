@@ -369,6 +369,13 @@ pf_status pf_conv_in(const float* x, int n, int cin, int h, int w, const float* 
                      int cout, int wrap, int out_dtype, void* y, void* stream);
 pf_status pf_conv_out(const void* x, int dtype, int n, int cin, int h, int w, const float* wgt,
                       const float* bias, int cout, int wrap, float* y, void* stream);
+/* The UNets' head in one launch (MVGenModel.py:279-294: conv_norm_out -> SiLU -> conv_out): x fp32 NHWC
+ * [n][h][w][cin] BEFORE the GroupNorm, scale / shift fp32 [n][cin] from pf_groupnorm_* (y = act(x * scale + shift),
+ * act 1 = SiLU), wgt_t fp32 [3][3][cin][4] (the conv_out weight transposed, output channels padded to 4 with
+ * zeros), cout <= 4, cin % 32 == 0; y fp32 NCHW [n][cout][h][w].  Zero padding / wrap apply to the ACTIVATED
+ * tensor, as in pf_conv_out. */
+pf_status pf_conv_out_gn(const float* x, int n, int cin, int h, int w, const float* scale, const float* shift, int act,
+                         const float* wgt_t, const float* bias, int cout, int wrap, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flash attention on MFMA (replaces xformers memory_efficient_attention, transformer.py:71,

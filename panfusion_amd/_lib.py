@@ -140,6 +140,8 @@ SIGNATURES = {
                            c_void_p, c_void_p]),
     "pf_conv_out": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                             c_void_p, c_void_p]),
+    "pf_conv_out_gn": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                               c_void_p, c_void_p]),
     "pf_attention": (c_int, [C.POINTER(AttnDesc), c_void_p]),
     "pf_attention_delta": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_void_p, c_void_p]),
     "pf_attention_bwd": (c_int, [C.POINTER(AttnBwdDesc), c_void_p]),

@@ -738,15 +738,27 @@ __global__ void k_conv_in(const float* __restrict__ x, int n, int cin, int h, in
 // generic kernel above re-reads its 72 weight quads (9 taps x 4 channels x 32 B) for every pixel -- 73 KB per wavefront from
 // L1 / L2, 7.5 GB per launch for 210 MB of output; here they are read once per four pixels and the 72 input values of the
 // 3 x 6 patch are requested up front.  w % 4 == 0.
+// Round 5: the 36 x cout weights (46 KB at 320 channels) are staged ONCE per block in LDS and a block walks n_iter x 256
+// (pixel group, octet) items (n_iter <= CONV_IN4_ITER, fewer when that would leave CUs without a block): read from global memory per item they do not fit the 32 KB L1 -- every wavefront streamed all of
+// them from L2 again (1.2 GB per launch for 210 MB of output, 196 us at 40 x 64 x 64).  LDS layout [tap, c][half][octet] float4:
+// consecutive lanes (octets) read consecutive 16 bytes.
+constexpr int CONV_IN4_ITER = 8;
 template <typename T, bool OUT_F32>
-__global__ __launch_bounds__(256) void k_conv_in4(const float* __restrict__ x, int n, int h, int w,
+__global__ __launch_bounds__(256, 3) void k_conv_in4(const float* __restrict__ x, int n, int h, int w,
                                                 const float* __restrict__ wgt, const float* __restrict__ bias, int cout,
-                                                int wrap, void* __restrict__ y) {
+                                                int wrap, void* __restrict__ y, int n_iter) {
     constexpr int CIN = 4, PX = 4;
-    const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float4 wl4[];                 // [36][2][OCT]
     const int OCT = cout / 8, wq = w / PX;
     const long total = static_cast<long>(n) * h * wq * OCT;
-    if (i >= total) return;
+    for (int s4 = threadIdx.x; s4 < 36 * 2 * OCT; s4 += 256) {
+        const int tc = s4 / (2 * OCT), r = s4 - tc * 2 * OCT;
+        wl4[(tc * 2 + (r & 1)) * OCT + (r >> 1)] = reinterpret_cast<const float4*>(wgt)[s4];
+    }
+    __syncthreads();
+    for (int it = 0; it < n_iter; ++it) {
+    const long i = (blockIdx.x * static_cast<long>(n_iter) + it) * 256 + threadIdx.x;
+    if (i >= total) continue;
     const int oct = i % OCT;
     const long pg = i / OCT;
     const int x0 = (pg % wq) * PX, yy = (pg / wq) % h, b = pg / (static_cast<long>(wq) * h);
@@ -769,32 +781,39 @@ __global__ __launch_bounds__(256) void k_conv_in4(const float* __restrict__ x, i
                 v[ky][j][c] = ok ? t : 0.f;
             }
         }
-    float acc[PX][8];
+    typedef __attribute__((ext_vector_type(2))) float f32x2;       // two output channels per v_pk_fma_f32
+    f32x2 acc2[PX][4];
 #pragma unroll
     for (int q = 0; q < PX; ++q)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[q][j] = bias ? bias[oct * 8 + j] : 0.f;
-    const float* wb = wgt + oct * 8;
+        for (int j = 0; j < 4; ++j) acc2[q][j] = bias ? f32x2{bias[oct * 8 + 2 * j], bias[oct * 8 + 2 * j + 1]} : f32x2{0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
-                const float4* wp = reinterpret_cast<const float4*>(wb + static_cast<long>((ky * 3 + kx) * CIN + c) * cout);
-                const float4 w0 = wp[0], w1 = wp[1];
+                const int tc = (ky * 3 + kx) * CIN + c;
+                const float4 w0 = wl4[(tc * 2) * OCT + oct], w1 = wl4[(tc * 2 + 1) * OCT + oct];
+                const f32x2 wa = {w0.x, w0.y}, wb = {w0.z, w0.w}, wc = {w1.x, w1.y}, wd = {w1.z, w1.w};
 #pragma unroll
                 for (int q = 0; q < PX; ++q) {
                     const float t = v[ky][q + kx][c];
-                    acc[q][0] += t * w0.x; acc[q][1] += t * w0.y; acc[q][2] += t * w0.z; acc[q][3] += t * w0.w;
-                    acc[q][4] += t * w1.x; acc[q][5] += t * w1.y; acc[q][6] += t * w1.z; acc[q][7] += t * w1.w;
+                    const f32x2 tt = {t, t};
+                    acc2[q][0] += tt * wa; acc2[q][1] += tt * wb; acc2[q][2] += tt * wc; acc2[q][3] += tt * wd;
                 }
             }
     const long pix0 = (static_cast<long>(b) * h + yy) * w + x0;
+    float acc[PX][8];
+#pragma unroll
+    for (int q = 0; q < PX; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[q][2 * j] = acc2[q][j][0]; acc[q][2 * j + 1] = acc2[q][j][1]; }
 #pragma unroll
     for (int q = 0; q < PX; ++q) {
         if (OUT_F32) store8_f32(static_cast<float*>(y) + (pix0 + q) * cout + oct * 8, acc[q]);
         else *reinterpret_cast<u16x8*>(static_cast<unsigned short*>(y) + (pix0 + q) * cout + oct * 8) = pack8<T>(acc[q]);
+    }
     }
 }
 
@@ -843,6 +862,104 @@ __global__ void k_conv_out(const typename In8<TI>::elem* __restrict__ x, int n, 
 #pragma unroll
         for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (sub == 0 && live) y[((static_cast<long>(b) * cout + co) * h + yy) * w + xx] = s + (bias ? bias[co] : 0.f);
+    }
+}
+
+
+// conv_out with its GroupNorm-apply + SiLU folded in (the UNets' head, fp32 streams): x fp32 NHWC [n][h][w][cin] (un-normalised),
+// scale / shift [n][cin] (pf_groupnorm_*), weights fp32 [3][3][cin][4] (cout padded to 4), y fp32 NCHW [n][cout <= 4][h][w].
+// The two-launch form wrote the activated tensor (210 MB at 40 x 64 x 64 x 320) only for k_conv_out to read it nine times
+// through L2 (0.1 + 0.3 ms per denoiser pass on the view branch's stream).  Here a block owns an 8 x 32 tile of output pixels:
+// per 32-channel chunk it normalises + activates the 10 x 34 halo tile ONCE into LDS (zero outside the image: the padding is
+// applied to the ACTIVATED tensor; circular in width for the panorama), then every thread accumulates its pixel's 9 x 32 x 4
+// products from LDS (ds_read_b128, pixel stride 36 floats: conflict free) against wavefront-uniform weights (scalar loads).
+constexpr int COG_TH = 8, COG_TW = 32, COG_CH = 32, COG_PS = COG_CH + 4;
+__global__ __launch_bounds__(256, 3) void k_conv_out_gn(const float* __restrict__ x, int cin, int h, int w,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                   const float* __restrict__ wt, const float* __restrict__ bias, int cout,
+                                                   int wrap, float* __restrict__ y) {
+    constexpr int HP = COG_TH + 2, WP = COG_TW + 2, NPIX = HP * WP, NQ = COG_CH / 4;
+    constexpr int FILL = (NPIX * NQ + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float tile[NPIX * COG_PS];
+    __shared__ __attribute__((aligned(16))) float4 wl[9 * COG_CH];   // this chunk's weights [tap][c] (cout quad): broadcast reads
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const int t = threadIdx.x, tx = t % COG_TW, ty = t / COG_TW;
+    const int x0 = blockIdx.x * COG_TW, y0 = blockIdx.y * COG_TH, img = blockIdx.z;
+    const float* xb = x + static_cast<long>(img) * h * w * cin;
+    const float* scb = scale + static_cast<long>(img) * cin;
+    const float* shb = shift + static_cast<long>(img) * cin;
+    const int q = t % NQ;                                          // this thread's channel quad of a chunk (256 % NQ == 0)
+    // halo pixels this thread fills (the same for every chunk): source offset in pixels, or -1 = zero padding
+    int src[FILL];
+#pragma unroll
+    for (int k = 0; k < FILL; ++k) {
+        const int pixel = (t + 256 * k) / NQ;
+        const int py = pixel / WP, px = pixel - py * WP;
+        const int gy = y0 + py - 1;
+        int gx = x0 + px - 1;
+        if (wrap) gx = gx < 0 ? gx + w : (gx >= w ? gx - w : gx);
+        const bool ok = pixel < NPIX && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        src[k] = ok ? gy * w + gx : -1;
+    }
+    f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+    for (int c0 = 0; c0 < cin; c0 += COG_CH) {
+        float4 v[FILL];
+#pragma unroll
+        for (int k = 0; k < FILL; ++k)
+            v[k] = src[k] >= 0 ? *reinterpret_cast<const float4*>(xb + static_cast<long>(src[k]) * cin + c0 + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
+        const float4 sc = *reinterpret_cast<const float4*>(scb + c0 + 4 * q), sh = *reinterpret_cast<const float4*>(shb + c0 + 4 * q);
+        // (9 x 32 = 288 weight quads: one per thread + 32 more)
+        const float4 wv_fill = reinterpret_cast<const float4*>(wt)[static_cast<long>(t / COG_CH) * cin + c0 + t % COG_CH];
+        const float4 wv_fill2 = reinterpret_cast<const float4*>(wt)[static_cast<long>(8) * cin + c0 + t % COG_CH];
+        if (c0) __syncthreads();                                   // every thread is done reading the previous chunk
+        wl[t] = wv_fill;
+        if (t < COG_CH) wl[8 * COG_CH + t] = wv_fill2;
+#pragma unroll
+        for (int k = 0; k < FILL; ++k) {
+            const int pixel = (t + 256 * k) / NQ;
+            if (pixel >= NPIX) break;
+            float f[4] = {v[k].x * sc.x + sh.x, v[k].y * sc.y + sh.y, v[k].z * sc.z + sh.z, v[k].w * sc.w + sh.w};
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = f[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-f[e]));      // (as k_scale_shift_act)
+            }
+            const bool ok = src[k] >= 0;
+            *reinterpret_cast<float4*>(tile + pixel * COG_PS + 4 * q) = ok ? float4{f[0], f[1], f[2], f[3]} : float4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        // 36 groups of (tap, 8 channels): the 2 activation + 8 weight quads of group g + 1 are requested before the 16 packed
+        // FMAs of group g are issued (the scheduling barriers keep hipcc from sinking every read next to its use, which left
+        // one LDS round trip exposed per two FMAs)
+        constexpr int NG = 9 * (COG_CH / 8);
+        float4 av[2][2], wq[2][8];
+        auto load_group = [&](int g, int buf) __attribute__((always_inline)) {
+            const int tap = g / (COG_CH / 8), c8 = g % (COG_CH / 8);
+            const float* a = tile + ((ty + tap / 3) * WP + tx + tap % 3) * COG_PS + 8 * c8;
+            av[buf][0] = *reinterpret_cast<const float4*>(a);
+            av[buf][1] = *reinterpret_cast<const float4*>(a + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wq[buf][e] = wl[tap * COG_CH + 8 * c8 + e];      // wavefront-uniform address: an LDS broadcast
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_group(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int b = g & 1;
+            const float ae[8] = {av[b][0].x, av[b][0].y, av[b][0].z, av[b][0].w, av[b][1].x, av[b][1].y, av[b][1].z, av[b][1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc01 += f32x2{ae[e], ae[e]} * f32x2{wq[b][e].x, wq[b][e].y};
+                acc23 += f32x2{ae[e], ae[e]} * f32x2{wq[b][e].z, wq[b][e].w};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int gy = y0 + ty, gx = x0 + tx;
+    if (gy < h && gx < w) {
+        const float r[4] = {acc01[0], acc01[1], acc23[0], acc23[1]};
+        for (int co = 0; co < cout; ++co)
+            y[((static_cast<long>(img) * cout + co) * h + gy) * w + gx] = r[co] + (bias ? bias[co] : 0.f);
     }
 }
 
@@ -1264,13 +1381,18 @@ extern "C" pf_status pf_conv_in(const float* x, int n, int cin, int h, int w, co
     const long total = static_cast<long>(n) * h * w * (cout / 8);
     if (cin == 4 && w % 4 == 0) {                                 // the UNets' latent input: four pixels per thread
         const long total4 = total / 4;
+        const size_t wlds = static_cast<size_t>(36) * cout * sizeof(float);
+        PF_REQUIRE(wlds <= 64 * 1024, "pf_conv_in: cout = %d too wide for the weight tile in LDS", cout);
+        // items per block: up to CONV_IN4_ITER x 256, but at least ~3 blocks per CU (the panorama's 2 x 64 x 128 latent is 320 blocks)
+        const int n_iter = static_cast<int>(std::max<long>(1, std::min<long>(CONV_IN4_ITER, total4 / (256L * 768))));
+        const dim3 grid4(cdiv(total4, 256L * n_iter));
         if (out_dtype == PF_F32)
-            hipLaunchKernelGGL((k_conv_in4<Bf16, true>), dim3(cdiv(total4, 256)), dim3(256), 0, as_stream(stream), x, n, h, w,
-                               wgt, bias, cout, wrap, y);
+            hipLaunchKernelGGL((k_conv_in4<Bf16, true>), grid4, dim3(256), wlds, as_stream(stream), x, n, h, w,
+                               wgt, bias, cout, wrap, y, n_iter);
         else
             PF_DISPATCH_16(out_dtype, "pf_conv_in",
-                hipLaunchKernelGGL((k_conv_in4<T, false>), dim3(cdiv(total4, 256)), dim3(256), 0, as_stream(stream), x, n, h, w,
-                                   wgt, bias, cout, wrap, y));
+                hipLaunchKernelGGL((k_conv_in4<T, false>), grid4, dim3(256), wlds, as_stream(stream), x, n, h, w,
+                                   wgt, bias, cout, wrap, y, n_iter));
         PF_CHECK_LAUNCH("pf_conv_in");
         return PF_OK;
     }
@@ -1303,5 +1425,17 @@ extern "C" pf_status pf_conv_out(const void* x, int dtype, int n, int cin, int h
         if (lpp == 8) PF_CONV_OUT(8); else if (lpp == 16) PF_CONV_OUT(16); else if (lpp == 32) PF_CONV_OUT(32); else PF_CONV_OUT(64));
 #undef PF_CONV_OUT
     PF_CHECK_LAUNCH("pf_conv_out");
+    return PF_OK;
+}
+
+extern "C" pf_status pf_conv_out_gn(const float* x, int n, int cin, int h, int w, const float* scale, const float* shift, int act,
+                                    const float* wgt_t, const float* bias, int cout, int wrap, float* y, void* stream) {
+    PF_REQUIRE(x && scale && shift && wgt_t && y && n > 0 && h > 0 && w > 0, "pf_conv_out_gn: bad arguments");
+    PF_REQUIRE(cin % COG_CH == 0 && cout > 0 && cout <= 4, "pf_conv_out_gn: cin %% %d == 0 and cout <= 4 required", COG_CH);
+    PF_REQUIRE(aligned16(x) && aligned16(wgt_t) && aligned16(scale) && aligned16(shift), "pf_conv_out_gn: 16-byte alignment required");
+    PF_REQUIRE(n <= 65535 && cdiv(h, COG_TH) <= 65535, "pf_conv_out_gn: too many images / rows for one launch");
+    hipLaunchKernelGGL(k_conv_out_gn, dim3(cdiv(w, COG_TW), cdiv(h, COG_TH), n), dim3(256), 0, as_stream(stream),
+                       x, cin, h, w, scale, shift, act, wgt_t, bias, cout, wrap, y);
+    PF_CHECK_LAUNCH("pf_conv_out_gn");
     return PF_OK;
 }

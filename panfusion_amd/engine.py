@@ -38,6 +38,7 @@ def default_precision(dtype):
 
 RAW_PAIR_FUSED = os.environ.get("PF_RAW_PAIR", "1") != "0"      # A/B: 0 = the shortcut operand by its own split pass
 VIRTUAL_PAD = os.environ.get("PF_VIRTUAL_PAD", "1") != "0"      # A/B: 0 = materialised pad_pano / unpad_pano copies around the panorama convs
+FUSED_HEAD = os.environ.get("PF_FUSED_HEAD", "1") != "0"        # A/B: 0 = GroupNorm-apply + SiLU pass, then conv_out (two launches)
 
 
 def stream_dtype(dtype, precision):
@@ -252,6 +253,8 @@ def pack_unet(unet, dev, dtype, mixed=False):
         u.cout = co.weight.shape[0]
         u.src_conv_out = co
         u.w_conv_out = _f32(co.weight.detach().permute(0, 2, 3, 1), dev)      # [cout,3,3,cin]
+        # [3,3,cin,4]: the fused head kernel's layout (ops.conv_out_gn)
+        u.w_conv_out_t = ops.conv_out_weight_t(co.weight).to(dev) if u.cout <= 4 and co.weight.shape[1] % 32 == 0 else None
         u.b_conv_out = _bias(co, dev)
         u.norm_out = _norm(unet.conv_norm_out, dev)
     te = unet.time_embedding
@@ -658,6 +661,9 @@ class Branch:
         sc, sh = ops.groupnorm_scale_shift(self.h, None, n, h * w, u.norm_out.groups, u.norm_out.eps,
                                            u.norm_out.g, u.norm_out.b)
         # (mixed scheme: the 4-channel output conv reads the normalised activation in fp32 -- it is not an MFMA GEMM)
+        if FUSED_HEAD and u.w_conv_out_t is not None and self.h.dtype == torch.float32 and self.h.is_contiguous():
+            # GroupNorm-apply + SiLU inside the conv's LDS tile: one launch, the activated tensor never reaches HBM
+            return ops.conv_out_gn(self.h, sc, sh, 1, u.w_conv_out_t, u.b_conv_out, u.cout, wrap=self.pad)
         y = ops.scale_shift_act(self.h, None, n, h * w, sc, sh, 1, out_dtype=u.stream).view(n, h, w, Cc)
         return ops.conv_out(y, u.w_conv_out, u.b_conv_out, u.cout, wrap=self.pad)      # fp32 NCHW
 

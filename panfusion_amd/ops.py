@@ -725,6 +725,25 @@ def conv_out(x, wgt, bias, cout, wrap=False, out=None):
     return out
 
 
+def conv_out_weight_t(weight):
+    """conv_out weight [cout <= 4, cin, 3, 3] -> fp32 [3, 3, cin, 4] (output channels padded with zeros): conv_out_gn's layout."""
+    cout, cin = weight.shape[:2]
+    wt = torch.zeros(3, 3, cin, 4, device=weight.device, dtype=torch.float32)
+    wt[..., :cout] = weight.detach().float().permute(2, 3, 1, 0)
+    return wt.contiguous()
+
+
+def conv_out_gn(x, scale, shift, act, wgt_t, bias, cout, wrap=False, out=None):
+    """conv_out(act(x * scale + shift)) in one launch: x fp32 [n, h, w, cin] before the GroupNorm, scale / shift [n, cin]."""
+    n, h, w, cin = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and cin % 32 == 0 and cout <= 4
+    if out is None:
+        out = torch.empty(n, cout, h, w, device=x.device, dtype=torch.float32)
+    check(_lib.lib().pf_conv_out_gn(_p(x), n, cin, h, w, _p(scale), _p(shift), int(act), _p(wgt_t), _p(bias), cout, int(wrap),
+                                    _p(out), _stream()), "pf_conv_out_gn")
+    return out
+
+
 # ---------------------------------------------------------------------------- attention
 def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, k_bs, vt_bs, o_bs=None,
               scale=None, bias=None, flags=None, out=None, lse=None):

@@ -428,6 +428,21 @@ def conv_out(x, wgt, bias, cout, wrap=False, out=None):
     return F.conv2d(xi, w, bias, padding=1)
 
 
+def conv_out_weight_t(weight):
+    cout, cin = weight.shape[:2]
+    wt = torch.zeros(3, 3, cin, 4, dtype=torch.float32)
+    wt[..., :cout] = weight.detach().float().permute(2, 3, 1, 0)
+    return wt
+
+
+def conv_out_gn(x, scale, shift, act, wgt_t, bias, cout, wrap=False, out=None):
+    n, h, w, cin = x.shape
+    y = x.float() * scale.view(n, 1, 1, cin) + shift.view(n, 1, 1, cin)
+    if act:
+        y = F.silu(y)
+    return conv_out(y, wgt_t[..., :cout].permute(3, 0, 1, 2), bias, cout, wrap=wrap, out=out)
+
+
 def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, k_bs, vt_bs, o_bs=None,
               scale=None, bias=None, flags=None, out=None, lse=None):
     C = H * D

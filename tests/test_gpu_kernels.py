@@ -338,6 +338,34 @@ def test_boundary_convs(dtype, wrap):
     check("conv_out", y, want, 2e-5)
 
 
+@pytest.mark.parametrize("wrap", [False, True])
+@pytest.mark.parametrize("shape", [(3, 9, 16, 64, 4), (2, 8, 32, 96, 4), (2, 19, 70, 32, 3), (1, 64, 64, 320, 4)])
+def test_fused_head_conv_out_gn(shape, wrap):
+    """pf_conv_out_gn (GroupNorm-apply + SiLU inside conv_out's LDS tile, MVGenModel.py:279-294) against fp64 torch and
+    against the two-launch form it replaces; tiles cut by the image edge, circular width, cout 3."""
+    o = ops()
+    n, h, w, C, cout = shape
+    x = (rnd(n, h, w, C, seed=40) * 3 + 0.5).to(DEV)
+    conv = torch.nn.Conv2d(C, cout, 3, padding=1)
+    sc, sh = (rnd(n, C, seed=41) * 0.2 + 0.4).to(DEV), (rnd(n, C, seed=42) * 0.5).to(DEV)    # (per image and channel, as pf_groupnorm_* writes them)
+    wt = o.conv_out_weight_t(conv.weight).to(DEV)
+    got = o.conv_out_gn(x, sc, sh, 1, wt, conv.bias.detach().to(DEV), cout, wrap=wrap)
+    y = o.scale_shift_act(x, None, n, h * w, sc, sh, 1, out_dtype=torch.float32).view(n, h, w, C)
+    two = o.conv_out(y, conv.weight.detach().permute(0, 2, 3, 1).contiguous().to(DEV), conv.bias.detach().to(DEV), cout, wrap=wrap)
+    with torch.no_grad():
+        yi = F.silu(x.cpu().double() * sc.cpu().double().view(n, 1, 1, C) + sh.cpu().double().view(n, 1, 1, C)).permute(0, 3, 1, 2)
+        cd = conv.double()
+        want = cd(G.pad_pano(yi, 1))[..., 1:-1] if wrap else cd(yi)
+    check("conv_out_gn", got, want.float(), 2e-5)
+    check("conv_out_gn vs two launches", got, two.cpu(), 2e-5)
+    # no activation: plain scale / shift
+    got0 = o.conv_out_gn(x, sc, sh, 0, wt, None, cout, wrap=wrap)
+    with torch.no_grad():
+        yi0 = (x.cpu().double() * sc.cpu().double().view(n, 1, 1, C) + sh.cpu().double().view(n, 1, 1, C)).permute(0, 3, 1, 2)
+        want0 = (cd(G.pad_pano(yi0, 1))[..., 1:-1] if wrap else cd(yi0)) - conv.bias.detach().double().view(1, -1, 1, 1)
+    check("conv_out_gn (no act, no bias)", got0, want0.float(), 2e-5)
+
+
 # ------------------------------------------------------------------------------------ GEMM / conv
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mnk", [(300, 320, 320), (128, 160, 64), (1000, 640, 1280), (77, 64, 128), (4100, 960, 320), (520, 200, 192)])

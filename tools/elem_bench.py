@@ -47,6 +47,27 @@ def main():
             us = timed(fn)
             print("   %-26s %8.1f us   %5.2f TB/s" % (name, us, byt / us / 1e6))
 
+    # the UNets' head (GroupNorm-apply + SiLU + conv_out 320 -> 4) and conv_in (4 -> 320) at the benchmark's sizes
+    for n, h, w, wrap in ((40, 64, 64, False), (2, 64, 128, True), (2, 128, 256, True)):
+        C = 320
+        x = torch.randn(n, h, w, C, device=DEV)
+        g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        sc, sh = ops.groupnorm_scale_shift(x, None, n, h * w, 32, 1e-5, g, b)
+        wo = torch.randn(4, C, 3, 3, device=DEV) * 0.02
+        w_old, w_t, bo = wo.permute(0, 2, 3, 1).contiguous(), ops.conv_out_weight_t(wo), torch.zeros(4, device=DEV)
+        lat = torch.randn(n, 4, h, w, device=DEV)
+        wi, bi = torch.randn(3, 3, 4, C, device=DEV) * 0.1, torch.zeros(C, device=DEV)
+        E = n * h * w * C
+
+        def two():
+            y = ops.scale_shift_act(x, None, n, h * w, sc, sh, 1, out_dtype=torch.float32).view(n, h, w, C)
+            return ops.conv_out(y, w_old, bo, 4, wrap=wrap)
+        print("head / conv_in  n %d  %d x %d  C %d  wrap %d" % (n, h, w, C, wrap))
+        for name, fn, byt in (("head: apply + conv_out", two, 12 * E), ("head: conv_out_gn (fused)", lambda: ops.conv_out_gn(x, sc, sh, 1, w_t, bo, 4, wrap=wrap), 4 * E),
+                              ("conv_in -> fp32 stream", lambda: ops.conv_in(lat, wi, bi, C, torch.float32, wrap=wrap), 4 * E)):
+            us = timed(fn)
+            print("   %-26s %8.1f us   %5.2f TB/s (algorithmic bytes)" % (name, us, byt / us / 1e6))
+
 
 if __name__ == "__main__":
     main()
