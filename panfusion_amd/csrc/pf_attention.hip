@@ -35,6 +35,7 @@ struct AttnParams {
     int pp_role;                 // k_attention_pp: how a wave finds its phase group (PF_ATTENTION_PP_ROLE, see the kernel)
     int xcd_map;                 // k_attention_lds: 1 = heads pinned to XCDs (PF_ATTENTION_XCD, default), 0 = plain block order
     int pp_prio;                 // k_attention_pp: wave priorities (PF_ATTENTION_PP_PRIO): 0 none, 1 group B static 1, 2 raised inside matrix segments
+    int steady2;                 // k_attention_lds (non-pipelined form): 1 = branch-free two-tile steady-state loop (PF_ATTENTION_STEADY2, default)
 };
 
 template <typename T, int D>
@@ -364,11 +365,11 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
     };
     auto softmax_pv = [&](int buf, float (&sv)[2][16]) {
         const unsigned short* Vs = smem + buf * (K_ELEMS + V_ELEMS) + K_ELEMS;
-        float mt = sv[0][0];
+        float mt = fmaxf(sv[0][0], sv[0][1]);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sv[hh][r]);
+            for (int r = (hh == 0 ? 2 : 0); r < 16; ++r) mt = fmaxf(mt, sv[hh][r]);
 #ifdef PF_ATTN_BPERMUTE
         mt = fmaxf(mt, __shfl_xor(mt, 32));
 #else
@@ -472,7 +473,28 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
     if constexpr (!PIPE) {
         __syncthreads();
         float sv[2][16];
-        for (int j = 0; j < nkt; ++j) {
+        int j = 0;
+        // steady state, two tiles per trip: tile j + 1 exists and is full -> no tail variants, no branches, and the LDS buffer of a tile
+        // (j & 1) is a compile-time offset.  The generic loop below carried both variants of stage_load / scores behind scalar
+        // compares and branches plus per-tile buffer selects: ~45 of its ~225 instructions per key tile, in a kernel that is bound by
+        // each wave's in-order issue (section 3.4 of DESIGN.md).  Same arithmetic in the same order: bit-identical results.
+        {
+            const int n_steady = nkt - 1 - (ragged ? 1 : 0);
+            auto body = [&](int jj, auto buf_tag) __attribute__((always_inline)) {
+                constexpr int B = decltype(buf_tag)::value;
+                stage_load(jj + 1, FULL);
+                scores(jj, B, sv, FULL);
+                softmax_pv(B, sv);
+                stage_store(B ^ 1);
+                __syncthreads();
+            };
+            if (p.steady2)
+            for (; j + 2 <= n_steady; j += 2) {
+                body(j, std::integral_constant<int, 0>());
+                body(j + 1, std::integral_constant<int, 1>());
+            }
+        }
+        for (; j < nkt; ++j) {
             if (j + 1 < nkt) load_tile(j + 1);          // global -> registers while this tile is processed
             if (j + 1 == nkt && ragged) scores(j, j & 1, sv, TAILY); else scores(j, j & 1, sv, FULL);
             softmax_pv(j & 1, sv);
@@ -1296,7 +1318,9 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     p.bias = d->bias; p.bias_ld = d->bias_ld; p.flags = d->flags; p.flags_ld = d->flags_ld;
     p.lse = d->lse;
     static const int env_role = attention_occupancy("PF_ATTENTION_PP_ROLE", 3), env_prio = attention_occupancy("PF_ATTENTION_PP_PRIO", 2),
-                     env_xcd = attention_occupancy("PF_ATTENTION_XCD", 1);       // (read once; PF_ATTENTION_PP below is read per call)
+                     env_xcd = attention_occupancy("PF_ATTENTION_XCD", 1),       // (read once; PF_ATTENTION_PP below is read per call)
+                     env_steady2 = attention_occupancy("PF_ATTENTION_STEADY2", 1);
+    p.steady2 = env_steady2;
     p.pp_role = env_role;
     p.pp_prio = env_prio;
     p.xcd_map = env_xcd;
