@@ -22,6 +22,9 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef PF_ATTN_BUFLOAD
+#define PF_ATTN_BUFLOAD 1
+#endif
 namespace pf {
 
 struct AttnParams {
@@ -269,9 +272,43 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
     u16x8 kreg[KCH], vreg[VCH];
     // staging ownership (fixed per thread): K chunk c = t + 256 i -> (row c / KCHUNKS, chunk c % KCHUNKS);
     // V^T chunk c -> (d = c >> 3, 8 keys starting at (c & 7) * 8)
+    // Full tiles are fetched through buffer descriptors (base = this (batch, head)'s K / V^T, SGPR) + a per-thread 32-bit offset
+    // computed once + a per-tile SCALAR offset: no 64-bit vector pointer arithmetic per key tile (four v_lshl_add_u64 and eight
+    // address registers in the global-load form, in a kernel bound by each wave's instruction issue).  -DPF_ATTN_BUFLOAD=0: A/B build.
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    auto uniform_ptr = [](const unsigned short* ptr) __attribute__((always_inline)) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+        const unsigned hi_ = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+        return reinterpret_cast<unsigned short*>(static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi_) << 32));
+    };
+    // (the launcher checks that the slices fit 32-bit offsets; the register-pipelined EPA form measured 3-5 % SLOWER with it on its
+    // view-query direction and keeps the global loads)
+    constexpr bool bufload = PF_ATTN_BUFLOAD != 0 && !PIPE;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(kp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(vp), 0, 0x7FFFFFFF, 0x00020000);
+    unsigned kvoff[KCH], vvoff[VCH];                   // bytes
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int c = t + 256 * i;
+        kvoff[i] = static_cast<unsigned>((c / KCHUNKS) * p.k_ld + (c % KCHUNKS) * 8) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+        const int c = t + 256 * i;
+        vvoff[i] = static_cast<unsigned>((c >> 3) * p.vt_ld + (c & 7) * 8) * 2u;
+    }
     auto stage_load = [&](int j, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         const int k0 = j * KT;
+        if constexpr (!TAIL && bufload) {
+            const int sk = __builtin_amdgcn_readfirstlane(k0 * p.k_ld * 2), sv_ = __builtin_amdgcn_readfirstlane(k0 * 2);
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) kreg[i] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_k, kvoff[i], sk, 0));
+#pragma unroll
+            for (int i = 0; i < VCH; ++i) vreg[i] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vvoff[i], sv_, 0));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             const int c = t + 256 * i, row = c / KCHUNKS, chunk = c % KCHUNKS;
@@ -365,11 +402,11 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
     };
     auto softmax_pv = [&](int buf, float (&sv)[2][16]) {
         const unsigned short* Vs = smem + buf * (K_ELEMS + V_ELEMS) + K_ELEMS;
-        float mt = fmaxf(sv[0][0], sv[0][1]);
+        float mt = -INFINITY;                            // (a constant first operand: no canonicalising v_max of the first two scores)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-            for (int r = (hh == 0 ? 2 : 0); r < 16; ++r) mt = fmaxf(mt, sv[hh][r]);
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sv[hh][r]);
 #ifdef PF_ATTN_BPERMUTE
         mt = fmaxf(mt, __shfl_xor(mt, 32));
 #else
@@ -417,11 +454,7 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const f32x2 x = f32x2{sv[hh][r], sv[hh][r + 1]} * c22 - mc2;
-#ifdef PF_ATTN_ABL_NOEXP          /* timing-only: what the 32 v_exp_f32 per key tile cost */
-                const f32x2 e = x * x;
-#else
                 const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-#endif
                 sv[hh][r] = e[0];
                 sv[hh][r + 1] = e[1];
                 if constexpr (!MSUM) ls2 += e;
@@ -1327,7 +1360,9 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     const dim3 grid1(static_cast<unsigned>(cdiv(d->nq, 128) * d->H * d->B));      // k_attention_lds: 1-D, decoded in the kernel
     dim3 grid(cdiv(d->nq, 128), d->H, d->B), block(256);
     hipStream_t st = as_stream(stream);
-    const bool lds = use_lds_attention() && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0;
+    // (k_attention_lds addresses K / V^T tiles with 32-bit byte offsets inside one (batch, head) slice)
+    const bool fits32 = !PF_ATTN_BUFLOAD || (static_cast<long>(d->nk + 64) * d->k_ld * 2 < (1L << 31) && static_cast<long>(d->vt_ld) * (d->D + 1) * 2 < (1L << 31));
+    const bool lds = use_lds_attention() && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0 && fits32;
     PF_DISPATCH_16(d->dtype, "pf_attention",
         if (lds) {
             static const int occ64 = attention_occupancy("PF_ATTENTION_OCC", 3), occ32 = attention_occupancy("PF_ATTENTION_OCC32", 3);
