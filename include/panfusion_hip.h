@@ -313,6 +313,12 @@ size_t pf_conv_gemm_workspace_size(const pf_conv_desc* desc);
 /* Rows per moment run R of pf_conv_desc.gn_partial for this problem, or 0 when the kernel that serves it cannot emit
  * the moments (split-K plans, batches, GEGLU / pair epilogues, images that are not whole runs of R rows). */
 int pf_conv_gemm_gn_rows(const pf_conv_desc* desc);
+/* Diagnostics / tests / the benchmark's shape classes: which tile kernel pf_conv_gemm's plan gives this problem --
+ * 0 the 4-wave 16x16x32 kernel (2 blocks per CU), 1 the persistent 8-wave 16x16x32 kernel (256 x 160 tiles),
+ * 2 the persistent 32x32x16 kernel of round 6 (256 x 320 tiles, pf_gemm32.hip); -1 for a bad descriptor.  Like the two
+ * queries above it reflects the plan only (workspace assumed available), it validates nothing.  The cuDNN / cuBLAS
+ * heuristics behind diffusers Conv2d / Linear are what it stands in for (MVGenModel.py:102-144,174-198,224-277). */
+int pf_conv_gemm_kernel_id(const pf_conv_desc* desc);
 /* Diagnostics only: while `device_buffer` (capacity_blocks x 32 uint64) is set, every pf_conv_gemm launch
  * with at most capacity_blocks workgroups records 4 shader-clock stamps per workgroup (entry, first
  * operand tile landed, K loop done, exit; the 8-wave kernel adds per-wave K-loop time split into

@@ -129,6 +129,7 @@ SIGNATURES = {
     "pf_conv_gemm": (c_int, [C.POINTER(ConvDesc), c_void_p]),
     "pf_conv_gemm_workspace_size": (c_size_t, [C.POINTER(ConvDesc)]),
     "pf_conv_gemm_gn_rows": (c_int, [C.POINTER(ConvDesc)]),
+    "pf_conv_gemm_kernel_id": (c_int, [C.POINTER(ConvDesc)]),
     "pf_groupnorm_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_scale_shift_act_pair": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,

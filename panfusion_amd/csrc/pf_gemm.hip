@@ -22,58 +22,14 @@
 // Replaces cuDNN / cuBLAS behind diffusers Conv2d / Linear (reference call sites
 // models/pano/MVGenModel.py:86-144,174-198,224-294; models/modules/transformer.py:8-74).
 #include "pf_common.h"
+#include "pf_gemm_params.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <atomic>
 #include <type_traits>
 
 namespace pf {
 
-struct GemmParams {
-    const unsigned short* a0; const unsigned short* a1;
-    int c0, c1, a0_ld, a1_ld;
-    int h_in, w_in, h_out, w_out;
-    int ksize, stride, pad, up;
-    int wrap, crop;              // virtual circular padding of the input WIDTH by `wrap` columns (pre-upsample) and output columns
-                                 // cropped by `crop` on both sides: pad_pano -> conv -> unpad_pano of the panorama branch without
-                                 // the padded copies (utils/pano.py:74-105, MVGenModel.py:98-144,224-294)
-    const unsigned short* w;
-    int M, N, K;                 // K = ksize*ksize*(c0+c1); a launch covers output rows [m_begin, M)
-    int m_begin;
-    int rows_per_img;
-    const float* bias; const float* rowvec; int rowvec_ld;
-    const void* residual; int res_ld; int res_f32;   // residual: 16-bit T, or fp32 (the fp32 residual stream)
-    void* out; int out_ld; int out_f32; int geglu;
-    int split_out;               // 16-bit pair output [M][hi(N) | lo(N)] (PF_EPILOGUE_SPLIT): the A operand of a split-precision GEMM
-    long a_bs, w_bs, out_bs, res_bs;
-    int mtiles, ntiles;
-    int splits, kb_per_split;      // split-K: blockIdx.y walks K-blocks [y*kb_per_split, ...)
-    float* partial;                // [split][batch][M][N] fp32 when splits > 1
-    int* tickets;                  // splits > 1: arrival counters, one per (batch, tile), all zero between launches; NULL = the
-                                   // slabs are combined by a second kernel (k_splitk_reduce)
-    int batch;
-    unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors of the 8-wave kernel (< 2 GiB)
-    int adv_img, adv_y, adv_x;              // (image, row, column) advance of one DMA pass of output rows (8-wave kernel)
-    unsigned long long* prof;      // diagnostics (pf_debug_gemm_profile): 4 s_memtime stamps per block, or NULL
-    int s3;                        // split-precision walk (pf_conv_desc.split3): every 64-element K block of A holds [hi(32) | lo(32)] of 32
-                                   // channels, of W [W_hi(32) | W_lo(32)]: a K step multiplies W_hi A_hi + W_hi A_lo + W_lo A_hi
-    float* gn_partial;             // [M / gn_rows][2][N / 2] fp32 per-column-pair (sum, sum of squares) of the finished output over
-    int gn_rows;                   // the gn_rows fragment rows of one wavefront (GroupNorm moments of the NEXT layer), or NULL
-};
-
-// phase stamp of wave 0 / lane 0 of a block: [block][4] = kernel entry, first tile landed, K loop done, exit
-#ifdef PF_GEMM_TIMELINE       /* debug build (make timeline): wave 0 of every block stamps the phases of ITS SECOND TILE (steady state of the
-                               * persistent loop) into slots 12..: tile begin, operands landed + barrier, stage 2 requested + first fragments,
-                               * after every K step (<= 8), after the epilogue -- tools/gemm_bench.py --timeline prints the differences */
-#define PF_TL(p, cond, slot) do { if ((cond) && (p).prof && threadIdx.x == 0) { const long b_ = blockIdx.x + static_cast<long>(gridDim.x) * (blockIdx.y + static_cast<long>(gridDim.y) * blockIdx.z); (p).prof[b_ * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
-#else
-#define PF_TL(p, cond, slot) do { } while (0)
-#endif
-__device__ __forceinline__ void stamp(const GemmParams& p, int slot) {
-    if (p.prof && threadIdx.x == 0) {
-        const long b = blockIdx.x + static_cast<long>(gridDim.x) * (blockIdx.y + static_cast<long>(gridDim.y) * blockIdx.z);
-        p.prof[b * 32 + slot] = __builtin_amdgcn_s_memtime();
-    }
-}
 
 template <typename T> struct Mfma;
 template <> struct Mfma<Bf16> {
@@ -101,59 +57,6 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // in 16-bit elem
     return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-// Epilogue of one output row m, 4 consecutive columns n4..n4+3 (fp32 accumulators v): bias, per-image
-// row vector, residual, then either a plain 16-bit / fp32 store or the GEGLU pairing
-// (columns interleaved (value, gate): out[m][n4/2 + {0,1}] = value * gelu(gate), transformer.py:8-21).
-template <typename T>
-__device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int m, int n4, float (&v)[4]) {
-    if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n4);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
-    if (p.rowvec) {
-        const int img = m / p.rows_per_img;
-        const float4 b = *reinterpret_cast<const float4*>(p.rowvec + static_cast<long>(img) * p.rowvec_ld + n4);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
-    if (p.residual && p.res_f32) {
-        const float4 r = *reinterpret_cast<const float4*>(static_cast<const float*>(p.residual) + bz * p.res_bs + static_cast<long>(m) * p.res_ld + n4);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-    } else if (p.residual) {
-        const u16x4 r = *reinterpret_cast<const u16x4*>(static_cast<const unsigned short*>(p.residual) + bz * p.res_bs + static_cast<long>(m) * p.res_ld + n4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(r[e]);
-    }
-    if (p.geglu) {
-        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + (n4 >> 1);
-        typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
-        u16x2 w2;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float g = v[2 * e + 1];
-            w2[e] = from_f32<T>(geglu_value(v[2 * e], g));
-        }
-        *reinterpret_cast<u16x2*>(o) = w2;
-    } else if (p.split_out) {
-        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
-        u16x4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            hi[e] = from_f32<T>(v[e]);
-            lo[e] = from_f32<T>(v[e] - to_f32<T>(hi[e]));
-        }
-        *reinterpret_cast<u16x4*>(o + (pair_off(n4) - n4)) = hi;
-        *reinterpret_cast<u16x4*>(o + (pair_off(n4) - n4) + 32) = lo;
-    } else if (p.out_f32) {
-        float* o = static_cast<float*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
-        *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
-    } else {
-        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
-        u16x4 w4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w4[e] = from_f32<T>(v[e]);
-        *reinterpret_cast<u16x4*>(o) = w4;
-    }
-}
 
 // GroupNorm moments of the layer's OUTPUT as a by-product of the epilogue (the consumer's statistics pass re-read
 // the whole tensor: 210 MB per fp32 stream tensor at 64 x 64 x 320 x 40 views).  A lane holds 4 consecutive
@@ -595,22 +498,6 @@ generic:
 // s_waitcnt vmcnt(0) in every wave -> barrier -> lane 0: relaxed agent-scope fetch_add; the last arriver: lane 0
 // agent-scope acquire fence (drops this CU's L1) -> barrier -> plain loads.  Nobody waits for anybody:
 // no residency assumption, no deadlock.  The last arriver zeroes the counter for the next launch that is handed the slot.
-// fp32 slab store of a split-K partial: WRITE-THROUGH (sc1) when the slabs are combined inside the launch -- the bytes leave
-// the XCD's L2 with the store itself, so publishing needs no agent-scope release fence (buffer_wbl2 writes back EVERY dirty
-// line of the L2, the concurrently running branch's outputs included: with one fence per K-slice workgroup the step lost
-// 4.4 ms, profiles/archive/r3k_ab_splitk.txt).
-__device__ __forceinline__ void slab_store(const GemmParams& p, long elem, const f32x4& v) {
-    if (p.tickets) {
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-        const unsigned long long a = reinterpret_cast<unsigned long long>(p.partial);
-        const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a >> 32));
-        float* base = reinterpret_cast<float*>(static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32));
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFFu, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, static_cast<int>(static_cast<unsigned>(elem * 4)), 0, /* sc1 */ 16);
-    } else {
-        *reinterpret_cast<float4*>(p.partial + elem) = float4{v[0], v[1], v[2], v[3]};
-    }
-}
 
 template <typename T, int BM, int BN, int NT>
 __device__ __forceinline__ void splitk_finish(const GemmParams& p, long bz, int tile_lin, int m0, int n0, int* flag, int t) {
@@ -1657,6 +1544,41 @@ static int gn_rows_for(const GemmParams& p, const GemmPlan& g, int batch) {
     return staged ? rows : 0;
 }
 
+
+// Which problems take the 32x32x16 kernel of pf_gemm32.hip (256 x 320 tiles, one persistent block per CU): plain (not split-precision)
+// layers with N a multiple of 320 and a long K whose tiles fill whole rounds of 256 CUs -- or whole rounds plus a tail that a split-K
+// launch spreads over the chip once more (640 tiles = 2 rounds + 128 tiles x 2 K slices; 320 = 1 round + 64 x 4).  PF_GEMM32=0 turns it
+// off (A/B), PF_GEMM32_MINK is the least K, PF_GEMM32_K1=1 also admits 1x1 layers.
+struct Plan32 { bool use; int m_split, tail_splits, tail_kb; };
+static Plan32 plan32(const GemmParams& p, int batch, bool allow_split) {
+    Plan32 r{false, 0, 0, 0};
+    static const int on = tuning("PF_GEMM32", 1), min_k = tuning("PF_GEMM32_MINK", 2560), k1 = tuning("PF_GEMM32_K1", 0);
+    if (!on || p.s3 || batch != 1 || p.N % 320 != 0 || p.K < min_k || p.K % 64 != 0 || p.geglu) return r;
+    if (p.ksize != 3 && !k1) return r;
+    const long ntl = p.N / 320, mt = cdiv(p.M, 256), tiles = mt * ntl;
+    const long full = tiles / 256 * 256, rest = tiles - full;
+    if (rest == 0) { r.use = true; return r; }
+    if (full == 0 || !allow_split || p.N % 4 != 0) return r;
+    const long rows1 = full / ntl;                                  // tile rows of the unsplit launch (ntl divides 256)
+    long sp = (256 + rest / 2) / rest;
+    const int nkb = p.K / 64;
+    if (sp > nkb / 8) sp = nkb / 8;
+    if (sp < 2 || rest * sp > 256) return r;
+    r.use = true;
+    r.m_split = static_cast<int>(rows1 * 256);
+    r.tail_kb = static_cast<int>(cdiv(nkb, sp));
+    r.tail_splits = static_cast<int>(cdiv(nkb, r.tail_kb));
+    return r;
+}
+// Rows per GroupNorm-moment run of the 32x32 kernel (a wave's 64 rows), or 0: a split-K tail (the reduce kernel writes those rows), a
+// residual (left to the consumer's pass, see gn_rows_for), a row vector over images that are not whole runs, pair output.
+static int gn_rows32(const GemmParams& p, const Plan32& g) {
+    if (!g.use || g.m_split > 0 || p.residual || p.split_out || p.geglu) return 0;
+    if (p.rows_per_img % 64 != 0) return 0;
+    const bool ok = p.out_f32 ? (p.out_ld & 3) == 0 : (p.out_ld & 7) == 0;
+    return ok ? 64 : 0;
+}
+
 }  // namespace pf
 
 using namespace pf;
@@ -1712,6 +1634,43 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     }
     GemmParams p;
     params_from_desc(d, p);
+    Plan32 g32 = plan32(p, d->batch, d->workspace != nullptr);
+    if (g32.use && d->gn_partial && gn_rows32(p, g32) == 0) g32.use = false;     // (moments asked for: the plan that can emit them)
+    if (g32.use) {
+        if (d->gn_partial) {
+            PF_REQUIRE(aligned16(d->gn_partial), "pf_conv_gemm: gn_partial must be 16-byte aligned");
+            p.gn_partial = d->gn_partial;
+            p.gn_rows = 64;
+        }
+        const long npix = static_cast<long>(d->n_img) * d->h_in * d->w_in;
+        const long a0b = ((npix - 1) * p.a0_ld + p.c0) * 2, a1b = p.a1 ? ((npix - 1) * p.a1_ld + p.c1) * 2 : 0;
+        const long wb = static_cast<long>(p.N) * p.K * 2;
+        PF_REQUIRE(a0b < (1L << 31) && a1b < (1L << 31) && wb < (1L << 31),
+                   "pf_conv_gemm: each operand must be smaller than 2 GiB (32-bit buffer offsets)");
+        p.a0_bytes = static_cast<unsigned>(a0b); p.a1_bytes = static_cast<unsigned>(a1b); p.w_bytes = static_cast<unsigned>(wb);
+        p.splits = 1; p.kb_per_split = p.K / 64;
+        {
+            const ProfState ps = prof_snapshot();
+            p.prof = (ps.buf && ps.blocks >= 256) ? ps.buf : nullptr;
+        }
+        hipStream_t st32 = as_stream(stream);
+        if (g32.m_split == 0) return launch_gemm32(p, d->dtype, 1, st32);
+        const size_t need = static_cast<size_t>(g32.tail_splits) * (p.M - g32.m_split) * p.N * sizeof(float);
+        PF_REQUIRE(d->workspace_bytes >= need && aligned16(d->workspace),
+                   "pf_conv_gemm: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, d->workspace_bytes);
+        GemmParams p1 = p, p2 = p;
+        p1.M = g32.m_split;
+        p2.m_begin = g32.m_split; p2.splits = g32.tail_splits; p2.kb_per_split = g32.tail_kb;
+        p2.partial = static_cast<float*>(d->workspace);
+        pf_status s1 = launch_gemm32(p1, d->dtype, 1, st32);
+        if (s1 != PF_OK) return s1;
+        s1 = launch_gemm32(p2, d->dtype, 1, st32);
+        if (s1 != PF_OK) return s1;
+        const long total = static_cast<long>(p2.M - p2.m_begin) * (p2.N / 4);
+        PF_DISPATCH_16(d->dtype, "pf_conv_gemm", hipLaunchKernelGGL((k_splitk_reduce<T>), dim3(cdiv(total, 256)), dim3(256), 0, st32, p2));
+        PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
+        return PF_OK;
+    }
     GemmPlan g = plan_gemm(p.M, p.N, p.K, d->batch, d->workspace != nullptr);
     if (d->gn_partial) {
         const int r = gn_rows_for(p, g, d->batch);
@@ -1784,7 +1743,22 @@ extern "C" int pf_conv_gemm_gn_rows(const pf_conv_desc* d) {
     if (!d || d->batch < 1 || d->n_out < 1 || d->n_img < 1) return 0;
     GemmParams p;
     params_from_desc(d, p);
+    {
+        const Plan32 g32 = plan32(p, d->batch, true);
+        if (g32.use) {
+            const int r = gn_rows32(p, g32);
+            if (r > 0) return r;                                    // else: the 16x16 kernels' plan below serves a launch that asks for moments
+        }
+    }
     return gn_rows_for(p, plan_gemm(p.M, p.N, p.K, d->batch, true), d->batch);
+}
+
+extern "C" int pf_conv_gemm_kernel_id(const pf_conv_desc* d) {
+    if (!d || d->batch < 1 || d->n_out < 1 || d->n_img < 1) return -1;
+    GemmParams p;
+    params_from_desc(d, p);
+    if (plan32(p, d->batch, true).use) return 2;
+    return plan_gemm(p.M, p.N, p.K, d->batch, true).big ? 1 : 0;
 }
 
 extern "C" size_t pf_conv_gemm_workspace_size(const pf_conv_desc* d) {
@@ -1792,7 +1766,18 @@ extern "C" size_t pf_conv_gemm_workspace_size(const pf_conv_desc* d) {
     const int c1 = d->a1 ? d->c1 : 0;
     const long M = static_cast<long>(d->n_img) * d->h_out * d->w_out;
     const int K = d->ksize * d->ksize * (d->c0 + c1);
+    size_t need32 = 0;
+    {
+        GemmParams p;
+        params_from_desc(d, p);
+        const Plan32 g32 = plan32(p, d->batch, true);
+        if (g32.use) {
+            need32 = g32.m_split > 0 ? static_cast<size_t>(g32.tail_splits) * (M - g32.m_split) * d->n_out * sizeof(float) : 0;
+            if (gn_rows32(p, g32) > 0 || p.residual) return need32;      // (no launch of this problem falls back to the 16x16 plan)
+        }
+    }
+    // (a launch that asks for GroupNorm moments the 32x32 plan cannot emit takes the 16x16 plan: room for either)
     const GemmPlan g = plan_gemm(M, d->n_out, K, d->batch, true);
-    if (g.big && g.m_split > 0) return static_cast<size_t>(g.tail_splits) * (M - g.m_split) * d->n_out * sizeof(float);
-    return g.splits > 1 ? static_cast<size_t>(g.splits) * d->batch * M * d->n_out * sizeof(float) : 0;
+    if (g.big && g.m_split > 0) return std::max(need32, static_cast<size_t>(g.tail_splits) * (M - g.m_split) * d->n_out * sizeof(float));
+    return std::max(need32, g.splits > 1 ? static_cast<size_t>(g.splits) * d->batch * M * d->n_out * sizeof(float) : static_cast<size_t>(0));
 }

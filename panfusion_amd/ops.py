@@ -452,7 +452,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,
               a_bstride=0, w_bstride=0, out_bstride=0, res_bstride=0, a0_ld=None, a1_ld=None, c0=None, c1=None,
               out_ld=None, res_ld=None, geglu=False, algo_k=None, split_out=False, pad_hi=0, gn_stats=False,
-              wrap_pad=0, crop=0, split3=False):
+              wrap_pad=0, crop=0, split3=False, plan_only=False):
     """out[m, n] = sum_k A[m, k] W[n, k] (+bias +rowvec[img] +residual).  a0/a1 NHWC, the last
     dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out).  The output takes the
     residual's dtype unless out_dtype says otherwise (fp32 residual stream in, fp32 out).
@@ -463,7 +463,8 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     gn_stats: the result feeds a GroupNorm -- where the kernel serving this problem can, its epilogue leaves the per-column
     moments of the output behind (attribute `_pf_gn` of the returned tensor, read by groupnorm_scale_shift).
     wrap_pad / crop: the input is read as if its width had been padded circularly by wrap_pad columns (pad_pano), the output
-    loses `crop` columns on both sides (unpad_pano): pad -> conv -> crop of the panorama branch without the padded copies."""
+    loses `crop` columns on both sides (unpad_pano): pad -> conv -> crop of the panorama branch without the padded copies.
+    plan_only: launch nothing, return pf_conv_gemm_kernel_id of the problem (0 / 1: the 16x16x32 tile kernels, 2: the 32x32x16 kernel)."""
     c0 = c0 if c0 is not None else a0.shape[-1]
     c1 = (c1 if c1 is not None else a1.shape[-1]) if a1 is not None else 0
     if w_in is None:
@@ -510,8 +511,10 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
         d.a0, d.a1, d.w, d.bias, d.rowvec, d.residual, d.out = _p(a0), _p(a1), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
         if len(plans) >= _PLANS.LIMIT:
             plans.pop(next(iter(plans)))
-        plan = plans[pkey] = [_lib.lib().pf_conv_gemm_workspace_size(C.byref(d)), None, d]
+        plan = plans[pkey] = [_lib.lib().pf_conv_gemm_workspace_size(C.byref(d)), None, d, _lib.lib().pf_conv_gemm_kernel_id(C.byref(d))]
     d = plan[2]
+    if plan_only:
+        return plan[3]
     d.a0, d.a1, d.w, d.bias, d.rowvec, d.residual, d.out = _p(a0), _p(a1), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
     d.gn_partial, d.tickets, d.n_tickets = None, None, 0
     nbytes = plan[0]
@@ -534,7 +537,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     else:
         _traced("k_conv_gemm", 2.0 * M * n_out * (algo_k or ksize * ksize * (c0 + c1)) * batch,
                 lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"),
-                "M%d N%d K%d k%d s%d u%d b%d" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch))
+                "M%d N%d K%d k%d s%d u%d b%d%s" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch, " g32" if plan[3] == 2 else ""))
     if gn is not None:
         out._pf_gn = gn                      # (a tensor that carries moments must not be written in place afterwards)
     elif hasattr(out, "_pf_gn"):

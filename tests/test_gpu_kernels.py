@@ -1222,3 +1222,119 @@ def test_split_k_in_kernel_under_concurrent_streams():
     o.SPLITK_INKERNEL = saved
     for a, bb in outs:
         assert torch.equal(a[0], want[0]) and torch.equal(a[1], want[3]) and torch.equal(bb[0], want[1]) and torch.equal(bb[1], want[2])
+
+
+# ------------------------------------------------------------------------------------ the 32x32x16 tile kernel (pf_gemm32.hip)
+
+
+def _conv_ref_gpu(xs, wq, cout, ks, bias, *, stride=1, up=False, wrap=0, crop=0):
+    """fp32 reference on the device: the same 16-bit-rounded operands through torch's fp32 convolution."""
+    xin = torch.cat([x.float().permute(0, 3, 1, 2) for x in xs], 1)
+    ctot = xin.shape[1]
+    wref = wq.float().reshape(cout, ks, ks, ctot).permute(0, 3, 1, 2).contiguous()
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if wrap:
+        xin = F.pad(xin, (wrap, wrap, 0, 0), mode="circular")
+    y = F.conv2d(xin, wref, bias, stride=stride, padding=ks // 2)
+    if crop:
+        y = y[..., crop:-crop]
+    return y.permute(0, 2, 3, 1).reshape(-1, cout)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["s1_rowvec", "tail_res32", "cat", "up_n640", "s2", "pano_wrap_crop", "ragged", "res16", "pair_out"])
+def test_conv_gemm32_vs_conv2d(dtype, case):
+    """The 32x32x16 kernel (256 x 320 tiles, four-slot ring of 32-wide K stages) on every addressing mode and operand mix of the layers it
+    serves: whole rounds of 256 tiles, the split-K tail launch, channel concat, fused x2 upsampling, stride 2, the panorama's virtual
+    circular padding, a ragged last row tile; bias / per-image row vector / 16-bit and fp32 residual / fp32 and pair outputs."""
+    o = ops()
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    n, h, w, cin, cout, ks = 16, 64, 64, 320, 320, 3
+    kw, ref_kw = {}, {}
+    c1 = 0
+    if case == "tail_res32":
+        n = 20                                                     # 320 tiles: one round + 64 tiles x 4 K slices
+    elif case == "cat":
+        c1 = 320
+    elif case == "up_n640":
+        h = w = 32
+        cout = 640
+        kw["upsample"] = 1
+        ref_kw["up"] = True
+    elif case == "s2":
+        n = 64
+        kw["stride"] = 2
+        ref_kw["stride"] = 2
+    elif case == "pano_wrap_crop":
+        n, w = 8, 128
+        kw.update(wrap_pad=2, crop=2)
+        ref_kw.update(wrap=2, crop=2)
+    elif case == "ragged":
+        n, w = 17, 62                                              # 67456 rows = 263 tiles + 128 rows: 256 + 8 tiles x 5 K slices
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(n, h, w, cin, device=DEV, generator=g).to(dtype)
+    a1 = torch.randn(n, h, w, c1, device=DEV, generator=g).to(dtype) if c1 else None
+    ctot = cin + c1
+    wq = (torch.randn(cout, ks * ks * ctot, device=DEV, generator=g) / (ks * ks * ctot) ** 0.5).to(dtype)
+    b = torch.randn(cout, device=DEV, generator=g)
+    want = _conv_ref_gpu([x] + ([a1] if c1 else []), wq, cout, ks, b, **ref_kw)
+    M = want.shape[0]
+    kw.update(n_img=n, h_in=h, w_in=w, ksize=ks, pad=1, bias=b, a1=a1)
+    tol = TOL[dtype]
+    if case == "s1_rowvec":
+        table = torch.randn(n, cout, device=DEV, generator=g)
+        kw["rowvec"] = table
+        want = want + table.repeat_interleave(M // n, 0)
+    elif case in ("tail_res32", "ragged"):
+        r = torch.randn(M, cout, device=DEV, generator=g)
+        kw["residual"] = r
+        want = want + r
+        tol = 2e-3 if dtype == torch.bfloat16 else 3e-4           # fp32 out: only the operands are rounded (K = 2880 products)
+    elif case == "res16":
+        r = torch.randn(M, cout, device=DEV, generator=g).to(dtype)
+        kw["residual"] = r
+        want = want + r.float()
+    elif case == "pair_out":
+        kw["split_out"] = True
+    assert o.conv_gemm(x, wq, cout, plan_only=True, **kw) == 2, "this shape is expected to take the 32x32x16 kernel"
+    got = o.conv_gemm(x, wq, cout, **kw)
+    if case == "pair_out":
+        hi, lo = unpair(got)
+        got = hi.float() + lo.float()
+        tol = 2e-3 if dtype == torch.bfloat16 else 3e-4
+    # the reference differs from the kernel only by fp32 summation order; the operands are identical
+    check("conv32 " + case, got, want, tol)
+    check("conv32 " + case + " (last rows)", got[-300:], want[-300:], tol)
+    check("conv32 " + case + " (first tile)", got[:256], want[:256], tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("f32out", [False, True])
+def test_conv_gemm32_groupnorm_moments(dtype, f32out):
+    """The 32x32x16 kernel's GroupNorm-moment by-product (pf_conv_desc.gn_partial, runs of 64 rows): scale / shift from the moments equal
+    the statistics pass over the stored tensor."""
+    o = ops()
+    n, h, w, cin, cout = 16, 64, 64, 320, 320
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, h, w, cin, device=DEV, generator=g).to(dtype)
+    wq = (torch.randn(cout, 9 * cin, device=DEV, generator=g) / (9 * cin) ** 0.5).to(dtype)
+    b = torch.randn(cout, device=DEV, generator=g)
+    table = torch.randn(n, cout, device=DEV, generator=g)
+    kw = dict(n_img=n, h_in=h, w_in=w, ksize=3, pad=1, bias=b, rowvec=None if f32out else table, out_dtype=torch.float32 if f32out else None)
+    assert o.conv_gemm(x, wq, cout, plan_only=True, **kw) == 2
+    y = o.conv_gemm(x, wq, cout, gn_stats=True, **kw)
+    assert hasattr(y, "_pf_gn") and y._pf_gn[1] == 64, "the 32x32x16 plan of a whole-round problem emits moments over runs of 64 rows"
+    gamma, beta = torch.randn(cout, device=DEV, generator=g), torch.randn(cout, device=DEV, generator=g)
+    sc, sh = o.groupnorm_scale_shift(y, None, n, h * w, 32, 1e-5, gamma, beta)
+    yf = y.float().view(n, h * w, 32, cout // 32)
+    mean = yf.mean(dim=(1, 3), keepdim=True)
+    var = yf.var(dim=(1, 3), unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    sc_ref = (rstd.expand(n, 1, 32, cout // 32).reshape(n, cout) * gamma)
+    sh_ref = beta - (mean.expand(n, 1, 32, cout // 32).reshape(n, cout)) * sc_ref
+    # 16-bit outputs: the moments are taken BEFORE the rounding, the reference after it
+    tol = 2e-5 if f32out else (3e-3 if dtype == torch.bfloat16 else 4e-4)
+    check("scale", sc, sc_ref, tol)
+    check("shift", sh, sh_ref, max(tol, 1e-4) * 10)

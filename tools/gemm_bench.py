@@ -32,6 +32,11 @@ SHAPES = {
     "conv8cat": (40, 8, 8, 2560, 1280, 3, {}),
     "lin_mid": (1, 1, 2560, 1280, 1280, 1, {"res": True}),
     # resnet conv2: + residual (fp32 stream in / out with --stream32: the 17-25 k-clock epilogue of DESIGN.md section 3.1)
+    # whole rounds of the 32x32x16 kernel's 256 x 320 tiles (no split-K tail launch): 2 rounds, 5 rounds, 1 round
+    "conv64_2r": (32, 64, 64, 320, 320, 3, {}),
+    "conv64_2r_res": (32, 64, 64, 320, 320, 3, {"res": True}),
+    "conv64_n640": (40, 64, 64, 640, 640, 3, {}),
+    "conv32_1r": (32, 32, 32, 640, 640, 3, {}),
     "conv64res": (40, 64, 64, 320, 320, 3, {"res": True}),
     "conv32res": (40, 32, 32, 640, 640, 3, {"res": True}),
     "conv16res": (40, 16, 16, 1280, 1280, 3, {"res": True}),
@@ -47,6 +52,9 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--gn", action="store_true", help="ask the epilogue for GroupNorm moments (pf_conv_desc.gn_partial)")
+    ap.add_argument("--data", default="randn", choices=["randn", "zeros", "ones", "small"],
+                    help="operand values: the chip clocks to its power budget (MI355X_MICROARCH.md, DVFS give-back), so the same kernel runs faster on "
+                         "zero / constant operands -- the difference is what the power cap costs")
     ap.add_argument("--stream32", action="store_true", help="fp32 residual in / fp32 out where the shape has a residual (mixed scheme)")
     args = ap.parse_args()
     dev = "cuda"
@@ -56,6 +64,12 @@ def main():
         g = torch.Generator(device=dev).manual_seed(1)
         x = torch.randn(n, h, w, cin, device=dev, generator=g).to(T16)
         wt = (torch.randn(cout, ks * ks * cin, device=dev, generator=g) / (ks * ks * cin) ** 0.5).to(T16)
+        if args.data == "zeros":
+            x.zero_(); wt.zero_()
+        elif args.data == "ones":
+            x.fill_(1.0); wt.fill_(1.0 / (ks * ks * cin))
+        elif args.data == "small":                                 # few significant bits toggling: +-1 activations, +-2^-k weights
+            x.sign_(); wt = (wt.sign() / 64).to(T16)
         b = torch.randn(cout, device=dev, generator=g)
         M = n * h * w
         n_store = cout // 2 if ex.get("geglu") else cout
@@ -115,6 +129,11 @@ def main():
                 names = ["ring barrier", "next-tile setup+DMA issue", "fragments->LDS (slice 0)", "barrier", "copy-out issue",
                          "fragments->LDS (slice 1)", "barrier", "copy-out issue"]
                 print("   epilogue: " + "  ".join("%s %.0f" % (n, (full[:, b] - full[:, a]).mean()) for n, a, b in zip(names, seq[:-1], seq[1:])))
+            if float(full[:, 6].abs().sum()) > 0 and float(full[:, 8:28].abs().sum()) == 0:       # the 32x32x16 kernel's accumulated clocks
+                tiles, nit = full[:, 6], full[:, 7]
+                print("   g32: %d blocks, %.1f tiles per block, %d K stages per tile: K loop %.0f clocks per tile = %.0f per stage; between K loops (ring barrier, "
+                      "next tile's DMA issue, epilogue, landing wait) %.0f per tile" % (full.shape[0], tiles.mean(), nit.mean(),
+                      (full[:, 4] / tiles).mean(), (full[:, 4] / tiles / nit).mean(), (full[:, 5] / tiles).mean()))
             d = (st[:, 1:] - st[:, :-1])
             span = float(st[:, 3].max() - st[:, 0].min())
             print("   phases (shader clocks, %d blocks): first tile %.0f  K loop %.0f  epilogue %.0f  | block total %.0f  kernel span %.0f (100 MHz memtime ticks?)"
