@@ -1547,12 +1547,16 @@ static int gn_rows_for(const GemmParams& p, const GemmPlan& g, int batch) {
 
 // Which problems take the 32x32x16 kernel of pf_gemm32.hip (256 x 320 tiles, one persistent block per CU): plain (not split-precision)
 // layers with N a multiple of 320 and a long K whose tiles fill whole rounds of 256 CUs -- or whole rounds plus a tail that a split-K
-// launch spreads over the chip once more (640 tiles = 2 rounds + 128 tiles x 2 K slices; 320 = 1 round + 64 x 4).  PF_GEMM32=0 turns it
-// off (A/B), PF_GEMM32_MINK is the least K, PF_GEMM32_K1=1 also admits 1x1 layers.
+// launch spreads over the chip once more (640 tiles = 2 rounds + 128 tiles x 2 K slices; 320 = 1 round + 64 x 4).  OFF by default
+// (PF_GEMM32=1 enables it; PF_GEMM32_MINK is the least K, PF_GEMM32_K1=1 also admits 1x1 layers): its K loop needs 1680 clocks per 32-wide
+// stage against the 16x16 kernel's 2140 per equal-FLOP step, and on N(0,1) operands it is no faster -- the chip is POWER capped there
+// (zero operands: +7 %), v_mfma_f32_32x32x16 draws ~13 % more per FLOP than v_mfma_f32_16x16x32 on random data, and the step is 0.6 ms
+// slower with it because of the split-K tails its 2.5 / 1.25 rounds need (profiles/r6_gemm32_power_cap.txt).
 struct Plan32 { bool use; int m_split, tail_splits, tail_kb; };
 static Plan32 plan32(const GemmParams& p, int batch, bool allow_split) {
     Plan32 r{false, 0, 0, 0};
-    static const int on = tuning("PF_GEMM32", 1), min_k = tuning("PF_GEMM32_MINK", 2560), k1 = tuning("PF_GEMM32_K1", 0);
+    static const int min_k = tuning("PF_GEMM32_MINK", 2560), k1 = tuning("PF_GEMM32_K1", 0);
+    const int on = tuning("PF_GEMM32", 0);                         // (read per call: the tests switch it on for their own launches)
     if (!on || p.s3 || batch != 1 || p.N % 320 != 0 || p.K < min_k || p.K % 64 != 0 || p.geglu) return r;
     if (p.ksize != 3 && !k1) return r;
     const long ntl = p.N / 320, mt = cdiv(p.M, 256), tiles = mt * ntl;

@@ -229,10 +229,18 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm32(const GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     // DMA passes of 128 tile rows: thread -> (row lrow, 16-byte chunk t & 3); the chunk a lane FETCHES is the one its lane-linear
     // LDS position holds under the swizzle
+#ifdef PF_ABL_FULLLINE       /* timing-only (wrong results): the same bytes per DMA instruction as 8 rows x 128 contiguous bytes instead of 16 rows x 64,
+                               * the scalar offset advancing 128 bytes per stage: every 128-byte line is requested ONCE instead of by two consecutive stages */
+    const int lrow = (t >> 3) * 2;
+    const int lchunk8 = (t & 7) * 8;
+    const int hrow = wave * 8 + (lane >> 3) * 2;
+    const int hchunk8 = (lane & 7) * 8;
+#else
     const int lrow = t >> 2;
     const int lchunk8 = ((t & 3) ^ ((lrow >> 2) & 3)) * 8;
     const int hrow = wave * 8 + (lane >> 2);                      // half pass (lanes 0..31 of every wave): weight rows 256 + hrow
     const int hchunk8 = ((lane & 3) ^ ((hrow >> 2) & 3)) * 8;
+#endif
 
     int a_img[2], a_y[2], a_x[2];
     constexpr unsigned OOB = 0x80000000u;                         // launcher guarantees tensors < 2 GiB
@@ -319,8 +327,13 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm32(const GemmParams p) {
 
     int st_soff_a = 0, st_soff_w = 0;
     auto stage_begin = [&]() __attribute__((always_inline)) {
+#ifdef PF_ABL_FULLLINE
+        st_soff_a = __builtin_amdgcn_readfirstlane(((seg1 ? cc - p.c0 : cc) * 4) % ((seg1 ? p.c1 : p.c0) * 2));
+        st_soff_w = __builtin_amdgcn_readfirstlane((kg * 4) % (p.K * 2));
+#else
         st_soff_a = __builtin_amdgcn_readfirstlane((seg1 ? cc - p.c0 : cc) * 2);
         st_soff_w = __builtin_amdgcn_readfirstlane(kg * 2);
+#endif
         return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(seg1 ? a1 : a0), 0,
                                                  __builtin_amdgcn_readfirstlane(seg1 ? p.a1_bytes : p.a0_bytes), 0x00020000);
     };
@@ -350,6 +363,22 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm32(const GemmParams p) {
 
     f32x16 acc[MI][NJ];
     typedef typename Mfma32<T>::frag frag;
+#ifdef PF_ABL_MFMA16          /* timing-only (wrong results): every v_mfma_f32_32x32x16 replaced by two v_mfma_f32_16x16x32 on the same fragment
+                               * registers -- the same FLOPs and operand traffic in the other instruction shape: what the MFMA shape costs under the power cap */
+    auto mfma = [&](frag a, frag b, f32x16& c) __attribute__((always_inline)) {
+        f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[8], c[9], c[10], c[11]};
+        if constexpr (std::is_same<T, F16>::value) {
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, lo, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, hi, 0, 0, 0);
+        } else {
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, hi, 0, 0, 0);
+        }
+        c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3]; c[8] = hi[0]; c[9] = hi[1]; c[10] = hi[2]; c[11] = hi[3];
+    };
+#else
+    auto mfma = [&](frag a, frag b, f32x16& c) __attribute__((always_inline)) { c = Mfma32<T>::run(a, b, c); };
+#endif
     // fragment reads: lane -> tile row (lane & 31), 16-byte chunk 2 s + (lane >> 5) of the 64-byte row, swizzled
     const int rowl = lane & 31, kh = lane >> 5, sw = (rowl >> 2) & 3;
     const int fa_base0 = (wm * 64 + rowl) * BK + ((kh ^ sw) << 3);                     // + slot * STAGE + i * 32 * BK; s = 1: ^ 16
@@ -368,6 +397,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm32(const GemmParams p) {
     };
     const std::integral_constant<int, 0> S0;
     const std::integral_constant<int, 1> S1;
+#ifdef PF_ABL_NOLDS           /* timing-only: no fragment reads; the MFMAs run on (real, fixed) weight values fetched once */
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { fa0[i] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(wg + (lane + 64 * i) * 8)); fa1[i] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(wg + (lane + 64 * (i + 2)) * 8)); }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { fw0[j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(wg + (lane + 64 * (j + 4)) * 8)); fw1[j] = __builtin_bit_cast(frag, *reinterpret_cast<const u16x8*>(wg + (lane + 64 * (j + 9)) * 8)); }
+#endif
 
     auto issue_prologue = [&]() __attribute__((always_inline)) {
         dma_stage(0);
@@ -388,7 +423,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm32(const GemmParams p) {
 #pragma unroll
         for (int idx = 0; idx < MI * NJ; ++idx) {
             const int j = idx / MI, i = idx % MI;
-            acc[i][j] = Mfma32<T>::run(fw0[j], fa0[i], acc[i][j]);
+            mfma(fw0[j], fa0[i], acc[i][j]);
             if (idx == 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_frags(cur, S1, fa1, fw1);
@@ -411,7 +446,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gemm32(const GemmParams p) {
 #pragma unroll
         for (int idx = 0; idx < MI * NJ; ++idx) {
             const int j = idx / MI, i = idx % MI;
-            acc[i][j] = Mfma32<T>::run(fw1[j], fa1[i], acc[i][j]);
+            mfma(fw1[j], fa1[i], acc[i][j]);
             if (MORE && idx == 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_frags(nxt, S0, fa0, fw0);

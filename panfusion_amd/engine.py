@@ -580,6 +580,8 @@ class Branch:
         # (attn_split = its ShardInfo), a view rank's branch helps right after its own (attn_help = callable(transformer pack))
         self.attn_split = None
         self.attn_help = None
+        self.split_streams = None       # (main, side) when this branch runs on a side stream while its attentions are split
+        self.keep = None                # the forward's list of tensors that cross streams (cleared at every join)
 
     def precompute_text_kv(self):
         """All 16 cross-attentions' K / V^T of the text tokens in one go: 32 tiny GEMMs that would otherwise sit
@@ -619,7 +621,21 @@ class Branch:
             from . import sharding
             if sharding.splits_pano_attention(self.attn_split, self.h.shape[1] * self.h.shape[2]) and self.h.shape[0] == 1:
                 split = self.attn_split
-        self.h = run_transformer(t, self.h, self.text, self.text_kv.get(id(t)), split=split)
+        if split is not None and self.split_streams is not None:
+            # The branch runs on a side stream (an owner that also holds views): the split's collectives break the hipGraph
+            # segment (SegmentedGraph.eager ends the capture), which a forked side stream forbids -- and a collective issued from
+            # the side stream would fall out of the one issue order every rank keeps.  Join, run this attention on the main
+            # stream, fork again.  Tensors that cross the streams stay referenced until the next join.
+            main, side = self.split_streams
+            main.wait_stream(side)
+            x_in = self.h
+            with torch.cuda.stream(main):
+                self.h = run_transformer(t, x_in, self.text, self.text_kv.get(id(t)), split=split)
+            side.wait_stream(main)
+            if self.keep is not None:
+                self.keep.extend((x_in, self.h))
+        else:
+            self.h = run_transformer(t, self.h, self.text, self.text_kv.get(id(t)), split=split)
         if self.attn_help is not None:
             self.attn_help(t, self.h)
 
@@ -718,7 +734,7 @@ def _epa_tail(e, attn_out, x, Cc):
     return ops.linear(g, e.w_ff2, bias=e.b_ff2, residual=y, gn_stats=True)
 
 
-def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None, pers_hw=None):
+def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None, pers_hw=None, posted=None):
     """EPA when this rank holds views [v0, v1) of the m (one CFG sample per rank, b == 1).
     One all-gather of LN1(x_p + PE) inside the CFG half; K / V^T of all views are projected locally.
     Replicated layout: every rank holds the panorama and computes the panorama-query direction redundantly.
@@ -726,7 +742,11 @@ def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None, pers_hw=None):
     broadcasts LN1(x_e + PE), from which every rank projects the panorama K / V^T for its own view queries;
     the other ranks pass xe = None (equi_hw = its spatial size) and get None back for it.  An owner without
     views (explicit split 0, ...) passes xp = None and pers_hw = (ph, pw): it contributes an empty block to the
-    gather, computes the panorama-query direction only and gets None back for the views."""
+    gather, computes the panorama-query direction only and gets None back for the views.
+    The two collectives are POSTED (sharding.ASYNC: async_op on the backend's communication stream) and awaited in front of their
+    consumers: the owner layer-norms the panorama tokens while the view tokens travel, a view rank projects its own queries while
+    the panorama tokens travel and never waits for the gathered view tokens it does not read.  posted: the all-gather handle a
+    panorama-only owner posted before it ran the level's panorama resnets (WarpAttn.post_view_gather)."""
     from . import sharding
     owner = xe is not None
     if xp is None:
@@ -762,17 +782,30 @@ def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None, pers_hw=None):
     else:
         tp = xe.new_empty(0, Cc)
         lnp_loc = torch.empty(0, Cc, device=xe.device, dtype=e.cdtype)
-    lnp = sharding.gather_view_tokens(lnp_loc, shard, P=P)                  # [mP, C] (every rank takes part)
+    if posted is not None:
+        gathered = posted                                                   # (a rank without views: its block of the gather is empty)
+    elif sharding.ASYNC:
+        gathered = sharding.gather_view_tokens_async(lnp_loc, shard, P=P)   # posted; every rank takes part
+    else:
+        gathered = sharding._Ready(sharding.gather_view_tokens(lnp_loc, shard, P=P))     # [mP, C]
     lne = None
     if owner:
         te = xe.view(E, Cc)
         lne = ops.layernorm(te, e.ln1.g, e.ln1.b, e.ln1.eps, pe=t.pe_e, out_dtype=e.cdtype)
-    lne = sharding.share_pano_tokens(lne, E, Cc, lnp_loc, shard)                 # broadcast in the panorama-rank layout
+    if sharding.ASYNC:
+        shared = sharding.share_pano_tokens_async(lne, E, Cc, lnp_loc, shard)        # broadcast in the panorama-rank layout
+    else:
+        shared = sharding._Ready(sharding.share_pano_tokens(lne, E, Cc, lnp_loc, shard))
+    q_loc = None
+    if not owner:
+        q_loc = ops.linear(lnp_loc, e.wqk)                                  # only the local queries are needed: while the tokens travel
+    lne = shared.result()
     qk_e = ops.linear(lne, e.wqk)
     vt_e = ops.linear_t(lne.view(1, E, Cc), e.wv)
     ld = 2 * Cc
     out_e = None
     if owner:
+        lnp = gathered.result()
         qk_p = ops.linear(lnp, e.wqk)
         vt_p = ops.linear_vt(lnp, e.wv, 1)
         if vt_p is None:
@@ -784,17 +817,17 @@ def run_epa_sharded(e, t, xp, xe, m, shard, equi_hw=None, pers_hw=None):
         if not mloc:
             return None, out_e
         q_loc = qk_p[r0:r1]
-    else:
-        q_loc = ops.linear(lnp_loc, e.wqk)                                  # only the local queries are needed
     nq = mloc * P
     a_p = ops.attention(q_loc, qk_e[:, Cc:], vt_e, 1, e.heads, 32, nq, E, q_ld=ld, k_ld=ld,
                         vt_ld=vt_e.shape[-1], q_bs=nq * ld, k_bs=E * ld, vt_bs=vt_e.shape[1] * vt_e.shape[2],
                         bias=t.bias_p[r0:r1], flags=flags_p_loc)
     out_p = _epa_tail(e, a_p, tp, Cc)
+    if not owner and hasattr(gathered, "finish"):
+        gathered.finish()                                                   # (the all-gather this rank only contributed to)
     return out_p.view(mloc, ph, pw, Cc), out_e
 
 
-def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None, side=None, pers_hw=None, n_samples=None):
+def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None, side=None, pers_hw=None, n_samples=None, posted=None):
     """EPA fusion (modules.py:15-59) on NHWC activations.
     xp [b*m, ph, pw, C], xe [b, eh, ew, C]; tables: list with one EPATables entry per batch
     element (or a single shared entry)."""
@@ -803,7 +836,7 @@ def run_epa(e, tables, xp, xe, m, shard=None, equi_hw=None, side=None, pers_hw=N
         if b == 1:
             if len(tables) != 1:
                 raise ValueError("sharded EPA needs one camera set per sample")
-            return run_epa_sharded(e, tables[0], xp, xe, m, shard, equi_hw, pers_hw)
+            return run_epa_sharded(e, tables[0], xp, xe, m, shard, equi_hw, pers_hw, posted=posted)
         # a multi-prompt batch on a sharded rank (b samples of the rank's CFG half): sample by sample -- every rank walks the samples
         # in the same order, so the collectives of the b passes line up
         mloc = xp.shape[0] // b if xp is not None else 0

@@ -343,6 +343,8 @@ class MultiViewBaseModel(nn.Module):
                 pano.on_side = side is not None     # (train_engine.backward walks its entries on the same stream)
                 if shard is not None and shard.pano_g is not None and tape is None and pano_latent.shape[0] == 1:
                     pano.attn_split = shard
+                    if side is not None:
+                        pano.split_streams, pano.keep = (main, side), keep
                 if not keeps:
                     pano.precompute_text_kv()
                 if pano_layout_cond is not None:    # reference :75-83: plain convolutions on the un-padded latent
@@ -357,11 +359,27 @@ class MultiViewBaseModel(nn.Module):
                 else:
                     fn(br)
 
+        # A panorama-only owner contributes nothing to an EPA block's all-gather of view tokens: it POSTS it before it runs the
+        # level's panorama resnets and collects the tokens when it reaches the block.  Not when a
+        # self-attention of the level is query-split: those collectives would then be issued in a different order than on the view ranks.
+        posted = {}
+        can_post = False
+        if pano_only and b == 1:
+            from ... import sharding as _sh
+            can_post = _sh.ASYNC and not _sh.splits_pano_attention(shard, pano_latent.shape[-2] * pano_latent.shape[-1])
+
+        def prepost(block, after_down=False):
+            if not can_post:
+                return
+            sc = pano_latent.shape[-2] // pano.h.shape[1] * (2 if after_down else 1)
+            hw = (latents.shape[-2] // sc, latents.shape[-1] // sc)
+            posted[id(block)] = block.post_view_gather(shard, hw, dev)
+
         def fuse(block):
             if pano_only:                           # view feature map size at this level, from the latents' ratio
                 sc = pano_latent.shape[-2] // (pano.h.shape[1])
                 hw = (latents.shape[-2] // sc, latents.shape[-1] // sc)
-                _, pano.h = block.forward_nhwc(None, pano.h, groups, m_total, shard=shard, pers_hw=hw)
+                _, pano.h = block.forward_nhwc(None, pano.h, groups, m_total, shard=shard, pers_hw=hw, posted=posted.pop(id(block), None))
                 return
             if view_only:                           # panorama feature map size at this level, from the latents' ratio
                 sc = latents.shape[-2] // pers.h.shape[1]
@@ -396,6 +414,8 @@ class MultiViewBaseModel(nn.Module):
                 if blk.down is not None:
                     br.downsample(blk.down)
                     br.push()
+            if pu.down[i].down is not None and two:
+                prepost(self.cp_blocks_encoder[i], after_down=True)
             each_branch(level)
             if pu.down[i].down is not None and two:
                 fuse(self.cp_blocks_encoder[i])
@@ -419,6 +439,8 @@ class MultiViewBaseModel(nn.Module):
                 br.h = engine.ops.add(br.h, cn_res[id(br)][1])
                 if id(br) in cn_recs:
                     tape.append(("cn_mid", br, cn_recs[id(br)]))
+        if two:
+            prepost(self.cp_blocks_mid)
         each_branch(middle)
         if two:
             fuse(self.cp_blocks_mid)
@@ -430,6 +452,8 @@ class MultiViewBaseModel(nn.Module):
                     br.resnet(r, skip=True)
                     if blk.attns is not None:
                         br.attention(blk.attns[j])
+            if pu.up[i].up is not None and two:
+                prepost(self.cp_blocks_decoder[i])
             each_branch(level_up)
             if pu.up[i].up is not None:
                 if two:

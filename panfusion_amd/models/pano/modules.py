@@ -74,7 +74,16 @@ class WarpAttn(nn.Module):
         return [self._tables.get(f, t, p, ph, pw, eh, ew, e.freq, device) for f, t, p in uniq]
 
     @torch.no_grad()
-    def forward_nhwc(self, xp, xe, groups, m, shard=None, equi_hw=None, side=None, pers_hw=None):
+    def post_view_gather(self, shard, pers_hw, device):
+        """A panorama owner WITHOUT views posts this block's all-gather of the view tokens ahead of time (its own block of it is
+        empty) and hands the handle to forward_nhwc(posted=...): the tokens of the view ranks travel while it runs the panorama
+        resnets of the level (sharding.gather_view_tokens_async)."""
+        from ... import sharding
+        e = self.packed(device)
+        return sharding.gather_view_tokens_async(None, shard, P=pers_hw[0] * pers_hw[1], C=e.wqk.shape[-1], dtype=e.cdtype, device=device)
+
+    @torch.no_grad()
+    def forward_nhwc(self, xp, xe, groups, m, shard=None, equi_hw=None, side=None, pers_hw=None, posted=None):
         """xp [b*m, ph, pw, C], xe [b, eh, ew, C] NHWC in the stream dtype (the denoiser's internal layout:
         16-bit, or fp32 in the mixed scheme).
         With ``shard`` (sharding.ShardInfo) xp holds only this rank's views of the m; on a rank without the
@@ -85,7 +94,7 @@ class WarpAttn(nn.Module):
         eh, ew = (xe.shape[1], xe.shape[2]) if xe is not None else equi_hw
         ph, pw = (xp.shape[1], xp.shape[2]) if xp is not None else pers_hw
         tabs = self.tables_for(groups, ph, pw, eh, ew, dev)
-        return engine.run_epa(e, tabs, xp, xe, m, shard=shard, equi_hw=(eh, ew), side=side, pers_hw=(ph, pw), n_samples=len(groups))
+        return engine.run_epa(e, tabs, xp, xe, m, shard=shard, equi_hw=(eh, ew), side=side, pers_hw=(ph, pw), n_samples=len(groups), posted=posted)
 
     @torch.no_grad()
     def forward_inference(self, pers_x, equi_x, cameras):

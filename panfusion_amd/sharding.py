@@ -330,6 +330,111 @@ def _collective(call):
         call()
 
 
+# Collectives that do not block the compute stream.  PF_SHARD_ASYNC=0 restores the blocking calls (A/B).
+# `issue` posts the collective with async_op=True: the backend runs it on its own communication stream behind what the compute stream
+# has enqueued so far; the compute stream goes on with kernels that do not need the result, and `wait()` -- placed right in front of the
+# consumer -- makes it wait for the collective.  Every rank issues the collectives of a step in the SAME order (the order of the
+# `issue` calls, which is program order on every rank); where a rank waits is its own business.  Under SegmentedGraph both the issue and the
+# wait are eager calls between graph segments.
+ASYNC = os.environ.get("PF_SHARD_ASYNC", "1") != "0"
+
+
+class Pending:
+    """Handle of a posted collective: wait() before the first kernel that reads its output (idempotent)."""
+
+    def __init__(self, issue):
+        self._work = None
+        self._waited = False
+
+        def post():
+            self._work = issue()
+        _collective(post)
+
+    def wait(self):
+        if self._waited:
+            return
+        self._waited = True
+
+        def block():
+            w, self._work = self._work, None
+            if w is not None:
+                w.wait()            # NCCL: the current stream waits for the communication stream; gloo: the host blocks
+        _collective(block)
+
+
+class _Ready:
+    """A result that needed no collective (one rank per CFG half), with the interface of a posted one."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
+
+
+class _Gathered:
+    def __init__(self, pending, out, counts, rows, P, G):
+        self.pending, self.out, self.counts, self.rows, self.P, self.G = pending, out, counts, rows, P, G
+
+    def result(self):
+        """[m * P, C] in view order; waits for the all-gather first."""
+        self.pending.wait()
+        if len(set(self.counts)) == 1:
+            return self.out
+        return torch.cat([self.out[g * self.rows:g * self.rows + self.counts[g] * self.P] for g in range(self.G)])
+
+    def finish(self):
+        """A rank that does not read the gathered tokens still has to complete the collective before its buffers go away."""
+        self.pending.wait()
+
+
+def gather_view_tokens_async(x_local, shard, P=None, C=None, dtype=None, device=None):
+    """gather_view_tokens posted without blocking the compute stream: returns a handle whose result() waits.  A rank without views
+    may post it EARLY (x_local = None: it contributes an empty block and needs P, C, dtype, device) -- the panorama-only owner posts the
+    all-gather of an EPA block before it runs the panorama resnets of that level and collects the tokens when it gets to the block."""
+    if shard.G == 1:
+        return _Ready(x_local)
+    counts = shard.counts
+    if x_local is None:
+        x_local = torch.empty(0, C, dtype=dtype, device=device)
+    x_local = x_local.contiguous()
+    if P is None:
+        P = x_local.shape[0] // counts[shard.g]
+    rows = shard.vmax * P
+    if x_local.shape[0] != rows:
+        padded = torch.empty(rows, x_local.shape[1], dtype=x_local.dtype, device=x_local.device)
+        padded[:x_local.shape[0]] = x_local
+        x_local = padded
+    out = torch.empty(shard.G * rows, x_local.shape[1], dtype=x_local.dtype, device=x_local.device)
+
+    def issue():
+        _note("all_gather view tokens (EPA, group of %d)" % shard.G, x_local)
+        return dist.all_gather_into_tensor(out, x_local, group=shard.group, async_op=True)
+    return _Gathered(Pending(issue), out, counts, rows, P, shard.G)
+
+
+class _Shared:
+    def __init__(self, pending, buf):
+        self.pending, self.buf = pending, buf
+
+    def result(self):
+        if self.pending is not None:
+            self.pending.wait()
+        return self.buf
+
+
+def share_pano_tokens_async(x, rows, cols, like, shard):
+    """share_pano_tokens posted without blocking the compute stream (result() waits)."""
+    if shard.pano_g is None or shard.G == 1:
+        return _Shared(None, x)
+    buf = x.contiguous() if x is not None else torch.empty(rows, cols, dtype=like.dtype, device=like.device)
+
+    def issue():
+        _note("broadcast panorama tokens (EPA, group of %d)" % shard.G, buf)
+        return dist.broadcast(buf, src=shard.pano_src, group=shard.group, async_op=True)
+    return _Shared(Pending(issue), buf)
+
+
 def gather_view_tokens(x_local, shard, P=None):
     """All-gather [views_local * P, C] token blocks of the CFG half in view order -> [m * P, C].
     Unequal view counts (panorama-rank layout) travel padded to the largest group and are compacted.

@@ -1242,9 +1242,20 @@ def _conv_ref_gpu(xs, wq, cout, ks, bias, *, stride=1, up=False, wrap=0, crop=0)
     return y.permute(0, 2, 3, 1).reshape(-1, cout)
 
 
+@pytest.fixture
+def gemm32_on(monkeypatch):
+    """The 32x32x16 tile kernel is off by default (no faster than the 16x16 kernel under the power cap, profiles/r6_gemm32_power_cap.txt):
+    PF_GEMM32 is read per launch, the cached plans of ops.conv_gemm are dropped on both sides of the switch."""
+    o = ops()
+    o._PLANS.plans.clear()
+    monkeypatch.setenv("PF_GEMM32", "1")
+    yield
+    o._PLANS.plans.clear()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ["s1_rowvec", "tail_res32", "cat", "up_n640", "s2", "pano_wrap_crop", "ragged", "res16", "pair_out"])
-def test_conv_gemm32_vs_conv2d(dtype, case):
+def test_conv_gemm32_vs_conv2d(dtype, case, gemm32_on):
     """The 32x32x16 kernel (256 x 320 tiles, four-slot ring of 32-wide K stages) on every addressing mode and operand mix of the layers it
     serves: whole rounds of 256 tiles, the split-K tail launch, channel concat, fused x2 upsampling, stride 2, the panorama's virtual
     circular padding, a ragged last row tile; bias / per-image row vector / 16-bit and fp32 residual / fp32 and pair outputs."""
@@ -1312,7 +1323,7 @@ def test_conv_gemm32_vs_conv2d(dtype, case):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("f32out", [False, True])
-def test_conv_gemm32_groupnorm_moments(dtype, f32out):
+def test_conv_gemm32_groupnorm_moments(dtype, f32out, gemm32_on):
     """The 32x32x16 kernel's GroupNorm-moment by-product (pf_conv_desc.gn_partial, runs of 64 rows): scale / shift from the moments equal
     the statistics pass over the stored tensor."""
     o = ops()
