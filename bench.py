@@ -389,6 +389,9 @@ def main():
                        "devices_visible": torch.cuda.device_count(),
                        "rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms), "per_rank": [round(v, 3) for v in per_rank_ms]},
                        "layout": getattr(loop, "layout_desc", None),
+                       # hipGraph segments still in use after the run on EVERY rank (the fallback to eager launches is collective: a capture
+                       # that fails anywhere drops the graphs everywhere), and whether the EPA collectives were posted asynchronously
+                       "graphs_in_use": bool(getattr(loop, "use_graphs", False)), "async_collectives": bool(sharding.ASYNC),
                        "collectives_rank0": sharding.comm_stats(args.steps),
                        "note": "rank_ms = each rank's own wall time of the timed steps up to its final synchronize (no closing barrier); "
                                "collectives: issued per step on rank 0, bytes = what that rank contributes per call"}
@@ -434,22 +437,73 @@ def main():
                 fh.write("%-60s launches %3d  ms %8.3f  TF/s %7.1f\n" % (k, n, sec * 1e3, fl / sec / 1e12))
     dom = max(fam, key=lambda k: fam[k][1]) if fam else None
     roofline = None
-    traffic = None                                    # PMC-derived bytes per launch of the dominant kernel (profiles/)
-    traffic_file = None
-    for name in ("r5_traffic.json", "r4_traffic.json", "archive/r3_traffic.json", "archive/r2_traffic.json", "archive/r1_traffic.json"):   # newest committed PMC summary (r2+: fp16 mixed; r1: bf16 all-16-bit)
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                traffic, traffic_file = json.load(fh), name
-            break
-        except (OSError, ValueError):
-            pass
+    # Committed rocprofv3 summaries this line quotes (profiles/, produced by tools/gpu_run.sh <tag> pmc / serial / mfma on the same command): each
+    # carries the sha256 of the kernel sources it was measured on; one measured on OTHER sources is not quoted -- the field is null and the
+    # note says why.
+    from panfusion_amd import _lib as _pf_lib
+    src_hash = _pf_lib.source_hash()
+    stale = []
+
+    def committed(names, parse):
+        for name in names:
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    doc, h = parse(fh.read())
+            except (OSError, ValueError, KeyError, IndexError):
+                continue
+            if h != src_hash:
+                stale.append("profiles/%s was measured on kernel sources %s, this build is %s" % (name, h or "(no hash recorded)", src_hash))
+                return None, name
+            return doc, name
+        return None, None
+
+    def parse_json(text):
+        doc = json.loads(text)
+        return doc, doc.get("csrc_sha256")
+
+    def parse_hashed_text(text):
+        first = text.split("\n", 1)[0]
+        return text, first.split(":", 1)[1].strip() if first.startswith("csrc_sha256:") else None
+
+    traffic, traffic_file = committed(("r6_traffic.json", "r5_traffic.json"), parse_json)
+    instep, instep_file = committed(("r6_final_mfma_instep.txt", "r5_final_mfma_instep.txt"), parse_hashed_text)
+    steady, steady_file = committed(("r6_final_kernels_steady.txt", "r5_final_kernels_steady.txt"), parse_hashed_text)
+    import re as _re
+    mfma_busy = None
+    if instep:
+        ma = _re.search(r"attention, all launches, cycle-weighted: MFMA busy ([0-9.]+) %", instep)
+        mg = _re.search(r"GEMM family .* cycle-weighted: MFMA busy ([0-9.]+) %", instep)
+        mfma_busy = {"attention": float(ma.group(1)) / 100 if ma else None, "gemm_family": float(mg.group(1)) / 100 if mg else None,
+                     "source": "SQ_VALU_MFMA_BUSY_CYCLES over every dispatch of one eager step, profiles/%s" % instep_file}
+    tail = None
+    if steady:
+        mt = _re.search(r"non-MFMA tail .*: ([0-9.]+) ms and ([0-9.]+) launches per step", steady)
+        if mt:
+            tail = (float(mt.group(1)) * 1e-3, float(mt.group(2)))
     if dom:
         fl, sec, n = fam[dom]
         roofline = {"bound": "mfma", "kernel": "k_conv_gemm+k_linear_ws" if dom == "k_conv_gemm" else dom, "achieved": fl / sec / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS,
                     "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_DENSE_TFLOPS,
                     "traffic": traffic["bytes_per_launch"] if traffic and dom in traffic.get("kernel", "") else None,
-                    "traffic_note": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, L2<->fabric incl. Infinity-Cache hits: an upper bound on HBM bytes) from the "
-                                    "rocprofv3 PMC passes committed in profiles/%s (not re-measured in this run)" % traffic_file,
+                    "traffic_note": ("bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, L2<->fabric incl. Infinity-Cache hits: an upper bound on HBM bytes) from the "
+                                     "rocprofv3 PMC passes committed in profiles/%s (not re-measured in this run)" % traffic_file) if traffic
+                                    else "no committed PMC summary matches this build: " + ("; ".join(stale) or "none found"),
+                    # achieved L2<->fabric bandwidth against the 8 TB/s HBM spec (north_star: rocprof HBM GB/s beside MFMA utilisation):
+                    # the family's PMC bytes per launch over ITS time in this run; the non-MFMA tail's PMC bytes over its time in the
+                    # committed steady-state kernel table
+                    "hbm": {"peak_tbps": 8.0,
+                            "family_tbps": traffic["bytes_per_launch"] * n / sec / 1e12 if traffic else None,
+                            "family_frac": traffic["bytes_per_launch"] * n / sec / 8e12 if traffic else None,
+                            "tail_tbps": traffic["tail_bytes_per_launch"] * tail[1] / tail[0] / 1e12 if traffic and tail and traffic.get("tail_bytes_per_launch") else None,
+                            "tail_ms_per_step": tail[0] * 1e3 if tail else None, "tail_launches_per_step": tail[1] if tail else None,
+                            "sources": [f for f in (traffic_file and "profiles/" + traffic_file, steady_file and "profiles/" + steady_file) if f]},
+                    "mfma_busy": mfma_busy,
+                    "attention_mfma_busy": mfma_busy["attention"] if mfma_busy else None,
+                    # what the power budget leaves of the 2.5 PF dense peak on N(0,1) fp16 operands when a kernel issues NOTHING but MFMAs
+                    # (tools/ubench/mfma_power.hip, profiles/r6_gemm32_power_cap.txt): the ceiling the family is really priced against
+                    "peak_power_capped": {"v_mfma_f32_16x16x32_f16": 1867.0, "v_mfma_f32_32x32x16_f16": 1645.0, "zero_operands": 2483.0, "unit": "TFLOP/s",
+                                          "frac_of_16x16x32_cap": fl / sec / 1e12 / 1867.0, "source": "profiles/r6_gemm32_power_cap.txt section 1"},
+                    "stale_profiles": stale or None,
                     "launches_per_step": n, "avg_launch_us": sec / n * 1e6, "algorithmic_flop_per_launch": fl / n,
                     "share_of_step_time": sec / (elapsed / args.steps),
                     "family": "k_conv_gemm (implicit-GEMM tile kernels) + k_linear_ws (weight-stationary linear, C = 320 layers)",

@@ -210,3 +210,20 @@ def check(status, what=""):
     if status != PF_OK:
         msg = lib().pf_last_error_string()
         raise PanFusionHipError("%s failed (status %d): %s" % (what, status, msg.decode() if msg else ""))
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, *.h, Makefile and the C-ABI header):
+    committed rocprof summaries carry it (tools/prof_summary.py, tools/gpu_mfma_instep.sh) and bench.py refuses to quote one that was
+    measured on other sources."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) +
+                   [os.path.join(here, "csrc", "Makefile"), os.path.join(os.path.dirname(here), "include", "panfusion_hip.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

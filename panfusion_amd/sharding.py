@@ -80,13 +80,17 @@ class ShardInfo:
 # panorama branch IS the step: an owner without views is 3x slower than a 7-view rank, whatever the split.
 TIME_MODEL = {
     # (pano_hw, lat_hw, layout_cond): milliseconds; `pano` / `pano_only` are what the panorama branch adds ABOVE `base` on an owner
-    # with / without views (round 4, profiles/r4_sim_ranks.txt: 7-view rank 14.44, 14-view rank 21.13, owner alone 11.78 / 28.50
-    # (cfg 4) / 16.54 (cfg 5), owner with 6 views 19.98 / 34.10 (cfg 4))
-    ((64, 128), (64, 64), False): dict(base=7.75, per_view=0.956, pano=6.5, pano_only=4.0),       # cfg 2 / 3
-    ((64, 128), (64, 64), True): dict(base=7.75, per_view=0.956, pano=11.3, pano_only=8.8),       # cfg 5: + the panorama ControlNet
-    # cfg 4; attn = the five 32 768-token self-attentions of the panorama branch (part of pano / pano_only): what the query split
-    # (split_pano_attention) spreads over the ranks of the CFG half
-    ((128, 256), (64, 64), False): dict(base=7.75, per_view=0.956, pano=20.6, pano_only=20.75, attn=11.0),
+    # with / without views.  Round 6: re-measured at HEAD by tools/fit_time_model.py, raw timings and fit in
+    # profiles/r6_time_model.json -- cfg 2: 7-view rank 14.19, 14-view rank 20.16, owner alone 11.84, owner with 6 views 19.53; cfg 5: 14.18 /
+    # 20.11 / 16.43 / 24.32; cfg 4 (query split off): 14.79 / 21.01 / 24.16 / 32.74.  (Round 4's constants -- base 7.75, per_view 0.956,
+    # pano 6.5 / 4.0 -- were still in here through round 5 while the kernels under them changed: the per-view cost fell by 11 %, the base rose.)
+    ((64, 128), (64, 64), False): dict(base=8.22, per_view=0.853, pano=6.19, pano_only=3.62),       # cfg 2 / 3
+    ((64, 128), (64, 64), True): dict(base=8.25, per_view=0.847, pano=10.99, pano_only=8.18),       # cfg 5: + the panorama ControlNet
+    # cfg 4; the query split of the five 32 768-token self-attentions of the panorama branch (split_pano_attention), measured at 4 ranks per
+    # half: the owner sheds 3.24 ms (24.16 -> 20.92: attn (1 - 1 / G) with attn = 4.32 -- a quarter of the rows is 320 workgroups on 256 CUs and
+    # costs 0.4 of the whole attention, and every attention adds two graph-segment breaks), every other rank takes on 2.92 ms
+    # (14.79 -> 17.71: attn_help / G with attn_help = 11.68).  Round 5 carried ONE constant (11 ms) for both sides and overstated what the owner sheds.
+    ((128, 256), (64, 64), False): dict(base=8.57, per_view=0.889, pano=18.84, pano_only=15.59, attn=4.32, attn_help=11.68),
 }
 _DEFAULT_KEY = ((64, 128), (64, 64), False)
 _WARNED = set()
@@ -97,7 +101,7 @@ def time_model(pano_hw=None, lat_hw=None, layout_cond=False):
     self-attention term grows faster: an underestimate, flagged by `measured=False`)."""
     key = (tuple(pano_hw), tuple(lat_hw), bool(layout_cond)) if pano_hw is not None and lat_hw is not None else _DEFAULT_KEY
     if key in TIME_MODEL:
-        return dict(TIME_MODEL[key], measured=True)
+        return dict(TIME_MODEL[key], measured=True, pano_tokens=key[0][0] * key[0][1])
     # unmeasured: scale the cfg-2 row that matches the layout condition (a ControlNet rides on the owner: ADVICE r4) and say so once
     ref = TIME_MODEL[(_DEFAULT_KEY[0], _DEFAULT_KEY[1], key[2])]
     if key not in _WARNED:
@@ -109,15 +113,23 @@ def time_model(pano_hw=None, lat_hw=None, layout_cond=False):
                           "carry too many views); pass split=... or PF_SHARD_SPLIT to override" % (key[0], key[1], key[2]))
     r_p = (key[0][0] * key[0][1]) / (64.0 * 128.0)
     r_v = (key[1][0] * key[1][1]) / (64.0 * 64.0)
-    return dict(base=ref["base"], per_view=ref["per_view"] * r_v, pano=ref["pano"] * r_p, pano_only=ref["pano_only"] * r_p, measured=False)
+    return dict(base=ref["base"], per_view=ref["per_view"] * r_v, pano=ref["pano"] * r_p, pano_only=ref["pano_only"] * r_p, measured=False,
+                pano_tokens=key[0][0] * key[0][1])
+
+
+def _split_rule(G, tokens):
+    """Is a panorama self-attention of `tokens` tokens query-split over a CFG half of G ranks?  The ONE predicate of the planner
+    (_attn_shares) and of the run time (splits_pano_attention): ADVICE r5 -- with G = 3 or 5 the 32-row granularity fails and the
+    planner must not book a saving that does not happen."""
+    return G is not None and G >= max(2, ATTN_SPLIT_MIN_GROUP) and tokens >= ATTN_SPLIT_MIN_TOKENS and tokens % (32 * G) == 0
 
 
 def _attn_shares(tm, G):
     """(ms the owner sheds, ms every other rank of the half takes on) under the self-attention query split."""
     a = tm.get("attn", 0.0)
-    if not a or G is None or G < max(2, ATTN_SPLIT_MIN_GROUP):
+    if not a or not _split_rule(G, tm.get("pano_tokens", 0)):
         return 0.0, 0.0
-    return a * (1.0 - 1.0 / G), a / G
+    return a * (1.0 - 1.0 / G), tm.get("attn_help", a) / G
 
 
 def owner_cost(m0, tm=None, G=None):
@@ -490,8 +502,7 @@ ATTN_SPLIT_MIN_GROUP = int(os.environ.get("PF_SHARD_ATTN_MIN_GROUP", "3"))
 
 def splits_pano_attention(shard, tokens):
     """The rule both sides evaluate (owner: in its panorama self-attention; view ranks: after their own)."""
-    return (shard is not None and shard.pano_g is not None and shard.G >= max(2, ATTN_SPLIT_MIN_GROUP)
-            and tokens >= ATTN_SPLIT_MIN_TOKENS and tokens % (32 * shard.G) == 0)
+    return shard is not None and shard.pano_g is not None and _split_rule(shard.G, tokens)
 
 
 def split_pano_attention(shard, a, tokens, nq, dtype=None, device=None):

@@ -80,12 +80,21 @@ def test_cfg2_headline_config_vs_oracle(full_oracle):
         a, b = rel_l2(got["epa%d_pers" % i], torch.from_numpy(gd["epa%d_pers" % i])), \
             rel_l2(got["epa%d_pano" % i], torch.from_numpy(gd["epa%d_pano" % i]))
         print("  after EPA block %d: views %.2e  pano %.2e" % (i, a, b))
-        assert a <= 2e-3 and b <= 2e-3, (i, a, b)               # (8-channel slices of intermediate streams)
+        # per-block error budget: measured 4.5e-4 ... 6.8e-4 on these 8-channel slices of the intermediate streams;
+        # a regression is caught at the block where it enters, before it flips the 1e-3 gate on the outputs (round 5: 2e-3)
+        assert a <= 8e-4 and b <= 8e-4, (i, a, b)
     # per CFG half too: the null-prompt half and the prompted half separately
     for h in (0, 1):
         assert rel_l2(s[h].cpu(), torch.from_numpy(gd["sample"][h])) <= 1e-3
         assert rel_l2(ps[h].cpu(), torch.from_numpy(gd["pano_sample"][h])) <= 1e-3
     assert es <= 1e-3 and ep <= 1e-3, (es, ep)
+    # ... and against the fixture the REFERENCE CLASS itself produced for the conditional half (tools/make_golden_cfg.py cfg2ref:
+    # models/pano/MVGenModel.py:38-297 with its own WarpAttn / get_masks / dense per-head bias, 3.0e-6 / 2.5e-6 from the port's file)
+    if _have("cfg2_ref_cond.npz"):
+        gr = np.load(os.path.join(GOLDEN, "cfg2_ref_cond.npz"))
+        rv, rp = rel_l2(s[1:].cpu(), torch.from_numpy(gr["sample"])), rel_l2(ps[1:].cpu(), torch.from_numpy(gr["pano_sample"]))
+        print("  conditional half vs the reference class's own output: views %.3e  pano %.3e" % (rv, rp))
+        assert rv <= 1e-3 and rp <= 1e-3, (rv, rp)
 
 
 @pytest.mark.skipif(not _have("cfg2b_eps.npz"), reason="fixture not generated")

@@ -11,7 +11,7 @@ cd /tmp
 rm -rf /tmp/mi1 /tmp/mi2
 PF_STREAMS=1 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/mi1 -o g -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-training-leg --no-graphs > $R/gpurun_out/${TAG}_mfma_instep_1.log 2>&1
 PF_STREAMS=1 timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/mi2 -o g -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-training-leg --no-graphs > $R/gpurun_out/${TAG}_mfma_instep_2.log 2>&1
-python - $(find /tmp/mi1 -name '*counter_collection.csv' | head -1) $(find /tmp/mi2 -name '*counter_collection.csv' | head -1) $R/gpurun_out/${TAG}_mfma_instep.txt <<'PY'
+python - $(find /tmp/mi1 -name '*counter_collection.csv' | head -1) $(find /tmp/mi2 -name '*counter_collection.csv' | head -1) $R/gpurun_out/${TAG}_mfma_instep.txt $R <<'PY'
 import csv, re, sys
 from collections import defaultdict
 def short(n):
@@ -42,7 +42,10 @@ for x, y in zip(mf, gb):
     t[1] += y.get("GRBM_GUI_ACTIVE", 0.0) / 8 * 1024
     t[2] += 4 * x.get("SQ_ACTIVE_INST_VALU", 0.0)
     t[3] += 1
+sys.path.insert(0, sys.argv[4])
+from panfusion_amd import _lib
 with open(sys.argv[3], "w") as fh:
+    fh.write("csrc_sha256: %s\n" % _lib.source_hash())
     fh.write("MFMA-pipe utilisation inside the step (all dispatches of the last denoiser passes of `bench.py --steps 1 --no-graphs`, PF_STREAMS=1)\n")
     fh.write("%-44s %9s %12s %12s\n" % ("kernel", "launches", "MFMA busy %", "VALU busy %"))
     tot_a, tot_g = [0.0, 0.0], [0.0, 0.0]

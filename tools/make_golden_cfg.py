@@ -74,6 +74,28 @@ def cfg2():
     np.savez_compressed(os.path.join(OUT, "cfg2_eps.npz"), sample=s.numpy(), pano_sample=ps.numpy(), **got)
 
 
+def cfg2ref():
+    """cfg 2's first denoiser call, CONDITIONAL half of the CFG pair (the samples of a batch are independent), through the REFERENCE's own
+    class -- models/pano/MVGenModel.py:38-297 with its WarpAttn / get_masks / CrossAttention (dense per-head bias: 20 heads x 2048 x 20480
+    fp32 = 3.4 GB per direction at C = 640) -- around the restated UNet objects (the 20-view / 20 480-key EPA path of
+    the reference code had never produced a golden file).  Stored next to the port-generated cfg2_eps.npz together with the measured
+    port-vs-reference difference on this half; tests/test_oracle_vs_reference.py asserts the two files agree to 1e-5, the GPU test compares
+    the HIP path with this one too."""
+    om = FX.build_full_width()
+    rm = FX.reference_denoiser(om)
+    print("cfg2ref: denoiser =", type(rm).__module__, type(rm).__name__, flush=True)
+    args = FX.first_step_call(FX.ico_cameras(), (64, 64), (64, 128), cfg_pair=False)
+    t0 = time.time()
+    s, ps = call(rm, args)
+    print("cfg2ref reference forward (one CFG half) %.0f s" % (time.time() - t0), flush=True)
+    old = np.load(os.path.join(OUT, "cfg2_eps.npz"))
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+    d_v, d_p = rel(old["sample"][1:], s.numpy()), rel(old["pano_sample"][1:], ps.numpy())
+    print("cfg2ref: port-generated cfg2_eps.npz (conditional half) vs the reference class: %.2e views / %.2e panorama" % (d_v, d_p), flush=True)
+    np.savez_compressed(os.path.join(OUT, "cfg2_ref_cond.npz"), sample=s.numpy(), pano_sample=ps.numpy(),
+                        port_vs_reference=np.array([d_v, d_p]))
+
+
 def cfg2b():
     model = FX.build_full_width()
     args = FX.first_step_call(FX.ico_cameras(), (64, 64), (64, 128), cfg_pair=True, t=21, rot=180.0)

@@ -5,8 +5,16 @@
     python tools/prof_summary.py pmc    <counter_collection.csv> <out.txt>
 """
 import csv
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def csrc_hash():
+    from panfusion_amd import _lib
+    return _lib.source_hash()
 
 
 def short(name):
@@ -74,6 +82,7 @@ def trace_steady(path, out, steps, warmup):
     tail = sum(v[1] for k, v in fam.items() if not k.startswith(mfma))
     tail_n = sum(v[0] for k, v in fam.items() if not k.startswith(mfma))
     with open(out, "w") as fh:
+        fh.write("csrc_sha256: %s\n" % csrc_hash())
         fh.write("steady-state window: %d timed steps (one stream, no graphs) = %.2f ms of kernels and %.0f launches per step\n" % (steps, tot / steps, n / steps))
         fh.write("non-MFMA tail (everything but k_conv_gemm* / k_linear_ws / k_attention*): %.2f ms and %.0f launches per step\n" % (tail / steps, tail_n / steps))
         fh.write("kernels that are not this library's (torch / runtime copies, fills, casts) inside the window: %s\n\n"
@@ -102,7 +111,8 @@ def traffic(fetch_txt, write_txt, out, family=("k_conv_gemm", "k_linear_ws")):
     """profiles/r<N>_traffic.json (read by bench.py for roofline.traffic) from the two PMC summaries: the GEMM family
     (tile kernels + the weight-stationary linear kernel), and every kernel of the run together (`all_kernels`)."""
     import json
-    tot, n, everything = {}, {}, {}
+    tot, n, everything, tail, tail_n = {}, {}, {}, {}, {}
+    mfma = family + ("k_attention",)
     for path in (fetch_txt, write_txt):
         for line in open(path):
             f = line.split()
@@ -110,12 +120,18 @@ def traffic(fetch_txt, write_txt, out, family=("k_conv_gemm", "k_linear_ws")):
                 continue
             c = f[f.index("total") - 1]
             everything[c] = everything.get(c, 0.0) + float(f[f.index("total") + 1])
+            if line.startswith("k_") and not line.startswith(mfma):        # this library's non-MFMA kernels: the tail
+                tail[c] = tail.get(c, 0.0) + float(f[f.index("total") + 1])
+                tail_n[c] = tail_n.get(c, 0) + int(f[f.index("dispatches") + 1])
             if not line.startswith(family):
                 continue
             tot[c] = tot.get(c, 0.0) + float(f[f.index("total") + 1])
             n[c] = n.get(c, 0) + int(f[f.index("dispatches") + 1])
     assert n["FETCH_SIZE"] == n["WRITE_SIZE"], n
     doc = {
+        "csrc_sha256": csrc_hash(),
+        "tail_launches": tail_n.get("FETCH_SIZE", 0),
+        "tail_bytes_per_launch": (2.0 * tail.get("FETCH_SIZE", 0.0) + tail.get("WRITE_SIZE", 0.0)) * 1024.0 / max(tail_n.get("FETCH_SIZE", 0), 1),
         "kernel": "k_conv_gemm (all tile variants) + k_linear_ws",
         "all_kernels_bytes_total": (2.0 * everything["FETCH_SIZE"] + everything["WRITE_SIZE"]) * 1024.0,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, PF_STREAMS=1 bench.py --steps 1 --warmup 0 --no-graphs",

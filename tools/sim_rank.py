@@ -25,12 +25,18 @@ def fake_dist(world, rank):
     dist.get_rank = lambda group=None: rank
     dist.new_group = lambda ranks=None, **k: tuple(ranks)
 
-    def all_gather_into_tensor(out, x, group=None):
-        n = out.numel() // x.numel()
-        out.view(n, -1).copy_(x.reshape(1, -1).expand(n, -1))
+    class Done:                                   # what async_op=True returns: nothing to wait for
+        def wait(self):
+            return True
+
+    def all_gather_into_tensor(out, x, group=None, async_op=False):
+        n = out.numel() // max(x.numel(), 1) if x.numel() else 0
+        if n:
+            out.view(n, -1).copy_(x.reshape(1, -1).expand(n, -1))
+        return Done() if async_op else None
 
     dist.all_gather_into_tensor = all_gather_into_tensor
-    dist.broadcast = lambda t, src=0, group=None: None
+    dist.broadcast = lambda t, src=0, group=None, async_op=False: Done() if async_op else None
     dist.all_reduce = lambda t, op=None, group=None: None
     dist.barrier = lambda *a, **k: None
 
