@@ -302,6 +302,15 @@ typedef struct {
                           * pf_scale_shift_act(out_split) / PF_EPILOGUE_SPLIT write) -- and w holds per tap and block of 32 channels
                           * [W_hi(32) | W_lo(32)]; every 64-element K block is multiplied as W_hi A_hi + W_hi A_lo + W_lo A_hi (2^-22
                           * relative: an fp32-grade product from 16-bit MFMA operands).  a1 must be NULL.                       */
+    int subpixel;        /* 1: a nearest-x2-upsampling 3x3 convolution (ksize 3, upsample 1, stride 1, pad 1; diffusers Upsample2D:
+                          * F.interpolate(scale_factor=2, mode="nearest") + Conv2d, reference call sites MVGenModel.py:272-277) computed as FOUR 2x2
+                          * convolutions on the LOW-resolution grid, one per output phase (a, b) in {0, 1}^2: output pixel (2 y + a, 2 x + b) only
+                          * ever reads input rows y - 1 + a, y + a and columns x - 1 + b, x + b, so the nine taps collapse to four with summed
+                          * weights -- 4 instead of 9 MACs per (output value, input channel), the same sums in exact arithmetic.  `w` then holds
+                          * [4 phases][n_out][2][2][c0 + c1] (phase-major, 16-bit; panfusion_amd.engine._subpixel_weight builds it: row taps of
+                          * phase a = 0: {W[0]}, {W[1] + W[2]}; a = 1: {W[0] + W[1]}, {W[2]}; columns alike).  Bias only (no row vector,
+                          * residual, GEGLU / pair epilogue, split3), batch 1, h_out / w_out even; wrap_pad 0..1 with crop 2 x wrap_pad is the
+                          * panorama's pad 1 / upsample / conv / crop 2.  gn_partial is supported (runs of R LOW-resolution rows).            */
 } pf_conv_desc;
 
 enum { PF_EPILOGUE_NONE = 0, PF_EPILOGUE_GEGLU = 1, PF_EPILOGUE_SPLIT = 2 };

@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
         ("a_bstride", c_long), ("w_bstride", c_long), ("out_bstride", c_long), ("res_bstride", c_long),
         ("epilogue", c_int), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("gn_partial", c_void_p), ("wrap_pad", c_int), ("crop", c_int),
-        ("tickets", c_void_p), ("n_tickets", c_int), ("split3", c_int),
+        ("tickets", c_void_p), ("n_tickets", c_int), ("split3", c_int), ("subpixel", c_int),
     ]
 
 

@@ -87,7 +87,7 @@ __device__ __forceinline__ void gn_moments_phase_r(const GemmParams& p, long bz,
     const int NP = p.N >> 1;
     const int mw = m0 + row_base;                                 // first row of this wavefront
     if (mw >= p.M) return;
-    float* base = p.gn_partial + static_cast<long>(mw / p.gn_rows) * 2 * NP;
+    float* base = p.gn_partial + gn_part(p, bz, mw) * 2 * NP;
     const float* rv = p.rowvec ? p.rowvec + static_cast<long>(mw / p.rows_per_img) * p.rowvec_ld : nullptr;
     const int nb = n0 + col_base + cq4;                           // (whole N tiles: gn_rows_for) column of block j: nb + 16 j
     // operands are requested in batches (a few memory latencies for the whole phase, not one per column block): bias + row
@@ -271,7 +271,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmParams& p, long bz, f32x
             const int m = m0 + (r / WRH) * WR + h * WRH + r % WRH;
             if (q < BMH * CPR && m < p.M && nbase + c8 < n_store) {
                 const u16x8 x = *reinterpret_cast<const u16x8*>(smem16 + r * SLD + c8);
-                *reinterpret_cast<u16x8*>(outp + static_cast<long>(m) * p.out_ld + nbase + c8) = x;
+                *reinterpret_cast<u16x8*>(outp + out_row(p, bz, m) * p.out_ld + nbase + c8) = x;
             }
         }
     };
@@ -344,7 +344,7 @@ __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4
         for (int ii = 0; ii < G; ++ii) {
             const int i = g * G + ii;
             const int m = m0 + row_base + i * 16 + rl;
-            float* op = outp + static_cast<long>(min(m, p.M - 1)) * p.out_ld;
+            float* op = outp + out_row(p, bz, min(m, p.M - 1)) * p.out_ld;
 #pragma unroll
             for (int j = 0; j < NREP; ++j) {
                 float4 v = float4{acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z, acc[i][j][3] + bias[j].w};
@@ -354,7 +354,7 @@ __device__ __forceinline__ void epilogue_f32(const GemmParams& p, long bz, f32x4
                 }
                 if (PAIR) {
                     if (m < p.M && nok[j]) {
-                        unsigned short* o16 = outp16 + static_cast<long>(m) * p.out_ld + pair_off(ncl[j]);
+                        unsigned short* o16 = outp16 + out_row(p, bz, m) * p.out_ld + pair_off(ncl[j]);
                         const float f[4] = {v.x, v.y, v.z, v.w};
                         u16x4 hi, lo;
 #pragma unroll
@@ -385,7 +385,7 @@ __device__ __forceinline__ void epilogue_f32_stats(const GemmParams& p, long bz,
     const int NP = p.N >> 1;
     const int mw = m0 + row_base;                                 // first row of this wavefront
     if (mw >= p.M) return;
-    float* base = p.gn_partial + static_cast<long>(mw / p.gn_rows) * 2 * NP;
+    float* base = p.gn_partial + gn_part(p, bz, mw) * 2 * NP;
     const float* resp = RES ? static_cast<const float*>(p.residual) + bz * p.res_bs : nullptr;
     float* outp = static_cast<float*>(p.out) + bz * p.out_bs;
     const int nb = n0 + col_base + cq;
@@ -564,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     const int lchunk8 = (chunk ^ ((lrow >> 1) & 7)) * 8;
 
     // per-thread staging rows: output pixel -> top-left input coordinate
+    const int pad_y = p.subpix ? 1 - (static_cast<int>(bz) >> 1) : p.pad, pad_x = p.subpix ? 1 - (static_cast<int>(bz) & 1) : p.pad;   // (sub-pixel phase: pf_gemm_params.h)
     int a_img[MREP], a_y[MREP], a_x[MREP];
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
@@ -572,8 +573,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
             const int img = m / p.rows_per_img, rem = m - img * p.rows_per_img;
             const int yo = rem / p.w_out;
             a_img[i] = img;
-            a_y[i] = yo * p.stride - p.pad;
-            a_x[i] = (rem - yo * p.w_out + p.crop) * p.stride - p.pad;
+            a_y[i] = yo * p.stride - pad_y;
+            a_x[i] = (rem - yo * p.w_out + p.crop) * p.stride - pad_x;
         } else {
             a_img[i] = 0; a_y[i] = -(1 << 20); a_x[i] = 0;     // never in range
         }
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     unsigned a_off[MREP];                                         // bytes, or OOB
     bool seg1 = false;
     auto set_segment = [&]() {
-        const int ky = p.ksize == 3 ? tap / 3 : 0, kx = p.ksize == 3 ? tap - 3 * ky : 0;
+        const int ky = p.ksize == 3 ? tap / 3 : p.ksize == 2 ? tap >> 1 : 0, kx = p.ksize == 3 ? tap - 3 * ky : p.ksize == 2 ? tap & 1 : 0;
         seg1 = __builtin_amdgcn_readfirstlane(cc >= p.c0 ? 1 : 0) != 0;
         const int ld = seg1 ? p.a1_ld : p.a0_ld;
 #pragma unroll
@@ -767,6 +768,7 @@ __global__ __launch_bounds__(64 * NW, BM_ == 128 ? 2 : 1) void k_conv_gemm8(cons
     const unsigned short* a1 = p.a1 ? p.a1 + bz * p.a_bs : nullptr;
     const unsigned short* wg = p.w + bz * p.w_bs;
     int m0 = 0, n0 = 0;                              // origin of the tile being multiplied (set_tile)
+    const int pad_y = p.subpix ? 1 - (static_cast<int>(bz) >> 1) : p.pad, pad_x = p.subpix ? 1 - (static_cast<int>(bz) & 1) : p.pad;   // (sub-pixel phase: pf_gemm_params.h)
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(64 * NW, BM_ == 128 ? 2 : 1) void k_conv_gemm8(cons
     unsigned a_off[APASS];                                        // bytes, or OOB
     bool seg1 = false;                                            // current source is a1
     auto set_segment = [&]() __attribute__((always_inline)) {
-        const int ky = p.ksize == 3 ? tap / 3 : 0, kx = p.ksize == 3 ? tap - 3 * ky : 0;
+        const int ky = p.ksize == 3 ? tap / 3 : p.ksize == 2 ? tap >> 1 : 0, kx = p.ksize == 3 ? tap - 3 * ky : p.ksize == 2 ? tap & 1 : 0;
         seg1 = __builtin_amdgcn_readfirstlane(cc >= p.c0 ? 1 : 0) != 0;
         const int ld = seg1 ? p.a1_ld : p.a0_ld;
 #pragma unroll
@@ -853,8 +855,8 @@ __global__ __launch_bounds__(64 * NW, BM_ == 128 ? 2 : 1) void k_conv_gemm8(cons
             for (int i = 0; i < APASS; ++i) {
                 const bool ok = m0 + i * RPP + lrow < p.M;
                 a_img[i] = ok ? img : 0;
-                a_y[i] = ok ? yo * p.stride - p.pad : -(1 << 20);
-                a_x[i] = (xo + p.crop) * p.stride - p.pad;
+                a_y[i] = ok ? yo * p.stride - pad_y : -(1 << 20);
+                a_x[i] = (xo + p.crop) * p.stride - pad_x;
                 xo += p.adv_x;
                 if (xo >= p.w_out) { xo -= p.w_out; ++yo; }
                 yo += p.adv_y;
@@ -1515,13 +1517,25 @@ static void params_from_desc(const pf_conv_desc* d, GemmParams& p) {
     p.gn_partial = nullptr; p.gn_rows = 0;
     p.m_begin = 0; p.splits = 1; p.kb_per_split = 0; p.partial = nullptr; p.tickets = nullptr;
     p.a0_bytes = p.a1_bytes = p.w_bytes = 0; p.adv_img = p.adv_y = p.adv_x = 0;
+    p.subpix = 0;
+    if (d->subpixel) {
+        // nearest x2 + 3x3 conv == four 2x2 convolutions on the low-resolution grid, one per output phase (blockIdx.z): 4 Cin
+        // instead of 9 Cin MACs per output value.  Everything below is the LOW-resolution problem; out_row() scatters the rows.
+        p.subpix = 1; p.ksize = 2; p.up = 0; p.pad = 0;
+        p.h_out = d->h_out / 2; p.w_out = d->w_out / 2;
+        p.rows_per_img = p.h_out * p.w_out;
+        p.M = d->n_img * p.rows_per_img; p.K = 4 * Ctot;
+        p.crop = d->crop / 2;
+        p.batch = 4; p.a_bs = 0; p.out_bs = 0; p.res_bs = 0; p.w_bs = static_cast<long>(p.N) * p.K;
+    }
 }
+static inline int eff_batch(const pf_conv_desc* d) { return d->subpixel ? 4 : d->batch; }
 
 // Rows per GroupNorm-moment part (pf_conv_desc.gn_partial) of this problem under plan g: the fragment rows of one
 // wavefront -- or 0 where the moments cannot be produced: split K (the reduce kernel writes the output), a batch,
 // images that are not whole parts, or an operand mix that takes the per-fragment (generic) epilogue.
 static int gn_rows_for(const GemmParams& p, const GemmPlan& g, int batch) {
-    if (batch != 1 || g.splits > 1 || g.m_split > 0 || p.geglu || p.split_out) return 0;
+    if ((batch != 1 && !p.subpix) || g.splits > 1 || g.m_split > 0 || p.geglu || p.split_out) return 0;   // (the four sub-pixel phases of an image are contiguous runs: gn_part)
     // Layers with a residual are left to the consumer's statistics pass by default.  Round 3: the moment phase has to read the
     // residual tile a second time, which costs an HBM-bound layer as much as that pass saves (fp32-residual linear at
     // 163840 x 320: 141 -> 171 us, the pass it replaces 42 us; VAE decode 107 -> 122 ms; profiles/archive/r3d_gemm_gn.txt).  Round 4: fp32
@@ -1557,7 +1571,7 @@ static Plan32 plan32(const GemmParams& p, int batch, bool allow_split) {
     Plan32 r{false, 0, 0, 0};
     static const int min_k = tuning("PF_GEMM32_MINK", 2560), k1 = tuning("PF_GEMM32_K1", 0);
     const int on = tuning("PF_GEMM32", 0);                         // (read per call: the tests switch it on for their own launches)
-    if (!on || p.s3 || batch != 1 || p.N % 320 != 0 || p.K < min_k || p.K % 64 != 0 || p.geglu) return r;
+    if (!on || p.s3 || p.subpix || batch != 1 || p.N % 320 != 0 || p.K < min_k || p.K % 64 != 0 || p.geglu) return r;
     if (p.ksize != 3 && !k1) return r;
     const long ntl = p.N / 320, mt = cdiv(p.M, 256), tiles = mt * ntl;
     const long full = tiles / 256 * 256, rest = tiles - full;
@@ -1636,9 +1650,14 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
                    "pf_conv_gemm: output size (%d,%d) does not match (%d,%d) [or (%d,%d) with a trailing zero row / column]",
                    d->h_out, d->w_out, ho, wo, ho1, wo1);
     }
+    if (d->subpixel)
+        PF_REQUIRE(d->ksize == 3 && d->upsample == 1 && d->stride == 1 && d->pad == 1 && d->batch == 1 && !d->residual && !d->rowvec &&
+                   d->epilogue == PF_EPILOGUE_NONE && !d->split3 && d->h_out % 2 == 0 && d->w_out % 2 == 0 && d->crop % 2 == 0 && d->wrap_pad <= 1,
+                   "pf_conv_gemm: subpixel serves nearest x2 + 3x3 stride-1 pad-1 convolutions (bias only; weights packed [4][n_out][2][2][c0 + c1])");
+    const int batch = eff_batch(d);
     GemmParams p;
     params_from_desc(d, p);
-    Plan32 g32 = plan32(p, d->batch, d->workspace != nullptr);
+    Plan32 g32 = plan32(p, batch, d->workspace != nullptr);
     if (g32.use && d->gn_partial && gn_rows32(p, g32) == 0) g32.use = false;     // (moments asked for: the plan that can emit them)
     if (g32.use) {
         if (d->gn_partial) {
@@ -1675,9 +1694,9 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
         PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
         return PF_OK;
     }
-    GemmPlan g = plan_gemm(p.M, p.N, p.K, d->batch, d->workspace != nullptr);
+    GemmPlan g = plan_gemm(p.M, p.N, p.K, batch, d->workspace != nullptr);
     if (d->gn_partial) {
-        const int r = gn_rows_for(p, g, d->batch);
+        const int r = gn_rows_for(p, g, batch);
         PF_REQUIRE(r > 0 && aligned16(d->gn_partial), "pf_conv_gemm: gn_partial given but this problem cannot emit GroupNorm moments (ask pf_conv_gemm_gn_rows first)");
         p.gn_partial = d->gn_partial;
         p.gn_rows = r;
@@ -1685,7 +1704,7 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     {   // extents for the buffer descriptors of the 8-wave kernel (32-bit offsets, < 2 GiB)
         const long npix = static_cast<long>(d->n_img) * d->h_in * d->w_in;
         const long a0b = ((npix - 1) * p.a0_ld + p.c0) * 2, a1b = p.a1 ? ((npix - 1) * p.a1_ld + p.c1) * 2 : 0;
-        const long wb = static_cast<long>(p.N) * p.K * 2;
+        const long wb = static_cast<long>(p.N) * p.K * 2;      // (per batch element / sub-pixel phase: the kernels offset the base by w_bs)
         PF_REQUIRE(a0b < (1L << 31) && a1b < (1L << 31) && wb < (1L << 31),
                    "pf_conv_gemm: each operand must be smaller than 2 GiB (32-bit buffer offsets)");
         p.a0_bytes = static_cast<unsigned>(a0b); p.a1_bytes = static_cast<unsigned>(a1b); p.w_bytes = static_cast<unsigned>(wb);
@@ -1702,7 +1721,7 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
         // 4-wave kernel, <= 255 of the 8-wave one)
         const int bm = g.big ? g.bm : 32 * g.mrep, bn = 32 * g.nrep;
         const long rows = g.big && g.m_split > 0 ? p.M - g.m_split : p.M;
-        const long need = cdiv(rows, bm) * cdiv(p.N, bn) * d->batch;
+        const long need = cdiv(rows, bm) * cdiv(p.N, bn) * batch;
         PF_REQUIRE(d->n_tickets >= need && (reinterpret_cast<uintptr_t>(d->tickets) & 3) == 0,
                    "pf_conv_gemm: %ld arrival counters needed, %d given", need, d->n_tickets);
         p.tickets = d->tickets;
@@ -1721,18 +1740,18 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
             else { pf_status s1 = launch8<T, 4>(p1, 1, st, g.bm); if (s1 != PF_OK) return s1; return launch8<T, 4>(p2, 1, st, g.bm); });
     }
     if (p.splits > 1) {
-        const size_t need = static_cast<size_t>(p.splits) * d->batch * p.M * p.N * sizeof(float);
+        const size_t need = static_cast<size_t>(p.splits) * batch * p.M * p.N * sizeof(float);
         PF_REQUIRE(d->workspace_bytes >= need && aligned16(d->workspace),
                    "pf_conv_gemm: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, d->workspace_bytes);
     }
     if (g.big) {
         PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
-            if (g.nrep == 5) return launch8<T, 5>(p, d->batch, st, g.bm);
-            else return launch8<T, 4>(p, d->batch, st, g.bm));
+            if (g.nrep == 5) return launch8<T, 5>(p, batch, st, g.bm);
+            else return launch8<T, 4>(p, batch, st, g.bm));
     }
     PF_DISPATCH_16(d->dtype, "pf_conv_gemm",
-        if (g.nrep == 5) return g.mrep == 2 ? launch<T, 2, 5>(p, d->batch, st) : launch<T, 4, 5>(p, d->batch, st);
-        else return g.mrep == 2 ? launch<T, 2, 4>(p, d->batch, st) : launch<T, 4, 4>(p, d->batch, st));
+        if (g.nrep == 5) return g.mrep == 2 ? launch<T, 2, 5>(p, batch, st) : launch<T, 4, 5>(p, batch, st);
+        else return g.mrep == 2 ? launch<T, 2, 4>(p, batch, st) : launch<T, 4, 4>(p, batch, st));
     return PF_OK;
 }
 
@@ -1747,6 +1766,7 @@ extern "C" int pf_conv_gemm_gn_rows(const pf_conv_desc* d) {
     if (!d || d->batch < 1 || d->n_out < 1 || d->n_img < 1) return 0;
     GemmParams p;
     params_from_desc(d, p);
+    if (d->subpixel) return gn_rows_for(p, plan_gemm(p.M, p.N, p.K, 4, true), 4);
     {
         const Plan32 g32 = plan32(p, d->batch, true);
         if (g32.use) {
@@ -1761,13 +1781,19 @@ extern "C" int pf_conv_gemm_kernel_id(const pf_conv_desc* d) {
     if (!d || d->batch < 1 || d->n_out < 1 || d->n_img < 1) return -1;
     GemmParams p;
     params_from_desc(d, p);
-    if (plan32(p, d->batch, true).use) return 2;
-    return plan_gemm(p.M, p.N, p.K, d->batch, true).big ? 1 : 0;
+    if (plan32(p, eff_batch(d), true).use) return 2;
+    return plan_gemm(p.M, p.N, p.K, eff_batch(d), true).big ? 1 : 0;
 }
 
 extern "C" size_t pf_conv_gemm_workspace_size(const pf_conv_desc* d) {
     if (!d || d->batch < 1 || d->n_out < 1) return 0;
     const int c1 = d->a1 ? d->c1 : 0;
+    if (d->subpixel) {                                              // the four phase problems on the low-resolution grid (params_from_desc)
+        GemmParams p;
+        params_from_desc(d, p);
+        const GemmPlan g = plan_gemm(p.M, p.N, p.K, 4, true);
+        return g.splits > 1 ? static_cast<size_t>(g.splits) * 4 * p.M * p.N * sizeof(float) : 0;
+    }
     const long M = static_cast<long>(d->n_img) * d->h_out * d->w_out;
     const int K = d->ksize * d->ksize * (d->c0 + c1);
     size_t need32 = 0;

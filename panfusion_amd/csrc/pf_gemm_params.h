@@ -35,7 +35,24 @@ struct GemmParams {
                                    // channels, of W [W_hi(32) | W_lo(32)]: a K step multiplies W_hi A_hi + W_hi A_lo + W_lo A_hi
     float* gn_partial;             // [M / gn_rows][2][N / 2] fp32 per-column-pair (sum, sum of squares) of the finished output over
     int gn_rows;                   // the gn_rows fragment rows of one wavefront (GroupNorm moments of the NEXT layer), or NULL
+    int subpix;                    // nearest x2 upsampling + 3x3 convolution as FOUR 2x2 convolutions on the low-resolution grid (pf_conv_desc.subpixel):
+                                   // blockIdx.z = output phase (a, b) = (z >> 1, z & 1); taps of phase a read input rows y - 1 + a, y + a (columns alike): pad = 1 - phase;
+                                   // weights [4][N][2][2][C] (w_bs = N K), a_bs = out_bs = 0; M / h_out / w_out / rows_per_img are those of the LOW-resolution grid and
+                                   // the result of low-resolution pixel (q = img h + y, x) goes to output row (2 q + a) 2 w_out + 2 x + b (out_row)
 };
+
+// Row of the output tensor that holds the result of GEMM row m (identity except for the sub-pixel phases of an upsampling convolution).
+__device__ __forceinline__ long out_row(const GemmParams& p, long bz, int m) {
+    if (!p.subpix) return m;
+    const int q = m / p.w_out, x = m - q * p.w_out;
+    return (2L * q + (bz >> 1)) * (2 * p.w_out) + 2 * x + (bz & 1);
+}
+// Index of the GroupNorm-moment run that holds GEMM row m (runs of gn_rows rows; sub-pixel phases: the four phases of an image are contiguous).
+__device__ __forceinline__ long gn_part(const GemmParams& p, long bz, int m) {
+    if (!p.subpix) return m / p.gn_rows;
+    const int img = m / p.rows_per_img, rem = m - img * p.rows_per_img, ppi = p.rows_per_img / p.gn_rows;
+    return (static_cast<long>(img) * 4 + bz) * ppi + rem / p.gn_rows;
+}
 
 // phase stamp of wave 0 / lane 0 of a block: [block][4] = kernel entry, first tile landed, K loop done, exit
 #ifdef PF_GEMM_TIMELINE       /* debug build (make timeline): wave 0 of every block stamps the phases of ITS SECOND TILE (steady state of the
@@ -75,7 +92,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
         for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(r[e]);
     }
     if (p.geglu) {
-        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + (n4 >> 1);
+        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + out_row(p, bz, m) * p.out_ld + (n4 >> 1);
         typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
         u16x2 w2;
 #pragma unroll
@@ -85,7 +102,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
         }
         *reinterpret_cast<u16x2*>(o) = w2;
     } else if (p.split_out) {
-        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
+        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + out_row(p, bz, m) * p.out_ld + n4;
         u16x4 hi, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -95,10 +112,10 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, long bz, int
         *reinterpret_cast<u16x4*>(o + (pair_off(n4) - n4)) = hi;
         *reinterpret_cast<u16x4*>(o + (pair_off(n4) - n4) + 32) = lo;
     } else if (p.out_f32) {
-        float* o = static_cast<float*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
+        float* o = static_cast<float*>(p.out) + bz * p.out_bs + out_row(p, bz, m) * p.out_ld + n4;
         *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
     } else {
-        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + static_cast<long>(m) * p.out_ld + n4;
+        unsigned short* o = static_cast<unsigned short*>(p.out) + bz * p.out_bs + out_row(p, bz, m) * p.out_ld + n4;
         u16x4 w4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w4[e] = from_f32<T>(v[e]);

@@ -38,6 +38,7 @@ def default_precision(dtype):
 
 RAW_PAIR_FUSED = os.environ.get("PF_RAW_PAIR", "1") != "0"      # A/B: 0 = the shortcut operand by its own split pass
 VIRTUAL_PAD = os.environ.get("PF_VIRTUAL_PAD", "1") != "0"      # A/B: 0 = materialised pad_pano / unpad_pano copies around the panorama convs
+SUBPIXEL_UP = os.environ.get("PF_SUBPIXEL_UP", "1") != "0"      # A/B: 0 = the upsampling convolutions as nearest x2 + 3x3 (9 taps) instead of four 2x2 phase convolutions (4 taps)
 FUSED_HEAD = os.environ.get("PF_FUSED_HEAD", "1") != "0"        # A/B: 0 = GroupNorm-apply + SiLU pass, then conv_out (two launches)
 
 
@@ -66,6 +67,21 @@ def _processor_lora(attn, name):
 def _conv3_weight(conv, dev, dtype):
     # torch [Cout, Cin, ky, kx] -> [Cout, ky, kx, Cin] (K ordered tap-major, channel-minor)
     return _w16(conv.weight.detach().float().permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1), dev, dtype)
+
+
+def _subpixel_weight(conv, dev, dtype):
+    """Weights of an upsampling convolution (nearest x2, then 3x3) for the four-phase form of pf_conv_desc.subpixel: output pixel
+    (2 y + a, 2 x + b) reads low-resolution rows y - 1 + a, y + a and columns x - 1 + b, x + b only, so per phase the nine taps collapse
+    to 2 x 2 with summed weights (rows: a = 0 -> {W[0]}, {W[1] + W[2]}; a = 1 -> {W[0] + W[1]}, {W[2]}; columns alike).  Summed in
+    fp32, rounded once.  torch [Cout, Cin, 3, 3] -> [4 phases, Cout, 2, 2, Cin] -> [4 * Cout, 4 * Cin]."""
+    w = conv.weight.detach().float()
+    groups = (((0,), (1, 2)), ((0, 1), (2,)))
+    phases = []
+    for a in range(2):
+        for b in range(2):
+            taps = [[sum(w[:, :, ky, kx] for ky in groups[a][r] for kx in groups[b][c]) for c in range(2)] for r in range(2)]
+            phases.append(torch.stack([torch.stack(row, 1) for row in taps], 1))        # [Cout, 2, 2, Cin]
+    return _w16(torch.stack(phases).reshape(4 * w.shape[0], -1), dev, dtype)
 
 
 def _split_weight(w, taps, dev, dtype):
@@ -291,7 +307,8 @@ def pack_unet(unet, dev, dtype, mixed=False):
             b.attns = [pack_transformer(a, dev, dtype, mixed) for a in blk.attentions]
         if blk.upsamplers is not None:
             c = blk.upsamplers[0].conv
-            b.up = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0], src=c)
+            b.up = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0], src=c,
+                      w4=_subpixel_weight(c, dev, dtype) if SUBPIXEL_UP else None)
         u.up.append(b)
 
     # one GEMM for every resnet's Linear(silu(temb)) (diffusers ResnetBlock2D.time_emb_proj)
@@ -663,8 +680,9 @@ class Branch:
         x = to16(self.h if virt else self._padded(self.h, 1), self.u.dtype)
         n, h, w, Cc = x.shape
         geo = dict(wrap_pad=1, crop=2) if virt else {}
-        y = ops.conv_gemm(x, up.w, up.c, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1, bias=up.b,
-                          out_dtype=self.u.stream, gn_stats=not self.pad, **geo)
+        sub = getattr(up, "w4", None) is not None and (virt or not self.pad)
+        y = ops.conv_gemm(x, up.w4 if sub else up.w, up.c, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1, bias=up.b,
+                          out_dtype=self.u.stream, gn_stats=not self.pad, subpixel=sub, **geo)
         if virt:
             self.h = y.view(n, 2 * h, 2 * w, up.c)
             return

@@ -452,7 +452,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1,
               a_bstride=0, w_bstride=0, out_bstride=0, res_bstride=0, a0_ld=None, a1_ld=None, c0=None, c1=None,
               out_ld=None, res_ld=None, geglu=False, algo_k=None, split_out=False, pad_hi=0, gn_stats=False,
-              wrap_pad=0, crop=0, split3=False, plan_only=False):
+              wrap_pad=0, crop=0, split3=False, plan_only=False, subpixel=False):
     """out[m, n] = sum_k A[m, k] W[n, k] (+bias +rowvec[img] +residual).  a0/a1 NHWC, the last
     dim is the channel stride; returns [M, n_out] (M = n_img * h_out * w_out).  The output takes the
     residual's dtype unless out_dtype says otherwise (fp32 residual stream in, fp32 out).
@@ -464,6 +464,8 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     moments of the output behind (attribute `_pf_gn` of the returned tensor, read by groupnorm_scale_shift).
     wrap_pad / crop: the input is read as if its width had been padded circularly by wrap_pad columns (pad_pano), the output
     loses `crop` columns on both sides (unpad_pano): pad -> conv -> crop of the panorama branch without the padded copies.
+    subpixel: an upsampling convolution (ksize 3, upsample 1) as four 2x2 phase convolutions on the low-resolution grid; w = engine._subpixel_weight
+    ([4 * n_out, 4 * C]): 4 instead of 9 MACs per output value and input channel (pf_conv_desc.subpixel).
     plan_only: launch nothing, return pf_conv_gemm_kernel_id of the problem (0 / 1: the 16x16x32 tile kernels, 2: the 32x32x16 kernel)."""
     c0 = c0 if c0 is not None else a0.shape[-1]
     c1 = (c1 if c1 is not None else a1.shape[-1]) if a1 is not None else 0
@@ -493,7 +495,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     # GroupNorm-moment rows), asked once.  Per call only the pointers change.
     pkey = (c0, c1, a0_ld, a1_ld, n_img, h_in, w_in, h_out, w_out, ksize, stride, pad, upsample, n_out, batch, epilogue, wrap_pad,
             crop, dt(a0), dt(out_dtype), residual is not None, res_dtype, res_ld, rowvec is not None, rowvec_ld, bias is not None,
-            out_ld, a_bstride, w_bstride, out_bstride, res_bstride, bool(split3))
+            out_ld, a_bstride, w_bstride, out_bstride, res_bstride, bool(split3), bool(subpixel))
     plans = _PLANS.plans
     plan = plans.get(pkey)
     if plan is None:
@@ -508,6 +510,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
         d.epilogue = epilogue
         d.wrap_pad, d.crop = wrap_pad, crop
         d.split3 = int(bool(split3))
+        d.subpixel = int(bool(subpixel))
         d.a0, d.a1, d.w, d.bias, d.rowvec, d.residual, d.out = _p(a0), _p(a1), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
         if len(plans) >= _PLANS.LIMIT:
             plans.pop(next(iter(plans)))
@@ -537,7 +540,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
     else:
         _traced("k_conv_gemm", 2.0 * M * n_out * (algo_k or ksize * ksize * (c0 + c1)) * batch,
                 lambda: check(_lib.lib().pf_conv_gemm(C.byref(d), _stream()), "pf_conv_gemm"),
-                "M%d N%d K%d k%d s%d u%d b%d%s" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch, " g32" if plan[3] == 2 else ""))
+                "M%d N%d K%d k%d s%d u%d b%d%s" % (M, n_out, ksize * ksize * (c0 + c1), ksize, stride, upsample, batch, " g32" if plan[3] == 2 else " subpixel" if subpixel else ""))
     if gn is not None:
         out._pf_gn = gn                      # (a tensor that carries moments must not be written in place afterwards)
     elif hasattr(out, "_pf_gn"):
@@ -546,7 +549,7 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
 
 
 def gemm_workspace_bytes(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0,
-                         upsample=0, batch=1, **_):
+                         upsample=0, batch=1, wrap_pad=0, crop=0, subpixel=False, **_):
     """Split-K scratch pf_conv_gemm wants for this problem (0: the K range is not split)."""
     d = ConvDesc()
     d.c0, d.c1 = a0.shape[-1], (a1.shape[-1] if a1 is not None else 0)
@@ -554,8 +557,9 @@ def gemm_workspace_bytes(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, k
     if w_in is None:
         w_in = a0.numel() // (a0.shape[-1] * max(batch, 1))
     d.n_img, d.ksize, d.batch, d.n_out = n_img, ksize, batch, n_out
+    d.wrap_pad, d.crop, d.subpixel = wrap_pad, crop, int(bool(subpixel))
     d.h_out = ((h_in << upsample) + 2 * pad - ksize) // stride + 1
-    d.w_out = ((w_in << upsample) + 2 * pad - ksize) // stride + 1
+    d.w_out = (((w_in + 2 * wrap_pad) << upsample) + 2 * pad - ksize) // stride + 1 - 2 * crop
     return _lib.lib().pf_conv_gemm_workspace_size(C.byref(d))
 
 

@@ -284,7 +284,35 @@ def cfg_ddim_step_pair(x, eps_uncond, eps_cond, guidance, coef, roll=0, out=None
 def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, stride=1, pad=0, upsample=0,
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, c1=None,
               a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, split_out=False, pad_hi=0,
-              gn_stats=False, wrap_pad=0, crop=0, split3=False, **kw):
+              gn_stats=False, wrap_pad=0, crop=0, split3=False, subpixel=False, **kw):
+    if subpixel:
+        # pf_conv_desc.subpixel: nearest x2 + 3x3 as four 2x2 phase convolutions on the low-resolution grid; w = [4][n_out][2][2][C].
+        # Output pixel (2 y + a, 2 x + b) reads rows y - 1 + a, y + a and columns x - 1 + b, x + b (zero outside the image).
+        assert ksize == 3 and upsample == 1 and stride == 1 and pad == 1 and residual is None and rowvec is None and not geglu and not split3
+        x = a0.float().reshape(-1, a0_ld or a0.shape[-1])[:, :(c0 or a0.shape[-1])]
+        if a1 is not None:
+            x = torch.cat([x, a1.float().reshape(-1, a1_ld or a1.shape[-1])[:, :(c1 or a1.shape[-1])]], -1)
+        C = x.shape[-1]
+        x = x.reshape(n_img, h_in, w_in, C).permute(0, 3, 1, 2)
+        if wrap_pad:
+            x = torch.cat([x[..., -wrap_pad:], x, x[..., :wrap_pad]], -1)
+        w4 = w.float().reshape(4, n_out, 2, 2, C)
+        y = torch.zeros(n_img, n_out, 2 * x.shape[2], 2 * x.shape[3])
+        for a in range(2):
+            for b in range(2):
+                xp = F.pad(x, (1 - b, b, 1 - a, a))
+                y[:, :, a::2, b::2] = F.conv2d(xp, w4[2 * a + b].permute(0, 3, 1, 2))
+        if bias is not None:
+            y = y + bias.float()[None, :, None, None]
+        if crop:
+            y = y[..., crop:-crop]
+        ho, wo = y.shape[2:]
+        y = y.permute(0, 2, 3, 1).reshape(n_img * ho * wo, n_out)
+        y = y.to(out_dtype or a0.dtype)
+        if out is not None:
+            out.copy_(y.reshape(out.shape))
+            return out
+        return y
     if split3:
         # split-precision walk (pf_conv_desc.split3): a0 is a pair tensor, w holds per tap and 32-channel block [W_hi | W_lo];
         # W_hi A_hi + W_hi A_lo + W_lo A_hi  (W_lo A_lo is not formed)

@@ -1349,3 +1349,65 @@ def test_conv_gemm32_groupnorm_moments(dtype, f32out, gemm32_on):
     tol = 2e-5 if f32out else (3e-3 if dtype == torch.bfloat16 else 4e-4)
     check("scale", sc, sc_ref, tol)
     check("shift", sh, sh_ref, max(tol, 1e-4) * 10)
+
+
+# ------------------------------------------------------------------------------------ sub-pixel upsampling convolution
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["small", "pano", "level1_f32_gn", "level0_16bit", "splitk"])
+def test_conv_gemm_subpixel_upsample(dtype, case):
+    """pf_conv_desc.subpixel: nearest x2 + 3x3 convolution as four 2x2 phase convolutions on the low-resolution grid (4 instead of 9 MACs
+    per output value and input channel).  Against (a) the same four phase convolutions in fp32 torch on the SAME rounded weights and
+    (b) the textbook F.interpolate + conv2d with the fp32 weights (the algebra: only the weights' rounding differs).  Cases: a small
+    one (4-wave kernel), the panorama's pad 1 / upsample / conv / crop 2 (virtual circular padding), the 16^2 -> 32^2 level with fp32
+    output and the GroupNorm moments, the 32^2 -> 64^2 level in 16 bit (persistent 8-wave kernel), a split-K plan (8^2 level)."""
+    from panfusion_amd import engine
+    o = ops()
+    torch.backends.cudnn.allow_tf32 = False
+    n, h, w, cin, cout, wrap, crop, f32, gn = {"small": (3, 10, 12, 128, 192, 0, 0, False, False), "pano": (2, 8, 20, 128, 192, 1, 2, False, False),
+                                                "level1_f32_gn": (40, 16, 16, 1280, 1280, 0, 0, True, True), "level0_16bit": (40, 32, 32, 640, 640, 0, 0, False, False),
+                                                "splitk": (2, 8, 16, 1280, 1280, 1, 2, True, False)}[case]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / (9 * cin) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, device=DEV, generator=g))
+    x = torch.randn(n, h, w, cin, device=DEV, generator=g).to(dtype)
+    w4 = engine._subpixel_weight(conv, DEV, dtype)
+    assert w4.shape == (4 * cout, 4 * cin)
+    kw = dict(n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1, bias=conv.bias.detach(), wrap_pad=wrap, crop=crop,
+              out_dtype=torch.float32 if f32 else None)
+    got = o.conv_gemm(x, w4, cout, subpixel=True, gn_stats=gn, **kw)
+    xin = x.float().permute(0, 3, 1, 2)
+    if wrap:
+        xin = torch.cat([xin[..., -wrap:], xin, xin[..., :wrap]], -1)
+    # (a) the same four phase convolutions on the same rounded weights
+    w4f = w4.float().reshape(4, cout, 2, 2, cin)
+    ya = torch.zeros(n, cout, 2 * xin.shape[2], 2 * xin.shape[3], device=DEV)
+    for a in range(2):
+        for b in range(2):
+            ya[:, :, a::2, b::2] = F.conv2d(F.pad(xin, (1 - b, b, 1 - a, a)), w4f[2 * a + b].permute(0, 3, 1, 2).contiguous())
+    ya = ya + conv.bias.detach()[None, :, None, None]
+    # (b) the textbook form on the fp32 weights
+    yb = F.conv2d(F.interpolate(xin, scale_factor=2.0, mode="nearest"), conv.weight.detach(), conv.bias.detach(), padding=1)
+    if crop:
+        ya, yb = ya[..., crop:-crop], yb[..., crop:-crop]
+    ho, wo = ya.shape[2:]
+    assert got.shape == (n * ho * wo, cout)
+    tol = (2e-3 if dtype == torch.bfloat16 else 3e-4) if f32 else TOL[dtype]
+    check("subpixel " + case + " vs phase convs", got, ya.permute(0, 2, 3, 1).reshape(-1, cout), tol)
+    check("subpixel " + case + " vs interpolate + conv3x3", got, yb.permute(0, 2, 3, 1).reshape(-1, cout), 8e-3 if dtype == torch.bfloat16 else 1.2e-3)
+    if gn:
+        assert hasattr(got, "_pf_gn"), "whole-round sub-pixel problems emit GroupNorm moments"
+        gamma, beta = torch.randn(cout, device=DEV, generator=g), torch.randn(cout, device=DEV, generator=g)
+        sc, sh = o.groupnorm_scale_shift(got, None, n, ho * wo, 32, 1e-5, gamma, beta)
+        yf = got.float().view(n, ho * wo, 32, cout // 32)
+        mean, var = yf.mean(dim=(1, 3), keepdim=True), yf.var(dim=(1, 3), unbiased=False, keepdim=True)
+        sc_ref = (var + 1e-5).rsqrt().expand(n, 1, 32, cout // 32).reshape(n, cout) * gamma
+        sh_ref = beta - mean.expand(n, 1, 32, cout // 32).reshape(n, cout) * sc_ref
+        check("subpixel moments: scale", sc, sc_ref, 2e-5)
+        check("subpixel moments: shift", sh, sh_ref, 2e-4)
+    if case == "splitk":
+        assert o.gemm_workspace_bytes(x, w4, cout, subpixel=True, **{k: v for k, v in kw.items() if k not in ("bias", "out_dtype")}) > 0, \
+            "this shape is expected to take a split-K plan"
