@@ -309,7 +309,7 @@ typedef struct {
                           * weights -- 4 instead of 9 MACs per (output value, input channel), the same sums in exact arithmetic.  `w` then holds
                           * [4 phases][n_out][2][2][c0 + c1] (phase-major, 16-bit; panfusion_amd.engine._subpixel_weight builds it: row taps of
                           * phase a = 0: {W[0]}, {W[1] + W[2]}; a = 1: {W[0] + W[1]}, {W[2]}; columns alike).  Bias only (no row vector,
-                          * residual, GEGLU / pair epilogue, split3), batch 1, h_out / w_out even; wrap_pad 0..1 with crop 2 x wrap_pad is the
+                          * residual, GEGLU / pair epilogue; split3 allowed: c0 = 2 x channels per tap), batch 1, h_out / w_out even; wrap_pad 0..1 with crop 2 x wrap_pad is the
                           * panorama's pad 1 / upsample / conv / crop 2.  gn_partial is supported (runs of R LOW-resolution rows).            */
 } pf_conv_desc;
 

@@ -1652,7 +1652,7 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
     }
     if (d->subpixel)
         PF_REQUIRE(d->ksize == 3 && d->upsample == 1 && d->stride == 1 && d->pad == 1 && d->batch == 1 && !d->residual && !d->rowvec &&
-                   d->epilogue == PF_EPILOGUE_NONE && !d->split3 && d->h_out % 2 == 0 && d->w_out % 2 == 0 && d->crop % 2 == 0 && d->wrap_pad <= 1,
+                   d->epilogue == PF_EPILOGUE_NONE && d->h_out % 2 == 0 && d->w_out % 2 == 0 && d->crop % 2 == 0 && d->wrap_pad <= 1,
                    "pf_conv_gemm: subpixel serves nearest x2 + 3x3 stride-1 pad-1 convolutions (bias only; weights packed [4][n_out][2][2][c0 + c1])");
     const int batch = eff_batch(d);
     GemmParams p;

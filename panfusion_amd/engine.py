@@ -38,6 +38,7 @@ def default_precision(dtype):
 
 RAW_PAIR_FUSED = os.environ.get("PF_RAW_PAIR", "1") != "0"      # A/B: 0 = the shortcut operand by its own split pass
 VIRTUAL_PAD = os.environ.get("PF_VIRTUAL_PAD", "1") != "0"      # A/B: 0 = materialised pad_pano / unpad_pano copies around the panorama convs
+EXACT_UP0 = os.environ.get("PF_EXACT_UP0", "1") != "0"          # A/B: 0 = the level-0 upsampling convolution single-pass 16 bit like the other two (mixed scheme)
 SUBPIXEL_UP = os.environ.get("PF_SUBPIXEL_UP", "1") != "0"      # A/B: 0 = the upsampling convolutions as nearest x2 + 3x3 (9 taps) instead of four 2x2 phase convolutions (4 taps)
 FUSED_HEAD = os.environ.get("PF_FUSED_HEAD", "1") != "0"        # A/B: 0 = GroupNorm-apply + SiLU pass, then conv_out (two launches)
 
@@ -308,7 +309,12 @@ def pack_unet(unet, dev, dtype, mixed=False):
         if blk.upsamplers is not None:
             c = blk.upsamplers[0].conv
             b.up = NS(w=_conv3_weight(c, dev, dtype), b=_bias(c, dev), c=c.weight.shape[0], src=c,
-                      w4=_subpixel_weight(c, dev, dtype) if SUBPIXEL_UP else None)
+                      w4=_subpixel_weight(c, dev, dtype) if SUBPIXEL_UP else None, w4s=None)
+            # mixed scheme: the LAST upsampling convolution (32^2 -> 64^2, level 0) maps the stream in split precision -- tools/precision_study.py
+            # (S1+sp+d+hd+u@0, round 6): 10 % of the views' error and 9 % of the panorama's sit in this one layer's operand / weight rounding
+            # (the other two: < 1 %); with the sub-pixel form's 2.25x fewer MACs the three products still cost less than the plain 9-tap conv did
+            if mixed and SUBPIXEL_UP and EXACT_UP0 and len(u.up) == len(unet.up_blocks) - 2 and c.weight.shape[1] % 32 == 0:
+                b.up.w4s = _split_weight(_subpixel_weight(c, dev, torch.float32), 4, dev, dtype)
         u.up.append(b)
 
     # one GEMM for every resnet's Linear(silu(temb)) (diffusers ResnetBlock2D.time_emb_proj)
@@ -677,6 +683,12 @@ class Branch:
 
     def upsample(self, up):             # pano: pad 1, nearest x2 + conv, crop 2   (:272-277)
         virt = self.pad and VIRTUAL_PAD
+        if getattr(up, "w4s", None) is not None and (virt or not self.pad) and self.h.dtype == torch.float32:
+            n, h, w, Cc = self.h.shape                # split precision: the pair of the fp32 stream against [W_hi | W_lo] of the phase weights
+            y = exact_gemm(split_operand(self.h, dtype=self.u.dtype), up.w4s, up.c, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1,
+                           bias=up.b, out_dtype=self.u.stream, gn_stats=not self.pad, subpixel=True, **(dict(wrap_pad=1, crop=2) if virt else {}))
+            self.h = y.view(n, 2 * h, 2 * w, up.c) if virt else ops.carry(y.view(n, 2 * h, 2 * w, up.c), y)
+            return
         x = to16(self.h if virt else self._padded(self.h, 1), self.u.dtype)
         n, h, w, Cc = x.shape
         geo = dict(wrap_pad=1, crop=2) if virt else {}

@@ -285,10 +285,34 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
               bias=None, rowvec=None, residual=None, out=None, out_dtype=None, batch=1, geglu=False, c0=None, c1=None,
               a0_ld=None, a1_ld=None, algo_k=None, a_bstride=0, w_bstride=0, out_bstride=0, split_out=False, pad_hi=0,
               gn_stats=False, wrap_pad=0, crop=0, split3=False, subpixel=False, **kw):
+    if split3:
+        # split-precision walk (pf_conv_desc.split3): a0 is a pair tensor, w holds per tap and 32-channel block [W_hi | W_lo];
+        # W_hi A_hi + W_hi A_lo + W_lo A_hi  (W_lo A_lo is not formed)
+        assert a1 is None and batch == 1
+        C2 = c0 or a0.shape[-1]
+        a_hi, a_lo = _unpair(a0.reshape(-1, a0_ld or a0.shape[-1])[:, :C2])
+        wrows = 4 * n_out if subpixel else n_out                   # (sub-pixel form: [4 phases x n_out] rows of 4 taps)
+        w_hi, w_lo = _unpair(w.reshape(wrows, 4 if subpixel else ksize * ksize, C2))
+        common = dict(n_img=n_img, h_in=h_in, w_in=w_in, ksize=ksize, stride=stride, pad=pad, upsample=upsample, pad_hi=pad_hi,
+                      wrap_pad=wrap_pad, crop=crop, out_dtype=torch.float32, subpixel=subpixel)
+        part = conv_gemm(a_hi, w_lo.reshape(wrows, -1), n_out, **common)
+        if w_in is None:
+            w_in = a_hi.shape[0]
+        if subpixel:                                               # (no residual operand in that form: add the W_lo A_hi part afterwards)
+            y = conv_gemm(a_hi + a_lo, w_hi.reshape(wrows, -1), n_out, bias=bias, **common) + part
+            y = y.to(out_dtype or a0.dtype)
+            if out is not None:
+                out.copy_(y.reshape(out.shape))
+                return out
+            return y
+        return conv_gemm(a_hi + a_lo, w_hi.reshape(n_out, -1), n_out, bias=bias, rowvec=rowvec,
+                         residual=part if residual is None else part + residual.float().reshape(part.shape[0], -1)[:, :n_out],
+                         out=out, out_dtype=out_dtype or (residual.dtype if residual is not None else a0.dtype), geglu=geglu,
+                         split_out=split_out, gn_stats=gn_stats, **{k: v for k, v in common.items() if k != "out_dtype"})
     if subpixel:
         # pf_conv_desc.subpixel: nearest x2 + 3x3 as four 2x2 phase convolutions on the low-resolution grid; w = [4][n_out][2][2][C].
         # Output pixel (2 y + a, 2 x + b) reads rows y - 1 + a, y + a and columns x - 1 + b, x + b (zero outside the image).
-        assert ksize == 3 and upsample == 1 and stride == 1 and pad == 1 and residual is None and rowvec is None and not geglu and not split3
+        assert ksize == 3 and upsample == 1 and stride == 1 and pad == 1 and residual is None and rowvec is None and not geglu
         x = a0.float().reshape(-1, a0_ld or a0.shape[-1])[:, :(c0 or a0.shape[-1])]
         if a1 is not None:
             x = torch.cat([x, a1.float().reshape(-1, a1_ld or a1.shape[-1])[:, :(c1 or a1.shape[-1])]], -1)
@@ -313,22 +337,6 @@ def conv_gemm(a0, w, n_out, *, a1=None, n_img=1, h_in=1, w_in=None, ksize=1, str
             out.copy_(y.reshape(out.shape))
             return out
         return y
-    if split3:
-        # split-precision walk (pf_conv_desc.split3): a0 is a pair tensor, w holds per tap and 32-channel block [W_hi | W_lo];
-        # W_hi A_hi + W_hi A_lo + W_lo A_hi  (W_lo A_lo is not formed)
-        assert a1 is None and batch == 1
-        C2 = c0 or a0.shape[-1]
-        a_hi, a_lo = _unpair(a0.reshape(-1, a0_ld or a0.shape[-1])[:, :C2])
-        w_hi, w_lo = _unpair(w.reshape(n_out, ksize * ksize, C2))
-        common = dict(n_img=n_img, h_in=h_in, w_in=w_in, ksize=ksize, stride=stride, pad=pad, upsample=upsample, pad_hi=pad_hi,
-                      wrap_pad=wrap_pad, crop=crop, out_dtype=torch.float32)
-        part = conv_gemm(a_hi, w_lo.reshape(n_out, -1), n_out, **common)
-        if w_in is None:
-            w_in = a_hi.shape[0]
-        return conv_gemm(a_hi + a_lo, w_hi.reshape(n_out, -1), n_out, bias=bias, rowvec=rowvec,
-                         residual=part if residual is None else part + residual.float().reshape(part.shape[0], -1)[:, :n_out],
-                         out=out, out_dtype=out_dtype or (residual.dtype if residual is not None else a0.dtype), geglu=geglu,
-                         split_out=split_out, gn_stats=gn_stats, **{k: v for k, v in common.items() if k != "out_dtype"})
     if batch > 1:          # independent problems (attention scores / P.V of the VAE): plain linears only
         assert ksize == 1 and a1 is None and bias is None and residual is None and rowvec is None and not geglu
         K = c0 or a0.shape[-1]

@@ -138,11 +138,15 @@ def test_cfg1_ten_ddim_steps_vs_oracle(full_oracle, graphs):
     print("  " + "  ".join("%d: %.2e/%.2e" % (i + 1, a, b) for i, (a, b) in enumerate(drift)))
     lat, pano = loop.result()
     el, ep = rel_l2(lat.cpu(), torch.from_numpy(gd["latents"][-1])), rel_l2(pano.cpu(), torch.from_numpy(gd["pano_latent"][-1]))
-    print("  final: views %.3e  pano %.3e  (tolerance 1.3e-3)" % (el, ep))
-    # (one step already carries the CFG merge: eps = u + 9 (c - u) amplifies the two calls' 8e-4 by ~12 relative to eps, the
-    # DDIM update scales it back by the step's eps coefficient: measured 1.0e-3 / 9.3e-4 after step 1, flat from there on)
-    assert drift[0][0] <= 1.2e-3 and drift[0][1] <= 1.2e-3, drift[0]
-    assert el <= 1.3e-3 and ep <= 1.3e-3, (el, ep)
+    print("  final: views %.3e  pano %.3e  (tolerance 1.0e-3 at every step)" % (el, ep))
+    # One step already carries the CFG merge: eps = u + 9 (c - u) amplifies the two calls' error by ~12 relative to eps, the DDIM update
+    # scales it back by the step's eps coefficient -- flat from step 2 on.  Round 6: the gate is north_star's 1e-3 at
+    # EVERY step for views AND panorama (rounds 3-5: 1.2e-3 / 1.3e-3 around a measured 1.02e-3): the level-0 upsampling convolution in split
+    # precision and the sub-pixel form of all three brought the trajectory to 9.05e-4 / 8.72e-4 at its worst step
+    # (profiles/r6_final_configs_parity.log).
+    for i, (a, b) in enumerate(drift):
+        assert a <= 1.0e-3 and b <= 1.0e-3, (i + 1, a, b)
+    assert el <= 1.0e-3 and ep <= 1.0e-3, (el, ep)
 
 
 STRESS_TOL = 1e-3
