@@ -1363,6 +1363,17 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     // (k_attention_lds addresses K / V^T tiles with 32-bit byte offsets inside one (batch, head) slice)
     const bool fits32 = !PF_ATTN_BUFLOAD || (static_cast<long>(d->nk + 64) * d->k_ld * 2 < (1L << 31) && static_cast<long>(d->vt_ld) * (d->D + 1) * 2 < (1L << 31));
     const bool lds = use_lds_attention() && d->vt_ld % 8 == 0 && d->vt_bs % 8 == 0 && fits32;
+    // The experimental ping-pong kernels (PF_ATTENTION_PP = 1 / 2) address K and V^T with 32-bit byte offsets inside a (batch, head) slice.
+    // Evaluated HERE, outside PF_DISPATCH_16: a preprocessor conditional inside that macro's argument had swallowed the K-offset guard
+    // of the one-tile form -- no directives inside macro arguments.
+    const bool pp_fits = static_cast<long>(d->nk) * d->k_ld * 2 < (1L << 31) && static_cast<long>(d->vt_ld) * 64 * 2 < (1L << 31);
+#ifdef PF_ATTN_PP_TIMING
+    const bool pp_lse_ok = true;                                                   // (the timing build writes its stamps over lse)
+#else
+    const bool pp_lse_ok = !d->lse;                                                // (lse = training forward: exact fp32 row sums there)
+#endif
+    const bool pp1_ok = pp_lse_ok && d->nk % 8 == 0 && d->nk >= 128 && pp_fits;
+    const bool pp2_ok = !d->lse && d->nk % 128 == 0 && d->nk >= 256 && pp_fits;
     PF_DISPATCH_16(d->dtype, "pf_attention",
         if (lds) {
             static const int occ64 = attention_occupancy("PF_ATTENTION_OCC", 3), occ32 = attention_occupancy("PF_ATTENTION_OCC32", 3);
@@ -1372,15 +1383,9 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
             if (d->D == 64) {
                 if (d->bias) {                 // (not pipelined it needs 169 registers at three waves per SIMD)
                     hipLaunchKernelGGL((k_attention_lds<T, 64, true>), grid1, block, 0, st, p);
-                } else if (pingpong == 2 && !d->lse && d->nk % 128 == 0 && d->nk >= 256 && static_cast<long>(d->nk) * d->k_ld * 2 < (1L << 31) &&
-                           static_cast<long>(d->vt_ld) * 64 * 2 < (1L << 31)) {
+                } else if (pingpong == 2 && pp2_ok) {
                     hipLaunchKernelGGL((k_attention_pp2<T>), dim3(static_cast<unsigned>(cdiv(d->nq, 256) * d->H * d->B)), dim3(512), 0, st, p);
-#ifdef PF_ATTN_PP_TIMING
-                } else if (pingpong && d->nk % 8 == 0 && d->nk >= 128 &&                  // (the timing build writes its stamps over lse)
-#else
-                } else if (pingpong && !d->lse && d->nk % 8 == 0 && d->nk >= 128 &&      // (lse = training forward: exact fp32 row sums there)
-#endif static_cast<long>(d->nk) * d->k_ld * 2 < (1L << 31) &&
-                           static_cast<long>(d->vt_ld) * 64 * 2 < (1L << 31)) {
+                } else if (pingpong && pp1_ok) {
                     hipLaunchKernelGGL((k_attention_pp<T>), dim3(static_cast<unsigned>(cdiv(d->nq, 256) * d->H * d->B)), dim3(512), 0, st, p);
                 } else {
                     if (occ64 == 2) hipLaunchKernelGGL((k_attention_lds<T, 64, false>), grid1, block, 0, st, p);

@@ -615,8 +615,10 @@ class Branch:
         cache = self.u.__dict__.setdefault("text_kv_cache", {})
         hit = cache.get(key)
         if hit is None:
-            if len(cache) >= 4:                       # a handful of prompts at most (graphs read these by address)
-                cache.pop(next(iter(cache)))
+            if len(cache) >= 4:                       # a handful of prompts at most; entries a captured graph still reads are never evicted
+                victim = next((ck for ck, h in cache.items() if not h.get("pins")), None)
+                if victim is not None:
+                    cache.pop(victim)
             hit = {id(t): text_kv(t.attn2, self.text) for t in all_transformers(self.u)}
             hit["text"] = self.text                   # keeps the storage (and so the key) alive
             cache[key] = hit

@@ -215,7 +215,7 @@ class MultiViewBaseModel(nn.Module):
             # for tensors nobody would read again).  The refresh runs on the CURRENT stream: a caller that replays a DenoiseLoop graph
             # on another stream while training on this one must order the two itself (wait_stream), as for any shared weight.
             cache = getattr(u, "text_kv_cache", {})
-            for ck in [ck for ck, hit in cache.items() if not hit.get("pinned")]:
+            for ck in [ck for ck, hit in cache.items() if not hit.get("pins")]:     # (an empty WeakSet: every graph that read the entry is gone)
                 del cache[ck]
             for hit in cache.values():
                 for t in engine.all_transformers(u):

@@ -146,11 +146,19 @@ class DenoiseLoop:
     def _graph_keepalive(self):
         """Tensors a captured graph reads by address but that live in bounded caches of the model (16-bit prompt
         casts, text K / V^T per UNet): referenced from the graph entry so that an eviction cannot free them under it."""
-        keep = [list(getattr(self.model, "_prompt_cache", {}).values())]
+        import weakref
+
+        class _Pin:                               # lives exactly as long as the graph entry that holds the returned list
+            pass
+        owner = _Pin()
+        keep = [owner, list(getattr(self.model, "_prompt_cache", {}).values())]
         for packed in getattr(self.model, "_packed", {}).values():
             hits = list(getattr(packed, "text_kv_cache", {}).values())
             for hit in hits:
-                hit["pinned"] = True          # a captured graph reads these buffers by address: refold_lora refreshes them IN PLACE
+                # a captured graph reads these buffers by address: refold_lora refreshes them IN PLACE for as long as some graph entry
+                # is alive (a WeakSet of the entries' tokens: dropping the loop / its graphs un-pins the entry -- ADVICE r5), and
+                # Branch.precompute_text_kv does not evict a pinned entry
+                hit.setdefault("pins", weakref.WeakSet()).add(owner)
             keep.append(hits)
         return keep
 

@@ -217,9 +217,12 @@ def test_sharded_loop_equals_single_process(world, split, layout, precision):
 @pytest.mark.parametrize("world,split,precision", [(4, None, "fast"), (4, (1, 3), "mixed"), (8, None, "fast")])
 def test_panorama_self_attention_split_over_the_cfg_half(world, split, precision):
     """SURVEY.md 8e, configs[3]: the panorama owner's big self-attentions are query-split over the ranks of its CFG half
-    (sharding.split_pano_attention: broadcast of q | k and V^T, every rank computes nq / G rows, one all-gather) -- here forced at toy
+    (sharding.split_pano_attention: broadcast of the layer-normed TOKENS, every rank projects q | k | V^T itself and computes nq / G rows
+    of the output, one all-gather returns them) -- here forced at toy
     sizes (>= 128 tokens: the 16 x 32 and 8 x 16 levels).  Same result as the single process, bit-identical replicas, and the
-    collectives show up in the accounting bench.py prints."""
+    collectives show up in the accounting bench.py prints.  CPU / gloo coverage only; the graph-segment side (SegmentedGraph with a split
+    attention on an owner that also holds views and runs the panorama branch on its side stream) is exercised by the real-kernel dry run
+    profiles/r6_dist_dry_cfg4_owner_with_views_split.txt (tools/gpu_dist_dry.sh, graphs_in_use True on every rank)."""
     want = _run_loop(False, precision=precision)
     with tempfile.TemporaryDirectory() as out:
         mp.spawn(_worker, args=(world, _free_port(), out, split, None, precision, False, 128), nprocs=world, join=True)

@@ -256,8 +256,13 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
         hip(*args)                                        # an inference forward (validation, DenoiseLoop): caches the prompts' K / V^T
     # (a captured DenoiseLoop graph pins the entries it reads by address -- pipeline.DenoiseLoop._graph_keepalive; the panorama
     # UNet's entry stays unpinned here: the re-fold must DROP it instead of recomputing K / V^T nobody will read)
+    import weakref
+
+    class _GraphEntry:                                    # stands for the graph entry whose keep-alive list holds the pin token
+        pass
+    entry = _GraphEntry()
     for hit in pack_before.text_kv_cache.values():
-        hit["pinned"] = True
+        hit.setdefault("pins", weakref.WeakSet()).add(entry)
     pano_pack = hip.packed("pano_unet", args[1].device)
     assert getattr(pano_pack, "text_kv_cache", {})
     kv_before = {k: (hit, {i: (v[0].data_ptr(), v[0].clone()) for i, v in hit.items() if isinstance(i, int)})
@@ -275,11 +280,20 @@ def test_optimizer_step_refolds_lora_into_the_forward_weights(fake_denoiser_back
         s2, ps2 = hip(*args)                              # served from the cache
     assert rel_l2(s2, want_s) < 5e-5 and rel_l2(ps2, want_ps) < 5e-5
     assert kv_before
-    assert all(h.get("pinned") is None for h in pano_pack.text_kv_cache.values())      # dropped at the re-fold, rebuilt on use
+    assert all(not h.get("pins") for h in pano_pack.text_kv_cache.values())            # dropped at the re-fold, rebuilt on use
     for k, (hit, olds) in kv_before.items():                 # same entries, same storage, new contents
         assert pack_before.text_kv_cache[k] is hit
         for i, (ptr, old) in olds.items():
             assert hit[i][0].data_ptr() == ptr and not torch.equal(hit[i][0], old)
+    # once the graph entry is gone the pin is gone -- the next re-fold drops the entry instead of refreshing it for ever
+    del entry
+    import gc
+    gc.collect()
+    assert all(not h.get("pins") for h in pack_before.text_kv_cache.values())
+    ((s1 * w_s).sum() + (ps1 * w_p).sum()).backward()
+    opt.step()
+    hip.refold_lora()
+    assert not pack_before.text_kv_cache, "un-pinned text K / V^T entries are dropped at the re-fold"
 
 
 def test_training_step_with_layout_condition_frozen_controlnet(fake_denoiser_backend):

@@ -37,6 +37,15 @@ SHAPES = {
     "conv64_2r_res": (32, 64, 64, 320, 320, 3, {"res": True}),
     "conv64_n640": (40, 64, 64, 640, 640, 3, {}),
     "conv32_1r": (32, 32, 32, 640, 640, 3, {}),
+    # small-M linears of the panorama branch / the deep levels (180 launches per step at 0.106 of peak)
+    "sm1024_1280": (1, 1, 1024, 1280, 1280, 1, {}),
+    "sm1024_2560": (1, 1, 1024, 2560, 1280, 1, {}),
+    "sm256_1280": (1, 1, 256, 1280, 1280, 1, {}),
+    "sm256_5120": (1, 1, 256, 5120, 1280, 1, {}),
+    "sm4096_640": (1, 1, 4096, 640, 640, 1, {}),
+    "sm4096_1280": (1, 1, 4096, 1280, 640, 1, {}),
+    "sm1024_ff1": (1, 1, 1024, 1280, 10240, 1, {"geglu": True}),
+    "sm2560_1280": (1, 1, 2560, 1280, 1280, 1, {}),
     "conv64res": (40, 64, 64, 320, 320, 3, {"res": True}),
     "conv32res": (40, 32, 32, 640, 640, 3, {"res": True}),
     "conv16res": (40, 16, 16, 1280, 1280, 3, {"res": True}),
