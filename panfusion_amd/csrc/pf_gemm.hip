@@ -531,12 +531,17 @@ __device__ __forceinline__ void splitk_finish(const GemmParams& p, long bz, int 
     if (t == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T, int MREP, int NREP, bool STATS = false, bool S3 = false>
-__global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
+// STAGES (round 6): ring depth.  2 = the original form, two blocks per CU, ONE K step of DMA look-ahead and a full drain per step -- every
+// step then costs a whole L2 round trip (~1 us per 64-wide step measured on the panorama branch's small-M layers: M 1024 N 1280 K 1280
+// ran 20 steps in 20.8 us, 0.1 of peak).  4 = one block per CU (115 KB), stage it+3 requested while stage it is multiplied and awaited with a
+// COUNTED s_waitcnt that leaves the two younger stages in flight: the launch-latency-bound problems whose grid is one round of the chip
+// anyway (180 launches per step; the floor of every sharded rank).
+template <typename T, int MREP, int NREP, bool STATS = false, bool S3 = false, int STAGES = 2>
+__global__ __launch_bounds__(256, STAGES > 2 ? 1 : 2) void k_conv_gemm(const GemmParams p) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    unsigned short* As = smem;                       // [2][BM][64]
-    unsigned short* Bs = smem + 2 * BM * 64;         // [2][BN][64]
+    unsigned short* As = smem;                       // [STAGES][BM][64]
+    unsigned short* Bs = smem + STAGES * BM * 64;    // [STAGES][BN][64]
 
     // XCD-aware, bijective remap of the 1-D tile id (8 XCDs, block b runs on XCD b % 8).
     const int ntile_total = p.mtiles * p.ntiles;
@@ -701,15 +706,41 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const GemmParams p) {
     };
 
     stamp(p, 0);
-    dma_stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    stamp(p, 1);
-    for (int kb = kb0, it = 0; kb < kb1; ++kb, ++it) {
-        if (kb + 1 < kb1) dma_stage((it + 1) & 1);            // in flight during the MFMAs
-        compute(it & 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's DMA has landed ...
-        __syncthreads();                                      // ... before anyone reads the tile
+    if constexpr (STAGES == 2) {
+        dma_stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stamp(p, 1);
+        for (int kb = kb0, it = 0; kb < kb1; ++kb, ++it) {
+            if (kb + 1 < kb1) dma_stage((it + 1) & 1);            // in flight during the MFMAs
+            compute(it & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's DMA has landed ...
+            __syncthreads();                                      // ... before anyone reads the tile
+        }
+    } else {
+        // Deep ring: stages it+1 .. it+STAGES-1 are in flight while stage it is multiplied.  Every wave issues exactly L = MREP + NREP DMA
+        // instructions per stage and loads retire in order among themselves, so "at most (STAGES - 2) L outstanding" means stage it+1
+        // has landed whatever the younger ones are doing; the last STAGES - 2 steps (nothing left to request) drain fully.
+        constexpr int L = MREP + NREP, KEEP = (STAGES - 2) * L;
+        const int n_it = kb1 - kb0;
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < n_it) dma_stage(s);
+        if (n_it >= STAGES - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stamp(p, 1);
+        int slot = 0, fill = STAGES - 1;                          // slot of stage it; slot stage it+STAGES-1 goes to (= the one step it-1 read)
+        for (int it = 0; it < n_it; ++it) {
+            const bool more = it + STAGES - 1 < n_it;
+            if (more) dma_stage(fill);
+            compute(slot);
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                      // stage it+1 complete on every wave; slot of stage it free
+            slot = slot == STAGES - 1 ? 0 : slot + 1;
+            fill = fill == STAGES - 1 ? 0 : fill + 1;
+        }
     }
     stamp(p, 2);
 
@@ -1280,6 +1311,21 @@ static inline ProfState prof_snapshot() {
 }
 
 
+static int tuning(const char* name, int dflt);
+template <typename T, int MREP, int NREP, bool STATS, bool S3, int STAGES>
+static pf_status launch_ring(const GemmParams& p, int batch, hipStream_t st) {
+    constexpr int BM = 32 * MREP, BN = 32 * NREP;
+    const size_t smem = static_cast<size_t>(STAGES) * (BM + BN) * 64 * sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP, STATS, S3, STAGES>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP, STATS, S3, STAGES>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(256), smem, st, p);
+    return PF_OK;
+}
+
 template <typename T, int MREP, int NREP, bool STATS = false, bool S3 = false>
 static pf_status launch_s(const GemmParams& gp, int batch, hipStream_t st) {
     constexpr int BM = 32 * MREP, BN = 32 * NREP;
@@ -1288,14 +1334,16 @@ static pf_status launch_s(const GemmParams& gp, int batch, hipStream_t st) {
     p.ntiles = static_cast<int>(cdiv(p.N, BN));
     const ProfState ps = prof_snapshot();
     p.prof = (ps.buf && static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch <= ps.blocks) ? ps.buf : nullptr;
-    const size_t smem = static_cast<size_t>(2) * (BM + BN) * 64 * sizeof(unsigned short);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_gemm<T, MREP, NREP, STATS, S3>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
-        attr_set = true;
+    // a grid of at most one block per CU runs the four-slot ring (one block per CU: nothing to share the CU with anyway)
+    static const int deep_max = tuning("PF_GEMM_DEEP_RING", 1) ? tuning("PF_GEMM_DEEP_RING_MAX_BLOCKS", 256) : 0;
+    const long blocks = static_cast<long>(p.mtiles) * p.ntiles * p.splits * batch;
+    // (instantiated for the plain kernels only: the moment / split-precision variants keep the two-slot form -- compile time)
+    if constexpr (!STATS && !S3) {
+        if (blocks <= deep_max && p.K / 64 / p.splits >= 3) launch_ring<T, MREP, NREP, false, false, 4>(p, batch, st);
+        else launch_ring<T, MREP, NREP, false, false, 2>(p, batch, st);
+    } else {
+        launch_ring<T, MREP, NREP, STATS, S3, 2>(p, batch, st);
     }
-    hipLaunchKernelGGL((k_conv_gemm<T, MREP, NREP, STATS, S3>), dim3(p.mtiles * p.ntiles, p.splits, batch), dim3(256), smem, st, p);
     PF_CHECK_LAUNCH("pf_conv_gemm");
     if (p.splits > 1 && !p.tickets) {
         const long total = static_cast<long>(batch) * (p.M - p.m_begin) * (p.N / 4);
@@ -1478,6 +1526,19 @@ static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_spli
     g.kb_per_split = nkb;
     // split-K when the grid cannot fill the chip and K is long: aim at ~640 blocks, >= 6 K-blocks each
     static const int split_min_kb = tuning("PF_GEMM_SPLIT_MINKB", 12);   // least K depth (64-blocks) for split-K on the 4-wave kernel
+    // Round 6: a grid of <= 256 blocks runs the four-slot ring, one block per CU (launch_s): there the split aims at ONE round of the chip
+    // (fewer fp32 slabs for the reduce kernel: 128 tiles x 2 K slices instead of x 5) and a K slice may be as short as 4 steps.
+    static const int deep = tuning("PF_GEMM_DEEP_RING", 1);
+    if (deep && tiles <= 256) {
+        long s = allow_split && N % 4 == 0 && nkb >= split_min_kb ? 256 / tiles : 1;
+        if (s > nkb / 4) s = nkb / 4;
+        if (s > 32) s = 32;
+        if (s > 1) {
+            g.kb_per_split = static_cast<int>(cdiv(nkb, s));
+            g.splits = static_cast<int>(cdiv(nkb, g.kb_per_split));
+        }
+        return g;
+    }
     if (allow_split && N % 4 == 0 && tiles <= 320 && nkb >= split_min_kb) {
         long s = (640 + tiles - 1) / tiles;
         if (s > nkb / 6) s = nkb / 6;

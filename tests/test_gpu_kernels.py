@@ -1163,7 +1163,7 @@ SPLITK_INKERNEL_CASES = [
     (40, 16, 16, 1280, 1280, 3, "rowvec16"),   # tail split: full rounds unsplit + split tail rows
     (2, 8, 20, 1280, 1280, 3, "res32"),        # the panorama's innermost level: 4-wave kernel, deep split
     (2, 16, 36, 640, 1280, 3, "plain16"),
-    (1, 1, 4096, 1920, 640, 1, "res32"),       # long-K linear on few rows
+    (1, 1, 2048, 1920, 640, 1, "res32"),       # long-K linear on few rows (128 tiles x 2 K slices: one round of the four-slot ring)
     (3, 6, 10, 256, 64, 3, "res16"),           # ragged tiles
 ]
 
