@@ -1429,8 +1429,8 @@ static int tuning(const char* name, int dflt) {     // A/B switches for benchmar
 
 // Tile shape + split-K plan of one problem (shared by the launcher and the workspace query).
 struct GemmPlan { int mrep, nrep, splits, kb_per_split; bool big; int m_split; int tail_splits, tail_kb; int bm = 256; };
-static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split);
-static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split);
+static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split, bool s3);
+static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split, bool s3);
 // Which plans of the 8-wave kernel run as 128-row blocks, two per CU (k_conv_gemm8<..., BM_ = 128>): PF_GEMM_BM128 = 0 none,
 // 1 all of them (A/B), 2 (default) the measured rule: the 128-row blocks win where the tile is ramp / epilogue-bound -- short K
 // (K <= PF_GEMM_BM128_MAXK: isolated +7 % at K = 320, +15...22 % at K = 640, +12...16 % at K = 1280; long-K convolutions lose
@@ -1438,8 +1438,8 @@ static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split);
 // 61.36 ms (profiles/r5b_ab_gemm_bm128.txt).  PF_GEMM_BM128_ONEROUND=1 also takes every problem that is ONE round of 256-row tiles
 // (a CU then runs a single ramp + K loop + epilogue with nothing to overlap -- the per-rank GEMMs of the sharded layouts): measured
 // neutral to slightly slower on the simulated ranks (8 ranks 14.35 -> 14.48 ms, 4 ranks 19.9 -> 20.4), so off.
-static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
-    GemmPlan g = plan_gemm0(M, N, K, batch, allow_split);
+static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split, bool s3 = false) {
+    GemmPlan g = plan_gemm0(M, N, K, batch, allow_split, s3);
     static const int mode = tuning("PF_GEMM_BM128", 2);
     static const int max_k = tuning("PF_GEMM_BM128_MAXK", 1280);
     static const int one_round = tuning("PF_GEMM_BM128_ONEROUND", 0);
@@ -1451,7 +1451,7 @@ static GemmPlan plan_gemm(long M, int N, int K, int batch, bool allow_split) {
     }
     return g;
 }
-static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split) {
+static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split, bool s3) {
     static const int big_min_tiles = tuning("PF_GEMM8_MIN_TILES", 128);   // 0 disables the 8-wave kernel
     const int nrep = (N % 160 == 0) ? 5 : 4;
     const long tiles256 = cdiv(M, 256) * cdiv(N, 32 * nrep) * batch;
@@ -1509,9 +1509,9 @@ static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split) {
             return g;
         }
     }
-    return plan_gemm_small(M, N, K, batch, allow_split);
+    return plan_gemm_small(M, N, K, batch, allow_split, s3);
 }
-static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split) {
+static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_split, bool s3) {
     GemmPlan g;
     g.big = false; g.m_split = 0;
     // 160-wide N tiles when they divide N exactly (all UNet widths are multiples of 160), 128-wide
@@ -1529,7 +1529,7 @@ static GemmPlan plan_gemm_small(long M, int N, int K, int batch, bool allow_spli
     // Round 6: a grid of <= 256 blocks runs the four-slot ring, one block per CU (launch_s): there the split aims at ONE round of the chip
     // (fewer fp32 slabs for the reduce kernel: 128 tiles x 2 K slices instead of x 5) and a K slice may be as short as 4 steps.
     static const int deep = tuning("PF_GEMM_DEEP_RING", 1);
-    if (deep && tiles <= 256) {
+    if (deep && !s3 && tiles <= 256) {                               // (the split-precision kernels keep the two-slot ring and its plan)
         long s = allow_split && N % 4 == 0 && nkb >= split_min_kb ? 256 / tiles : 1;
         if (s > nkb / 4) s = nkb / 4;
         if (s > 32) s = 32;
@@ -1755,7 +1755,7 @@ extern "C" pf_status pf_conv_gemm(const pf_conv_desc* d, void* stream) {
         PF_CHECK_LAUNCH("pf_conv_gemm (split-K reduce)");
         return PF_OK;
     }
-    GemmPlan g = plan_gemm(p.M, p.N, p.K, batch, d->workspace != nullptr);
+    GemmPlan g = plan_gemm(p.M, p.N, p.K, batch, d->workspace != nullptr, p.s3 != 0);
     if (d->gn_partial) {
         const int r = gn_rows_for(p, g, batch);
         PF_REQUIRE(r > 0 && aligned16(d->gn_partial), "pf_conv_gemm: gn_partial given but this problem cannot emit GroupNorm moments (ask pf_conv_gemm_gn_rows first)");
@@ -1827,7 +1827,7 @@ extern "C" int pf_conv_gemm_gn_rows(const pf_conv_desc* d) {
     if (!d || d->batch < 1 || d->n_out < 1 || d->n_img < 1) return 0;
     GemmParams p;
     params_from_desc(d, p);
-    if (d->subpixel) return gn_rows_for(p, plan_gemm(p.M, p.N, p.K, 4, true), 4);
+    if (d->subpixel) return gn_rows_for(p, plan_gemm(p.M, p.N, p.K, 4, true, p.s3 != 0), 4);
     {
         const Plan32 g32 = plan32(p, d->batch, true);
         if (g32.use) {
@@ -1835,7 +1835,7 @@ extern "C" int pf_conv_gemm_gn_rows(const pf_conv_desc* d) {
             if (r > 0) return r;                                    // else: the 16x16 kernels' plan below serves a launch that asks for moments
         }
     }
-    return gn_rows_for(p, plan_gemm(p.M, p.N, p.K, d->batch, true), d->batch);
+    return gn_rows_for(p, plan_gemm(p.M, p.N, p.K, d->batch, true, p.s3 != 0), d->batch);
 }
 
 extern "C" int pf_conv_gemm_kernel_id(const pf_conv_desc* d) {
@@ -1843,7 +1843,7 @@ extern "C" int pf_conv_gemm_kernel_id(const pf_conv_desc* d) {
     GemmParams p;
     params_from_desc(d, p);
     if (plan32(p, eff_batch(d), true).use) return 2;
-    return plan_gemm(p.M, p.N, p.K, eff_batch(d), true).big ? 1 : 0;
+    return plan_gemm(p.M, p.N, p.K, eff_batch(d), true, p.s3 != 0).big ? 1 : 0;
 }
 
 extern "C" size_t pf_conv_gemm_workspace_size(const pf_conv_desc* d) {
@@ -1852,7 +1852,7 @@ extern "C" size_t pf_conv_gemm_workspace_size(const pf_conv_desc* d) {
     if (d->subpixel) {                                              // the four phase problems on the low-resolution grid (params_from_desc)
         GemmParams p;
         params_from_desc(d, p);
-        const GemmPlan g = plan_gemm(p.M, p.N, p.K, 4, true);
+        const GemmPlan g = plan_gemm(p.M, p.N, p.K, 4, true, p.s3 != 0);
         return g.splits > 1 ? static_cast<size_t>(g.splits) * 4 * p.M * p.N * sizeof(float) : 0;
     }
     const long M = static_cast<long>(d->n_img) * d->h_out * d->w_out;
@@ -1868,7 +1868,7 @@ extern "C" size_t pf_conv_gemm_workspace_size(const pf_conv_desc* d) {
         }
     }
     // (a launch that asks for GroupNorm moments the 32x32 plan cannot emit takes the 16x16 plan: room for either)
-    const GemmPlan g = plan_gemm(M, d->n_out, K, d->batch, true);
+    const GemmPlan g = plan_gemm(M, d->n_out, K, d->batch, true, d->split3 != 0);
     if (g.big && g.m_split > 0) return std::max(need32, static_cast<size_t>(g.tail_splits) * (M - g.m_split) * d->n_out * sizeof(float));
     return std::max(need32, g.splits > 1 ? static_cast<size_t>(g.splits) * d->batch * M * d->n_out * sizeof(float) : static_cast<size_t>(0));
 }
