@@ -1457,10 +1457,12 @@ static GemmPlan plan_gemm0(long M, int N, int K, int batch, bool allow_split, bo
     const long tiles256 = cdiv(M, 256) * cdiv(N, 32 * nrep) * batch;
     // one 8-wave block per CU: take it only when the tiles fill their rounds of 256 CUs to >= 60 % overall (320
     // tiles would idle for 37 % of the launch; the 4-wave kernel's 2 blocks per CU degrade more gracefully).
-    // The threshold is flat at the single-GPU sizes (17.4-17.5 steps/s from 50 to 95 %) and was set on the smaller
-    // per-rank GEMMs of 2 / 4 / 8 ranks (tools/sim_rank.py: 37.1 -> 33.9 ms per step at 2 ranks from 88 to 60 %).
+    // The threshold was flat at the single-GPU sizes in round 2 (17.4-17.5 steps/s from 50 to 95 %) and was set to 60 on the smaller
+    // per-rank GEMMs of 2 / 4 / 8 ranks (tools/sim_rank.py: 37.1 -> 33.9 ms per step at 2 ranks from 88 to 60 %).  Round 6, last sweep
+    // on the final kernels (profiles/r6n_ab_plan_knobs.txt): 30-50 read -0.2 ... -0.5 ms per step on three boxes, cfg 4 -0.9 ms, the
+    // simulated ranks unchanged (half-filled rounds of the panorama's 64 x 128 level and of the 8 x 8 level now take the persistent kernel): 30.
     const long rounds = cdiv(tiles256, 256);
-    static const int fill_pct = tuning("PF_GEMM8_FILL", 60);
+    static const int fill_pct = tuning("PF_GEMM8_FILL", 30);
     const bool filled = tiles256 * 100 >= rounds * 256 * fill_pct;
     // a badly filled last round of a LONG-K layer (320 tiles of a 16x16-level 3x3 conv = 1.25 rounds) is better spent on a
     // split-K tail launch than on a second full round: the tail split below goes first when the fill is under
