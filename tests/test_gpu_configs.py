@@ -152,6 +152,17 @@ def test_cfg1_ten_ddim_steps_vs_oracle(full_oracle, graphs):
 STRESS_TOL = 1e-3
 
 
+def _against_reference_class(name, s, ps):
+    """The conditional half of the CFG pair against the fixture the REFERENCE's own MultiViewBaseModel produced for it
+    (tools/make_golden_cfg.py cfg4ref / cfg5ref; the port equals it to fp32 round-off: tests/test_oracle_golden.py)."""
+    if not _have(name):
+        return
+    gr = np.load(os.path.join(GOLDEN, name))
+    rv, rp = rel_l2(s[1:].cpu(), torch.from_numpy(gr["sample"])), rel_l2(ps[1:].cpu(), torch.from_numpy(gr["pano_sample"]))
+    print("  conditional half vs the reference class's own output (%s): views %.3e  pano %.3e" % (name, rv, rp))
+    assert rv <= 1e-3 and rp <= 1e-3, (name, rv, rp)
+
+
 @pytest.mark.skipif(not _have("cfg1_stress_eps.npz"), reason="fixture not generated")
 def test_cfg1_range_stress_vs_oracle():
     """RANGE STRESS: the fan-in-scaled synthetic weights keep every residual stream at O(1); here the layers
@@ -185,6 +196,7 @@ def test_cfg4_large_panorama_vs_oracle(full_oracle):
     es, ep = rel_l2(s.cpu(), torch.from_numpy(gd["sample"])), rel_l2(ps.cpu(), torch.from_numpy(gd["pano_sample"]))
     print("\ncfg4 (128x256 pano latent) rel-L2 vs oracle: views %.3e  pano %.3e" % (es, ep))
     assert es <= 1e-3 and ep <= 1e-3, (es, ep)
+    _against_reference_class("cfg4_ref_cond.npz", s, ps)
 
 
 @pytest.mark.skipif(not _have("cfg5_eps.npz"), reason="fixture not generated")
@@ -201,3 +213,4 @@ def test_cfg5_layout_controlnet_vs_oracle():
     es, ep = rel_l2(s.cpu(), torch.from_numpy(gd["sample"])), rel_l2(ps.cpu(), torch.from_numpy(gd["pano_sample"]))
     print("\ncfg5 (panorama ControlNet) rel-L2 vs oracle: views %.3e  pano %.3e" % (es, ep))
     assert es <= 1e-3 and ep <= 1e-3, (es, ep)
+    _against_reference_class("cfg5_ref_cond.npz", s, ps)

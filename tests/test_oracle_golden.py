@@ -1,6 +1,7 @@
 """The oracle restatement vs the fixtures tools/make_golden.py generated from the
 reference's own code (runs everywhere, CPU only)."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import build_tiny_oracle, cam4, golden, rel_l2
@@ -177,3 +178,21 @@ def test_cfg2_port_fixture_equals_the_reference_class_fixture():
     assert float(ref["port_vs_reference"].max()) <= 1e-5
     # the unconditional half differs (another prompt): the comparison above is not vacuous
     assert rel(port["sample"][:1], ref["sample"]) > 1e-2
+
+
+@pytest.mark.parametrize("port_file,ref_file,pano_hw", [("cfg4_eps.npz", "cfg4_ref_cond.npz", (128, 256)), ("cfg5_eps.npz", "cfg5_ref_cond.npz", (64, 128))])
+def test_cfg4_cfg5_port_fixtures_equal_the_reference_class_fixtures(port_file, ref_file, pano_hw):
+    """The same for configs[3] (128 x 256 panorama latent: the reference's dense per-head bias is 6.7 GB per direction) and configs[4]
+    (panorama ControlNet through MVGenModel.py:68-83): the conditional half produced by the reference class agrees with the port-generated
+    fixture to fp32 round-off (tools/make_golden_cfg.py cfg4ref / cfg5ref)."""
+    import os
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if not os.path.exists(os.path.join(here, ref_file)):
+        pytest.skip("reference-class fixture not generated")
+    port, ref = np.load(os.path.join(here, port_file)), np.load(os.path.join(here, ref_file))
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+    assert ref["sample"].shape == (1, 20, 4, 64, 64) and ref["pano_sample"].shape == (1, 1, 4) + pano_hw
+    dv, dp = rel(port["sample"][1:], ref["sample"]), rel(port["pano_sample"][1:], ref["pano_sample"])
+    assert dv <= 1e-5 and dp <= 1e-5, (dv, dp)
+    assert float(ref["port_vs_reference"].max()) <= 1e-5

@@ -96,6 +96,36 @@ def cfg2ref():
                         port_vs_reference=np.array([d_v, d_p]))
 
 
+def _ref_cond(name, fixture, out, pano_hw, controlnet=False):
+    """Conditional half of a configuration's first denoiser call through the REFERENCE's own class (see cfg2ref), compared with the
+    conditional half of the port-generated fixture and stored next to it."""
+    om = FX.build_full_width(controlnet=controlnet)
+    rm = FX.reference_denoiser(om)
+    print("%s: denoiser =" % name, type(rm).__module__, type(rm).__name__, flush=True)
+    args = FX.first_step_call(FX.ico_cameras(), (64, 64), pano_hw, cfg_pair=False)
+    extra = {}
+    if controlnet:
+        extra["pano_layout_cond"] = torch.roll(FX.layout_image(pano_hw), pano_hw[1] * 8 // 4, dims=-1)
+    t0 = time.time()
+    s, ps = call(rm, args, **extra)
+    print("%s reference forward (one CFG half) %.0f s" % (name, time.time() - t0), flush=True)
+    old = np.load(os.path.join(OUT, fixture))
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+    d_v, d_p = rel(old["sample"][1:], s.numpy()), rel(old["pano_sample"][1:], ps.numpy())
+    print("%s: port-generated %s (conditional half) vs the reference class: %.2e views / %.2e panorama" % (name, fixture, d_v, d_p), flush=True)
+    np.savez_compressed(os.path.join(OUT, out), sample=s.numpy(), pano_sample=ps.numpy(), port_vs_reference=np.array([d_v, d_p]))
+
+
+def cfg4ref():
+    """configs[3] (128 x 256 panorama latent): the reference class's dense bias is 10 heads x 8192 x 20480 fp32 = 6.7 GB per direction at C = 320."""
+    _ref_cond("cfg4ref", "cfg4_eps.npz", "cfg4_ref_cond.npz", (128, 256))
+
+
+def cfg5ref():
+    """configs[4] (panorama ControlNet): MVGenModel.py:68-83,154-170,200-203 of the reference class around the restated ControlNet."""
+    _ref_cond("cfg5ref", "cfg5_eps.npz", "cfg5_ref_cond.npz", (64, 128), controlnet=True)
+
+
 def cfg2b():
     model = FX.build_full_width()
     args = FX.first_step_call(FX.ico_cameras(), (64, 64), (64, 128), cfg_pair=True, t=21, rot=180.0)
