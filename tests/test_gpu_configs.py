@@ -112,6 +112,7 @@ def test_cfg2_late_step_second_rotation_vs_oracle(full_oracle):
         assert rel_l2(s[h].cpu(), torch.from_numpy(gd["sample"][h])) <= 1e-3
         assert rel_l2(ps[h].cpu(), torch.from_numpy(gd["pano_sample"][h])) <= 1e-3
     assert es <= 1e-3 and ep <= 1e-3, (es, ep)
+    _against_reference_class("cfg2b_ref_cond.npz", s, ps)
 
 
 @pytest.mark.parametrize("graphs", [True])

@@ -1411,3 +1411,33 @@ def test_conv_gemm_subpixel_upsample(dtype, case):
     if case == "splitk":
         assert o.gemm_workspace_bytes(x, w4, cout, subpixel=True, **{k: v for k, v in kw.items() if k not in ("bias", "out_dtype")}) > 0, \
             "this shape is expected to take a split-K plan"
+
+
+@pytest.mark.parametrize("wrap", [False, True])
+def test_conv_gemm_subpixel_upsample_in_split_precision(wrap):
+    """The level-0 upsampling convolution of the mixed scheme: sub-pixel form AND split precision (pf_conv_desc.subpixel + split3) -- the
+    pair operand of the fp32 stream against [W_hi | W_lo] of the four phase weights, three products per K block.  Reproduces the fp32
+    convolution (interpolate + conv3x3 on the fp32 weights and the fp32 input) to ~1e-6, where the single-pass fp16 form sits at 3e-4."""
+    from panfusion_amd import engine
+    o = ops()
+    torch.backends.cudnn.allow_tf32 = False
+    dtype = torch.float16
+    n, h, w, cin, cout = (2, 16, 32, 640, 640) if wrap else (6, 32, 32, 640, 640)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / (9 * cin) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, device=DEV, generator=g))
+    x = torch.randn(n, h, w, cin, device=DEV, generator=g)                      # the fp32 stream
+    w4s = engine._split_weight(engine._subpixel_weight(conv, DEV, torch.float32), 4, DEV, dtype)
+    assert w4s.shape == (4 * cout, 4 * 2 * cin)
+    geo = dict(wrap_pad=1, crop=2) if wrap else {}
+    got = engine.exact_gemm(engine.split_operand(x, dtype=dtype), w4s, cout, n_img=n, h_in=h, w_in=w, ksize=3, pad=1, upsample=1,
+                            bias=conv.bias.detach(), out_dtype=torch.float32, subpixel=True, **geo)
+    xin = x.permute(0, 3, 1, 2)
+    if wrap:
+        xin = torch.cat([xin[..., -1:], xin, xin[..., :1]], -1)
+    want = F.conv2d(F.interpolate(xin, scale_factor=2.0, mode="nearest"), conv.weight.detach(), conv.bias.detach(), padding=1)
+    if wrap:
+        want = want[..., 2:-2]
+    check("split-precision sub-pixel upsampling conv", got, want.permute(0, 2, 3, 1).reshape(-1, cout), 5e-6)

@@ -180,7 +180,8 @@ def test_cfg2_port_fixture_equals_the_reference_class_fixture():
     assert rel(port["sample"][:1], ref["sample"]) > 1e-2
 
 
-@pytest.mark.parametrize("port_file,ref_file,pano_hw", [("cfg4_eps.npz", "cfg4_ref_cond.npz", (128, 256)), ("cfg5_eps.npz", "cfg5_ref_cond.npz", (64, 128))])
+@pytest.mark.parametrize("port_file,ref_file,pano_hw", [("cfg4_eps.npz", "cfg4_ref_cond.npz", (128, 256)), ("cfg5_eps.npz", "cfg5_ref_cond.npz", (64, 128)),
+                                                        ("cfg2b_eps.npz", "cfg2b_ref_cond.npz", (64, 128))])
 def test_cfg4_cfg5_port_fixtures_equal_the_reference_class_fixtures(port_file, ref_file, pano_hw):
     """The same for configs[3] (128 x 256 panorama latent: the reference's dense per-head bias is 6.7 GB per direction) and configs[4]
     (panorama ControlNet through MVGenModel.py:68-83): the conditional half produced by the reference class agrees with the port-generated

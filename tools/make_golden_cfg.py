@@ -116,6 +116,21 @@ def _ref_cond(name, fixture, out, pano_hw, controlnet=False):
     np.savez_compressed(os.path.join(OUT, out), sample=s.numpy(), pano_sample=ps.numpy(), port_vs_reference=np.array([d_v, d_p]))
 
 
+def cfg2bref():
+    """cfg 2's LATE call (t = 21, accumulated rotation 180 degrees) through the reference class, conditional half."""
+    om = FX.build_full_width()
+    rm = FX.reference_denoiser(om)
+    args = FX.first_step_call(FX.ico_cameras(), (64, 64), (64, 128), cfg_pair=False, t=21, rot=180.0)
+    t0 = time.time()
+    s, ps = call(rm, args)
+    print("cfg2bref reference forward (one CFG half) %.0f s" % (time.time() - t0), flush=True)
+    old = np.load(os.path.join(OUT, "cfg2b_eps.npz"))
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+    d_v, d_p = rel(old["sample"][1:], s.numpy()), rel(old["pano_sample"][1:], ps.numpy())
+    print("cfg2bref: port-generated cfg2b_eps.npz (conditional half) vs the reference class: %.2e views / %.2e panorama" % (d_v, d_p), flush=True)
+    np.savez_compressed(os.path.join(OUT, "cfg2b_ref_cond.npz"), sample=s.numpy(), pano_sample=ps.numpy(), port_vs_reference=np.array([d_v, d_p]))
+
+
 def cfg4ref():
     """configs[3] (128 x 256 panorama latent): the reference class's dense bias is 10 heads x 8192 x 20480 fp32 = 6.7 GB per direction at C = 320."""
     _ref_cond("cfg4ref", "cfg4_eps.npz", "cfg4_ref_cond.npz", (128, 256))
