@@ -1316,7 +1316,8 @@ static bool use_lds_attention() {
 }
 
 // A/B switches.  PF_ATTENTION_OCC (D = 64): 3 = one score array, three waves per SIMD (default), 2 = register-pipelined
-// scores, two waves per SIMD.  PF_ATTENTION_OCC32 (D = 32): 3 = pipelined (default), 4 | 5 = not pipelined at that occupancy.
+// scores, two waves per SIMD.  PF_ATTENTION_OCC32 (D = 32): 4 (default since round 6: 122 registers, no scratch; -0.2 ... -0.35 ms per step on three boxes,
+// profiles/r6o_ab_epa_occupancy.txt) | 5 = not pipelined at that occupancy, 3 = register-pipelined scores at three waves per SIMD (rounds 3-5).
 static int attention_occupancy(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -1376,7 +1377,7 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     const bool pp2_ok = !d->lse && d->nk % 128 == 0 && d->nk >= 256 && pp_fits;
     PF_DISPATCH_16(d->dtype, "pf_attention",
         if (lds) {
-            static const int occ64 = attention_occupancy("PF_ATTENTION_OCC", 3), occ32 = attention_occupancy("PF_ATTENTION_OCC32", 3);
+            static const int occ64 = attention_occupancy("PF_ATTENTION_OCC", 3), occ32 = attention_occupancy("PF_ATTENTION_OCC32", 4);
             static const int msum = attention_occupancy("PF_ATTENTION_MSUM", 1);      // 0: softmax row sums on the vector ALU (A/B)
             static const int msum32 = attention_occupancy("PF_ATTENTION_MSUM32", 0);  // the same for the EPA (D = 32, bias) kernel: 168 registers + 3 spilled
             const int pingpong = attention_occupancy("PF_ATTENTION_PP", 0);                // (read per call: the tests switch it)      // 0: k_attention_lds for the D = 64 self-attentions too (A/B)

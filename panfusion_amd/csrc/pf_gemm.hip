@@ -583,6 +583,7 @@ __global__ __launch_bounds__(256, STAGES > 2 ? 1 : 2) void k_conv_gemm(const Gem
         } else {
             a_img[i] = 0; a_y[i] = -(1 << 20); a_x[i] = 0;     // never in range
         }
+        if (p.fastseg) seg_pack(a_img[i], a_y[i], a_x[i], p.h_in, p.w_in);      // (pf_gemm_params.h: a_img = pixel index, a_y = validity bits from here on)
     }
     // DMA addressing as in k_conv_gemm8: scalar buffer descriptors + per-thread byte offset (VGPR) +
     // per-stage scalar offset; out-of-range offsets (zero padding, ragged tiles) read as zero.
@@ -615,6 +616,16 @@ __global__ __launch_bounds__(256, STAGES > 2 ? 1 : 2) void k_conv_gemm(const Gem
         const int ky = p.ksize == 3 ? tap / 3 : p.ksize == 2 ? tap >> 1 : 0, kx = p.ksize == 3 ? tap - 3 * ky : p.ksize == 2 ? tap & 1 : 0;
         seg1 = __builtin_amdgcn_readfirstlane(cc >= p.c0 ? 1 : 0) != 0;
         const int ld = seg1 ? p.a1_ld : p.a0_ld;
+        if (p.fastseg) {
+            const unsigned sel = (1u << ky) | (16u << kx);
+            const int tap_pix = ky * p.w_in + kx;
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) {
+                const unsigned off = ((static_cast<unsigned>(a_img[i]) + static_cast<unsigned>(tap_pix)) * static_cast<unsigned>(ld) + static_cast<unsigned>(lchunk8)) * 2u;
+                a_off[i] = (static_cast<unsigned>(a_y[i]) & sel) == sel ? off : OOB;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
             const int yi = a_y[i] + ky, xi = a_x[i] + kx;             // xi: column in the (virtually wrap-padded, upsampled) input
@@ -851,6 +862,16 @@ __global__ __launch_bounds__(64 * NW, BM_ == 128 ? 2 : 1) void k_conv_gemm8(cons
         const int ky = p.ksize == 3 ? tap / 3 : p.ksize == 2 ? tap >> 1 : 0, kx = p.ksize == 3 ? tap - 3 * ky : p.ksize == 2 ? tap & 1 : 0;
         seg1 = __builtin_amdgcn_readfirstlane(cc >= p.c0 ? 1 : 0) != 0;
         const int ld = seg1 ? p.a1_ld : p.a0_ld;
+        if (p.fastseg) {                                               // (pf_gemm_params.h: a_img = pixel index, a_y = validity bits)
+            const unsigned sel = (1u << ky) | (16u << kx);
+            const int tap_pix = ky * p.w_in + kx;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const unsigned off = ((static_cast<unsigned>(a_img[i]) + static_cast<unsigned>(tap_pix)) * static_cast<unsigned>(ld) + static_cast<unsigned>(lchunk8)) * 2u;
+                a_off[i] = (static_cast<unsigned>(a_y[i]) & sel) == sel ? off : OOB;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int yi = a_y[i] + ky, xi = a_x[i] + kx;             // xi: column in the (virtually wrap-padded, upsampled) input
@@ -888,6 +909,7 @@ __global__ __launch_bounds__(64 * NW, BM_ == 128 ? 2 : 1) void k_conv_gemm8(cons
                 a_img[i] = ok ? img : 0;
                 a_y[i] = ok ? yo * p.stride - pad_y : -(1 << 20);
                 a_x[i] = (xo + p.crop) * p.stride - pad_x;
+                if (p.fastseg) seg_pack(a_img[i], a_y[i], a_x[i], p.h_in, p.w_in);
                 xo += p.adv_x;
                 if (xo >= p.w_out) { xo -= p.w_out; ++yo; }
                 yo += p.adv_y;
@@ -1581,6 +1603,7 @@ static void params_from_desc(const pf_conv_desc* d, GemmParams& p) {
     p.m_begin = 0; p.splits = 1; p.kb_per_split = 0; p.partial = nullptr; p.tickets = nullptr;
     p.a0_bytes = p.a1_bytes = p.w_bytes = 0; p.adv_img = p.adv_y = p.adv_x = 0;
     p.subpix = 0;
+    p.fastseg = (d->upsample == 0 || d->subpixel) && d->wrap_pad == 0 && tuning("PF_CONV_FASTSEG", 1) ? 1 : 0;
     if (d->subpixel) {
         // nearest x2 + 3x3 conv == four 2x2 convolutions on the low-resolution grid, one per output phase (blockIdx.z): 4 Cin
         // instead of 9 Cin MACs per output value.  Everything below is the LOW-resolution problem; out_row() scatters the rows.

@@ -35,11 +35,29 @@ struct GemmParams {
                                    // channels, of W [W_hi(32) | W_lo(32)]: a K step multiplies W_hi A_hi + W_hi A_lo + W_lo A_hi
     float* gn_partial;             // [M / gn_rows][2][N / 2] fp32 per-column-pair (sum, sum of squares) of the finished output over
     int gn_rows;                   // the gn_rows fragment rows of one wavefront (GroupNorm moments of the NEXT layer), or NULL
+    int fastseg;                   // 1: no upsampling and no circular wrap -- the kernels keep, per staged tile row, the linear index of its top-left input pixel and
+                                   // one validity bit per tap row / tap column (seg_pack) instead of (image, y, x), and the per-tap source offsets are an add, a
+                                   // multiply-add and a select (set_segment used to be ~20 dependent vector instructions in front of the next stage's DMA: 5-7 % of a
+                                   // 3x3 convolution, profiles/r6_seg_ablate.txt).  PF_CONV_FASTSEG=0: the general form everywhere (A/B)
     int subpix;                    // nearest x2 upsampling + 3x3 convolution as FOUR 2x2 convolutions on the low-resolution grid (pf_conv_desc.subpixel):
                                    // blockIdx.z = output phase (a, b) = (z >> 1, z & 1); taps of phase a read input rows y - 1 + a, y + a (columns alike): pad = 1 - phase;
                                    // weights [4][N][2][2][C] (w_bs = N K), a_bs = out_bs = 0; M / h_out / w_out / rows_per_img are those of the LOW-resolution grid and
                                    // the result of low-resolution pixel (q = img h + y, x) goes to output row (2 q + a) 2 w_out + 2 x + b (out_row)
 };
+
+// fastseg: (image, top-left input row y, column x) of a staged tile row -> (linear pixel index, validity bits: bit k = input row y + k exists, bit 4 + k = column x + k
+// exists, k < 3).  Rows past M carry y = -(1 << 20): no bit set.
+__device__ __forceinline__ void seg_pack(int& img_pix, int& y_msk, int x, int h_in, int w_in) {
+    const int img = img_pix, y = y_msk;
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        m |= (static_cast<unsigned>(y + k) < static_cast<unsigned>(h_in) ? 1u : 0u) << k;
+        m |= (static_cast<unsigned>(x + k) < static_cast<unsigned>(w_in) ? 16u : 0u) << k;
+    }
+    img_pix = static_cast<int>((static_cast<unsigned>(img) * static_cast<unsigned>(h_in) + static_cast<unsigned>(y)) * static_cast<unsigned>(w_in) + static_cast<unsigned>(x));
+    y_msk = static_cast<int>(m);
+}
 
 // Row of the output tensor that holds the result of GEMM row m (identity except for the sub-pixel phases of an upsampling convolution).
 __device__ __forceinline__ long out_row(const GemmParams& p, long bz, int m) {
