@@ -1354,6 +1354,44 @@ def test_conv_gemm32_groupnorm_moments(dtype, f32out, gemm32_on):
 # ------------------------------------------------------------------------------------ sub-pixel upsampling convolution
 
 
+@pytest.mark.parametrize("case", ["conv3_8wave", "conv3_4wave", "conv3_ragged", "concat", "stride2_pad_hi", "subpixel", "splitk", "split3_1x1"])
+def test_conv_gemm_packed_tap_offsets_same_bits(case, monkeypatch):
+    """GemmParams.fastseg: layers without upsampling / circular wrap keep a linear pixel index + one validity bit per tap row /
+    column per staged tile row, and a tap change is an add, a multiply-add and a select.  Same addresses -> the results must be bit-identical to
+    the general per-tap computation (PF_CONV_FASTSEG=0, read per call): 8-wave and 4-wave plans, a ragged last tile, a channel concat (two sources,
+    two leading dimensions), stride 2 with the VAE's bottom / right zero row, the sub-pixel upsampling form, a split-K plan, a split-precision 1x1."""
+    from panfusion_amd import engine
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    n, h, w, c0, c1, cout, ks, stride, pad, pad_hi = {
+        "conv3_8wave": (8, 32, 32, 320, 0, 320, 3, 1, 1, 0), "conv3_4wave": (2, 12, 20, 128, 0, 192, 3, 1, 1, 0), "conv3_ragged": (3, 13, 17, 192, 0, 320, 3, 1, 1, 0),
+        "concat": (4, 16, 16, 320, 192, 320, 3, 1, 1, 0), "stride2_pad_hi": (2, 32, 32, 128, 0, 128, 3, 2, 0, 1), "subpixel": (3, 10, 12, 128, 0, 192, 3, 1, 1, 0),
+        "splitk": (2, 8, 8, 1280, 0, 1280, 3, 1, 1, 0), "split3_1x1": (1, 1, 4096, 320, 0, 320, 1, 1, 0, 0)}[case]
+    x0 = torch.randn(n, h, w, c0, device=DEV, generator=g).half()
+    x1 = torch.randn(n, h, w, c1, device=DEV, generator=g).half() if c1 else None
+    bias = torch.randn(cout, device=DEV, generator=g)
+    kw = dict(n_img=n, h_in=h, w_in=w, ksize=ks, stride=stride, pad=pad, bias=bias)
+    if case == "subpixel":
+        conv = torch.nn.Conv2d(c0, cout, 3, padding=1).to(DEV)
+        wt = engine._subpixel_weight(conv, DEV, torch.float16)
+        kw.update(upsample=1, subpixel=True)
+    elif case == "split3_1x1":
+        wt32 = torch.randn(cout, c0, device=DEV, generator=g) / c0 ** 0.5
+        wt = engine._split_weight(wt32, 1, DEV, torch.float16)
+        x0 = engine.split_operand(torch.randn(n * h * w, c0, device=DEV, generator=g), dtype=torch.float16)
+        kw = dict(w_in=n * h * w, bias=bias, split3=True, out_dtype=torch.float32)
+    else:
+        wt = (torch.randn(cout, ks * ks * (c0 + c1), device=DEV, generator=g) / (ks * ks * (c0 + c1)) ** 0.5).half()
+        if pad_hi:
+            kw.update(pad_hi=1)
+    outs = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("PF_CONV_FASTSEG", env)
+        outs.append(o.conv_gemm(x0, wt, cout, a1=x1, **kw).clone())
+    assert torch.isfinite(outs[0].float()).all() and outs[0].float().abs().max() > 0
+    assert torch.equal(outs[0], outs[1]), "packed tap offsets changed the result (%s): max |d| %.3e" % (case, (outs[0].float() - outs[1].float()).abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ["small", "pano", "level1_f32_gn", "level0_16bit", "splitk"])
 def test_conv_gemm_subpixel_upsample(dtype, case):
