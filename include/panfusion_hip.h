@@ -412,9 +412,15 @@ typedef struct {
     const uint8_t* flags; int flags_ld;
     float* lse;      /* optional fp32 [B][H][nq]: log2 of the softmax denominator in the exp2 domain,
                       * lse = log2(sum_j exp2(log2e * (scale * q.k_j + bias_j))) -- what pf_attention_bwd reads */
+    void* workspace; size_t workspace_bytes; /* optional scratch of pf_attention_workspace_size(desc) bytes (round 6): lets a launch with FEW query
+                      * blocks and MANY keys (the panorama-query direction of an EPA block: 2048 queries x 20 480 keys, 320-640 workgroups for 1024
+                      * slots) split its key range over several workgroups -- normalised 16-bit partial outputs + their log-sum-exps, combined
+                      * by a second launch in a fixed order (no atomics).  NULL: never split. */
 } pf_attn_desc;
 
 pf_status pf_attention(const pf_attn_desc* desc, void* stream);
+/* Bytes of pf_attn_desc.workspace that let pf_attention split the key range of this problem (0: it would not split). */
+size_t pf_attention_workspace_size(const pf_attn_desc* desc);
 
 /* ------------------------------------------------------------------------------------------
  * Training: backward of the EPA block (reference models/pano/modules.py:15-59 under autograd;

@@ -46,6 +46,7 @@ class AttnDesc(C.Structure):
         ("scale", c_float),
         ("bias", c_void_p), ("bias_ld", c_long), ("flags", c_void_p), ("flags_ld", c_int),
         ("lse", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
     ]
 
 
@@ -144,6 +145,7 @@ SIGNATURES = {
     "pf_conv_out_gn": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                c_void_p, c_void_p]),
     "pf_attention": (c_int, [C.POINTER(AttnDesc), c_void_p]),
+    "pf_attention_workspace_size": (c_size_t, [C.POINTER(AttnDesc)]),
     "pf_attention_delta": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_void_p, c_void_p]),
     "pf_attention_bwd": (c_int, [C.POINTER(AttnBwdDesc), c_void_p]),
     "pf_attention_bwd_workspace_size": (c_size_t, [C.POINTER(AttnBwdDesc)]),

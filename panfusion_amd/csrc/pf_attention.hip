@@ -20,6 +20,7 @@
 // (models/pano/MVGenModel.py:104,116,185,190,227,241).
 #include "pf_common.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 #ifndef PF_ATTN_BUFLOAD
@@ -39,6 +40,8 @@ struct AttnParams {
     int xcd_map;                 // k_attention_lds: 1 = heads pinned to XCDs (PF_ATTENTION_XCD, default), 0 = plain block order
     int pp_prio;                 // k_attention_pp: wave priorities (PF_ATTENTION_PP_PRIO): 0 none, 1 group B static 1, 2 raised inside matrix segments
     int steady2;                 // k_attention_lds (non-pipelined form): 1 = branch-free two-tile steady-state loop (PF_ATTENTION_STEADY2, default)
+    int split_tiles;             // k_attention_lds (non-pipelined form): > 0 = the key range is split over gridDim.y workgroups of split_tiles (EVEN) key tiles each;
+    long split_o, split_lse;     // split s writes its NORMALISED output at out + s * split_o and its log-sum-exp at lse + s * split_lse (k_attention_merge combines)
 };
 
 template <typename T, int D>
@@ -268,7 +271,11 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
         return row * D + ((chunk ^ sw) << 3);
     };
 
-    const int nkt = (p.nk + KT - 1) / KT;
+    // key tiles [jb, nkt) of this workgroup: all of them, or split blockIdx.y of a split key range (an EVEN number of tiles per split: the LDS buffer
+    // of tile j is j & 1 in the non-pipelined form, which is the only one launched with a split)
+    const int nkt_all = (p.nk + KT - 1) / KT;
+    const int jb = p.split_tiles > 0 ? static_cast<int>(blockIdx.y) * p.split_tiles : 0;
+    const int nkt = p.split_tiles > 0 ? min(nkt_all, jb + p.split_tiles) : nkt_all;
     u16x8 kreg[KCH], vreg[VCH];
     // staging ownership (fixed per thread): K chunk c = t + 256 i -> (row c / KCHUNKS, chunk c % KCHUNKS);
     // V^T chunk c -> (d = c >> 3, 8 keys starting at (c & 7) * 8)
@@ -498,15 +505,15 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
 
     const std::true_type TAILY;
     const std::false_type FULL;
-    const bool ragged = (p.nk % KT) != 0;              // only the last tile can be partial
+    const bool ragged = (p.nk % KT) != 0 && nkt == nkt_all;      // only the last tile (of the last split) can be partial
     auto load_tile = [&](int j) { if (j + 1 == nkt && ragged) stage_load(j, TAILY); else stage_load(j, FULL); };
     auto score_tile = [&](int j, float (&sv)[2][16]) { if (j + 1 == nkt && ragged) scores(j, j % 3, sv, TAILY); else scores(j, j % 3, sv, FULL); };
-    load_tile(0);
-    stage_store(0);
+    load_tile(jb);
+    stage_store(0);                                    // (jb is even: buffer jb & 1; the pipelined form is never split, jb = 0)
     if constexpr (!PIPE) {
         __syncthreads();
         float sv[2][16];
-        int j = 0;
+        int j = jb;
         // steady state, two tiles per trip: tile j + 1 exists and is full -> no tail variants, no branches, and the LDS buffer of a tile
         // (j & 1) is a compile-time offset.  The generic loop below carried both variants of stage_load / scores behind scalar
         // compares and branches plus per-tile buffer selects: ~45 of its ~225 instructions per key tile, in a kernel that is bound by
@@ -595,6 +602,8 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
     if (q0 + ql < p.nq) {
         const float inv = 1.0f / l_run;
         unsigned short* op = p.out + b * p.o_bs + static_cast<long>(q0 + ql) * p.o_ld + h * D;
+        float* lsep = p.lse;
+        if (p.split_tiles > 0) { op += blockIdx.y * p.split_o; lsep += blockIdx.y * p.split_lse; }
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -605,8 +614,39 @@ __global__ __launch_bounds__(256, OCC) void k_attention_lds(const AttnParams p) 
                 *reinterpret_cast<u16x4*>(op + d * 32 + 8 * g + 4 * hi) = w;
             }
         // (m_run is a reference point in raw-score units, not necessarily the maximum: deferred rescale)
-        if (p.lse && hi == 0) p.lse[(b * p.H + h) * p.nq + q0 + ql] = m_run * c2 + __log2f(l_run);
+        if (p.lse && hi == 0) lsep[(b * p.H + h) * p.nq + q0 + ql] = m_run * c2 + __log2f(l_run);
     }
+}
+
+// Combine of a split key range (AttnParams.split_tiles): out[b][q][c] = sum_s w_s part[s][b][q][c] / sum_s w_s, w_s = exp2(lse[s][b][h][q] - max_s lse),
+// in split order (fixed: no atomics).  part [S][B][nq][C] 16-bit (normalised partial outputs), lse [S][B][H][nq] fp32 (log2 domain).  One thread = 8 channels.
+template <typename T>
+__global__ __launch_bounds__(256) void k_attention_merge(const unsigned short* __restrict__ part, const float* __restrict__ lse, int S, int B, int H, int D, int nq,
+                                                          unsigned short* __restrict__ out, int o_ld, long o_bs) {
+    const int C8 = H * D / 8;
+    const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x, total = static_cast<long>(B) * nq * C8;
+    if (i >= total) return;
+    const int c8 = static_cast<int>(i % C8);
+    const long bq = i / C8;
+    const int q = static_cast<int>(bq % nq), b = static_cast<int>(bq / nq), h = c8 * 8 / D;
+    const long so = static_cast<long>(B) * nq * H * D, sl = static_cast<long>(B) * H * nq;
+    const float* lp = lse + (static_cast<long>(b) * H + h) * nq + q;
+    float m = -INFINITY;
+    for (int s = 0; s < S; ++s) m = fmaxf(m, lp[s * sl]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+    const unsigned short* pp = part + bq * (H * D) + c8 * 8;
+    for (int s = 0; s < S; ++s) {
+        const float w = __builtin_amdgcn_exp2f(lp[s * sl] - m);
+        const u16x8 v = *reinterpret_cast<const u16x8*>(pp + s * so);
+        wsum += w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w * to_f32<T>(v[e]);
+    }
+    const float inv = 1.0f / wsum;
+    u16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = from_f32<T>(acc[e] * inv);
+    *reinterpret_cast<u16x8*>(out + b * o_bs + static_cast<long>(q) * o_ld + c8 * 8) = r;
 }
 
 
@@ -1323,9 +1363,41 @@ static int attention_occupancy(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// Split of the key range (round 6): a launch of the biased D = 32 kernel (EPA) whose query blocks fill less than ~0.95 of the chip's workgroup slots
+// (256 CUs x 4) with a long key walk is cut into S splits of an even number of key tiles, at least MIN_TILES each, aiming at ~1.9 rounds of
+// workgroups.  PF_ATTENTION_SPLIT=0 disables it (read per call: the tests run both).
+struct AttnSplit { int S, tiles; size_t o_bytes, bytes; };
+static AttnSplit attention_split(const pf_attn_desc* d) {
+    AttnSplit r{1, 0, 0, 0};
+    if (!attention_occupancy("PF_ATTENTION_SPLIT", 1) || d->D != 32 || !d->bias || d->lse || d->o_ld % 8 != 0 || d->o_bs % 8 != 0) return r;
+    static const int occ32 = attention_occupancy("PF_ATTENTION_OCC32", 4), min_tiles = attention_occupancy("PF_ATTENTION_SPLIT_MIN_TILES", 8);
+    if (occ32 != 4 && occ32 != 5) return r;                                   // (the register-pipelined form walks three LDS buffers: never split)
+    const long blocks = cdiv(d->nq, 128) * d->H * d->B, slots = 256L * occ32;
+    const int nkt = (d->nk + 63) / 64;
+    if (blocks * 20 >= slots * 19) return r;
+    int S = static_cast<int>((slots * 19 / 10 + blocks / 2) / blocks);
+    S = std::min(S, 8);
+    S = std::min(S, nkt / std::max(min_tiles, 2));
+    if (S < 2) return r;
+    int tiles = static_cast<int>(cdiv(nkt, S));
+    tiles += tiles & 1;
+    S = static_cast<int>(cdiv(nkt, tiles));
+    if (S < 2) return r;
+    r.S = S; r.tiles = tiles;
+    r.o_bytes = static_cast<size_t>(S) * d->B * d->nq * d->H * d->D * 2;
+    r.bytes = r.o_bytes + static_cast<size_t>(S) * d->B * d->H * d->nq * sizeof(float);
+    return r;
+}
+
 }  // namespace pf
 
 using namespace pf;
+
+extern "C" size_t pf_attention_workspace_size(const pf_attn_desc* d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->nq <= 0 || d->nk <= 0) return 0;
+    const AttnSplit sp = attention_split(d);
+    return sp.S > 1 ? sp.bytes : 0;
+}
 
 extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     PF_REQUIRE(d, "pf_attention: null descriptor");
@@ -1351,6 +1423,7 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
     p.scale_log2e = d->scale * 1.44269504088896340736f;
     p.bias = d->bias; p.bias_ld = d->bias_ld; p.flags = d->flags; p.flags_ld = d->flags_ld;
     p.lse = d->lse;
+    p.split_tiles = 0; p.split_o = 0; p.split_lse = 0;
     static const int env_role = attention_occupancy("PF_ATTENTION_PP_ROLE", 3), env_prio = attention_occupancy("PF_ATTENTION_PP_PRIO", 2),
                      env_xcd = attention_occupancy("PF_ATTENTION_XCD", 1),       // (read once; PF_ATTENTION_PP below is read per call)
                      env_steady2 = attention_occupancy("PF_ATTENTION_STEADY2", 1);
@@ -1395,7 +1468,24 @@ extern "C" pf_status pf_attention(const pf_attn_desc* d, void* stream) {
                 }
             } else {
                 if (d->bias) {
-                    if (occ32 == 4) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 4>), grid1, block, 0, st, p);
+                    const AttnSplit sp = attention_split(d);
+                    if (sp.S > 1 && d->workspace && d->workspace_bytes >= sp.bytes && aligned16(d->workspace)) {
+                        // split key range: S workgroups per query block write normalised partial outputs + their log-sum-exps, one more launch combines them
+                        AttnParams ps = p;
+                        ps.out = static_cast<unsigned short*>(d->workspace);
+                        ps.lse = reinterpret_cast<float*>(static_cast<char*>(d->workspace) + sp.o_bytes);
+                        ps.o_ld = d->H * 32; ps.o_bs = static_cast<long>(d->nq) * d->H * 32;
+                        ps.split_tiles = sp.tiles;
+                        ps.split_o = static_cast<long>(d->B) * d->nq * d->H * 32;
+                        ps.split_lse = static_cast<long>(d->B) * d->H * d->nq;
+                        const dim3 grid_s(grid1.x, static_cast<unsigned>(sp.S));
+                        if (occ32 == 5) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 5>), grid_s, block, 0, st, ps);
+                        else hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 4>), grid_s, block, 0, st, ps);
+                        const long total = static_cast<long>(d->B) * d->nq * (d->H * 32 / 8);
+                        hipLaunchKernelGGL((k_attention_merge<T>), dim3(static_cast<unsigned>(cdiv(total, 256))), dim3(256), 0, st, ps.out, ps.lse, sp.S, d->B, d->H, 32,
+                                           d->nq, p.out, d->o_ld, d->o_bs);
+                    }
+                    else if (occ32 == 4) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 4>), grid1, block, 0, st, p);
                     else if (occ32 == 5) hipLaunchKernelGGL((k_attention_lds<T, 32, true, false, 5>), grid1, block, 0, st, p);
                     else if (msum32 && !d->lse) hipLaunchKernelGGL((k_attention_lds<T, 32, true, true, 3, true>), grid1, block, 0, st, p);
                     else hipLaunchKernelGGL((k_attention_lds<T, 32, true>), grid1, block, 0, st, p);

@@ -768,6 +768,14 @@ def attention(q, k, vt, B, H, D, nq, nk, *, q_ld, k_ld, vt_ld, o_ld=None, q_bs, 
     d.bias, d.bias_ld = _p(bias), (_ld(bias) if bias is not None else 0)
     d.flags, d.flags_ld = _p(flags), (_ld(flags) if flags is not None else 0)
     d.lse = _p(lse)
+    d.workspace, d.workspace_bytes = None, 0
+    if bias is not None and lse is None:
+        # few query blocks, many keys (the panorama-query direction of an EPA block): scratch that lets the library split the key range over more
+        # workgroups (pf_attn_desc.workspace; 0 bytes = this problem is not split)
+        nbytes = _lib.lib().pf_attention_workspace_size(C.byref(d))
+        if nbytes:
+            ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+            d.workspace, d.workspace_bytes = _p(ws), nbytes
     _traced("k_attention", 4.0 * B * H * nq * nk * D,
             lambda: check(_lib.lib().pf_attention(C.byref(d), _stream()), "pf_attention"),
             "B%d H%d D%d nq%d nk%d bias%d" % (B, H, D, nq, nk, bias is not None))

@@ -81,16 +81,17 @@ class ShardInfo:
 TIME_MODEL = {
     # (pano_hw, lat_hw, layout_cond): milliseconds; `pano` / `pano_only` are what the panorama branch adds ABOVE `base` on an owner
     # with / without views.  Round 6: re-measured at HEAD by tools/fit_time_model.py, raw timings and fit in
-    # profiles/r6_time_model.json -- cfg 2: 7-view rank 14.19, 14-view rank 20.16, owner alone 11.84, owner with 6 views 19.53; cfg 5: 14.18 /
-    # 20.11 / 16.43 / 24.32; cfg 4 (query split off): 14.79 / 21.01 / 24.16 / 32.74.  (Round 4's constants -- base 7.75, per_view 0.956,
+    # profiles/r6_time_model.json (final build: packed conv offsets, EPA kernel at four waves per SIMD with its key range split on the owner) -- cfg 2: 7-view
+    # rank 13.72, 14-view rank 19.65, owner alone 10.53, owner with 6 views 18.12; cfg 5: 13.71 / 19.68 / 14.91 / 22.81; cfg 4 (query split off): 14.21 / 20.46 /
+    # 22.82 / 30.86.  (The first fit of the round, two builds earlier: 14.19 / 20.16 / 11.84 / 19.53 -- the owner's EPA attentions were 0.6 ms slower.)  (Round 4's constants -- base 7.75, per_view 0.956,
     # pano 6.5 / 4.0 -- were still in here through round 5 while the kernels under them changed: the per-view cost fell by 11 %, the base rose.)
-    ((64, 128), (64, 64), False): dict(base=8.22, per_view=0.853, pano=6.19, pano_only=3.62),       # cfg 2 / 3
-    ((64, 128), (64, 64), True): dict(base=8.25, per_view=0.847, pano=10.99, pano_only=8.18),       # cfg 5: + the panorama ControlNet
+    ((64, 128), (64, 64), False): dict(base=7.79, per_view=0.847, pano=5.25, pano_only=2.74),       # cfg 2 / 3
+    ((64, 128), (64, 64), True): dict(base=7.74, per_view=0.853, pano=9.95, pano_only=7.17),        # cfg 5: + the panorama ControlNet
     # cfg 4; the query split of the five 32 768-token self-attentions of the panorama branch (split_pano_attention), measured at 4 ranks per
-    # half: the owner sheds 3.24 ms (24.16 -> 20.92: attn (1 - 1 / G) with attn = 4.32 -- a quarter of the rows is 320 workgroups on 256 CUs and
-    # costs 0.4 of the whole attention, and every attention adds two graph-segment breaks), every other rank takes on 2.92 ms
-    # (14.79 -> 17.71: attn_help / G with attn_help = 11.68).  Round 5 carried ONE constant (11 ms) for both sides and overstated what the owner sheds.
-    ((128, 256), (64, 64), False): dict(base=8.57, per_view=0.889, pano=18.84, pano_only=15.59, attn=4.32, attn_help=11.68),
+    # half: the owner sheds 3.13 ms (22.82 -> 19.69: attn (1 - 1 / G) with attn = 4.17 -- a quarter of the rows is 320 workgroups on 256 CUs and
+    # costs 0.4 of the whole attention, and every attention adds two graph-segment breaks), every other rank takes on 2.94 ms
+    # (14.21 -> 17.15: attn_help / G with attn_help = 11.76).  Round 5 carried ONE constant (11 ms) for both sides and overstated what the owner sheds.
+    ((128, 256), (64, 64), False): dict(base=7.96, per_view=0.893, pano=17.54, pano_only=14.86, attn=4.17, attn_help=11.76),
 }
 _DEFAULT_KEY = ((64, 128), (64, 64), False)
 _WARNED = set()

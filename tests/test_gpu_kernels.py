@@ -799,6 +799,43 @@ def test_attention_fused_qk_buffer_and_bias(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 4, 256, 4096), (1, 10, 128, 1280), (2, 3, 200, 2084), (1, 2, 96, 1156)])
+def test_attention_split_key_range(dtype, cfg, monkeypatch):
+    """pf_attn_desc.workspace (round 6): a biased D = 32 launch with few query blocks and many keys (the panorama-query direction of an EPA block) splits its key
+    range over several workgroups -- normalised 16-bit partial outputs + log-sum-exps, combined by a second launch.  Against the fp32 reference, against the unsplit
+    launch (PF_ATTENTION_SPLIT=0), with ragged query / key counts (a partial last key tile in the last split, bias tiles flagged off)."""
+    import ctypes as C
+    from panfusion_amd import _lib
+    B, H, nq, nk = cfg
+    D, Cq = 32, H * 32
+    q, qf = q16(rnd(B, nq, Cq, seed=61), dtype)
+    k, kf = q16(rnd(B, nk, Cq, seed=62), dtype)
+    v, vf = q16(rnd(B, nk, Cq, seed=63), dtype)
+    ld = ((nk + 31) // 32) * 32
+    vt = torch.zeros(B, Cq, ld, dtype=dtype, device=DEV)
+    vt[:, :, :nk] = v.transpose(1, 2)
+    g = torch.Generator().manual_seed(64)
+    nqt, nkt32 = (nq + 31) // 32, (nk + 31) // 32
+    bias_full = torch.rand(nqt * 32, nkt32 * 32, generator=g) * 2
+    on = torch.rand(nqt, nkt32, generator=g) < 0.05                       # 5 % of the 32 x 32 tiles carry a bias (the tables: 1-2 %)
+    bias_full = bias_full * on.repeat_interleave(32, 0).repeat_interleave(32, 1)
+    bias = bias_full[:nq, :nk].contiguous()
+    flags = on.to(torch.uint8)
+    kw = dict(q_ld=Cq, k_ld=Cq, vt_ld=ld, q_bs=nq * Cq, k_bs=nk * Cq, vt_bs=Cq * ld, bias=bias.to(DEV), flags=flags.to(DEV))
+    d = _lib.AttnDesc()
+    d.B, d.H, d.D, d.nq, d.nk, d.o_ld, d.o_bs, d.bias = B, H, D, nq, nk, Cq, nq * Cq, 1
+    assert _lib.lib().pf_attention_workspace_size(C.byref(d)) > 0, "this problem should split"
+    out = ops().attention(q, k, vt, B, H, D, nq, nk, **kw)
+    monkeypatch.setenv("PF_ATTENTION_SPLIT", "0")
+    assert _lib.lib().pf_attention_workspace_size(C.byref(d)) == 0
+    whole = ops().attention(q, k, vt, B, H, D, nq, nk, **kw)
+    want = attn_ref(qf, kf, vf, H, D ** -0.5, bias)
+    check("split attention vs fp32", out, want, 2.5 * TOL[dtype])
+    check("unsplit attention vs fp32", whole, want, 2.5 * TOL[dtype])
+    check("split vs unsplit", out, whole, 1.5 * TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("pp,cfg", [(1, (2, 5, 64, 512, 512)), (1, (1, 3, 64, 300, 1000)), (1, (1, 2, 64, 64, 136)), (1, (3, 2, 64, 257, 4096)),
                                     (2, (2, 5, 64, 512, 512)), (2, (1, 3, 64, 300, 1152)), (2, (1, 2, 64, 33, 256)), (2, (3, 2, 64, 257, 4096))])
 def test_pingpong_attention_kernels(dtype, pp, cfg):
